@@ -1,0 +1,191 @@
+/*
+ * rcn_hip.h -- C ABI of the MI355X-native (gfx950) implementation of the `rcn` crate's hot path:
+ * Sobel-separable conv + ReLU + 2x2 max-pool feature extraction, standardise+clamp, the dense
+ * sigmoid/MSE forward + backward pass and the minibatch SGD update.
+ *
+ * The reference (jtstrader/mercer-research, crate `rcn`) is a pure-Rust CPU program with NO
+ * FFI / plugin boundary; this header cuts one at the private seams of `RCN`
+ * (flatten_feature_set / gen_scales / train_batch / classify_test) and at its public operator
+ * traits (Convolve2D / Pool2D).  Each entry point names the reference code it replaces as
+ * file:line under rcn/src/.  The Rust-side binding a maintainer would add is in INTEGRATION.md
+ * (and rust/rcn-hip-sys/src/lib.rs).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no C++ / torch types, no exceptions or unwinding across
+ *     the boundary.  Every function returns an rcn_hip_status (0 = ok, <0 = error) unless noted;
+ *     rcn_hip_last_error(ctx) gives the text.  Where the reference would panic!() the call
+ *     returns RCN_HIP_ERR_SHAPE / RCN_HIP_ERR_UNSUPPORTED instead.
+ *   - "host" pointers are caller-owned host memory, copied in/out synchronously (blocking).
+ *     "_dev" entry points take device pointers (same HIP device as the context), are enqueued on
+ *     the context's stream and do not synchronise.  The library never frees caller memory.
+ *   - host matrices are f64 column-major exactly as nalgebra::DMatrix stores them and as the
+ *     reference's bincode checkpoint holds them (utils/serialization.rs:16-24,98): element (r,c)
+ *     of an R x C matrix lives at [c*R + r].  Sample batches are "sample-major": sample i's
+ *     vector is contiguous at [i*len .. (i+1)*len).
+ *   - device buffers handed to _dev calls hold the context's arithmetic type (rcn_hip_dtype):
+ *     float for RCN_HIP_F32, double for RCN_HIP_F64, same index layout as the host forms.
+ *   - threading: a context is Send, not Sync (RCN::train takes &mut self, rcn.rs:126; the backend
+ *     gives each worker a private model, backend/src/main.rs:64-70): calls on one context must be
+ *     serialised by the caller; different contexts are independent.
+ */
+#ifndef RCN_HIP_H
+#define RCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCN_HIP_ABI_VERSION 1
+
+typedef struct rcn_hip_ctx rcn_hip_ctx;
+
+typedef enum rcn_hip_status {
+    RCN_HIP_OK = 0,
+    RCN_HIP_ERR_INVALID_ARG = -1,  /* NULL pointer, bad enum, bad size                                       */
+    RCN_HIP_ERR_SHAPE = -2,        /* the reference panics on this shape (kernel.rs:127,133,156,200,247; gemv dims) */
+    RCN_HIP_ERR_UNSUPPORTED = -3,  /* Pooling::Average -> panic!("Not implemented") kernel.rs:283,341; size limits  */
+    RCN_HIP_ERR_HIP = -4,          /* a HIP runtime call failed                                             */
+    RCN_HIP_ERR_NO_DEVICE = -5,    /* no gfx950 device / device ordinal out of range                        */
+    RCN_HIP_ERR_STATE = -6,        /* call order (e.g. train before parameters were set)                    */
+    RCN_HIP_ERR_OOM = -7
+} rcn_hip_status;
+
+/* enum values = declaration order in the reference = bincode variant tags */
+typedef enum { RCN_HIP_PAD_NONE = 0, RCN_HIP_PAD_SAME = 1 } rcn_hip_padding;                 /* utils/kernel.rs:25-28 */
+typedef enum { RCN_HIP_POOL_AVERAGE = 0, RCN_HIP_POOL_MAX = 1 } rcn_hip_pooling;             /* utils/kernel.rs:32-35 */
+typedef enum { RCN_HIP_OP_TOP = 0, RCN_HIP_OP_BOTTOM = 1, RCN_HIP_OP_LEFT = 2, RCN_HIP_OP_RIGHT = 3 } rcn_hip_sep_op; /* kernel.rs:16-21 */
+typedef enum { RCN_HIP_LAYER_CONVOLVE2D = 0, RCN_HIP_LAYER_POOL2D = 1 } rcn_hip_layer_kind;  /* rcn.rs:35-38 */
+typedef enum { RCN_HIP_F32 = 0, RCN_HIP_F64 = 1 } rcn_hip_dtype;
+
+/* RCNLayer::Convolve2D(Padding) | RCNLayer::Pool2D(Pooling)                              rcn.rs:35-38 */
+typedef struct rcn_hip_layer { int32_t kind; int32_t arg; } rcn_hip_layer;
+
+/* Mirrors the arguments of RCN::new (rcn.rs:58-75) plus what a device context needs. */
+typedef struct rcn_hip_cfg {
+    uint32_t struct_size;          /* = sizeof(rcn_hip_cfg)                                                   */
+    int32_t  device;               /* HIP device ordinal                                                      */
+    int32_t  dtype;                /* rcn_hip_dtype: device arithmetic type (the reference is f64 throughout) */
+    int32_t  in_h, in_w;           /* input image height / width (rows / cols of get_pixel_matrix, lib.rs:27) */
+    int32_t  n_convpool;           /* convpool_cfg.len()                                                      */
+    const rcn_hip_layer* convpool; /* convpool_cfg                                                            */
+    int32_t  n_hidden;             /* feedforward_cfg.len()  (>= 1: rcn.rs:444 indexes [0])                   */
+    const int32_t* hidden;         /* feedforward_cfg                                                         */
+    int32_t  classes;              /* classes                                                                 */
+    void*    stream;               /* hipStream_t to enqueue on; NULL = the context creates its own stream    */
+} rcn_hip_cfg;
+
+/* ---------------------------------------------------------------- lifecycle */
+int  rcn_hip_abi_version(void);
+const char* rcn_hip_status_string(int status);
+/* RCN::new (rcn.rs:58-75) + the dimension bookkeeping of load_weights_and_bias (rcn.rs:425-457).
+ * Fails with RCN_HIP_ERR_SHAPE / _UNSUPPORTED where EVERY later use panics in the reference (conv on
+ * <3x3 / pool on <2x2 maps, Pooling::Average).  A stack whose feature path works but whose dense part
+ * cannot -- first-layer fan-in 4^c/2^p*l (rcn.rs:443) != flattened feature length, so gemv panics at
+ * rcn.rs:287, or no Convolve2D layer at all -- creates fine (as RCN::new does); the feature entry points
+ * work and every dense entry point returns RCN_HIP_ERR_SHAPE.
+ * *out is set even on failure (when non-NULL) so that rcn_hip_last_error can be read; destroy it. */
+int  rcn_hip_create(const rcn_hip_cfg* cfg, rcn_hip_ctx** out);
+void rcn_hip_destroy(rcn_hip_ctx* ctx);
+const char* rcn_hip_last_error(const rcn_hip_ctx* ctx);      /* "" if none; valid until the next call on ctx */
+int  rcn_hip_set_stream(rcn_hip_ctx* ctx, void* hip_stream);
+int  rcn_hip_synchronize(rcn_hip_ctx* ctx);
+
+/* ---------------------------------------------------------------- introspection */
+int  rcn_hip_feature_len(const rcn_hip_ctx* ctx, int64_t* out);               /* len of flatten_feature_set's vector */
+int  rcn_hip_num_layers(const rcn_hip_ctx* ctx);                              /* feedforward_cfg.len()+1, rcn.rs:426 */
+int  rcn_hip_layer_dims(const rcn_hip_ctx* ctx, int layer, int32_t* rows_out, int32_t* cols_in); /* W_l is rows x cols */
+int  rcn_hip_param_count(const rcn_hip_ctx* ctx, int64_t* out);               /* total scalars in all W_l, b_l */
+
+/* ---------------------------------------------------------------- parameters (Weights / Bias, rcn.rs:28,31) */
+/* W: rows x cols column-major f64 (= Weights.0 / the bincode `data` field), b: rows f64 (= Bias.0) */
+int  rcn_hip_set_params(rcn_hip_ctx* ctx, int layer, const double* W_colmajor, const double* b);
+int  rcn_hip_get_params(rcn_hip_ctx* ctx, int layer, double* W_colmajor, double* b);
+/* load_weights_and_bias (rcn.rs:425-457): every W, b ~ N(0,1), un-scaled (rcn.rs:500-523).  The reference
+ * draws from the unseeded thread_rng; here the stream is a seeded generator (seed 0 = nondeterministic). */
+int  rcn_hip_init_params(rcn_hip_ctx* ctx, uint64_t seed);
+/* device view of the flat parameter buffer [W_0|b_0|W_1|b_1|...] in the context dtype (for DP broadcast /
+ * all-reduce of replicas); valid until destroy */
+int  rcn_hip_params_dev(rcn_hip_ctx* ctx, void** dev_ptr, int64_t* count);
+
+/* ---------------------------------------------------------------- operator API (traits Convolve2D / Pool2D) */
+/* Pure shape helpers (no device work).  Return RCN_HIP_ERR_SHAPE exactly where the reference panics. */
+int  rcn_hip_conv_out_shape(int R, int C, int kr, int kc, int padding, int* out_R, int* out_C);
+int  rcn_hip_pool_out_shape(int R, int C, int padding, int* out_R, int* out_C);
+/* Convolve2D::convolve_2d (utils/kernel.rs:110-194): cross-correlation of `n` R x C matrices with one
+ * kr x kc kernel, Padding::None or Padding::Same (incl. the pad-copy index quirk of :154-158).
+ * f64 arithmetic on the device in the reference's summation order.  m: n matrices back to back. */
+int  rcn_hip_convolve_2d(rcn_hip_ctx* ctx, const double* m, int n, int R, int C,
+                         const double* kernel, int kr, int kc, int padding, double* out);
+/* Convolve2D::convolve_2d_separated (kernel.rs:196-207): relu(conv(conv(m, col3x1), row1x3)) */
+int  rcn_hip_convolve_2d_separated(rcn_hip_ctx* ctx, const double* m, int n, int R, int C,
+                                   int sep_op, int padding, double* out);
+/* Convolve2D::relu (kernel.rs:209-216) over `count` scalars */
+int  rcn_hip_relu(rcn_hip_ctx* ctx, const double* m, size_t count, double* out);
+/* Pool2D::pool_2d (kernel.rs:245-349): 2x2 stride-2 max; Same zero-pads odd dims, None truncates */
+int  rcn_hip_pool_2d(rcn_hip_ctx* ctx, const double* m, int n, int R, int C, int padding, int pooling, double* out);
+
+/* ---------------------------------------------------------------- feature pipeline */
+/* get_pixel_matrix + flatten_feature_set for `n` images (lib.rs:27-41, rcn.rs:317-356): imgs is
+ * n x in_h x in_w u8, row-major pixel order (the order image::pixels() yields); out is n x F f64,
+ * per-sample map order / column-major flatten as the reference.  NOT standardised. */
+int  rcn_hip_features(rcn_hip_ctx* ctx, const uint8_t* imgs, size_t n, double* out);
+/* device form: out_dev n x F in the context dtype.  standardize != 0 additionally applies
+ * max((x-mean)/sd, 0) with the context's scale_set (rcn.rs:407-412) in the same kernel. */
+int  rcn_hip_features_dev(rcn_hip_ctx* ctx, const uint8_t* imgs_dev, size_t n, void* out_dev, int standardize);
+/* gen_scales (rcn.rs:230-251): population mean / sd over all n*F values; also stores them as the context's
+ * scale_set, as the reference does (rcn.rs:249-250). */
+int  rcn_hip_gen_scales(rcn_hip_ctx* ctx, const double* feats, size_t n, double* mean, double* sd);
+int  rcn_hip_gen_scales_dev(rcn_hip_ctx* ctx, const void* feats_dev, size_t n, double* mean, double* sd); /* blocks */
+int  rcn_hip_set_scale(rcn_hip_ctx* ctx, double mean, double sd);            /* RCN.scale_set, rcn.rs:21 */
+int  rcn_hip_get_scale(const rcn_hip_ctx* ctx, double* mean, double* sd);
+/* x <- max((x-mean)/sd, 0) in place (rcn.rs:407-412 / 86-89) */
+int  rcn_hip_standardize(rcn_hip_ctx* ctx, double* feats, size_t count);
+int  rcn_hip_standardize_dev(rcn_hip_ctx* ctx, void* feats_dev, size_t count);
+
+/* ---------------------------------------------------------------- dense network */
+/* train_batch (rcn.rs:176-223): per-sample backprop (rcn.rs:260-314) summed over the batch, then
+ * W <- W - (eta/B) sum dW, b <- b - (eta/B) sum db.  x: B x F, y: B x classes (one-hot in the reference,
+ * any target accepted), sample-major f64.  loss_out (nullable) receives the quadratic cost
+ * 1/(2B) sum ||a_L - y||^2 evaluated before the update (the reference never computes it). */
+int  rcn_hip_train_batch(rcn_hip_ctx* ctx, const double* x, const double* y, size_t B, double eta, double* loss_out);
+int  rcn_hip_train_batch_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t B, double eta,
+                             void* loss_dev /* nullable, 1 scalar of the ctx dtype */);
+/* The batch loop of RCN::train (rcn.rs:147-149): n_batches consecutive train_batch calls over the resident
+ * set X_dev (N x F), Y_dev (N x classes).  Batch j takes samples perm_dev[j*B .. (j+1)*B) (int32 indices
+ * into X/Y; NULL = identity, i.e. chunks_exact over the set as stored).  The caller shuffles
+ * (rcn.rs:146) by filling perm_dev.  loss_dev: nullable, n_batches scalars.  Launch-bound loop: captured
+ * once into a hipGraph per (pointers, B, n_batches, eta) and replayed. */
+int  rcn_hip_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
+                             size_t B, size_t n_batches, double eta, void* loss_dev);
+/* Data-parallel halves of train_batch: summed gradients of one shard into a flat buffer laid out like the
+ * parameters (no update), and the update from an (all-reduced) flat gradient: p <- p - scale * g. */
+int  rcn_hip_batch_gradient_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t B,
+                                void* grad_dev, void* loss_sum_dev /* nullable: sum ||a_L-y||^2, not normalised */);
+int  rcn_hip_apply_gradient_dev(rcn_hip_ctx* ctx, const void* grad_dev, double scale);
+/* classify_test (rcn.rs:105-116) for n samples: a <- sigmoid(W a + b) through every layer. out: n x classes */
+int  rcn_hip_forward(rcn_hip_ctx* ctx, const double* x, size_t n, double* out);
+int  rcn_hip_forward_dev(rcn_hip_ctx* ctx, const void* x_dev, size_t n, void* out_dev);
+/* arg-max of classify (rcn.rs:92-97): max_by(total_cmp) keeps the LAST maximal index */
+int  rcn_hip_classify(rcn_hip_ctx* ctx, const double* x, size_t n, int32_t* class_out);
+/* per-epoch evaluation of RCN::train (rcn.rs:152-157): counts samples whose one-hot(v == max) equals y */
+int  rcn_hip_evaluate(rcn_hip_ctx* ctx, const double* x, const double* y, size_t n, int64_t* accepted);
+int  rcn_hip_evaluate_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t n, int64_t* accepted); /* blocks */
+/* RCN::classify minus the PNG decode (rcn.rs:82-98): features -> standardise with scale_set -> forward -> arg-max */
+int  rcn_hip_classify_images(rcn_hip_ctx* ctx, const uint8_t* imgs, size_t n, int32_t* class_out);
+
+/* ---------------------------------------------------------------- measurement aid (bench.py's roofline leg) */
+/* Times the two kernels of one train_batch with HIP events on the context's stream: `reps` back-to-back launches of
+ * each kernel (one hipGraph of `reps` dependent nodes per kernel, so the host launch rate does not bound the result),
+ * events recorded immediately before and after each graph.  Returns the mean microseconds per launch, which therefore
+ * INCLUDES one dependent-launch boundary per launch.  us_wgrad times the gradient-only form (APPLY=false) so the
+ * parameters do not drift while timing.  Blocks. */
+int  rcn_hip_time_kernels_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t B, int reps,
+                              double* us_fwd, double* us_wgrad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCN_HIP_H */

@@ -1,0 +1,46 @@
+"""Builds librcn_hip.so (the C-ABI library of include/rcn_hip.h) for gfx950 with hipcc, in-tree.
+
+    python -m mercer_research_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librcn_hip.so")
+SOURCES = ["rcn_hip_api.hip"]
+DEPS = ["common.hpp", "dense.hpp", "features.hpp", "ops.hpp", os.path.join("..", "..", "include", "rcn_hip.h")]
+# -ffp-contract=off: the reference (rustc) never fuses a*b+c; the operator kernels reproduce its f64 rounding.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-result",
+         "-Wno-pass-failed"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

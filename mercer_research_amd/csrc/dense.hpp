@@ -1,0 +1,359 @@
+// dense.hpp -- gfx950 kernels for rcn's dense sigmoid/MSE network (rcn.rs:105-116, 176-314).
+//
+// The reference walks the batch sample by sample (gemv + outer product, rcn.rs:260-314) and sums the
+// per-sample gradients under a mutex (rcn.rs:190-205).  Here the batch is the N dimension of
+// 16x16x4 MFMA tiles (f32 or f64 inputs, exact fused-multiply-add chains in that type):
+//
+//   k_dense_fwd   one workgroup per 16-sample tile: streams the tile's feature rows through LDS,
+//                 Z = W.A + b and sigmoid for every layer, then (TRAIN) the output delta
+//                 (a_L - y) * s'(z_L) (rcn.rs:299) and the back-propagated deltas (rcn.rs:305-309).
+//                 K of every small GEMM is split over the 8 waves and combined through LDS in a
+//                 fixed order, so results are bit-reproducible run to run.
+//   k_dense_wgrad one workgroup per 16-column tile of [W_l | b_l]: dW = Delta . A^T with K = the
+//                 whole batch (the sum over samples of rcn.rs:190-205 is the MFMA contraction), the
+//                 bias gradient is the extra column whose A-value is the constant 1, and the SGD
+//                 update W <- W - (eta/B) dW (rcn.rs:210-222) is the epilogue.  With APPLY=false the
+//                 summed gradient is written out instead (data-parallel all-reduce path).
+#pragma once
+
+#include "common.hpp"
+
+namespace rcn {
+
+constexpr int kDenseThreads = 512;
+constexpr int kDenseWaves = kDenseThreads / kWave;     // 8: K-split factor
+constexpr int kMtp = 2;                                // M-tiles (16 rows each) accumulated per pass
+constexpr int kRedTile = kTileS * kLd;                 // 272: one padded 16x16 partial tile
+constexpr int kChunkK = 32;                            // features staged per wave per chunk
+
+// LDS elements (of T) k_dense_fwd needs
+inline size_t dense_fwd_lds_elems(const NetDesc& nd) {
+    int sumd = 0, maxd = 0;
+    for (int j = 1; j <= nd.L; ++j) { sumd += nd.dims[j]; if (nd.dims[j] > maxd) maxd = nd.dims[j]; }
+    return (size_t)kLd * (size_t)(sumd + 2 * maxd + kDenseWaves * kChunkK) + (size_t)kDenseWaves * kMtp * kRedTile + 64;
+}
+inline size_t dense_wgrad_lds_elems() { return (size_t)kDenseWaves * kMtp * kRedTile + 64; }
+
+// wave w's slice [kb, ke) of a K-long contraction, 4-aligned so MFMA k-steps never straddle slices
+__device__ inline void wave_k_range(int K, int wave, int& kb, int& ke) {
+    const int kw = (((K + kDenseWaves - 1) / kDenseWaves) + 3) & ~3;
+    kb = wave * kw;
+    ke = kb + kw < K ? kb + kw : K;
+    if (kb > K) kb = K;
+}
+
+// Partial accumulators -> LDS as [col][row] padded tiles (col = MFMA N index = lane&15).
+template <typename T>
+__device__ inline void store_partials(T* red, int wave, int lane, const typename Mfma16<T>::acc_t (&acc)[kMtp]) {
+#pragma unroll
+    for (int mt = 0; mt < kMtp; ++mt) {
+        T* t = red + (wave * kMtp + mt) * kRedTile + (lane & 15) * kLd;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[Mfma16<T>::row(lane, i)] = acc[mt][i];
+    }
+}
+
+// Sum of the 8 waves' partials for element (col c, row r) of M-tile mt, fixed order w = 0..7.
+template <typename T>
+__device__ inline T sum_partials(const T* red, int mt, int c, int r) {
+    T v = red[(0 * kMtp + mt) * kRedTile + c * kLd + r];
+#pragma unroll
+    for (int w = 1; w < kDenseWaves; ++w) v += red[(w * kMtp + mt) * kRedTile + c * kLd + r];
+    return v;
+}
+
+template <typename T, bool TRAIN>
+__global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
+    NetDesc nd, const T* __restrict__ params, const T* __restrict__ X, const T* __restrict__ Y,
+    const int* __restrict__ idx, int B, T* __restrict__ acts, T* __restrict__ deltas,
+    T* __restrict__ loss_part, T* __restrict__ out) {
+    using acc_t = typename Mfma16<T>::acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int L = nd.L;
+    const int s0 = blockIdx.x * kTileS;
+    int sumd = 0, maxd = 0;
+    for (int j = 1; j <= L; ++j) { sumd += nd.dims[j]; maxd = nd.dims[j] > maxd ? nd.dims[j] : maxd; }
+
+    // LDS carve (all in units of T)
+    T* actT = smem;                                   // a_j tiles, j = 1..L : [d_j][kLd] at kLd*act_off[j]
+    T* dT0 = actT + kLd * sumd;                       // delta ping
+    T* dT1 = dT0 + kLd * maxd;                        // delta pong
+    T* xs = dT1 + kLd * maxd;                         // per-wave staging [kChunkK][kLd]
+    T* red = xs + kDenseWaves * kChunkK * kLd;        // [wave][mt][16][kLd]
+    long long* rowoff = reinterpret_cast<long long*>(red + kDenseWaves * kMtp * kRedTile);  // 16 row bases (elements)
+    T* lossred = reinterpret_cast<T*>(rowoff + kTileS);                                        // kDenseWaves scalars
+
+    if (tid < kTileS) {
+        const int gs = s0 + tid;
+        long long r = -1;
+        if (gs < B) r = idx ? (long long)idx[gs] : (long long)gs;
+        rowoff[tid] = r;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ forward (rcn.rs:281-291 / 105-116)
+    for (int j = 0; j < L; ++j) {
+        const int K = nd.dims[j], M = nd.dims[j + 1];
+        const T* __restrict__ Wj = params + nd.w_off[j];
+        const T* __restrict__ bj = Wj + (size_t)M * K;
+        const T* aPrev = actT + kLd * nd.act_off[j];          // valid for j >= 1
+        T* aNext = actT + kLd * nd.act_off[j + 1];
+        int kb, ke;
+        wave_k_range(K, wave, kb, ke);
+        for (int mbase = 0; mbase < M; mbase += 16 * kMtp) {
+            acc_t acc[kMtp];
+#pragma unroll
+            for (int mt = 0; mt < kMtp; ++mt) acc[mt] = acc_t{0, 0, 0, 0};
+            if (j == 0) {
+                // stream this wave's K-slice of the 16 feature rows through a private LDS chunk
+                T* xw = xs + wave * kChunkK * kLd;
+                const int kl = lane & 31, sh = lane >> 5;
+                for (int kc = kb; kc < ke; kc += kChunkK) {
+                    T v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const long long r = rowoff[2 * q + sh];
+                        const int k = kc + kl;
+                        v[q] = (r >= 0 && k < ke) ? X[r * (long long)K + k] : (T)0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xw[kl * kLd + 2 * q + sh] = v[q];
+                    const int rem = ke - kc;
+                    const int nks = ((rem < kChunkK ? rem : kChunkK) + 3) >> 2;
+                    for (int ks = 0; ks < nks; ++ks) {
+                        const int k = kc + 4 * ks + g;
+                        const T bv = xw[(4 * ks + g) * kLd + n];
+#pragma unroll
+                        for (int mt = 0; mt < kMtp; ++mt) {
+                            const int row = mbase + mt * 16 + n;
+                            const T av = (row < M && k < ke) ? Wj[(size_t)k * M + row] : (T)0;
+                            acc[mt] = Mfma16<T>::mfma(av, bv, acc[mt]);
+                        }
+                    }
+                }
+            } else {
+                for (int k0 = kb; k0 < ke; k0 += 4) {
+                    const int k = k0 + g;
+                    const T bv = (k < ke) ? aPrev[k * kLd + n] : (T)0;
+#pragma unroll
+                    for (int mt = 0; mt < kMtp; ++mt) {
+                        const int row = mbase + mt * 16 + n;
+                        const T av = (row < M && k < ke) ? Wj[(size_t)k * M + row] : (T)0;
+                        acc[mt] = Mfma16<T>::mfma(av, bv, acc[mt]);
+                    }
+                }
+            }
+            store_partials<T>(red, wave, lane, acc);
+            __syncthreads();
+            {
+                const int mt = tid >> 8, o = tid & 255, s = o >> 4, ml = o & 15;
+                const int m = mbase + mt * 16 + ml;
+                if (m < M) {
+                    const T z = sum_partials<T>(red, mt, s, ml) + bj[m];     // z = W.a + b   rcn.rs:287
+                    const T a = sigmoid_ref(z);                               //               rcn.rs:289
+                    aNext[m * kLd + s] = a;
+                    const int gs = s0 + s;
+                    if (gs < B) {
+                        if (TRAIN && j + 1 < L) acts[(size_t)B * nd.act_off[j + 1] + (size_t)gs * M + m] = a;
+                        if (!TRAIN && j + 1 == L) out[(size_t)gs * M + m] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!TRAIN) return;
+
+    // ------------------------------------------------------------------ output delta (rcn.rs:299)
+    {
+        const int M = nd.dims[L];
+        const T* aL = actT + kLd * nd.act_off[L];
+        T lsum = 0;
+        for (int e = tid; e < kTileS * M; e += kDenseThreads) {
+            const int s = e / M, m = e - s * M;
+            const long long r = rowoff[s];
+            T d = 0;
+            if (r >= 0) {
+                const T a = aL[m * kLd + s];
+                const T diff = a - Y[r * (long long)M + m];
+                d = diff * (a * ((T)1 - a));                 // (a_L - y) (*) sigmoid'(z_L), sigmoid' = s(1-s)  rcn.rs:491
+                deltas[(size_t)B * nd.act_off[L] + (size_t)(s0 + s) * M + m] = d;
+                lsum += diff * diff;
+            }
+            dT0[m * kLd + s] = d;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+        if (lane == 0) lossred[wave] = lsum;
+    }
+    __syncthreads();
+    if (tid == 0 && loss_part) {
+        T t = lossred[0];
+        for (int w = 1; w < kDenseWaves; ++w) t += lossred[w];
+        loss_part[blockIdx.x] = t;
+    }
+
+    // ------------------------------------------------------------------ hidden deltas (rcn.rs:305-309)
+    T* dCur = dT0;
+    T* dNxt = dT1;
+    for (int j = L - 1; j >= 1; --j) {
+        const int M = nd.dims[j], K = nd.dims[j + 1];          // delta_j = (W_j^T delta_{j+1}) (*) s'(z_j)
+        const T* __restrict__ Wj = params + nd.w_off[j];        // K x M column-major: (k, m) at m*K + k
+        const T* aJ = actT + kLd * nd.act_off[j];
+        int kb, ke;
+        wave_k_range(K, wave, kb, ke);
+        for (int mbase = 0; mbase < M; mbase += 16 * kMtp) {
+            acc_t acc[kMtp];
+#pragma unroll
+            for (int mt = 0; mt < kMtp; ++mt) acc[mt] = acc_t{0, 0, 0, 0};
+            for (int k0 = kb; k0 < ke; k0 += 4) {
+                const int k = k0 + g;
+                const T bv = (k < ke) ? dCur[k * kLd + n] : (T)0;
+#pragma unroll
+                for (int mt = 0; mt < kMtp; ++mt) {
+                    const int row = mbase + mt * 16 + n;
+                    const T av = (row < M && k < ke) ? Wj[(size_t)row * K + k] : (T)0;
+                    acc[mt] = Mfma16<T>::mfma(av, bv, acc[mt]);
+                }
+            }
+            store_partials<T>(red, wave, lane, acc);
+            __syncthreads();
+            {
+                const int mt = tid >> 8, o = tid & 255, s = o >> 4, ml = o & 15;
+                const int m = mbase + mt * 16 + ml;
+                if (m < M) {
+                    const T a = aJ[m * kLd + s];
+                    const int gs = s0 + s;
+                    T d = 0;
+                    if (gs < B) {
+                        d = sum_partials<T>(red, mt, s, ml) * (a * ((T)1 - a));
+                        deltas[(size_t)B * nd.act_off[j] + (size_t)gs * M + m] = d;
+                    }
+                    dNxt[m * kLd + s] = d;
+                }
+            }
+            __syncthreads();
+        }
+        T* t = dCur; dCur = dNxt; dNxt = t;
+    }
+}
+
+// grid = nd.tile_start[L] workgroups; workgroup -> (layer j, 16 columns of [W_j | b_j])
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(kDenseThreads) void k_dense_wgrad(
+    NetDesc nd, T* __restrict__ params, T* __restrict__ grad_out, const T* __restrict__ X,
+    const int* __restrict__ idx, const T* __restrict__ acts, const T* __restrict__ deltas, int B, T scale,
+    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out) {
+    using acc_t = typename Mfma16<T>::acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    int j = 0;
+    while (j + 1 < nd.L && (int)blockIdx.x >= nd.tile_start[j + 1]) ++j;
+    const int n0 = ((int)blockIdx.x - nd.tile_start[j]) * 16;
+    const int Kin = nd.dims[j], M = nd.dims[j + 1];
+    const T* __restrict__ D = deltas + (size_t)B * nd.act_off[j + 1];          // delta_{j+1}: [B][M]
+    const T* __restrict__ Aprev = (j == 0) ? X : acts + (size_t)B * nd.act_off[j];  // a_j: [B][Kin]
+    const int c = n0 + n;                                                        // this lane's column of [W|b]
+
+    // quadratic cost 1/(2B) sum ||a_L - y||^2 (what rcn.rs:299 is the gradient of); fixed-order sum
+    if (blockIdx.x == 0 && tid == 0 && loss_out) {
+        T t = 0;
+        for (int i = 0; i < n_loss; ++i) t += loss_part[i];
+        *loss_out = t * loss_scale;
+    }
+
+    int kb, ke;
+    wave_k_range(B, wave, kb, ke);
+    for (int mbase = 0; mbase < M; mbase += 16 * kMtp) {
+        acc_t acc[kMtp];
+#pragma unroll
+        for (int mt = 0; mt < kMtp; ++mt) acc[mt] = acc_t{0, 0, 0, 0};
+#pragma unroll 4
+        for (int k0 = kb; k0 < ke; k0 += 4) {
+            const int s = k0 + g;                              // contraction index = sample
+            T bv = 0;
+            if (s < ke) {
+                if (c < Kin) {
+                    const long long r = (j == 0 && idx) ? (long long)idx[s] : (long long)s;
+                    bv = Aprev[r * (long long)Kin + c];
+                } else if (c == Kin) {
+                    bv = (T)1;                                 // bias column: db = sum_s delta  (rcn.rs:302,309)
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < kMtp; ++mt) {
+                const int row = mbase + mt * 16 + n;
+                const T av = (row < M && s < ke) ? D[(size_t)s * M + row] : (T)0;
+                acc[mt] = Mfma16<T>::mfma(av, bv, acc[mt]);
+            }
+        }
+        store_partials<T>(red, wave, lane, acc);
+        __syncthreads();
+        {
+            const int mt = tid >> 8, o = tid & 255, cl = o >> 4, ml = o & 15;
+            const int m = mbase + mt * 16 + ml, cc = n0 + cl;
+            if (m < M && cc <= Kin) {
+                const T gsum = sum_partials<T>(red, mt, cl, ml);
+                const size_t p = (size_t)nd.w_off[j] + (size_t)cc * M + m;
+                if (APPLY) params[p] = params[p] - scale * gsum;                // rcn.rs:214,221
+                else grad_out[p] = gsum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// p <- p - scale * g  (the update half of train_batch when gradients were all-reduced first)
+template <typename T>
+__global__ void k_apply_gradient(T* __restrict__ p, const T* __restrict__ gsrc, T scale, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = p[i] - scale * gsrc[i];
+}
+
+// fixed-order sum of per-tile loss partials
+template <typename T>
+__global__ void k_sum_loss(const T* __restrict__ part, int n, T scale, T* __restrict__ out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        T t = 0;
+        for (int i = 0; i < n; ++i) t += part[i];
+        *out = t * scale;
+    }
+}
+
+// rcn.rs:152-157: accept iff one-hot(v == max) equals the expectation vector
+template <typename T>
+__global__ void k_eval_accept(const T* __restrict__ outv, const T* __restrict__ y, int n, int C, unsigned long long* count) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    int ok = 0;
+    if (s < n) {
+        const T* o = outv + (size_t)s * C;
+        const T* e = y + (size_t)s * C;
+        T mx = o[0];
+        for (int i = 1; i < C; ++i) mx = o[i] > mx ? o[i] : mx;
+        ok = 1;
+        for (int i = 0; i < C; ++i) {
+            const T oh = (o[i] == mx) ? (T)1 : (T)0;
+            if (oh != e[i]) ok = 0;
+        }
+    }
+    const unsigned long long b = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
+}
+
+// rcn.rs:92-97: max_by(total_cmp) -> index of the LAST maximal element
+template <typename T>
+__global__ void k_argmax_last(const T* __restrict__ outv, int n, int C, int* __restrict__ cls) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const T* o = outv + (size_t)s * C;
+    int best = 0;
+    for (int i = 1; i < C; ++i)
+        if (!(o[i] < o[best])) best = i;
+    cls[s] = best;
+}
+
+}  // namespace rcn

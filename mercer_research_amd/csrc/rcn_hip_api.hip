@@ -1,0 +1,965 @@
+// rcn_hip_api.hip -- the C ABI of include/rcn_hip.h on top of the gfx950 kernels.
+// Host logic here mirrors the bookkeeping of RCN::{new, load_weights_and_bias, train_batch, classify}
+// (rcn/src/rcn.rs); all arithmetic on sample data happens in the HIP kernels -- there is no CPU fallback.
+#include "../../include/rcn_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <random>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "common.hpp"
+#include "dense.hpp"
+#include "features.hpp"
+#include "ops.hpp"
+
+using namespace rcn;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct EpochKey {
+    const void* X; const void* Y; const void* perm; size_t B; size_t nb; double eta; const void* loss;
+    bool operator<(const EpochKey& o) const {
+        return std::tie(X, Y, perm, B, nb, eta, loss) < std::tie(o.X, o.Y, o.perm, o.B, o.nb, o.eta, o.loss);
+    }
+};
+
+}  // namespace
+
+struct rcn_hip_ctx {
+    int device = 0;
+    int dtype = RCN_HIP_F32;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    FeatDesc fd{};
+    NetDesc nd{};
+    int n_conv = 0;
+    bool params_set = false;
+    std::string dense_err;                  // non-empty: every dense call panics in the reference (see rcn_hip_create)
+    double mean = 1.0, sd = 1.0;            // scale_set initial value (1,1): rcn.rs:71
+    DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
+    std::map<EpochKey, hipGraphExec_t> graphs;
+    std::map<const void*, size_t> lds_attr;   // kernels whose dynamic-LDS limit was already raised
+    std::string err;
+    size_t esz() const { return dtype == RCN_HIP_F64 ? 8 : 4; }
+};
+
+namespace {
+
+int fail(rcn_hip_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RCN_HIP_ERR_OOM : RCN_HIP_ERR_HIP,                  \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                  \
+    } while (0)
+
+#define RCN_TRY(expr)                      \
+    do {                                   \
+        int s_ = (expr);                   \
+        if (s_ != RCN_HIP_OK) return s_;   \
+    } while (0)
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// ---- shape logic shared by the operator API and the feature-stack validation --------------------------------
+int conv_shape(int R, int C, int kr, int kc, int padding, int* oR, int* oC) {
+    if (padding != RCN_HIP_PAD_NONE && padding != RCN_HIP_PAD_SAME) return RCN_HIP_ERR_INVALID_ARG;
+    if (kr <= 0 || kc <= 0 || kr > R || kc > C) return RCN_HIP_ERR_SHAPE;          // kernel.rs:123-128
+    if (padding == RCN_HIP_PAD_SAME) {
+        if (kr % 2 == 0 || kc % 2 == 0) return RCN_HIP_ERR_SHAPE;                  // kernel.rs:131-135
+        // the pad-copy loop (kernel.rs:154-158) reads self[(cy-1, cx-1)] up to cy = R+kr/2-1, cx = C+kc/2-1:
+        // out of bounds (a panic) as soon as a half-width reaches 2
+        const int cy_hi = R + kr / 2 - 1, cx_hi = C + kc / 2 - 1;
+        if (cy_hi >= 1 && cx_hi >= 1 && (cy_hi - 1 >= R || cx_hi - 1 >= C)) return RCN_HIP_ERR_SHAPE;
+        *oR = R; *oC = C;
+    } else {
+        *oR = R - kr + 1; *oC = C - kc + 1;
+    }
+    return RCN_HIP_OK;
+}
+
+int pool_shape(int R, int C, int padding, int* oR, int* oC) {
+    if (padding != RCN_HIP_PAD_NONE && padding != RCN_HIP_PAD_SAME) return RCN_HIP_ERR_INVALID_ARG;
+    if (R < 2 || C < 2) return RCN_HIP_ERR_SHAPE;                                  // kernel.rs:246-251
+    if (padding == RCN_HIP_PAD_SAME) { *oR = (R + 1) / 2; *oC = (C + 1) / 2; }
+    else { *oR = R / 2; *oC = C / 2; }
+    return RCN_HIP_OK;
+}
+
+int build_feat_desc(rcn_hip_ctx* c, const rcn_hip_cfg* cfg) {
+    FeatDesc& fd = c->fd;
+    fd.H = cfg->in_h; fd.W = cfg->in_w; fd.n = cfg->n_convpool;
+    long maps = 0;
+    int R = fd.H, C = fd.W;
+    long max_elems = (long)R * C;
+    c->n_conv = 0;
+    for (int i = 0; i < fd.n; ++i) {
+        const int kind = cfg->convpool[i].kind, arg = cfg->convpool[i].arg;
+        fd.kind[i] = kind; fd.arg[i] = arg;
+        if (kind == RCN_HIP_LAYER_CONVOLVE2D) {
+            if (arg != RCN_HIP_PAD_NONE && arg != RCN_HIP_PAD_SAME) return fail(c, RCN_HIP_ERR_INVALID_ARG, "Convolve2D: bad Padding");
+            if (R < 3 || C < 3)                                                      // kernel.rs:199-201
+                return fail(c, RCN_HIP_ERR_SHAPE, "convolve_2d_separated expects a matrix of at least 3x3");
+            if (arg == RCN_HIP_PAD_NONE) { R -= 2; C -= 2; }
+            maps = maps ? maps * 4 : 4;
+            ++c->n_conv;
+        } else if (kind == RCN_HIP_LAYER_POOL2D) {
+            if (arg != RCN_HIP_POOL_AVERAGE && arg != RCN_HIP_POOL_MAX) return fail(c, RCN_HIP_ERR_INVALID_ARG, "Pool2D: bad Pooling");
+            if (maps == 0) continue;                                                 // rcn.rs:343 on an empty feature_set
+            if (R < 2 || C < 2) return fail(c, RCN_HIP_ERR_SHAPE, "pool_2d expects a matrix of at least 2x2");
+            if (arg != RCN_HIP_POOL_MAX) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "Pooling::Average: Not implemented (kernel.rs:283)");
+            R = (R + 1) / 2; C = (C + 1) / 2;
+        } else {
+            return fail(c, RCN_HIP_ERR_INVALID_ARG, "unknown RCNLayer kind");
+        }
+        if (maps * R * C > max_elems) max_elems = maps * R * C;
+    }
+    if (maps * (long)R * C > 0x7fffffffL) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "feature vector too long");
+    fd.F = (int)(maps * R * C);
+    fd.max_elems = (int)max_elems;
+    return RCN_HIP_OK;
+}
+
+// load_weights_and_bias's fan-in: usize::pow(4,c) / usize::pow(2,p) * l with p += 2 per pool layer (rcn.rs:429-443)
+long first_layer_fan_in(const rcn_hip_cfg* cfg, long l) {
+    unsigned cc = 0, pp = 0;
+    for (int i = 0; i < cfg->n_convpool; ++i) {
+        if (cfg->convpool[i].kind == RCN_HIP_LAYER_CONVOLVE2D) cc += 1; else pp += 2;
+    }
+    unsigned long long num = 1, den = 1;
+    for (unsigned i = 0; i < cc; ++i) num *= 4ULL;
+    for (unsigned i = 0; i < pp; ++i) den *= 2ULL;
+    return (long)(num / den * (unsigned long long)l);
+}
+
+int build_net_desc(rcn_hip_ctx* c, const rcn_hip_cfg* cfg) {
+    NetDesc& nd = c->nd;
+    nd.L = cfg->n_hidden + 1;                                                        // rcn.rs:426
+    nd.dims[0] = c->fd.F;
+    for (int i = 0; i < cfg->n_hidden; ++i) nd.dims[i + 1] = cfg->hidden[i];
+    nd.dims[nd.L] = cfg->classes;
+    long off = 0;
+    nd.act_off[0] = 0; nd.act_off[1] = 0;
+    nd.tile_start[0] = 0;
+    for (int j = 0; j < nd.L; ++j) {
+        if (nd.dims[j] <= 0 || nd.dims[j + 1] <= 0) return fail(c, RCN_HIP_ERR_SHAPE, "every dense layer needs at least one input and one output");
+        nd.w_off[j] = (int)off;
+        off += (long)nd.dims[j] * nd.dims[j + 1] + nd.dims[j + 1];
+        if (off > 0x7fffffffL) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "more than 2^31 parameters");
+        if (j + 1 <= nd.L && j + 2 <= kMaxLayers) nd.act_off[j + 2] = nd.act_off[j + 1] + nd.dims[j + 1];
+        nd.tile_start[j + 1] = nd.tile_start[j] + (nd.dims[j] + 1 + 15) / 16;
+    }
+    nd.P = (int)off;
+    return RCN_HIP_OK;
+}
+
+int sum_hidden_dims(const NetDesc& nd) { int s = 0; for (int j = 1; j <= nd.L; ++j) s += nd.dims[j]; return s; }
+
+// ---- host <-> device dtype conversion ------------------------------------------------------------------------
+int upload(rcn_hip_ctx* c, DevBuf& buf, const double* src, size_t count) {
+    HIP_TRY(c, buf.ensure(count * c->esz()));
+    if (count == 0) return RCN_HIP_OK;
+    if (c->dtype == RCN_HIP_F64) {
+        HIP_TRY(c, hipMemcpyAsync(buf.p, src, count * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+        std::vector<float> tmp(count);
+        for (size_t i = 0; i < count; ++i) tmp[i] = (float)src[i];
+        HIP_TRY(c, hipMemcpyAsync(buf.p, tmp.data(), count * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return RCN_HIP_OK;
+}
+
+int download(rcn_hip_ctx* c, const void* dev, double* dst, size_t count) {
+    if (count == 0) return RCN_HIP_OK;
+    if (c->dtype == RCN_HIP_F64) {
+        HIP_TRY(c, hipMemcpyAsync(dst, dev, count * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+        std::vector<float> tmp(count);
+        HIP_TRY(c, hipMemcpyAsync(tmp.data(), dev, count * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < count; ++i) dst[i] = (double)tmp[i];
+    }
+    return RCN_HIP_OK;
+}
+
+template <typename K>
+int set_dyn_lds(rcn_hip_ctx* c, K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "layer sizes need more than 160 KiB of LDS per workgroup");
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    if (bytes > 64 * 1024 && c->lds_attr[fn] < bytes) {
+        HIP_TRY(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        c->lds_attr[fn] = bytes;
+    }
+    return RCN_HIP_OK;
+}
+
+// ---- dense launches ---------------------------------------------------------------------------------------------
+int ensure_dense_ws(rcn_hip_ctx* c, size_t B) {
+    const size_t sd = (size_t)sum_hidden_dims(c->nd);
+    HIP_TRY(c, c->acts.ensure(B * sd * c->esz()));
+    HIP_TRY(c, c->deltas.ensure(B * sd * c->esz()));
+    HIP_TRY(c, c->loss_part.ensure(((B + kTileS - 1) / kTileS) * c->esz()));
+    return RCN_HIP_OK;
+}
+
+template <typename T>
+int launch_fwd(rcn_hip_ctx* c, bool train, const void* x, const void* y, const int32_t* idx, size_t B, void* out) {
+    const NetDesc& nd = c->nd;
+    const int tiles = (int)((B + kTileS - 1) / kTileS);
+    const size_t lds = dense_fwd_lds_elems(nd) * sizeof(T);
+    if (train) {
+        RCN_TRY(set_dyn_lds(c, k_dense_fwd<T, true>, lds));
+        hipLaunchKernelGGL((k_dense_fwd<T, true>), dim3(tiles), dim3(kDenseThreads), lds, c->stream, nd, (const T*)c->params.p,
+                           (const T*)x, (const T*)y, idx, (int)B, (T*)c->acts.p, (T*)c->deltas.p, (T*)c->loss_part.p, (T*)nullptr);
+    } else {
+        RCN_TRY(set_dyn_lds(c, k_dense_fwd<T, false>, lds));
+        hipLaunchKernelGGL((k_dense_fwd<T, false>), dim3(tiles), dim3(kDenseThreads), lds, c->stream, nd, (const T*)c->params.p,
+                           (const T*)x, (const T*)nullptr, idx, (int)B, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)out);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+template <typename T>
+int launch_wgrad(rcn_hip_ctx* c, bool apply, const void* x, const int32_t* idx, size_t B, double scale, void* grad_out,
+                 void* loss_out, double loss_scale) {
+    const NetDesc& nd = c->nd;
+    const int grid = nd.tile_start[nd.L];
+    const size_t lds = dense_wgrad_lds_elems() * sizeof(T);
+    const int tiles = (int)((B + kTileS - 1) / kTileS);
+    if (apply) {
+        hipLaunchKernelGGL((k_dense_wgrad<T, true>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (T*)nullptr,
+                           (const T*)x, idx, (const T*)c->acts.p, (const T*)c->deltas.p, (int)B, (T)scale, (const T*)c->loss_part.p,
+                           tiles, (T)loss_scale, (T*)loss_out);
+    } else {
+        hipLaunchKernelGGL((k_dense_wgrad<T, false>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (T*)grad_out,
+                           (const T*)x, idx, (const T*)c->acts.p, (const T*)c->deltas.p, (int)B, (T)scale, (const T*)c->loss_part.p,
+                           tiles, (T)loss_scale, (T*)loss_out);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+// one train_batch (rcn.rs:176-223) on device-resident data; idx selects the batch's rows (or NULL)
+int enqueue_train_step(rcn_hip_ctx* c, const void* x, const void* y, const int32_t* idx, size_t B, double eta, void* loss_dev) {
+    const double scale = eta / (double)B;                       // rcn.rs:214: eta / batch.len() as f64
+    const double loss_scale = 1.0 / (2.0 * (double)B);
+    if (c->dtype == RCN_HIP_F64) {
+        RCN_TRY(launch_fwd<double>(c, true, x, y, idx, B, nullptr));
+        RCN_TRY(launch_wgrad<double>(c, true, x, idx, B, scale, nullptr, loss_dev, loss_scale));
+    } else {
+        RCN_TRY(launch_fwd<float>(c, true, x, y, idx, B, nullptr));
+        RCN_TRY(launch_wgrad<float>(c, true, x, idx, B, scale, nullptr, loss_dev, loss_scale));
+    }
+    return RCN_HIP_OK;
+}
+
+int check_ctx(const rcn_hip_ctx* c) { return c ? RCN_HIP_OK : RCN_HIP_ERR_INVALID_ARG; }
+
+int need_dense(rcn_hip_ctx* c) {
+    if (!c->dense_err.empty()) return fail(c, RCN_HIP_ERR_SHAPE, c->dense_err);
+    return RCN_HIP_OK;
+}
+
+int need_params(rcn_hip_ctx* c) {
+    RCN_TRY(need_dense(c));
+    if (!c->params_set) return fail(c, RCN_HIP_ERR_STATE, "parameters not set: call rcn_hip_set_params for every layer or rcn_hip_init_params first");
+    return RCN_HIP_OK;
+}
+
+void drop_graphs(rcn_hip_ctx* c) {
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+int rcn_hip_abi_version(void) { return RCN_HIP_ABI_VERSION; }
+
+const char* rcn_hip_status_string(int s) {
+    switch (s) {
+    case RCN_HIP_OK: return "ok";
+    case RCN_HIP_ERR_INVALID_ARG: return "invalid argument";
+    case RCN_HIP_ERR_SHAPE: return "shape error (the reference panics here)";
+    case RCN_HIP_ERR_UNSUPPORTED: return "unsupported (not implemented in the reference, or over a size limit)";
+    case RCN_HIP_ERR_HIP: return "HIP runtime error";
+    case RCN_HIP_ERR_NO_DEVICE: return "no usable HIP device";
+    case RCN_HIP_ERR_STATE: return "call-order error";
+    case RCN_HIP_ERR_OOM: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+int rcn_hip_create(const rcn_hip_cfg* cfg, rcn_hip_ctx** out) {
+    if (!cfg || !out) return RCN_HIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(rcn_hip_cfg)) return RCN_HIP_ERR_INVALID_ARG;
+    if (cfg->dtype != RCN_HIP_F32 && cfg->dtype != RCN_HIP_F64) return RCN_HIP_ERR_INVALID_ARG;
+    if (cfg->n_convpool < 0 || cfg->n_convpool > kMaxConvPool || (cfg->n_convpool > 0 && !cfg->convpool)) return RCN_HIP_ERR_INVALID_ARG;
+    if (cfg->n_hidden < 1 || cfg->n_hidden + 1 > kMaxLayers || !cfg->hidden) return RCN_HIP_ERR_INVALID_ARG;   // rcn.rs:444 indexes feedforward_cfg[0]
+    if (cfg->classes < 1 || cfg->in_h < 1 || cfg->in_w < 1) return RCN_HIP_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return RCN_HIP_ERR_NO_DEVICE;
+
+    rcn_hip_ctx* c = new (std::nothrow) rcn_hip_ctx();
+    if (!c) return RCN_HIP_ERR_OOM;
+    *out = c;                                   // handed back even on failure so the caller can read last_error
+    c->device = cfg->device;
+    c->dtype = cfg->dtype;
+    RCN_TRY(build_feat_desc(c, cfg));
+    // RCN::new itself never fails; a stack whose dense part cannot run in the reference is remembered and
+    // reported by the dense entry points (the reference panics inside train, not inside new).
+    const long fan = first_layer_fan_in(cfg, c->fd.F);
+    if (c->fd.F <= 0)
+        c->dense_err = "the conv/pool stack yields an empty feature vector (no Convolve2D layer)";
+    else if (fan != c->fd.F)
+        c->dense_err = "first-layer fan-in 4^c/2^p*l (rcn.rs:443) = " + std::to_string(fan) + " differs from the flattened feature length " +
+                       std::to_string(c->fd.F) + ": the reference panics in gemv (rcn.rs:287)";
+    if (c->fd.F <= 0) c->fd.F = 0;
+    {
+        const int savedF = c->fd.F;
+        if (savedF == 0) c->fd.F = 1;           // keep the dense bookkeeping well-formed; dense calls are refused anyway
+        const int st = build_net_desc(c, cfg);
+        c->fd.F = savedF;
+        if (st != RCN_HIP_OK) return st;
+    }
+    DevGuard g(c->device);
+    if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+    else { HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIP_TRY(c, c->params.ensure((size_t)c->nd.P * c->esz()));
+    HIP_TRY(c, hipMemsetAsync(c->params.p, 0, (size_t)c->nd.P * c->esz(), c->stream));
+    // LDS feasibility of the dense kernels for these layer sizes
+    if (dense_fwd_lds_elems(c->nd) * c->esz() > 160 * 1024)
+        return fail(c, RCN_HIP_ERR_UNSUPPORTED, "hidden layer sizes need more than 160 KiB of LDS per workgroup");
+    const size_t feat_lds = 2 * (size_t)c->fd.max_elems * (c->n_conv <= 5 ? 4 : 8);
+    if (feat_lds > 160 * 1024)
+        return fail(c, RCN_HIP_ERR_UNSUPPORTED, "image/feature maps need more than 160 KiB of LDS per workgroup (fused feature kernel)");
+    return RCN_HIP_OK;
+}
+
+void rcn_hip_destroy(rcn_hip_ctx* c) {
+    if (!c) return;
+    {
+        DevGuard g(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        drop_graphs(c);
+        for (DevBuf* b : {&c->params, &c->acts, &c->deltas, &c->loss_part, &c->grad, &c->xstage, &c->ystage, &c->ostage, &c->scratch0,
+                          &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
+            b->release();
+        if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+const char* rcn_hip_last_error(const rcn_hip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rcn_hip_set_stream(rcn_hip_ctx* c, void* s) {
+    RCN_TRY(check_ctx(c));
+    DevGuard g(c->device);
+    drop_graphs(c);
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
+    else { HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_synchronize(rcn_hip_ctx* c) {
+    RCN_TRY(check_ctx(c));
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_feature_len(const rcn_hip_ctx* c, int64_t* out) {
+    if (!c || !out) return RCN_HIP_ERR_INVALID_ARG;
+    *out = c->fd.F;
+    return RCN_HIP_OK;
+}
+int rcn_hip_num_layers(const rcn_hip_ctx* c) { return c ? c->nd.L : RCN_HIP_ERR_INVALID_ARG; }
+int rcn_hip_layer_dims(const rcn_hip_ctx* c, int layer, int32_t* rows, int32_t* cols) {
+    if (!c || !rows || !cols || layer < 0 || layer >= c->nd.L) return RCN_HIP_ERR_INVALID_ARG;
+    *rows = c->nd.dims[layer + 1]; *cols = c->nd.dims[layer];
+    return RCN_HIP_OK;
+}
+int rcn_hip_param_count(const rcn_hip_ctx* c, int64_t* out) {
+    if (!c || !out) return RCN_HIP_ERR_INVALID_ARG;
+    *out = c->nd.P;
+    return RCN_HIP_OK;
+}
+
+// ---------------------------------------------------------------- parameters
+int rcn_hip_set_params(rcn_hip_ctx* c, int layer, const double* W, const double* b) {
+    RCN_TRY(check_ctx(c));
+    RCN_TRY(need_dense(c));
+    if (!W || !b || layer < 0 || layer >= c->nd.L) return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_params: bad layer or NULL pointer");
+    DevGuard g(c->device);
+    const size_t rows = c->nd.dims[layer + 1], cols = c->nd.dims[layer];
+    std::vector<double> flat(rows * cols + rows);
+    std::memcpy(flat.data(), W, rows * cols * 8);
+    std::memcpy(flat.data() + rows * cols, b, rows * 8);
+    DevBuf tmp;
+    int st = upload(c, tmp, flat.data(), flat.size());
+    if (st == RCN_HIP_OK) {
+        hipError_t e = hipMemcpyAsync((char*)c->params.p + (size_t)c->nd.w_off[layer] * c->esz(), tmp.p, flat.size() * c->esz(),
+                                      hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = fail(c, RCN_HIP_ERR_HIP, hipGetErrorString(e));
+    }
+    tmp.release();
+    if (st == RCN_HIP_OK) c->params_set = true;
+    return st;
+}
+
+int rcn_hip_get_params(rcn_hip_ctx* c, int layer, double* W, double* b) {
+    RCN_TRY(check_ctx(c));
+    if (!W || !b || layer < 0 || layer >= c->nd.L) return fail(c, RCN_HIP_ERR_INVALID_ARG, "get_params: bad layer or NULL pointer");
+    DevGuard g(c->device);
+    const size_t rows = c->nd.dims[layer + 1], cols = c->nd.dims[layer];
+    std::vector<double> flat(rows * cols + rows);
+    RCN_TRY(download(c, (char*)c->params.p + (size_t)c->nd.w_off[layer] * c->esz(), flat.data(), flat.size()));
+    std::memcpy(W, flat.data(), rows * cols * 8);
+    std::memcpy(b, flat.data() + rows * cols, rows * 8);
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_init_params(rcn_hip_ctx* c, uint64_t seed) {
+    RCN_TRY(check_ctx(c));
+    RCN_TRY(need_dense(c));
+    // get_weight_matrix / get_bias_vector: StandardNormal samples, column-major fill order (rcn.rs:500-523)
+    std::mt19937_64 gen(seed ? seed : std::random_device{}());
+    std::normal_distribution<double> nrm(0.0, 1.0);
+    for (int l = 0; l < c->nd.L; ++l) {
+        const size_t rows = c->nd.dims[l + 1], cols = c->nd.dims[l];
+        std::vector<double> W(rows * cols), b(rows);
+        for (auto& v : W) v = nrm(gen);
+        for (auto& v : b) v = nrm(gen);
+        RCN_TRY(rcn_hip_set_params(c, l, W.data(), b.data()));
+    }
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_params_dev(rcn_hip_ctx* c, void** p, int64_t* count) {
+    if (!c || !p || !count) return RCN_HIP_ERR_INVALID_ARG;
+    *p = c->params.p; *count = c->nd.P;
+    c->params_set = true;      // the caller may fill the buffer directly (e.g. a DP broadcast)
+    return RCN_HIP_OK;
+}
+
+// ---------------------------------------------------------------- operator API
+int rcn_hip_conv_out_shape(int R, int C, int kr, int kc, int padding, int* oR, int* oC) {
+    if (!oR || !oC) return RCN_HIP_ERR_INVALID_ARG;
+    return conv_shape(R, C, kr, kc, padding, oR, oC);
+}
+int rcn_hip_pool_out_shape(int R, int C, int padding, int* oR, int* oC) {
+    if (!oR || !oC) return RCN_HIP_ERR_INVALID_ARG;
+    return pool_shape(R, C, padding, oR, oC);
+}
+
+static int grid_for(size_t total, int block) {
+    size_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+int rcn_hip_convolve_2d(rcn_hip_ctx* c, const double* m, int n, int R, int C, const double* k, int kr, int kc, int padding, double* out) {
+    RCN_TRY(check_ctx(c));
+    if (!m || !k || !out || n < 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "convolve_2d: NULL pointer");
+    int oR, oC;
+    int st = conv_shape(R, C, kr, kc, padding, &oR, &oC);
+    if (st != RCN_HIP_OK) return fail(c, st, "convolve_2d expects 'self.shape() >= kernel_shape() > 0' and odd kernels of half-width < 2 under Padding::Same (kernel.rs:123-135,156)");
+    if (n == 0) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    const size_t in_b = (size_t)n * R * C * 8, k_b = (size_t)kr * kc * 8, out_b = (size_t)n * oR * oC * 8;
+    HIP_TRY(c, c->scratch0.ensure(in_b)); HIP_TRY(c, c->scratch1.ensure(k_b)); HIP_TRY(c, c->scratch2.ensure(out_b));
+    HIP_TRY(c, hipMemcpyAsync(c->scratch0.p, m, in_b, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->scratch1.p, k, k_b, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_convolve_2d_f64, dim3(grid_for((size_t)n * oR * oC, 256)), dim3(256), 0, c->stream, (const double*)c->scratch0.p, n, R, C,
+                       (const double*)c->scratch1.p, kr, kc, padding == RCN_HIP_PAD_SAME ? 1 : 0, oR, oC, (double*)c->scratch2.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->scratch2.p, out_b, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_convolve_2d_separated(rcn_hip_ctx* c, const double* m, int n, int R, int C, int op, int padding, double* out) {
+    RCN_TRY(check_ctx(c));
+    if (!m || !out || n < 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "convolve_2d_separated: NULL pointer");
+    if (op < 0 || op > 3) return fail(c, RCN_HIP_ERR_INVALID_ARG, "convolve_2d_separated: bad SeparableOperator");
+    if (R < 3 || C < 3) return fail(c, RCN_HIP_ERR_SHAPE, "convolve_2d_separated expects a matrix of at least 3x3 (kernel.rs:199-201)");
+    // sobel_separated (kernel.rs:47-52): (3x1 column kernel, 1x3 row kernel)
+    static const double cols[4][3] = {{1, 0, -1}, {-1, 0, 1}, {1, 2, 1}, {1, 2, 1}};      // Top, Bottom, Left, Right
+    static const double rows[4][3] = {{1, 2, 1}, {1, 2, 1}, {1, 0, -1}, {-1, 0, 1}};
+    int r1, c1, r2, c2;
+    int st = conv_shape(R, C, 3, 1, padding, &r1, &c1);
+    if (st == RCN_HIP_OK) st = conv_shape(r1, c1, 1, 3, padding, &r2, &c2);
+    if (st != RCN_HIP_OK) return fail(c, st, "convolve_2d_separated: bad shape / padding");
+    if (n == 0) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    const size_t in_b = (size_t)n * R * C * 8, t_b = (size_t)n * r1 * c1 * 8, out_b = (size_t)n * r2 * c2 * 8;
+    HIP_TRY(c, c->scratch0.ensure(in_b > out_b ? in_b : out_b)); HIP_TRY(c, c->scratch1.ensure(64)); HIP_TRY(c, c->scratch2.ensure(t_b));
+    HIP_TRY(c, hipMemcpyAsync(c->scratch0.p, m, in_b, hipMemcpyHostToDevice, c->stream));
+    double kk[6];
+    std::memcpy(kk, cols[op], 24); std::memcpy(kk + 3, rows[op], 24);
+    HIP_TRY(c, hipMemcpyAsync(c->scratch1.p, kk, 48, hipMemcpyHostToDevice, c->stream));
+    const int same = padding == RCN_HIP_PAD_SAME ? 1 : 0;
+    // column pass (3x1), row pass (1x3), ReLU -- kernel.rs:204-206
+    hipLaunchKernelGGL(k_convolve_2d_f64, dim3(grid_for((size_t)n * r1 * c1, 256)), dim3(256), 0, c->stream, (const double*)c->scratch0.p, n, R, C,
+                       (const double*)c->scratch1.p, 3, 1, same, r1, c1, (double*)c->scratch2.p);
+    hipLaunchKernelGGL(k_convolve_2d_f64, dim3(grid_for((size_t)n * r2 * c2, 256)), dim3(256), 0, c->stream, (const double*)c->scratch2.p, n, r1, c1,
+                       (const double*)c->scratch1.p + 3, 1, 3, same, r2, c2, (double*)c->scratch0.p);
+    hipLaunchKernelGGL(k_relu_f64, dim3(grid_for((size_t)n * r2 * c2, 256)), dim3(256), 0, c->stream, (const double*)c->scratch0.p, (size_t)n * r2 * c2,
+                       (double*)c->scratch0.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->scratch0.p, out_b, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_relu(rcn_hip_ctx* c, const double* m, size_t count, double* out) {
+    RCN_TRY(check_ctx(c));
+    if ((!m || !out) && count) return fail(c, RCN_HIP_ERR_INVALID_ARG, "relu: NULL pointer");
+    if (count == 0) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    HIP_TRY(c, c->scratch0.ensure(count * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->scratch0.p, m, count * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_relu_f64, dim3(grid_for(count, 256)), dim3(256), 0, c->stream, (const double*)c->scratch0.p, count, (double*)c->scratch0.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->scratch0.p, count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_pool_2d(rcn_hip_ctx* c, const double* m, int n, int R, int C, int padding, int pooling, double* out) {
+    RCN_TRY(check_ctx(c));
+    if (!m || !out || n < 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "pool_2d: NULL pointer");
+    if (pooling != RCN_HIP_POOL_AVERAGE && pooling != RCN_HIP_POOL_MAX) return fail(c, RCN_HIP_ERR_INVALID_ARG, "pool_2d: bad Pooling");
+    int oR, oC;
+    int st = pool_shape(R, C, padding, &oR, &oC);
+    if (st != RCN_HIP_OK) return fail(c, st, "stride_2d expected a matrix with dimensions greater than (2, 2) (kernel.rs:246-251)");
+    if (pooling != RCN_HIP_POOL_MAX) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "Pooling::Average: Not implemented (kernel.rs:283-285)");
+    if (n == 0) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    const size_t in_b = (size_t)n * R * C * 8, out_b = (size_t)n * oR * oC * 8;
+    HIP_TRY(c, c->scratch0.ensure(in_b)); HIP_TRY(c, c->scratch2.ensure(out_b));
+    HIP_TRY(c, hipMemcpyAsync(c->scratch0.p, m, in_b, hipMemcpyHostToDevice, c->stream));
+    // Padding::None truncates odd tails: oR = R/2 so rows/cols >= 2*oR are simply never visited
+    hipLaunchKernelGGL(k_pool_2d_f64, dim3(grid_for((size_t)n * oR * oC, 256)), dim3(256), 0, c->stream, (const double*)c->scratch0.p, n, R, C, oR, oC,
+                       (double*)c->scratch2.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->scratch2.p, out_b, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RCN_HIP_OK;
+}
+
+// ---------------------------------------------------------------- feature pipeline
+int rcn_hip_features_dev(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, void* out, int standardize) {
+    RCN_TRY(check_ctx(c));
+    if ((!imgs || !out) && n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "features: NULL pointer");
+    if (n == 0 || c->fd.F == 0) return RCN_HIP_OK;          // an empty feature_set flattens to an empty vector (rcn.rs:350)
+    if (n > 0x7fffffffULL) return fail(c, RCN_HIP_ERR_INVALID_ARG, "features: too many images in one call");
+    DevGuard g(c->device);
+    const bool wide = c->n_conv > 5;             // |v| <= 255*8^n stays below 2^24 only up to 5 conv layers
+    const size_t lds = 2 * (size_t)c->fd.max_elems * (wide ? 8 : 4);
+    const int grid = (int)(n < 4096 ? n : 4096);
+#define LAUNCH_FEAT(TC, TO)                                                                                                   \
+    do {                                                                                                                      \
+        RCN_TRY(set_dyn_lds(c, k_features<TC, TO>, lds));                                                                     \
+        hipLaunchKernelGGL((k_features<TC, TO>), dim3(grid), dim3(kFeatThreads), lds, c->stream, c->fd, imgs, (int)n, (TO*)out, \
+                           standardize, (TO)c->mean, (TO)c->sd);                                                              \
+    } while (0)
+    if (c->dtype == RCN_HIP_F64) { if (wide) LAUNCH_FEAT(double, double); else LAUNCH_FEAT(float, double); }
+    else { if (wide) LAUNCH_FEAT(double, float); else LAUNCH_FEAT(float, float); }
+#undef LAUNCH_FEAT
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_features(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, double* out) {
+    RCN_TRY(check_ctx(c));
+    if ((!imgs || !out) && n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "features: NULL pointer");
+    if (n == 0 || c->fd.F == 0) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    const size_t img_b = n * (size_t)c->fd.H * c->fd.W, cnt = n * (size_t)c->fd.F;
+    HIP_TRY(c, c->xstage.ensure(img_b)); HIP_TRY(c, c->ostage.ensure(cnt * c->esz()));
+    HIP_TRY(c, hipMemcpyAsync(c->xstage.p, imgs, img_b, hipMemcpyHostToDevice, c->stream));
+    RCN_TRY(rcn_hip_features_dev(c, (const uint8_t*)c->xstage.p, n, c->ostage.p, 0));
+    return download(c, c->ostage.p, out, cnt);     // raw features are integers < 2^24: exact in either dtype
+}
+
+static int gen_scales_impl(rcn_hip_ctx* c, const void* dev, size_t count, double* mean, double* sd) {
+    const int grid = 1024;
+    HIP_TRY(c, c->redpart.ensure(grid * sizeof(double)));
+    std::vector<double> part(grid);
+    auto run = [&](bool sq, double m, double* result) -> int {
+        if (c->dtype == RCN_HIP_F64) {
+            if (sq) hipLaunchKernelGGL((k_reduce<double, true>), dim3(grid), dim3(256), 0, c->stream, (const double*)dev, count, m, (double*)c->redpart.p);
+            else hipLaunchKernelGGL((k_reduce<double, false>), dim3(grid), dim3(256), 0, c->stream, (const double*)dev, count, m, (double*)c->redpart.p);
+        } else {
+            if (sq) hipLaunchKernelGGL((k_reduce<float, true>), dim3(grid), dim3(256), 0, c->stream, (const float*)dev, count, m, (double*)c->redpart.p);
+            else hipLaunchKernelGGL((k_reduce<float, false>), dim3(grid), dim3(256), 0, c->stream, (const float*)dev, count, m, (double*)c->redpart.p);
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(part.data(), c->redpart.p, grid * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        double t = 0.0;
+        for (int i = 0; i < grid; ++i) t += part[i];
+        *result = t;
+        return RCN_HIP_OK;
+    };
+    double s = 0.0, q = 0.0;
+    RCN_TRY(run(false, 0.0, &s));
+    const double mu = s / (double)count;                      // rcn.rs:240
+    RCN_TRY(run(true, mu, &q));
+    const double sdv = std::sqrt(q / (double)count);          // rcn.rs:247
+    c->mean = mu; c->sd = sdv;                                // rcn.rs:249-250
+    if (mean) *mean = mu;
+    if (sd) *sd = sdv;
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_gen_scales_dev(rcn_hip_ctx* c, const void* feats, size_t n, double* mean, double* sd) {
+    RCN_TRY(check_ctx(c));
+    if (!feats || n == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "gen_scales: empty input (the reference indexes iv[0], rcn.rs:233)");
+    DevGuard g(c->device);
+    return gen_scales_impl(c, feats, n * (size_t)c->fd.F, mean, sd);
+}
+
+int rcn_hip_gen_scales(rcn_hip_ctx* c, const double* feats, size_t n, double* mean, double* sd) {
+    RCN_TRY(check_ctx(c));
+    if (!feats || n == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "gen_scales: empty input (the reference indexes iv[0], rcn.rs:233)");
+    DevGuard g(c->device);
+    // statistics are taken in f64 on the device regardless of the ctx dtype so that raw (integer) features lose nothing
+    const size_t cnt = n * (size_t)c->fd.F;
+    HIP_TRY(c, c->xstage.ensure(cnt * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->xstage.p, feats, cnt * 8, hipMemcpyHostToDevice, c->stream));
+    const int saved = c->dtype;
+    c->dtype = RCN_HIP_F64;
+    const int st = gen_scales_impl(c, c->xstage.p, cnt, mean, sd);
+    c->dtype = saved;
+    return st;
+}
+
+int rcn_hip_set_scale(rcn_hip_ctx* c, double mean, double sd) {
+    RCN_TRY(check_ctx(c));
+    c->mean = mean; c->sd = sd;
+    return RCN_HIP_OK;
+}
+int rcn_hip_get_scale(const rcn_hip_ctx* c, double* mean, double* sd) {
+    if (!c || !mean || !sd) return RCN_HIP_ERR_INVALID_ARG;
+    *mean = c->mean; *sd = c->sd;
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_standardize_dev(rcn_hip_ctx* c, void* feats, size_t count) {
+    RCN_TRY(check_ctx(c));
+    if (!feats && count) return fail(c, RCN_HIP_ERR_INVALID_ARG, "standardize: NULL pointer");
+    if (count == 0) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    if (c->dtype == RCN_HIP_F64)
+        hipLaunchKernelGGL((k_standardize<double>), dim3(grid_for(count, 256)), dim3(256), 0, c->stream, (double*)feats, count, c->mean, c->sd);
+    else
+        hipLaunchKernelGGL((k_standardize<float>), dim3(grid_for(count, 256)), dim3(256), 0, c->stream, (float*)feats, count, (float)c->mean, (float)c->sd);
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_standardize(rcn_hip_ctx* c, double* feats, size_t count) {
+    RCN_TRY(check_ctx(c));
+    if (!feats && count) return fail(c, RCN_HIP_ERR_INVALID_ARG, "standardize: NULL pointer");
+    if (count == 0) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    // host-buffer form works in f64 on the device whatever the ctx dtype (the caller's data is f64)
+    HIP_TRY(c, c->xstage.ensure(count * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->xstage.p, feats, count * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL((k_standardize<double>), dim3(grid_for(count, 256)), dim3(256), 0, c->stream, (double*)c->xstage.p, count, c->mean, c->sd);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(feats, c->xstage.p, count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RCN_HIP_OK;
+}
+
+// ---------------------------------------------------------------- dense network
+int rcn_hip_train_batch_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, double eta, void* loss_dev) {
+    RCN_TRY(check_ctx(c));
+    if (!x || !y) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_batch: NULL pointer");
+    if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_batch: batch size must be in 1..2^30 (eta / 0 in the reference)");
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    RCN_TRY(ensure_dense_ws(c, B));
+    return enqueue_train_step(c, x, y, nullptr, B, eta, loss_dev);
+}
+
+int rcn_hip_train_batch(rcn_hip_ctx* c, const double* x, const double* y, size_t B, double eta, double* loss_out) {
+    RCN_TRY(check_ctx(c));
+    if (!x || !y) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_batch: NULL pointer");
+    if (B == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_batch: empty batch");
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    RCN_TRY(upload(c, c->xstage, x, B * (size_t)c->nd.dims[0]));
+    RCN_TRY(upload(c, c->ystage, y, B * (size_t)c->nd.dims[c->nd.L]));
+    HIP_TRY(c, c->misc.ensure(64));
+    RCN_TRY(rcn_hip_train_batch_dev(c, c->xstage.p, c->ystage.p, B, eta, loss_out ? c->misc.p : nullptr));
+    if (loss_out) return download(c, c->misc.p, loss_out, 1);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+    RCN_TRY(check_ctx(c));
+    if (!X || !Y) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_epoch: NULL pointer");
+    if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_epoch: batch size must be in 1..2^30");
+    if (nb == 0) return RCN_HIP_OK;                 // chunks_exact yields nothing (rcn.rs:147)
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    RCN_TRY(ensure_dense_ws(c, B));
+    // make sure LDS attributes are set outside capture
+    const size_t lds = dense_fwd_lds_elems(c->nd) * c->esz();
+    if (c->dtype == RCN_HIP_F64) RCN_TRY(set_dyn_lds(c, k_dense_fwd<double, true>, lds)); else RCN_TRY(set_dyn_lds(c, k_dense_fwd<float, true>, lds));
+
+    const EpochKey key{X, Y, perm, B, nb, eta, loss_dev};
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        const size_t F = c->nd.dims[0], Cc = c->nd.dims[c->nd.L], es = c->esz();
+        hipGraph_t graph = nullptr;
+        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int st = RCN_HIP_OK;
+        for (size_t j = 0; j < nb && st == RCN_HIP_OK; ++j) {
+            const void* xb = perm ? X : (const char*)X + j * B * F * es;
+            const void* yb = perm ? Y : (const char*)Y + j * B * Cc * es;
+            const int32_t* ib = perm ? perm + j * B : nullptr;
+            void* lj = loss_dev ? (char*)loss_dev + j * es : nullptr;
+            st = enqueue_train_step(c, xb, yb, ib, B, eta, lj);
+        }
+        hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (st != RCN_HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+        HIP_TRY(c, e);
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(c, e);
+        if (c->graphs.size() >= 16) drop_graphs(c);
+        it = c->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_batch_gradient_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, void* grad, void* loss_sum) {
+    RCN_TRY(check_ctx(c));
+    if (!x || !y || !grad) return fail(c, RCN_HIP_ERR_INVALID_ARG, "batch_gradient: NULL pointer");
+    if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "batch_gradient: batch size must be in 1..2^30");
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    RCN_TRY(ensure_dense_ws(c, B));
+    if (c->dtype == RCN_HIP_F64) {
+        RCN_TRY(launch_fwd<double>(c, true, x, y, nullptr, B, nullptr));
+        RCN_TRY(launch_wgrad<double>(c, false, x, nullptr, B, 0.0, grad, loss_sum, 1.0));
+    } else {
+        RCN_TRY(launch_fwd<float>(c, true, x, y, nullptr, B, nullptr));
+        RCN_TRY(launch_wgrad<float>(c, false, x, nullptr, B, 0.0, grad, loss_sum, 1.0));
+    }
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_apply_gradient_dev(rcn_hip_ctx* c, const void* grad, double scale) {
+    RCN_TRY(check_ctx(c));
+    if (!grad) return fail(c, RCN_HIP_ERR_INVALID_ARG, "apply_gradient: NULL pointer");
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    const int n = c->nd.P;
+    if (c->dtype == RCN_HIP_F64)
+        hipLaunchKernelGGL((k_apply_gradient<double>), dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (double*)c->params.p, (const double*)grad, scale, n);
+    else
+        hipLaunchKernelGGL((k_apply_gradient<float>), dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (float*)c->params.p, (const float*)grad, (float)scale, n);
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_forward_dev(rcn_hip_ctx* c, const void* x, size_t n, void* out) {
+    RCN_TRY(check_ctx(c));
+    if ((!x || !out) && n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "forward: NULL pointer");
+    if (n == 0) return RCN_HIP_OK;
+    if (n > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "forward: too many samples in one call");
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    if (c->dtype == RCN_HIP_F64) return launch_fwd<double>(c, false, x, nullptr, nullptr, n, out);
+    return launch_fwd<float>(c, false, x, nullptr, nullptr, n, out);
+}
+
+int rcn_hip_forward(rcn_hip_ctx* c, const double* x, size_t n, double* out) {
+    RCN_TRY(check_ctx(c));
+    if ((!x || !out) && n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "forward: NULL pointer");
+    if (n == 0) return RCN_HIP_OK;
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    const size_t Cc = c->nd.dims[c->nd.L];
+    RCN_TRY(upload(c, c->xstage, x, n * (size_t)c->nd.dims[0]));
+    HIP_TRY(c, c->ostage.ensure(n * Cc * c->esz()));
+    RCN_TRY(rcn_hip_forward_dev(c, c->xstage.p, n, c->ostage.p));
+    return download(c, c->ostage.p, out, n * Cc);
+}
+
+static int argmax_dev(rcn_hip_ctx* c, const void* outv, size_t n, int32_t* host_cls) {
+    const int Cc = c->nd.dims[c->nd.L];
+    HIP_TRY(c, c->misc.ensure(n * sizeof(int32_t) + 64));
+    if (c->dtype == RCN_HIP_F64)
+        hipLaunchKernelGGL((k_argmax_last<double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)outv, (int)n, Cc, (int*)c->misc.p);
+    else
+        hipLaunchKernelGGL((k_argmax_last<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)outv, (int)n, Cc, (int*)c->misc.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(host_cls, c->misc.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_classify(rcn_hip_ctx* c, const double* x, size_t n, int32_t* cls) {
+    RCN_TRY(check_ctx(c));
+    if ((!x || !cls) && n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "classify: NULL pointer");
+    if (n == 0) return RCN_HIP_OK;
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    RCN_TRY(upload(c, c->xstage, x, n * (size_t)c->nd.dims[0]));
+    HIP_TRY(c, c->ostage.ensure(n * (size_t)c->nd.dims[c->nd.L] * c->esz()));
+    RCN_TRY(rcn_hip_forward_dev(c, c->xstage.p, n, c->ostage.p));
+    return argmax_dev(c, c->ostage.p, n, cls);
+}
+
+int rcn_hip_evaluate_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t n, int64_t* accepted) {
+    RCN_TRY(check_ctx(c));
+    if (!accepted || ((!x || !y) && n)) return fail(c, RCN_HIP_ERR_INVALID_ARG, "evaluate: NULL pointer");
+    *accepted = 0;
+    if (n == 0) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    const int Cc = c->nd.dims[c->nd.L];
+    HIP_TRY(c, c->ostage.ensure(n * (size_t)Cc * c->esz()));
+    RCN_TRY(rcn_hip_forward_dev(c, x, n, c->ostage.p));
+    HIP_TRY(c, c->misc.ensure(64));
+    HIP_TRY(c, hipMemsetAsync(c->misc.p, 0, 16, c->stream));
+    if (c->dtype == RCN_HIP_F64)
+        hipLaunchKernelGGL((k_eval_accept<double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->ostage.p, (const double*)y, (int)n, Cc,
+                           (unsigned long long*)c->misc.p);
+    else
+        hipLaunchKernelGGL((k_eval_accept<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->ostage.p, (const float*)y, (int)n, Cc,
+                           (unsigned long long*)c->misc.p);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long cnt = 0;
+    HIP_TRY(c, hipMemcpyAsync(&cnt, c->misc.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *accepted = (int64_t)cnt;
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_evaluate(rcn_hip_ctx* c, const double* x, const double* y, size_t n, int64_t* accepted) {
+    RCN_TRY(check_ctx(c));
+    if (!accepted || ((!x || !y) && n)) return fail(c, RCN_HIP_ERR_INVALID_ARG, "evaluate: NULL pointer");
+    *accepted = 0;
+    if (n == 0) return RCN_HIP_OK;
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    RCN_TRY(upload(c, c->xstage, x, n * (size_t)c->nd.dims[0]));
+    RCN_TRY(upload(c, c->ystage, y, n * (size_t)c->nd.dims[c->nd.L]));
+    return rcn_hip_evaluate_dev(c, c->xstage.p, c->ystage.p, n, accepted);
+}
+
+int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, int reps, double* us_fwd, double* us_wgrad) {
+    RCN_TRY(check_ctx(c));
+    if (!x || !y || !us_fwd || !us_wgrad || reps < 1 || B == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "time_kernels: bad argument");
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    RCN_TRY(ensure_dense_ws(c, B));
+    HIP_TRY(c, c->grad.ensure((size_t)c->nd.P * c->esz()));
+    const bool f64 = c->dtype == RCN_HIP_F64;
+    // warm both kernels (LDS attribute, code load) outside capture
+    RCN_TRY(f64 ? launch_fwd<double>(c, true, x, y, nullptr, B, nullptr) : launch_fwd<float>(c, true, x, y, nullptr, B, nullptr));
+    RCN_TRY(f64 ? launch_wgrad<double>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0) : launch_wgrad<float>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    double res[2] = {0, 0};
+    int st = RCN_HIP_OK;
+    for (int which = 0; which < 2 && st == RCN_HIP_OK; ++which) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+        for (int i = 0; i < reps && e == hipSuccess && st == RCN_HIP_OK; ++i) {
+            if (which == 0) st = f64 ? launch_fwd<double>(c, true, x, y, nullptr, B, nullptr) : launch_fwd<float>(c, true, x, y, nullptr, B, nullptr);
+            else st = f64 ? launch_wgrad<double>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0) : launch_wgrad<float>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0);
+        }
+        hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+        if (e == hipSuccess) e = e2;
+        if (e == hipSuccess && st == RCN_HIP_OK) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e == hipSuccess && st == RCN_HIP_OK) {
+            e = hipGraphLaunch(exec, c->stream);                       // untimed warm replay
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+            if (e == hipSuccess) e = hipGraphLaunch(exec, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            res[which] = (double)ms * 1000.0 / reps;
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess && st == RCN_HIP_OK) st = fail(c, RCN_HIP_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *us_fwd = res[0]; *us_wgrad = res[1];
+    return st;
+}
+
+int rcn_hip_classify_images(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, int32_t* cls) {
+    RCN_TRY(check_ctx(c));
+    if ((!imgs || !cls) && n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "classify_images: NULL pointer");
+    if (n == 0) return RCN_HIP_OK;
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    const size_t img_b = n * (size_t)c->fd.H * c->fd.W;
+    HIP_TRY(c, c->scratch0.ensure(img_b));
+    HIP_TRY(c, c->xstage.ensure(n * (size_t)c->fd.F * c->esz()));
+    HIP_TRY(c, c->ostage.ensure(n * (size_t)c->nd.dims[c->nd.L] * c->esz()));
+    HIP_TRY(c, hipMemcpyAsync(c->scratch0.p, imgs, img_b, hipMemcpyHostToDevice, c->stream));
+    RCN_TRY(rcn_hip_features_dev(c, (const uint8_t*)c->scratch0.p, n, c->xstage.p, 1));   // rcn.rs:84-89
+    RCN_TRY(rcn_hip_forward_dev(c, c->xstage.p, n, c->ostage.p));                          // rcn.rs:91
+    return argmax_dev(c, c->ostage.p, n, cls);                                             // rcn.rs:92-97
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""Device-resident driver: torch CUDA(ROCm) tensors are used purely as HBM buffers + stream handles; every
+kernel that touches sample data is one of ours, reached through the `_dev` entry points of include/rcn_hip.h."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .rcn import RCN, RCNLayer, default_convpool
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DeviceRCN:
+    """An RCN whose data set, parameters and training loop live on one GPU.
+
+    All work is enqueued on `self.stream` (a torch side stream whose HIP handle the context shares), so torch ops
+    issued under `with torch.cuda.stream(self.stream)` and our kernels are ordered with each other."""
+
+    def __init__(self, classes: int = 10, convpool_cfg: Optional[Sequence[RCNLayer]] = None, feedforward_cfg: Sequence[int] = (30,),
+                 input_shape: Tuple[int, int] = (28, 28), dtype: int = _lib.F32, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceRCN needs a GPU; there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.rcn = RCN(classes, convpool_cfg if convpool_cfg is not None else default_convpool(), list(feedforward_cfg),
+                       input_shape=input_shape, dtype=dtype, device=device, stream=self.stream.cuda_stream)
+        self.tdtype = torch.float64 if dtype == _lib.F64 else torch.float32
+        self.lib, self.ctx = self.rcn._lib, self.rcn._ctx
+        self.F, self.classes = self.rcn.feature_len, classes
+        self.P = sum(self.rcn.dims[l] * self.rcn.dims[l + 1] + self.rcn.dims[l + 1] for l in range(len(self.rcn.dims) - 1))
+
+    def _ck(self, st):
+        _lib.check(self.lib, self.ctx, st)
+
+    def empty(self, *shape, dtype=None) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def to_device(self, a: np.ndarray, dtype=None) -> torch.Tensor:
+        with torch.cuda.stream(self.stream):
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            return t.to(dtype) if dtype is not None else t
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    # ---- feature pipeline --------------------------------------------------------------------------------------
+    def features(self, imgs_u8: torch.Tensor, standardize: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert imgs_u8.dtype == torch.uint8 and imgs_u8.is_contiguous() and imgs_u8.device == self.device
+        n = imgs_u8.shape[0]
+        out = out if out is not None else self.empty(n, self.F)
+        self._ck(self.lib.rcn_hip_features_dev(self.ctx, _p(imgs_u8), n, _p(out), 1 if standardize else 0))
+        return out
+
+    def gen_scales(self, feats: torch.Tensor) -> Tuple[float, float]:
+        m, s = C.c_double(), C.c_double()
+        self._ck(self.lib.rcn_hip_gen_scales_dev(self.ctx, _p(feats), feats.shape[0], C.byref(m), C.byref(s)))
+        return m.value, s.value
+
+    def standardize_(self, feats: torch.Tensor) -> torch.Tensor:
+        self._ck(self.lib.rcn_hip_standardize_dev(self.ctx, _p(feats), feats.numel()))
+        return feats
+
+    def load_data(self, imgs_u8: torch.Tensor, labels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """rcn.rs:399-414 on resident images: features -> gen_scales -> standardise; one-hot expectations."""
+        x = self.features(imgs_u8)
+        self.gen_scales(x)
+        self.standardize_(x)
+        with torch.cuda.stream(self.stream):
+            y = torch.zeros(labels.shape[0], self.classes, dtype=self.tdtype, device=self.device)
+            y.scatter_(1, labels.to(torch.int64).view(-1, 1), 1.0)
+        return x, y
+
+    # ---- dense network -------------------------------------------------------------------------------------------
+    def set_params(self, weights, biases):
+        self.rcn.set_params(weights, biases)
+
+    def get_params(self):
+        self.synchronize()
+        return self.rcn.get_params()
+
+    def params_flat(self) -> torch.Tensor:
+        """Zero-copy torch view of the flat device parameter buffer [W_0|b_0|W_1|b_1|...]."""
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        self._ck(self.lib.rcn_hip_params_dev(self.ctx, C.byref(ptr), C.byref(cnt)))
+        esz = 8 if self.tdtype == torch.float64 else 4
+        iface = {"shape": (int(cnt.value),), "typestr": "<f8" if esz == 8 else "<f4", "data": (int(ptr.value), False), "version": 2}
+        holder = type("_Buf", (), {"__cuda_array_interface__": iface})()
+        return torch.as_tensor(holder, device=self.device)
+
+    def train_batch(self, x: torch.Tensor, y: torch.Tensor, eta: float, loss: Optional[torch.Tensor] = None):
+        self._ck(self.lib.rcn_hip_train_batch_dev(self.ctx, _p(x), _p(y), x.shape[0], float(eta), _p(loss)))
+
+    def train_epoch(self, X: torch.Tensor, Y: torch.Tensor, perm: Optional[torch.Tensor], B: int, n_batches: int, eta: float,
+                    loss: Optional[torch.Tensor] = None):
+        if perm is not None:
+            assert perm.dtype == torch.int32 and perm.numel() >= B * n_batches
+        else:
+            assert X.shape[0] >= B * n_batches
+        self._ck(self.lib.rcn_hip_train_epoch_dev(self.ctx, _p(X), _p(Y), _p(perm), B, n_batches, float(eta), _p(loss)))
+
+    def batch_gradient(self, x: torch.Tensor, y: torch.Tensor, grad: Optional[torch.Tensor] = None,
+                       loss_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+        grad = grad if grad is not None else self.empty(self.P)
+        self._ck(self.lib.rcn_hip_batch_gradient_dev(self.ctx, _p(x), _p(y), x.shape[0], _p(grad), _p(loss_sum)))
+        return grad
+
+    def apply_gradient(self, grad: torch.Tensor, scale: float):
+        self._ck(self.lib.rcn_hip_apply_gradient_dev(self.ctx, _p(grad), float(scale)))
+
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = out if out is not None else self.empty(x.shape[0], self.classes)
+        self._ck(self.lib.rcn_hip_forward_dev(self.ctx, _p(x), x.shape[0], _p(out)))
+        return out
+
+    def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> int:
+        n = C.c_int64()
+        self._ck(self.lib.rcn_hip_evaluate_dev(self.ctx, _p(x), _p(y), x.shape[0], C.byref(n)))
+        return int(n.value)
+
+    def time_kernels(self, x: torch.Tensor, y: torch.Tensor, reps: int = 200) -> Tuple[float, float]:
+        """Mean microseconds per launch of (k_dense_fwd, k_dense_wgrad) at this batch size, by HIP events."""
+        a, b = C.c_double(), C.c_double()
+        self._ck(self.lib.rcn_hip_time_kernels_dev(self.ctx, _p(x), _p(y), x.shape[0], reps, C.byref(a), C.byref(b)))
+        return a.value, b.value

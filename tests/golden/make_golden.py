@@ -60,7 +60,7 @@ def main():
 
     # ---- dense step (rcn.rs:176-314) -------------------------------------------------------------
     dense = {}
-    for name, dims, B, eta in (("tiny", [12, 5, 3], 4, 3.0), ("mid3", [49, 8, 6, 10], 7, 0.5), ("one", [20, 4, 10], 1, 3.0)):
+    for name, dims, B, eta in (("tiny", [16, 5, 3], 4, 3.0), ("mid3", [48, 8, 6, 10], 7, 0.5), ("one", [24, 4, 10], 1, 3.0)):
         ws, bs = synthetic_params(dims, seed=len(name) + B)
         ws = [w * 0.3 for w in ws]
         X = np.maximum(rng.standard_normal((B, dims[0])), 0.0)

@@ -1,0 +1,107 @@
+"""World-size-2 gloo test (CPU) of the data-parallel step logic in mercer_research_amd/dp.py: shard gradients ->
+all-reduce of the flat buffer -> identical update == one train_batch on the concatenated batch.
+The gradient engine here is a CPU stand-in backed by the oracle (tests may use the oracle); on GPUs the same
+DataParallelStep drives mercer_research_amd.device.DeviceRCN over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.rcn_oracle import COracle, one_hot, synthetic_params
+
+DIMS = [48, 8, 6, 10]
+
+
+class OracleEngine:
+    """GradientEngine protocol over the CPU oracle, flat layout [W_0|b_0|W_1|b_1|...] with W column-major."""
+
+    def __init__(self, ws, bs):
+        self.o = COracle()
+        self.flat = torch.from_numpy(self._pack(ws, bs))
+
+    @staticmethod
+    def _pack(ws, bs):
+        return np.concatenate([np.concatenate([w.ravel(order="F"), b]) for w, b in zip(ws, bs)])
+
+    def _unpack(self):
+        ws, bs, off = [], [], 0
+        a = self.flat.numpy()
+        for i in range(len(DIMS) - 1):
+            n = DIMS[i] * DIMS[i + 1]
+            ws.append(a[off:off + n].reshape((DIMS[i + 1], DIMS[i]), order="F").copy()); off += n
+            bs.append(a[off:off + DIMS[i + 1]].copy()); off += DIMS[i + 1]
+        return ws, bs
+
+    def params_flat(self):
+        return self.flat
+
+    def batch_gradient(self, x, y, grad=None, loss_sum=None):
+        ws, bs = self._unpack()
+        gW, gb, cost = self.o.batch_gradient(ws, bs, x.numpy(), y.numpy())
+        g = torch.from_numpy(self._pack(gW, gb))
+        if loss_sum is not None:
+            loss_sum[0] = cost * 2.0 * x.shape[0]
+        if grad is not None:
+            grad.copy_(g)
+            return grad
+        return g
+
+    def apply_gradient(self, grad, scale):
+        self.flat -= scale * grad
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, X, Y, ws, bs, eta, steps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mercer_research_amd.dp import DataParallelStep, shard_bounds
+        # rank 1 starts from garbage parameters: broadcast_params must repair it
+        eng = OracleEngine(ws, bs) if rank == 0 else OracleEngine([w * 0 + 7 for w in ws], [b * 0 - 3 for b in bs])
+        dp = DataParallelStep(eng)
+        dp.broadcast_params(0)
+        B = X.shape[1]
+        loss = torch.zeros(1, dtype=torch.float64)
+        for s in range(steps):
+            lo, hi = shard_bounds(B, world, rank)
+            dp.train_batch(torch.from_numpy(X[s, lo:hi]), torch.from_numpy(Y[s, lo:hi]), eta, B, loss)
+        out[rank] = (eng.flat.numpy().copy(), float(loss[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp2_equals_single_process_full_batch():
+    rng = np.random.default_rng(0)
+    steps, B = 3, 12
+    ws, bs = synthetic_params(DIMS, seed=4)
+    ws = [w * 0.2 for w in ws]
+    X = np.maximum(rng.standard_normal((steps, B, DIMS[0])), 0)
+    Y = np.stack([one_hot(rng.integers(0, 10, B), 10) for _ in range(steps)])
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, X, Y, ws, bs, 3.0, steps, out), nprocs=2, join=True)
+    o = COracle()
+    rw, rb, cost = ws, bs, 0.0
+    for s in range(steps):
+        rw, rb, cost = o.train_batch(rw, rb, X[s], Y[s], 3.0)
+    ref = OracleEngine._pack(rw, rb)
+    np.testing.assert_array_equal(out[0][0], out[1][0])                       # replicas stay bit-identical
+    np.testing.assert_allclose(out[0][0], ref, rtol=1e-12, atol=1e-14)        # == full-batch step (f64 sum order only)
+    assert abs(out[0][1] / (2 * B) - cost) <= 1e-12 * cost                    # all-reduced loss sum == full-batch cost
+
+
+def test_shard_bounds():
+    from mercer_research_amd.dp import shard_bounds
+    assert [shard_bounds(256, 4, r) for r in range(4)] == [(0, 64), (64, 128), (128, 192), (192, 256)]
+    with pytest.raises(ValueError):
+        shard_bounds(10, 4, 0)

@@ -1,0 +1,433 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU oracle on
+identical inputs; against the committed golden vectors; and, at the BASELINE.json sizes, through size-independent
+properties.  Tolerances:
+  * operators / raw features: bit-exact (f64 in the reference's summation order; integer-valued features)
+  * f64 context dense path: <= 1e-11 relative (only the summation order differs from the per-sample reference loop)
+  * f32 context dense path: activations abs <= 2e-6; one-step parameters |d| <= 1e-5*|ref| + 1e-6; loss rel <= 1e-5
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.rcn_oracle import (DEFAULT_LAYERS, LAYER_CONV, LAYER_POOL, PAD_NONE, PAD_SAME, POOL_MAX, one_hot,
+                               synthetic_images, synthetic_params)
+
+pytestmark = pytest.mark.gpu
+
+F32_ACT_ATOL = 2e-6
+F32_PARAM_RTOL, F32_PARAM_ATOL = 1e-5, 1e-6
+F64_RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import mercer_research_amd as m
+    return m
+
+
+def _layers(amd, spec):
+    out = []
+    for kind, arg in spec:
+        out.append(amd.RCNLayer.Convolve2D(amd.Padding(arg)) if kind == LAYER_CONV else amd.RCNLayer.Pool2D(amd.Pooling(arg)))
+    return out
+
+
+def _mk(amd, dims, dtype, layers=DEFAULT_LAYERS, shape=(28, 28)):
+    return amd.RCN(dims[-1], _layers(amd, layers), dims[1:-1], input_shape=shape, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------------------------------- operators
+
+@pytest.mark.parametrize("shape", [(3, 3), (5, 6), (7, 3), (28, 28), (30, 30), (9, 31), (64, 48)])
+def test_operators_bit_exact(amd, oracle, shape):
+    rng = np.random.default_rng(sum(shape))
+    ints = rng.integers(0, 256, shape).astype(np.float64)
+    reals = rng.standard_normal(shape) * 100
+    for m in (ints, reals):
+        for pad in (PAD_NONE, PAD_SAME):
+            for op in range(4):
+                assert np.array_equal(amd.convolve_2d_separated(m, amd.SeparableOperator(op), amd.Padding(pad)),
+                                      oracle.convolve_2d_separated(m, op, pad))
+            for ks in ((3, 3), (1, 3), (3, 1), (1, 1)):
+                k = rng.standard_normal(ks)
+                assert np.array_equal(amd.convolve_2d(m, k, amd.Padding(pad)), oracle.convolve_2d(m, k, pad))
+            assert np.array_equal(amd.pool_2d(m, amd.Padding(pad), amd.Pooling.MAX), oracle.pool_2d(m, pad, POOL_MAX))
+        assert np.array_equal(amd.relu(m - 50), oracle.relu(m - 50))
+    k5 = rng.standard_normal((5, 5))
+    if shape[0] >= 5 and shape[1] >= 5:
+        assert np.array_equal(amd.convolve_2d(reals, k5, amd.Padding.NONE), oracle.convolve_2d(reals, k5, PAD_NONE))
+
+
+def test_operator_reference_kats(amd):
+    """utils/kernel.rs:436-441 (identity Same conv on 0..900) through the HIP path."""
+    m = np.arange(900, dtype=np.float64).reshape(30, 30)
+    k = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=np.float64)
+    assert np.array_equal(amd.convolve_2d(m, k, amd.Padding.SAME), m)
+
+
+def test_operator_batched(amd, oracle):
+    rng = np.random.default_rng(5)
+    ms = rng.integers(0, 256, (7, 12, 9)).astype(np.float64)
+    got = amd.convolve_2d_separated(ms, amd.SeparableOperator.LEFT, amd.Padding.SAME)
+    for i in range(7):
+        assert np.array_equal(got[i], oracle.convolve_2d_separated(ms[i], 2, PAD_SAME))
+    got = amd.pool_2d(ms, amd.Padding.SAME, amd.Pooling.MAX)
+    for i in range(7):
+        assert np.array_equal(got[i], oracle.pool_2d(ms[i], PAD_SAME, POOL_MAX))
+
+
+def test_operator_panics(amd):
+    m = np.ones((8, 8))
+    for ks in ((2, 2), (2, 3), (5, 5), (5, 1), (1, 5)):
+        with pytest.raises(amd.RcnPanic):
+            amd.convolve_2d(m, np.ones(ks), amd.Padding.SAME)
+    with pytest.raises(amd.RcnPanic):
+        amd.convolve_2d(np.ones((2, 2)), np.ones((3, 3)), amd.Padding.NONE)
+    with pytest.raises(amd.RcnPanic):
+        amd.convolve_2d_separated(np.ones((2, 8)), amd.SeparableOperator.TOP, amd.Padding.SAME)
+    with pytest.raises(amd.RcnPanic):
+        amd.pool_2d(np.ones((1, 8)), amd.Padding.SAME, amd.Pooling.MAX)
+    with pytest.raises(amd.RcnPanic):
+        amd.pool_2d(np.ones((4, 4)), amd.Padding.SAME, amd.Pooling.AVERAGE)
+
+
+# ----------------------------------------------------------------------------------------------------- features
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_features_default_net_bit_exact(amd, oracle, dtype):
+    imgs, _ = synthetic_images(96, seed=21)
+    imgs[0] = 255                        # saturated image: largest magnitudes (16 320) still exact in f32
+    imgs[1] = 0
+    imgs[2] = np.random.default_rng(0).integers(0, 256, (28, 28))   # no black border: exercises the Q1 edge columns
+    r = _mk(amd, [784, 30, 10], dtype)
+    got = r.flatten_feature_set(imgs)
+    assert got.shape == (96, 784)
+    assert np.array_equal(got, oracle.features(imgs, DEFAULT_LAYERS))
+    assert got.max() == 16320.0
+
+
+@pytest.mark.parametrize("spec,shape", [
+    (((LAYER_CONV, PAD_NONE), (LAYER_POOL, POOL_MAX)), (9, 11)),
+    (((LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX)), (9, 11)),
+    (((LAYER_POOL, POOL_MAX), (LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX)), (9, 11)),
+    (((LAYER_CONV, PAD_NONE), (LAYER_POOL, POOL_MAX), (LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX)), (32, 32)),
+    (((LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX), (LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX),
+      (LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX)), (28, 28)),
+])
+def test_features_other_stacks_bit_exact(amd, oracle, spec, shape):
+    rng = np.random.default_rng(len(spec))
+    imgs = rng.integers(0, 256, (5,) + shape).astype(np.uint8)
+    F = oracle.feature_len(shape[0], shape[1], spec)
+    r = amd.RCN(10, _layers(amd, spec), [4], input_shape=shape, dtype=1)
+    assert r.feature_len == F
+    assert np.array_equal(r.flatten_feature_set(imgs), oracle.features(imgs, spec))
+
+
+def test_feature_stack_errors(amd):
+    P, L = amd.Padding, amd.RCNLayer
+    # fan-in formula 4^c/2^p*l != feature length (rcn.rs:443): RCN::new and the feature path work, train panics in gemv
+    r = amd.RCN(10, [L.Convolve2D(P.SAME), L.Convolve2D(P.SAME), L.Pool2D(amd.Pooling.MAX)], [4], input_shape=(12, 12))
+    assert r.feature_len == 16 * 36 and r.flatten_feature_set(np.zeros((12, 12), np.uint8)).shape == (576,)
+    with pytest.raises(amd.RcnPanic):
+        r.train_batch(np.zeros((2, 576)), np.zeros((2, 10)), 3.0)
+    with pytest.raises(amd.RcnPanic):
+        r.load_weights_and_bias(1)
+    with pytest.raises(amd.RcnPanic):          # conv on a map smaller than 3x3
+        amd.RCN(10, [L.Convolve2D(P.NONE), L.Pool2D(amd.Pooling.MAX)], [4], input_shape=(2, 9))
+    with pytest.raises(amd.RcnPanic):          # Pooling::Average -> "Not implemented"
+        amd.RCN(10, [L.Convolve2D(P.SAME), L.Pool2D(amd.Pooling.AVERAGE)], [4], input_shape=(8, 8))
+    r = amd.RCN(10, [L.Pool2D(amd.Pooling.MAX)], [4], input_shape=(8, 8))     # no conv layer: empty feature vector
+    assert r.feature_len == 0 and r.flatten_feature_set(np.zeros((3, 8, 8), np.uint8)).shape == (3, 0)
+    with pytest.raises(amd.RcnPanic):
+        r.load_weights_and_bias(1)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_gen_scales_and_standardize(amd, oracle, dtype):
+    imgs, _ = synthetic_images(200, seed=4)
+    f = oracle.features(imgs, DEFAULT_LAYERS)
+    r = _mk(amd, [784, 30, 10], dtype)
+    m, s = r.gen_scales(f)
+    mo, so = oracle.gen_scales(f)
+    assert abs(m - mo) <= 1e-12 * abs(mo) and abs(s - so) <= 1e-12 * abs(so)
+    assert r.scale_set == (m, s)                                   # gen_scales overwrites scale_set (rcn.rs:249-250)
+    r.scale_set = (mo, so)
+    assert np.array_equal(r.standardize(f), oracle.standardize(f, mo, so))
+
+
+def test_classify_images_path(amd, oracle):
+    """RCN::classify (rcn.rs:82-98): features -> standardise with scale_set -> classify_test -> last-max arg-max."""
+    imgs, _ = synthetic_images(40, seed=9)
+    ws, bs = synthetic_params([784, 30, 10], seed=3)
+    ws = [w * 0.05 for w in ws]
+    for dtype in (0, 1):
+        r = _mk(amd, [784, 30, 10], dtype)
+        r.set_params(ws, bs)
+        f = oracle.features(imgs, DEFAULT_LAYERS)
+        mo, so = oracle.gen_scales(f)
+        r.scale_set = (mo, so)
+        out = oracle.classify_test(ws, bs, oracle.standardize(f, mo, so))
+        srt = np.sort(out, axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-4                     # skip near-ties in the f32 context
+        expect = np.array([oracle.classify_argmax(o) for o in out])
+        got = r.classify_many(imgs)
+        assert clear.sum() > 20 and np.array_equal(got[clear], expect[clear])
+        assert r.classify(imgs[int(np.argmax(clear))]) == expect[int(np.argmax(clear))]
+
+
+# ----------------------------------------------------------------------------------------------------- dense path
+
+def _dense_case(dims, B, seed, wscale=1.0):
+    rng = np.random.default_rng(seed)
+    ws, bs = synthetic_params(dims, seed=seed)
+    ws = [w * wscale for w in ws]
+    X = np.maximum(rng.standard_normal((B, dims[0])), 0.0)
+    Y = one_hot(rng.integers(0, dims[-1], B), dims[-1])
+    return ws, bs, X, Y
+
+
+def _check_params(got, ref, dtype):
+    for a, b in zip(got, ref):
+        if dtype == 1:
+            np.testing.assert_allclose(a, b, rtol=F64_RTOL, atol=1e-13)
+        else:
+            assert np.all(np.abs(a - b) <= F32_PARAM_RTOL * np.abs(b) + F32_PARAM_ATOL), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dims,B", [([784, 30, 10], 32), ([784, 30, 10], 10), ([784, 10, 10, 10], 10), ([784, 30, 10], 1),
+                                    ([784, 30, 10], 17), ([16, 5, 3], 4), ([100, 70, 33, 40, 10], 33), ([48, 8, 6, 10], 255)])
+def test_train_batch_matches_oracle(amd, oracle, dims, B, dtype):
+    # wscale keeps |z| moderate so that sigmoid' is not identically zero (un-scaled N(0,1) init saturates)
+    ws, bs, X, Y = _dense_case(dims, B, seed=B + len(dims), wscale=0.1)
+    r = _dense_rcn(amd, dims, dtype)
+    r.set_params(ws, bs)
+    out = r.classify_test(X)
+    ref_out = oracle.classify_test(ws, bs, X)
+    assert np.abs(out - ref_out).max() <= (1e-13 if dtype == 1 else F32_ACT_ATOL)
+    loss = r.train_batch(X, Y, 3.0, want_loss=True)
+    nw, nb, cost = oracle.train_batch(ws, bs, X, Y, 3.0)
+    assert abs(loss - cost) <= (1e-12 if dtype == 1 else 1e-5) * max(cost, 1e-3)
+    gw, gb = r.get_params()
+    _check_params(gw + gb, nw + nb, dtype)
+
+
+def _dense_rcn(amd, dims, dtype):
+    """An RCN whose conv/pool stack yields exactly dims[0] features: conv(Same) + pool(Max) on a 2a x 2b image gives
+    4*a*b features and satisfies the reference's fan-in formula (one conv, one pool; rcn.rs:443)."""
+    if dims[0] == 784:
+        return _mk(amd, dims, dtype)
+    F = dims[0]
+    assert F % 4 == 0, "dense test sizes must be 4*a*b with a,b >= 2"
+    q = F // 4
+    a = next(d for d in range(int(np.sqrt(q)), 1, -1) if q % d == 0)
+    b = q // a
+    assert a >= 2 and b >= 2
+    r = amd.RCN(dims[-1], _layers(amd, ((LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX))), dims[1:-1], input_shape=(2 * a, 2 * b), dtype=dtype)
+    assert r.feature_len == F
+    return r
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_unscaled_n01_init_default_net(amd, oracle, dtype):
+    """The reference's actual init (N(0,1), un-scaled, rcn.rs:500-523) on the synthetic MNIST-shape workload."""
+    imgs, labels = synthetic_images(64, seed=11)
+    f = oracle.features(imgs, DEFAULT_LAYERS)
+    m, s = oracle.gen_scales(f)
+    X, Y = oracle.standardize(f, m, s), one_hot(labels)
+    ws, bs = synthetic_params([784, 30, 10], seed=42)
+    r = _mk(amd, [784, 30, 10], dtype)
+    r.set_params(ws, bs)
+    loss = r.train_batch(X, Y, 3.0, want_loss=True)
+    nw, nb, cost = oracle.train_batch(ws, bs, X, Y, 3.0)
+    assert abs(loss - cost) <= (1e-12 if dtype == 1 else 2e-5) * cost
+    gw, gb = r.get_params()
+    if dtype == 1:
+        _check_params(gw + gb, nw + nb, dtype)
+    else:
+        # |z| ~ sqrt(784)*|x| here: f32 rounding of z (~1e-5 abs) moves saturated sigmoids by up to ~1e-5 relative
+        for a, b in zip(gw + gb, nw + nb):
+            assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5)
+
+
+def test_golden_dense_fixtures(amd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "dense.npz"))
+    for name in ("tiny", "mid3", "one"):
+        dims = [int(d) for d in g[f"{name}_dims"]]
+        L = len(dims) - 1
+        ws = [g[f"{name}_W{l}"] for l in range(L)]
+        bs = [g[f"{name}_b{l}"] for l in range(L)]
+        for dtype in (0, 1):
+            r = _dense_rcn(amd, dims, dtype)
+            r.set_params(ws, bs)
+            out = r.classify_test(g[f"{name}_X"])
+            assert np.abs(out - g[f"{name}_out"]).max() <= (1e-13 if dtype == 1 else F32_ACT_ATOL)
+            loss = r.train_batch(g[f"{name}_X"], g[f"{name}_Y"], float(g[f"{name}_eta"]), want_loss=True)
+            assert abs(loss - float(g[f"{name}_cost"])) <= (1e-12 if dtype == 1 else 1e-5) * float(g[f"{name}_cost"])
+            gw, gb = r.get_params()
+            _check_params(gw + gb, [g[f"{name}_nW{l}"] for l in range(L)] + [g[f"{name}_nb{l}"] for l in range(L)], dtype)
+
+
+def test_golden_mnist_fixture_end_to_end(amd, golden_dir):
+    """u8 images -> HIP features -> HIP gen_scales/standardise -> HIP train_batch, against the committed numbers."""
+    g = np.load(os.path.join(golden_dir, "dense.npz"))
+    imgs, labels = synthetic_images(32, seed=11)
+    ws, bs = synthetic_params([784, 30, 10], seed=42)
+    r = _mk(amd, [784, 30, 10], 1)
+    r.set_params(ws, bs)
+    X, Y = r.load_data(imgs, labels)
+    assert np.abs(r.classify_test(X) - g["mnist_out"]).max() <= 1e-12
+    loss = r.train_batch(X, Y, 3.0, want_loss=True)
+    assert abs(loss - float(g["mnist_cost"])) <= 1e-11 * float(g["mnist_cost"])
+    gw, gb = r.get_params()
+    np.testing.assert_allclose(gb[0], g["mnist_nb0"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(gb[1], g["mnist_nb1"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(gw[1], g["mnist_nW1"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(gw[0].ravel(order="F")[::37], g["mnist_nW0_strided"], rtol=1e-10, atol=1e-13)
+
+
+def test_golden_feature_fixtures(amd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "features.npz"))
+    r = _mk(amd, [784, 30, 10], 0)
+    assert np.array_equal(r.flatten_feature_set(g["imgs"]), g["feats"])
+    for k in ("conv_none_pool", "conv_conv_pool", "pool_first"):
+        spec = [tuple(int(v) for v in row) for row in g[f"layers_{k}"]]
+        rr = amd.RCN(10, _layers(amd, spec), [4], input_shape=(9, 11), dtype=1)
+        assert np.array_equal(rr.flatten_feature_set(g["small"]), g[f"small_{k}"])
+
+
+def test_evaluate_semantics(amd, oracle):
+    ws, bs, X, _ = _dense_case([784, 30, 10], 300, seed=2, wscale=0.05)
+    r = _mk(amd, [784, 30, 10], 1)
+    r.set_params(ws, bs)
+    out = oracle.classify_test(ws, bs, X)
+    Y = one_hot(out.argmax(axis=1))
+    Y[::3] = np.roll(Y[::3], 1, axis=1)                       # make a third of the expectations wrong
+    expect = sum(oracle.eval_accept(o, y, 10) for o, y in zip(out, Y))
+    assert r.evaluate(X, Y) == expect and 150 < expect < 300
+    # a constant network ties every class: one-hot(v == max) is all ones -> never equals a one-hot label (rcn.rs:155)
+    r.set_params([w * 0 for w in ws], [b * 0 for b in bs])
+    assert r.evaluate(X, Y) == 0
+
+
+# ----------------------------------------------------------------------------------------------------- device-resident paths
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_epoch_graph_matches_sequential_oracle(amd, oracle, dtype):
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 32, 6, 256
+    ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=77, wscale=0.1)
+    d = DeviceRCN(dtype=dtype)
+    d.set_params(ws, bs)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    perm = np.random.default_rng(1).permutation(N).astype(np.int32)
+    permd = d.to_device(perm)
+    loss = d.empty(nb)
+    d.synchronize()
+    d.train_epoch(Xd, Yd, permd, B, nb, 3.0, loss)
+    d.train_epoch(Xd, Yd, permd, B, nb, 3.0, loss)             # replay of the cached graph: a second epoch
+    gw, gb = d.get_params()
+    losses = loss.cpu().numpy()
+    rw, rb = ws, bs
+    costs = []
+    for _ in range(2):
+        costs = []
+        for j in range(nb):
+            sel = perm[j * B:(j + 1) * B]
+            rw, rb, c = oracle.train_batch(rw, rb, X[sel], Y[sel], 3.0)
+            costs.append(c)
+    if dtype == 1:
+        _check_params(gw + gb, rw + rb, 1)
+        np.testing.assert_allclose(losses, costs, rtol=1e-10)
+    else:
+        for a, b in zip(gw + gb, rw + rb):                      # 12 chained f32 steps
+            assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)
+        np.testing.assert_allclose(losses, costs, rtol=1e-3)
+    # identity order (perm = NULL) == chunks_exact over the stored order
+    d.set_params(ws, bs)
+    d.train_epoch(Xd, Yd, None, B, 2, 3.0, None)
+    gw, gb = d.get_params()
+    rw, rb, _ = oracle.train_batch(ws, bs, X[:B], Y[:B], 3.0)
+    rw, rb, _ = oracle.train_batch(rw, rb, X[B:2 * B], Y[B:2 * B], 3.0)
+    if dtype == 1:
+        _check_params(gw + gb, rw + rb, 1)
+
+
+def test_data_parallel_halves_equal_full_batch(amd, oracle):
+    """Shard gradients + sum + one update == train_batch on the concatenated batch, single GPU."""
+    from mercer_research_amd.device import DeviceRCN
+    ws, bs, X, Y = _dense_case([784, 30, 10], 64, seed=5, wscale=0.1)
+    d = DeviceRCN(dtype=1)
+    d.set_params(ws, bs)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    d.synchronize()
+    g0 = d.batch_gradient(Xd[:32].contiguous(), Yd[:32].contiguous())
+    g1 = d.batch_gradient(Xd[32:].contiguous(), Yd[32:].contiguous())
+    gfull = d.batch_gradient(Xd, Yd)
+    d.synchronize()
+    np.testing.assert_allclose((g0 + g1).cpu().numpy(), gfull.cpu().numpy(), rtol=1e-10, atol=1e-13)
+    gW, gb, _ = oracle.batch_gradient(ws, bs, X, Y)
+    flat = np.concatenate([np.concatenate([w.ravel(order="F"), b]) for w, b in zip(gW, gb)])
+    np.testing.assert_allclose(gfull.cpu().numpy(), flat, rtol=1e-10, atol=1e-13)
+    d.apply_gradient(g0 + g1, 3.0 / 64)
+    gw, gbb = d.get_params()
+    nw, nb, _ = oracle.train_batch(ws, bs, X, Y, 3.0)
+    _check_params(gw + gbb, nw + nb, 1)
+    # params_flat is a live view of the same buffer
+    pf = d.params_flat()
+    assert pf.numel() == 23860
+    np.testing.assert_allclose(pf.cpu().numpy()[:784 * 30], gw[0].ravel(order="F"), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("B", [256, 4096])
+def test_full_size_properties(amd, B):
+    """BASELINE.json sizes (B=256 config 2, B=4096 config 5): additivity of the batch gradient over any split,
+    permutation invariance, and zero gradient for a perfectly-fit target -- no oracle needed."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    d = DeviceRCN(dtype=1)
+    ws, bs = synthetic_params([784, 30, 10], seed=1)
+    d.set_params([w * 0.05 for w in ws], bs)
+    imgs, labels = synthetic_images(B, seed=B)
+    with torch.cuda.stream(d.stream):
+        imgs_d = torch.from_numpy(imgs).to(d.device)
+        lab_d = torch.from_numpy(labels).to(d.device)
+    X, Y = d.load_data(imgs_d, lab_d)
+    full = d.batch_gradient(X, Y).clone()
+    with torch.cuda.stream(d.stream):
+        cut = B // 4 + 3
+        parts = d.batch_gradient(X[:cut].contiguous(), Y[:cut].contiguous()).clone() + d.batch_gradient(X[cut:].contiguous(), Y[cut:].contiguous())
+        p = torch.randperm(B, device=d.device)
+        permuted = d.batch_gradient(X[p].contiguous(), Y[p].contiguous()).clone()
+        fit = d.forward(X)
+        zero = d.batch_gradient(X, fit.contiguous())
+    d.synchronize()
+    scale = full.abs().max().item()
+    assert scale > 0
+    assert (parts - full).abs().max().item() <= 1e-11 * scale
+    assert (permuted - full).abs().max().item() <= 1e-11 * scale
+    assert zero.abs().max().item() == 0.0
+
+
+def test_full_size_feature_properties(amd, oracle):
+    """16 384 images (the bench set): device features are integers in range, invariant to batch order, and equal to
+    the oracle on a sample."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    d = DeviceRCN(dtype=0)
+    imgs, _ = synthetic_images(16384)
+    with torch.cuda.stream(d.stream):
+        imgs_d = torch.from_numpy(imgs).to(d.device)
+        f = d.features(imgs_d)
+        idx = torch.randperm(16384, device=d.device)
+        f2 = d.features(imgs_d[idx].contiguous())
+    d.synchronize()
+    assert torch.equal(f[idx], f2)
+    assert torch.equal(f, f.round()) and f.min().item() >= 0 and f.max().item() <= 16320
+    sel = np.arange(0, 16384, 331)
+    assert np.array_equal(f[sel].cpu().numpy().astype(np.float64), oracle.features(imgs[sel], DEFAULT_LAYERS))
+    m, s = d.gen_scales(f)
+    fo = f.double()
+    assert abs(m - fo.mean().item()) <= 1e-9 * m and abs(s - fo.std(unbiased=False).item()) <= 1e-9 * s
