@@ -97,14 +97,15 @@ def test_operator_panics(amd):
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_features_default_net_bit_exact(amd, oracle, dtype):
     imgs, _ = synthetic_images(96, seed=21)
-    imgs[0] = 255                        # saturated image: largest magnitudes (16 320) still exact in f32
+    imgs[0] = 255                        # saturated image
+    imgs[3, ::2] = 255; imgs[3, 1::2] = 0  # stripes: strongest edge responses
     imgs[1] = 0
     imgs[2] = np.random.default_rng(0).integers(0, 256, (28, 28))   # no black border: exercises the Q1 edge columns
     r = _mk(amd, [784, 30, 10], dtype)
     got = r.flatten_feature_set(imgs)
     assert got.shape == (96, 784)
     assert np.array_equal(got, oracle.features(imgs, DEFAULT_LAYERS))
-    assert got.max() == 16320.0
+    assert 2040 < got.max() <= 16320.0      # bound of SURVEY §8c: 255 * 8^2
 
 
 @pytest.mark.parametrize("spec,shape", [
@@ -304,7 +305,7 @@ def test_evaluate_semantics(amd, oracle):
     out = oracle.classify_test(ws, bs, X)
     Y = one_hot(out.argmax(axis=1))
     Y[::3] = np.roll(Y[::3], 1, axis=1)                       # make a third of the expectations wrong
-    expect = sum(oracle.eval_accept(o, y, 10) for o, y in zip(out, Y))
+    expect = sum(oracle.eval_accept(o, y) for o, y in zip(out, Y))
     assert r.evaluate(X, Y) == expect and 150 < expect < 300
     # a constant network ties every class: one-hot(v == max) is all ones -> never equals a one-hot label (rcn.rs:155)
     r.set_params([w * 0 for w in ws], [b * 0 for b in bs])
@@ -395,8 +396,8 @@ def test_full_size_properties(amd, B):
         imgs_d = torch.from_numpy(imgs).to(d.device)
         lab_d = torch.from_numpy(labels).to(d.device)
     X, Y = d.load_data(imgs_d, lab_d)
-    full = d.batch_gradient(X, Y).clone()
-    with torch.cuda.stream(d.stream):
+    with torch.cuda.stream(d.stream):             # torch ops must run on the context's stream to be ordered with our kernels
+        full = d.batch_gradient(X, Y).clone()
         cut = B // 4 + 3
         parts = d.batch_gradient(X[:cut].contiguous(), Y[:cut].contiguous()).clone() + d.batch_gradient(X[cut:].contiguous(), Y[cut:].contiguous())
         p = torch.randperm(B, device=d.device)
