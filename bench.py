@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline")
     args = ap.parse_args()
 
     import torch
@@ -109,36 +110,57 @@ def main():
     imgs, labels = synthetic_images(N_IMAGES, seed=1234 + rank)          # every rank owns a different shard of data
     ws, bs = synthetic_params(DIMS, seed=42)                             # identical replicas (rcn.rs:500-523 shapes)
     d.set_params(ws, bs)
+    d.set_dense_path(args.path)
     with torch.cuda.stream(d.stream):
         imgs_d = torch.from_numpy(imgs).to(d.device)
         labels_d = torch.from_numpy(labels).to(d.device)
     X, Y = d.load_data(imgs_d, labels_d)                                 # HIP features + gen_scales + standardise (load time)
     nb_epoch = N_IMAGES // B_PER_GPU
-    perm = torch.empty(N_IMAGES, dtype=torch.int32, device=d.device)
     B = B_PER_GPU
     step_no = [0]
+    # training_set.shuffle (rcn.rs:146): the permutation of epoch e+1 is drawn on a side stream while epoch e trains
+    # (two index buffers, events in both directions), so the epoch loop on the main stream is graph launch after graph
+    # launch.  It is still drawn once per epoch, inside the timed region.
+    perms = [torch.empty(N_IMAGES, dtype=torch.int32, device=d.device) for _ in range(2)]
+    shuf_stream = torch.cuda.Stream(device=d.device)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+    epoch_no = [0]
 
-    def reshuffle():
-        with torch.cuda.stream(d.stream):
-            perm.copy_(torch.randperm(N_IMAGES, device=d.device))        # training_set.shuffle (rcn.rs:146)
+    def draw(buf: int):
+        with torch.cuda.stream(shuf_stream):
+            shuf_stream.wait_event(consumed[buf])                        # the epoch that last read this buffer has finished
+            perms[buf].copy_(torch.randperm(N_IMAGES, device=d.device))
+            ready[buf].record(shuf_stream)
 
     if world == 1:
+        for b_ in range(2):
+            consumed[b_].record(d.stream)
+        draw(0)
+
         def run(k: int):
-            """k consecutive train_batch steps; epoch boundaries reshuffle."""
+            """k consecutive train_batch steps; every 64 steps (one pass over the set) a new permutation."""
             done = 0
             while done < k:
                 pos = step_no[0] % nb_epoch
+                buf = epoch_no[0] % 2
                 if pos == 0:
-                    reshuffle()
+                    d.stream.wait_event(ready[buf])
+                    draw(1 - buf)                                        # next epoch's permutation, off the critical path
                 take = min(k - done, nb_epoch - pos)
-                d.train_epoch(X, Y, perm[pos * B:], B, take, ETA, None)
+                d.train_epoch(X, Y, perms[buf][pos * B:], B, take, ETA, None)
                 step_no[0] += take
                 done += take
+                if step_no[0] % nb_epoch == 0:
+                    consumed[buf].record(d.stream)
+                    epoch_no[0] += 1
     else:
         dp = DataParallelStep(d)
         dp.broadcast_params(0)
         xb = d.empty(B, d.F)
         yb = d.empty(B, d.classes)
+
+        perm = perms[0]
 
         def run(k: int):
             with torch.cuda.stream(d.stream):
@@ -192,22 +214,27 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events on the stream the kernels run on) ----
-        us_fwd, us_wgrad = d.time_kernels(X[:B], Y[:B], reps=400)
+        us_first, us_second = d.time_kernels(X[:B], Y[:B], reps=400)
         es = 8 if args.dtype == "f64" else 4
-        P = d.P
-        sumd = sum(DIMS[1:])
-        # algorithmic bytes per launch (DESIGN.md "Kernels"): fwd reads the B feature rows, the B targets and every
-        # parameter once and writes hidden activations + deltas; wgrad reads deltas/activations and read-modify-writes
-        # the parameters.  Its second pass over the feature rows is an implementation artefact, not algorithmic.
-        bytes_fwd = (B * DIMS[0] + B * DIMS[-1] + P + B * (sumd - DIMS[-1]) + B * sumd) * es
-        bytes_wgrad = (B * DIMS[0] + B * sumd + B * (sumd - DIMS[-1]) + 2 * P) * es
-        dom = "k_dense_fwd" if us_fwd >= us_wgrad else "k_dense_wgrad"
-        us, by = (us_fwd, bytes_fwd) if dom == "k_dense_fwd" else (us_wgrad, bytes_wgrad)
-        flops_step = 2 * B * (sum(DIMS[i] * DIMS[i + 1] for i in range(2)) * 2 + DIMS[1] * DIMS[2])
+        P, F, H, C = d.P, DIMS[0], DIMS[1], DIMS[2]
+        G = (F + 15) // 16
+        # algorithmic bytes per launch (DESIGN.md "Kernels"), feature-sliced path:
+        #   k_pipe_a: both batches' feature rows once (finish step i-1, start step i), delta_1/delta_2/a_1 of step i-1,
+        #             every parameter read + written once.  (Its slab write is an implementation artefact, excluded.)
+        #   k_pipe_b: the targets, tail parameters + b_0; writes a_1, delta_1, delta_2.  (Slab read excluded likewise.)
+        bytes_a = (2 * B * F + B * (2 * H + C) + 2 * P) * es
+        bytes_b = (B * C + (P - F * H) + B * (2 * H + C)) * es
+        names = ("k_pipe_b", "k_pipe_a") if args.path != 1 else ("k_dense_fwd", "k_dense_wgrad")
+        if args.path == 1:
+            sumd = H + C
+            bytes_b = (B * F + B * C + P + B * H + B * sumd) * es          # k_dense_fwd
+            bytes_a = (B * F + B * sumd + B * H + 2 * P) * es              # k_dense_wgrad
+        dom, us, by = (names[0], us_first, bytes_b) if us_first >= us_second else (names[1], us_second, bytes_a)
+        flops_step = 2 * B * ((F * H + H * C) * 2 + H * C)
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(by / us / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 5), "traffic": None,
                               "algorithmic_bytes_per_launch": by, "us_per_launch_hip_events": round(us, 3),
-                              "us_fwd": round(us_fwd, 3), "us_wgrad": round(us_wgrad, 3),
+                              "us_" + names[0]: round(us_first, 3), "us_" + names[1]: round(us_second, 3),
                               "step_gflops_per_s": round(flops_step / (elapsed / args.steps) / 1e9, 1),
                               "note": "one train_batch at B=256 moves ~1 MB and ~25 MFLOP: launch/latency-bound, far from either roof"}
         if not args.no_cpu_baseline:

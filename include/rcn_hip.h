@@ -176,14 +176,19 @@ int  rcn_hip_evaluate_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev
 /* RCN::classify minus the PNG decode (rcn.rs:82-98): features -> standardise with scale_set -> forward -> arg-max */
 int  rcn_hip_classify_images(rcn_hip_ctx* ctx, const uint8_t* imgs, size_t n, int32_t* class_out);
 
-/* ---------------------------------------------------------------- measurement aid (bench.py's roofline leg) */
-/* Times the two kernels of one train_batch with HIP events on the context's stream: `reps` back-to-back launches of
- * each kernel (one hipGraph of `reps` dependent nodes per kernel, so the host launch rate does not bound the result),
- * events recorded immediately before and after each graph.  Returns the mean microseconds per launch, which therefore
- * INCLUDES one dependent-launch boundary per launch.  us_wgrad times the gradient-only form (APPLY=false) so the
- * parameters do not drift while timing.  Blocks. */
+/* ---------------------------------------------------------------- tuning / measurement aids */
+/* Which kernels implement train_batch / train_epoch: 0 = automatic (feature-sliced pipeline for batches <= 1024 when
+ * the layer stack allows it, sample-tile kernels otherwise), 1 = always the sample-tile kernels, 2 = always the
+ * feature-sliced pipeline.  Both compute the same step (summation grouping differs, within the stated tolerances). */
+int  rcn_hip_set_dense_path(rcn_hip_ctx* ctx, int mode);
+
+/* Times the two kernels of one train_batch at batch size B with HIP events on the context's stream: `reps`
+ * back-to-back launches of each kernel (one hipGraph of `reps` dependent nodes per kernel, so the host launch rate does
+ * not bound the result), events recorded immediately before and after each graph.  Returns the mean microseconds per
+ * launch.  us_first / us_second are (k_dense_fwd, k_dense_wgrad) on the sample-tile path and (k_pipe_b, k_pipe_a) on
+ * the feature-sliced path; updates run with a zero step so the parameters do not drift while timing.  Blocks. */
 int  rcn_hip_time_kernels_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t B, int reps,
-                              double* us_fwd, double* us_wgrad);
+                              double* us_first, double* us_second);
 
 #ifdef __cplusplus
 }

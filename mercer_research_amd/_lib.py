@@ -76,6 +76,7 @@ SIGNATURES = {
     "rcn_hip_evaluate": (_i, [_vp, _dp, _dp, _sz, _i64p]),
     "rcn_hip_evaluate_dev": (_i, [_vp, _vp, _vp, _sz, _i64p]),
     "rcn_hip_classify_images": (_i, [_vp, _u8p, _sz, _i32p]),
+    "rcn_hip_set_dense_path": (_i, [_vp, _i]),
     "rcn_hip_time_kernels_dev": (_i, [_vp, _vp, _vp, _sz, _i, _dp, _dp]),
 }
 

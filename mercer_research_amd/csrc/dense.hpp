@@ -26,11 +26,20 @@ constexpr int kMtp = 2;                                // M-tiles (16 rows each)
 constexpr int kRedTile = kTileS * kLd;                 // 272: one padded 16x16 partial tile
 constexpr int kChunkK = 32;                            // features staged per wave per chunk
 
+constexpr int kStageCap = 12288;                       // tail-layer parameters staged in LDS when they fit (elements)
+
+// parameters of layers >= 1 (everything after [W_0|b_0]) -- staged into LDS by k_dense_fwd when small enough
+inline int dense_tail_params(const NetDesc& nd) { return nd.L > 1 ? nd.P - nd.w_off[1] : 0; }
+inline bool dense_tail_staged(const NetDesc& nd) { return dense_tail_params(nd) <= kStageCap; }
+// feature rows can be loaded as 16-byte vectors straight into MFMA fragments
+inline bool dense_vec_rows(const NetDesc& nd, size_t esz) { return nd.dims[0] % 4 == 0 && (nd.dims[0] * esz) % 16 == 0; }
+
 // LDS elements (of T) k_dense_fwd needs
 inline size_t dense_fwd_lds_elems(const NetDesc& nd) {
     int sumd = 0, maxd = 0;
     for (int j = 1; j <= nd.L; ++j) { sumd += nd.dims[j]; if (nd.dims[j] > maxd) maxd = nd.dims[j]; }
-    return (size_t)kLd * (size_t)(sumd + 2 * maxd + kDenseWaves * kChunkK) + (size_t)kDenseWaves * kMtp * kRedTile + 64;
+    const size_t stage = dense_tail_staged(nd) ? (size_t)((dense_tail_params(nd) + 3) & ~3) : 0;
+    return (size_t)kLd * (size_t)(sumd + 2 * maxd + kDenseWaves * kChunkK) + (size_t)kDenseWaves * kMtp * kRedTile + 64 + stage;
 }
 inline size_t dense_wgrad_lds_elems() { return (size_t)kDenseWaves * kMtp * kRedTile + 64; }
 
@@ -62,7 +71,17 @@ __device__ inline T sum_partials(const T* red, int mt, int c, int r) {
     return v;
 }
 
-template <typename T, bool TRAIN>
+template <typename T> struct Vec4;
+template <> struct Vec4<float>  { using type = __attribute__((ext_vector_type(4))) float; };
+template <> struct Vec4<double> { using type = __attribute__((ext_vector_type(4))) double; };
+
+template <typename T> struct VecGroups { static constexpr int value = sizeof(T) == 8 ? 4 : 8; };   // 16-feature groups in flight (VGPR budget)
+
+// VECX:   feature rows are 16-byte aligned -> layer 0 loads them as vectors directly into MFMA B fragments (no LDS
+//         staging, every load of a wave's K-slice in flight at once); otherwise rows are staged through LDS chunks.
+// STAGED: the parameters of layers >= 1 are copied to LDS once at kernel start, so the small tail GEMMs and the
+//         delta back-propagation never wait on global memory.
+template <typename T, bool TRAIN, bool VECX, bool STAGED>
 __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
     NetDesc nd, const T* __restrict__ params, const T* __restrict__ X, const T* __restrict__ Y,
     const int* __restrict__ idx, int B, T* __restrict__ acts, T* __restrict__ deltas,
@@ -85,12 +104,18 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
     T* red = xs + kDenseWaves * kChunkK * kLd;        // [wave][mt][16][kLd]
     long long* rowoff = reinterpret_cast<long long*>(red + kDenseWaves * kMtp * kRedTile);  // 16 row bases (elements)
     T* lossred = reinterpret_cast<T*>(rowoff + kTileS);                                        // kDenseWaves scalars
+    T* wsm = red + kDenseWaves * kMtp * kRedTile + 64;                                         // staged tail parameters
+    const int tail0 = L > 1 ? nd.w_off[1] : nd.P;
 
+    if (STAGED) {
+        const int cnt = nd.P - tail0;
+        for (int e = tid; e < cnt; e += kDenseThreads) wsm[e] = params[tail0 + e];
+    }
     if (tid < kTileS) {
-        const int gs = s0 + tid;
-        long long r = -1;
-        if (gs < B) r = idx ? (long long)idx[gs] : (long long)gs;
-        rowoff[tid] = r;
+        // rows past the end of the batch alias the batch's last row (always a legal address) and are masked by value,
+        // so that no load in the kernel is conditional (a select after an unconditional load keeps them all in flight)
+        const int gs = s0 + tid < B ? s0 + tid : B - 1;
+        rowoff[tid] = idx ? (long long)idx[gs] : (long long)gs;
     }
     __syncthreads();
 
@@ -98,7 +123,8 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
     for (int j = 0; j < L; ++j) {
         const int K = nd.dims[j], M = nd.dims[j + 1];
         const T* __restrict__ Wj = params + nd.w_off[j];
-        const T* __restrict__ bj = Wj + (size_t)M * K;
+        const T* Ws = (STAGED && j >= 1) ? wsm + (nd.w_off[j] - tail0) : Wj;     // LDS copy for the tail layers
+        const T* bj = Ws + (size_t)M * K;
         const T* aPrev = actT + kLd * nd.act_off[j];          // valid for j >= 1
         T* aNext = actT + kLd * nd.act_off[j + 1];
         int kb, ke;
@@ -107,7 +133,42 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
             acc_t acc[kMtp];
 #pragma unroll
             for (int mt = 0; mt < kMtp; ++mt) acc[mt] = acc_t{0, 0, 0, 0};
-            if (j == 0) {
+            if (j == 0 && VECX) {
+                // lane (n, g) owns features k0+4g .. k0+4g+3 of row n as ONE 16-byte load and feeds them to four
+                // MFMAs; the A fragment of MFMA i takes W[:, k0+4g+i], so both operands agree on k.
+                using vec4 = typename Vec4<T>::type;
+                const long long r = rowoff[n];
+                const bool rv = s0 + n < B;
+                constexpr int kVecGroups = VecGroups<T>::value;
+                for (int kc = kb; kc < ke; kc += 16 * kVecGroups) {
+                    vec4 xv[kVecGroups];
+                    T wv[kVecGroups][4][kMtp];
+#pragma unroll
+                    for (int gi = 0; gi < kVecGroups; ++gi) {
+                        const int k0 = kc + 16 * gi + 4 * g;
+                        const int kk = k0 < ke ? k0 : kb;                 // K % 4 == 0 and kb % 4 == 0: whole vectors only
+                        xv[gi] = *reinterpret_cast<const vec4*>(X + r * (long long)K + kk);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int mt = 0; mt < kMtp; ++mt) {
+                                const int row = mbase + mt * 16 + n;
+                                wv[gi][i][mt] = Wj[(size_t)(kk + i) * M + (row < M ? row : M - 1)];
+                            }
+                    }
+#pragma unroll
+                    for (int gi = 0; gi < kVecGroups; ++gi) {
+                        const bool kin = kc + 16 * gi + 4 * g < ke;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int mt = 0; mt < kMtp; ++mt) {
+                                const bool rowin = mbase + mt * 16 + n < M;
+                                acc[mt] = Mfma16<T>::mfma((kin && rowin) ? wv[gi][i][mt] : (T)0, (kin && rv) ? xv[gi][i] : (T)0, acc[mt]);
+                            }
+                    }
+                }
+            } else if (j == 0) {
                 // stream this wave's K-slice of the 16 feature rows through a private LDS chunk
                 T* xw = xs + wave * kChunkK * kLd;
                 const int kl = lane & 31, sh = lane >> 5;
@@ -117,7 +178,8 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
                     for (int q = 0; q < 8; ++q) {
                         const long long r = rowoff[2 * q + sh];
                         const int k = kc + kl;
-                        v[q] = (r >= 0 && k < ke) ? X[r * (long long)K + k] : (T)0;
+                        const T xr = X[r * (long long)K + (k < ke ? k : kb)];
+                        v[q] = (s0 + 2 * q + sh < B && k < ke) ? xr : (T)0;
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) xw[kl * kLd + 2 * q + sh] = v[q];
@@ -141,7 +203,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
 #pragma unroll
                     for (int mt = 0; mt < kMtp; ++mt) {
                         const int row = mbase + mt * 16 + n;
-                        const T av = (row < M && k < ke) ? Wj[(size_t)k * M + row] : (T)0;
+                        const T av = (row < M && k < ke) ? Ws[(size_t)k * M + row] : (T)0;
                         acc[mt] = Mfma16<T>::mfma(av, bv, acc[mt]);
                     }
                 }
@@ -176,7 +238,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
             const int s = e / M, m = e - s * M;
             const long long r = rowoff[s];
             T d = 0;
-            if (r >= 0) {
+            if (s0 + s < B) {
                 const T a = aL[m * kLd + s];
                 const T diff = a - Y[r * (long long)M + m];
                 d = diff * (a * ((T)1 - a));                 // (a_L - y) (*) sigmoid'(z_L), sigmoid' = s(1-s)  rcn.rs:491
@@ -201,7 +263,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
     T* dNxt = dT1;
     for (int j = L - 1; j >= 1; --j) {
         const int M = nd.dims[j], K = nd.dims[j + 1];          // delta_j = (W_j^T delta_{j+1}) (*) s'(z_j)
-        const T* __restrict__ Wj = params + nd.w_off[j];        // K x M column-major: (k, m) at m*K + k
+        const T* Wj = STAGED ? wsm + (nd.w_off[j] - tail0) : params + nd.w_off[j];   // K x M column-major: (k, m) at m*K + k
         const T* aJ = actT + kLd * nd.act_off[j];
         int kb, ke;
         wave_k_range(K, wave, kb, ke);
@@ -241,55 +303,57 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
     }
 }
 
-// grid = nd.tile_start[L] workgroups; workgroup -> (layer j, 16 columns of [W_j | b_j])
+// One 16-column tile (columns n0..n0+15) of [W_j | b_j]: dW = Delta_{j+1} . [A_j | 1]^T summed over the whole batch
+// (the MFMA contraction index is the sample), then either the SGD update or the raw gradient.
 template <typename T, bool APPLY>
-__global__ __launch_bounds__(kDenseThreads) void k_dense_wgrad(
-    NetDesc nd, T* __restrict__ params, T* __restrict__ grad_out, const T* __restrict__ X,
-    const int* __restrict__ idx, const T* __restrict__ acts, const T* __restrict__ deltas, int B, T scale,
-    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out) {
+__device__ inline void wgrad_tile_ld(const NetDesc& nd, int j, int n0, T* __restrict__ params, T* __restrict__ grad_out,
+                                     const T* __restrict__ Aprev, long long ldAin, const int* __restrict__ idx,
+                                     const T* __restrict__ D, int ldD, int B, T scale, T* red) {
     using acc_t = typename Mfma16<T>::acc_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* red = reinterpret_cast<T*>(smem_raw);
-
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    int j = 0;
-    while (j + 1 < nd.L && (int)blockIdx.x >= nd.tile_start[j + 1]) ++j;
-    const int n0 = ((int)blockIdx.x - nd.tile_start[j]) * 16;
     const int Kin = nd.dims[j], M = nd.dims[j + 1];
-    const T* __restrict__ D = deltas + (size_t)B * nd.act_off[j + 1];          // delta_{j+1}: [B][M]
-    const T* __restrict__ Aprev = (j == 0) ? X : acts + (size_t)B * nd.act_off[j];  // a_j: [B][Kin]
     const int c = n0 + n;                                                        // this lane's column of [W|b]
-
-    // quadratic cost 1/(2B) sum ||a_L - y||^2 (what rcn.rs:299 is the gradient of); fixed-order sum
-    if (blockIdx.x == 0 && tid == 0 && loss_out) {
-        T t = 0;
-        for (int i = 0; i < n_loss; ++i) t += loss_part[i];
-        *loss_out = t * loss_scale;
-    }
-
+    // a bias-only tile may be called without the activation rows (Aprev == nullptr): its loads (never used, every
+    // column is >= Kin) are pointed at the delta buffer instead, so that they stay unconditional and legal
+    const T* __restrict__ Ald = Aprev ? Aprev : D;
+    const long long ldA = Aprev ? ldAin : 0;
     int kb, ke;
     wave_k_range(B, wave, kb, ke);
     for (int mbase = 0; mbase < M; mbase += 16 * kMtp) {
         acc_t acc[kMtp];
 #pragma unroll
         for (int mt = 0; mt < kMtp; ++mt) acc[mt] = acc_t{0, 0, 0, 0};
-#pragma unroll 4
-        for (int k0 = kb; k0 < ke; k0 += 4) {
-            const int s = k0 + g;                              // contraction index = sample
-            T bv = 0;
-            if (s < ke) {
-                if (c < Kin) {
-                    const long long r = (j == 0 && idx) ? (long long)idx[s] : (long long)s;
-                    bv = Aprev[r * (long long)Kin + c];
-                } else if (c == Kin) {
-                    bv = (T)1;                                 // bias column: db = sum_s delta  (rcn.rs:302,309)
+        // 8 k-steps (32 samples) per chunk: every index / activation / delta load of the chunk is issued before the
+        // first MFMA, so a wave pays the memory latency once per chunk instead of once per k-step
+        for (int kc = kb; kc < ke; kc += 32) {
+            long long r[8];
+            T bv[8], av[8][kMtp];
+            const int cc_ld = Aprev ? (c < Kin ? c : Kin - 1) : 0;   // clamped column: loads are unconditional, masked by value
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int s = kc + 4 * q + g;                  // contraction index = sample
+                const int sc = s < ke ? s : kb;
+                r[q] = idx ? (long long)idx[sc] : (long long)sc;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int s = kc + 4 * q + g;
+                const int sc = s < ke ? s : kb;
+                bv[q] = Ald[r[q] * ldA + cc_ld];
+#pragma unroll
+                for (int mt = 0; mt < kMtp; ++mt) {
+                    const int row = mbase + mt * 16 + n;
+                    av[q][mt] = D[(size_t)sc * ldD + (row < M ? row : M - 1)];
                 }
             }
 #pragma unroll
-            for (int mt = 0; mt < kMtp; ++mt) {
-                const int row = mbase + mt * 16 + n;
-                const T av = (row < M && s < ke) ? D[(size_t)s * M + row] : (T)0;
-                acc[mt] = Mfma16<T>::mfma(av, bv, acc[mt]);
+            for (int q = 0; q < 8; ++q) {
+                const bool sv = kc + 4 * q + g < ke;
+                // bias column: the activation is the constant 1, so db = sum_s delta  (rcn.rs:302,309)
+                const T b = sv ? (c < Kin ? bv[q] : (c == Kin ? (T)1 : (T)0)) : (T)0;
+#pragma unroll
+                for (int mt = 0; mt < kMtp; ++mt)
+                    acc[mt] = Mfma16<T>::mfma((sv && mbase + mt * 16 + n < M) ? av[q][mt] : (T)0, b, acc[mt]);
             }
         }
         store_partials<T>(red, wave, lane, acc);
@@ -306,6 +370,39 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_wgrad(
         }
         __syncthreads();
     }
+}
+
+// the same tile on the unpadded [B][d] activation / delta images the sample-tile and generic pipeline kernels use
+template <typename T, bool APPLY>
+__device__ inline void wgrad_tile(const NetDesc& nd, int j, int n0, T* __restrict__ params, T* __restrict__ grad_out,
+                                  const T* __restrict__ X, const int* __restrict__ idx, const T* __restrict__ acts,
+                                  const T* __restrict__ deltas, int B, T scale, T* red) {
+    const T* Aprev = (j == 0) ? X : acts + (size_t)B * nd.act_off[j];           // a_j: [B][Kin]
+    wgrad_tile_ld<T, APPLY>(nd, j, n0, params, grad_out, Aprev, nd.dims[j], (j == 0) ? idx : nullptr,
+                            deltas + (size_t)B * nd.act_off[j + 1], nd.dims[j + 1], B, scale, red);
+}
+
+// quadratic cost 1/(2B) sum ||a_L - y||^2 (what rcn.rs:299 is the gradient of); fixed-order sum by one thread
+template <typename T>
+__device__ inline void finish_loss(const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out) {
+    T t = 0;
+    for (int i = 0; i < n_loss; ++i) t += loss_part[i];
+    *loss_out = t * loss_scale;
+}
+
+// grid = nd.tile_start[L] workgroups; workgroup -> (layer j, 16 columns of [W_j | b_j])
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(kDenseThreads) void k_dense_wgrad(
+    NetDesc nd, T* __restrict__ params, T* __restrict__ grad_out, const T* __restrict__ X,
+    const int* __restrict__ idx, const T* __restrict__ acts, const T* __restrict__ deltas, int B, T scale,
+    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);
+    int j = 0;
+    while (j + 1 < nd.L && (int)blockIdx.x >= nd.tile_start[j + 1]) ++j;
+    const int n0 = ((int)blockIdx.x - nd.tile_start[j]) * 16;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) finish_loss<T>(loss_part, n_loss, loss_scale, loss_out);
+    wgrad_tile<T, APPLY>(nd, j, n0, params, grad_out, X, idx, acts, deltas, B, scale, red);
 }
 
 // p <- p - scale * g  (the update half of train_batch when gradients were all-reduced first)

@@ -1,0 +1,279 @@
+// dense_p2.hpp -- the feature-sliced pipeline of dense_pipe.hpp, specialised for the shape class of the reference's
+// own network (rcn/src/main.rs:53-59: ONE hidden layer): hidden <= 32, classes <= 16, batch a multiple of 256.
+//
+// Same algorithm and the same packed slice-major batch image (k_pack_epoch); what changes is the instruction count.
+// At this problem size a kernel runs at 1-2 waves per SIMD, so every instruction costs its full issue latency:
+// the generic kernels spend ~2000 instructions per wave on runtime div/mod, 64-bit clamped addressing and scalar LDS
+// loops.  Here every internal image has power-of-two padded rows (hidden -> 32, classes -> 16; pads are exact zeros),
+// so index math is shifts and immediates, no load needs a clamp, the tail layer runs on MFMA from fragments that are
+// loaded straight from global memory at kernel entry, and the slab sum is spread over all four waves.
+//
+//   internal images (device only; the parameter layout stays the reference's column-major W|b):
+//     a1 [B][32]  hidden activations      d1 [B][32]  delta of the hidden layer      d2 [B][16]  output delta
+//     slab [B/8][G][8][32]                partial z_1 per 16-feature slice, contiguous per k_p2_b workgroup
+#pragma once
+
+#include "common.hpp"
+#include "dense.hpp"
+#include "dense_pipe.hpp"
+
+namespace rcn {
+
+constexpr int kP2H = 32, kP2C = 16, kP2Ts = 8, kP2BThreads = 256, kP2MaxSlices = 64;
+
+inline bool p2_supported(const NetDesc& nd, size_t B) {
+    return nd.L == 2 && nd.dims[1] <= kP2H && nd.dims[2] <= kP2C && B % 256 == 0 && B >= 256 && pipe_slices(nd) <= kP2MaxSlices;
+}
+inline size_t p2_a_lds_elems() { return (size_t)kDenseWaves * kMtp * kRedTile + 16 * kP2H + 64; }
+
+template <typename T>
+__device__ inline void store4(T* dst, int lane, const typename Mfma16<T>::acc_t& v) {
+    // rows held by a lane: f32 4*(lane>>4)+i (contiguous -> one 16-byte store), f64 (lane>>4)+4i (strided)
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<typename Vec4<T>::type*>(dst + 4 * (lane >> 4)) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[(lane >> 4) + 4 * i] = v[i];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kDenseThreads) void k_p2_a(
+    NetDesc nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B,
+    const T* __restrict__ a1, const T* __restrict__ d1, const T* __restrict__ d2, T scale, T* __restrict__ slab, int G,
+    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd) {
+    using acc_t = typename Mfma16<T>::acc_t;
+    using vec4 = typename Vec4<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
+    const int F = nd.dims[0], H = nd.dims[1];
+    RCN_STAMP(0, 0);
+
+    if ((int)blockIdx.x >= G) {
+        // e == 0: bias column of W_0 (db_0 = sum_s delta_1);  e >= 1: 16-column tiles of [W_1 | b_1]
+        if (!do_update) return;
+        const int e = (int)blockIdx.x - G;
+        if (e == 0 && tid == 0 && loss_out) finish_loss<T>(loss_part, n_loss, loss_scale, loss_out);
+        if (e == 0) wgrad_tile_ld<T, true>(nd, 0, F, params, (T*)nullptr, (const T*)nullptr, 0, (const int*)nullptr, d1, kP2H, B, scale, red);
+        else        wgrad_tile_ld<T, true>(nd, 1, (e - 1) * 16, params, (T*)nullptr, a1, kP2H, (const int*)nullptr, d2, kP2C, B, scale, red);
+        return;
+    }
+
+    const int f0 = (int)blockIdx.x * 16;
+    const int nf = F - f0 < 16 ? F - f0 : 16;
+    T* wsl = red + kDenseWaves * kMtp * kRedTile;                   // this slice of W_0: [feature 0..15][32]
+    T* W0 = params + nd.w_off[0];
+    const T* __restrict__ cp = Xp + (size_t)blockIdx.x * B * 16;
+    const T* __restrict__ cn = Xn + (size_t)blockIdx.x * B * 16;
+    const int ntile = B >> 4;                                        // B % 256 == 0: 2*k tiles per wave, no remainder
+
+    // new batch first (needed last): lane (n, g4) <- features 4g4..4g4+3 of sample 16t+n
+    vec4 xn[2];
+    if (do_fwd) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xn[u] = *reinterpret_cast<const vec4*>(cn + (size_t)(16 * (wave + 8 * u) + n) * 16 + 4 * g4);
+    }
+
+    if (do_update) {
+        // ---- U: dW_0[:, slice] = sum_s delta_1[s] (x) x_s[slice]; W_0 <- W_0 - (eta/B) dW_0          rcn.rs:310, 214
+        const int ml = tid & 15, cl = (tid >> 4) & 15, mt = tid >> 8;
+        const int m = mt * 16 + ml;
+        const bool wvalid = m < H && cl < nf;
+        const T wold = W0[(size_t)(f0 + (cl < nf ? cl : 0)) * H + (m < H ? m : 0)];
+        acc_t acc[kMtp];
+#pragma unroll
+        for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        const int kw = B >> 3;                                       // samples per wave, a multiple of 32
+        for (int kc = wave * kw; kc < (wave + 1) * kw; kc += 32) {
+            const T* xb = cp + (size_t)(kc + g4) * 16 + n;
+            const T* db = d1 + (size_t)(kc + g4) * kP2H + n;
+            T bv[8], av[8][kMtp];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                bv[q] = xb[q * 64];
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) av[q][t] = db[q * 4 * kP2H + t * 16];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(av[q][t], bv[q], acc[t]);
+        }
+        RCN_STAMP(0, 1);
+        store_partials<T>(red, wave, lane, acc);
+        __syncthreads();
+        RCN_STAMP(0, 2);
+        {
+            const T w = wold - scale * sum_partials<T>(red, mt, cl, ml);
+            if (wvalid) W0[(size_t)(f0 + cl) * H + m] = w;
+            wsl[cl * kP2H + m] = wvalid ? w : (T)0;
+        }
+        __syncthreads();
+    } else {
+        for (int e = tid; e < 16 * kP2H; e += kDenseThreads) {
+            const int cl = e >> 5, m = e & 31;
+            const bool ok = m < H && cl < nf;
+            const T w = W0[(size_t)(f0 + (cl < nf ? cl : 0)) * H + (m < H ? m : 0)];
+            wsl[e] = ok ? w : (T)0;
+        }
+        __syncthreads();
+    }
+    RCN_STAMP(0, 3);
+    if (!do_fwd) return;
+
+    // ---- F: partial z_1 for all samples of the new batch from the slice that is still in LDS
+    T wf[4][kMtp];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < kMtp; ++t) wf[i][t] = wsl[(4 * g4 + i) * kP2H + t * 16 + n];
+    for (int tb = 0; tb < ntile; tb += 16) {
+        if (tb > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) xn[u] = *reinterpret_cast<const vec4*>(cn + (size_t)(16 * (tb + wave + 8 * u) + n) * 16 + 4 * g4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = 16 * (tb + wave + 8 * u) + n;
+            acc_t acc[kMtp];
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(wf[i][t], xn[u][i], acc[t]);
+            T* dst = slab + (((size_t)(s >> 3) * G + blockIdx.x) * kP2Ts + (s & 7)) * kP2H;
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) store4<T>(dst + t * 16, lane, acc[t]);
+        }
+    }
+    RCN_STAMP(0, 5);
+}
+
+// One workgroup per 8 samples, 4 waves.  All four waves sum slabs (slices w, w+4, ...).  Waves 1-3 additionally fetch
+// and mask the tail's operands into LDS as ready-made MFMA fragments, so that wave 0 -- the critical path, ~5.6 cycles
+// per instruction when a wave runs alone on its SIMD -- only reads fragments, issues 16 MFMAs and stores.
+template <typename T>
+__global__ __launch_bounds__(kP2BThreads) void k_p2_b(
+    NetDesc nd, const T* __restrict__ params, const T* __restrict__ slab, int G, const T* __restrict__ Ys, int B,
+    T* __restrict__ a1g, T* __restrict__ d1g, T* __restrict__ d2g, T* __restrict__ loss_part) {
+    using acc_t = typename Mfma16<T>::acc_t;
+    using vec4 = typename Vec4<T>::type;
+    constexpr int kFrag = 28;                                     // fragment words per lane: wz 8, wd 8, b1 4, y 4, b0 4
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(4 * 64 * 4 + kP2H * kLd + kP2C * kLd + kFrag * 64) * sizeof(T)];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    vec4* zred = reinterpret_cast<vec4*>(smem);                   // [4 waves][64 lanes]
+    T* a1s = smem + 4 * 64 * 4;                                   // a_1 tile  [hidden 32][kLd]  (MFMA B operand image)
+    T* d2s = a1s + kP2H * kLd;                                    // delta_2   [class 16][kLd]
+    T* frag = d2s + kP2C * kLd;                                   // [word][lane]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
+    const int F = nd.dims[0], H = nd.dims[1], C = nd.dims[2];
+    const int s0 = blockIdx.x * kP2Ts;
+    RCN_STAMP(1, 0);
+
+    // ---- slab loads: 16 slices per wave in flight (G <= 64); lane <- float4 `lane` of the [8][32] slice tile
+    const vec4* sp = reinterpret_cast<const vec4*>(slab + (size_t)blockIdx.x * G * kP2Ts * kP2H) + lane;
+    vec4 t[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int g = wave + 4 * q;
+        t[q] = sp[(size_t)(g < G ? g : wave) * 64];
+    }
+    const T* W1 = params + nd.w_off[1];                           // C x H column-major: (c, h) at h*C + c
+    if (wave == 1) {                                              // z_2 = W_1 a_1:   A[m = c][k = h]
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int h = 4 * ks + g4;
+            const T w = W1[(size_t)(h < H ? h : 0) * C + (n < C ? n : 0)];
+            frag[ks * 64 + lane] = (h < H && n < C) ? w : (T)0;
+        }
+    } else if (wave == 2) {                                       // W_1^T delta_2:  A[m = h][k = c]
+#pragma unroll
+        for (int mt = 0; mt < kMtp; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int h = mt * 16 + n, c = 4 * ks + g4;
+                const T w = W1[(size_t)(h < H ? h : 0) * C + (c < C ? c : 0)];
+                frag[(8 + mt * 4 + ks) * 64 + lane] = (h < H && c < C) ? w : (T)0;
+            }
+    } else if (wave == 3) {                                       // b_1, targets (per accumulator element), b_0
+        const T* b1 = W1 + (size_t)C * H;
+        const T* b0 = params + nd.w_off[0] + (size_t)H * F;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = Mfma16<T>::row(lane, i);                // class row of accumulator element i
+            const T bb = b1[c < C ? c : 0];
+            const T yy = Ys[(size_t)(s0 + (n & 7)) * C + (c < C ? c : 0)];
+            const int h = 4 * (lane & 7) + i;                     // hidden unit of slab float4 element i
+            const T b = b0[h < H ? h : 0];
+            frag[(16 + i) * 64 + lane] = c < C ? bb : (T)0;
+            frag[(20 + i) * 64 + lane] = yy;
+            frag[(24 + i) * 64 + lane] = h < H ? b : (T)0;
+        }
+    }
+    vec4 z = vec4{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (wave + 4 * q < G) z += t[q];                          // slice order within a wave ...
+    zred[wave * 64 + lane] = z;
+    RCN_STAMP(1, 1);
+    __syncthreads();
+    RCN_STAMP(1, 2);
+    if (wave != 0) return;
+    z = (zred[lane] + zred[64 + lane]) + (zred[128 + lane] + zred[192 + lane]);   // ... and a fixed order across waves
+
+    // ---- a_1 = sigmoid(z_1 + b_0); lane <- sample lane>>3, hidden 4*(lane&7)+i                       rcn.rs:287-289
+    {
+        const int s = lane >> 3, h0 = 4 * (lane & 7);
+        vec4 a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = (h0 + i < H) ? sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]) : (T)0;
+            a1s[(h0 + i) * kLd + s] = a[i];
+        }
+        *reinterpret_cast<vec4*>(a1g + (size_t)(s0 + s) * kP2H + h0) = a;
+    }
+    RCN_STAMP(1, 3);
+    // ---- z_2 = W_1 a_1 + b_1, a_2 = sigmoid, delta_2 = (a_2 - y)(*)a_2(1-a_2)                    rcn.rs:287-289, 299
+    acc_t acc = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const T bv = a1s[(4 * ks + g4) * kLd + (n & 7)];
+        acc = Mfma16<T>::mfma(frag[ks * 64 + lane], n < kP2Ts ? bv : (T)0, acc);
+    }
+    T lsum = 0;
+    acc_t dv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = Mfma16<T>::row(lane, i);
+        const T a2 = sigmoid_fast(acc[i] + frag[(16 + i) * 64 + lane]);
+        const T diff = a2 - frag[(20 + i) * 64 + lane];
+        const bool ok = c < C && n < kP2Ts;
+        dv[i] = ok ? diff * (a2 * ((T)1 - a2)) : (T)0;
+        lsum += ok ? diff * diff : (T)0;
+        d2s[c * kLd + n] = dv[i];
+    }
+    if (n < kP2Ts) store4<T>(d2g + (size_t)(s0 + n) * kP2C, lane, dv);
+    RCN_STAMP(1, 4);
+    // ---- delta_1 = (W_1^T delta_2) (*) a_1 (1 - a_1)                                                rcn.rs:305-309
+#pragma unroll
+    for (int mt = 0; mt < kMtp; ++mt) {
+        acc_t ad = acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ad = Mfma16<T>::mfma(frag[(8 + mt * 4 + ks) * 64 + lane], d2s[(4 * ks + g4) * kLd + n], ad);
+        acc_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T a = a1s[(mt * 16 + Mfma16<T>::row(lane, i)) * kLd + (n & 7)];
+            o[i] = ad[i] * (a * ((T)1 - a));                      // padded hidden rows hold a = 0 -> delta 0
+        }
+        if (n < kP2Ts) store4<T>(d1g + (size_t)(s0 + n) * kP2H + mt * 16, lane, o);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+    if (lane == 0 && loss_part) loss_part[blockIdx.x] = lsum;
+    RCN_STAMP(1, 6);
+}
+
+}  // namespace rcn

@@ -17,6 +17,8 @@
 
 #include "common.hpp"
 #include "dense.hpp"
+#include "dense_pipe.hpp"
+#include "dense_p2.hpp"
 #include "features.hpp"
 #include "ops.hpp"
 
@@ -58,6 +60,8 @@ struct rcn_hip_ctx {
     bool params_set = false;
     std::string dense_err;                  // non-empty: every dense call panics in the reference (see rcn_hip_create)
     double mean = 1.0, sd = 1.0;            // scale_set initial value (1,1): rcn.rs:71
+    int dense_path = 0;                     // 0 auto, 1 sample-tile kernels (dense.hpp), 2 feature-sliced pipeline (dense_pipe.hpp)
+    DevBuf slab, xpack, ypack, p2buf;
     DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
     std::map<EpochKey, hipGraphExec_t> graphs;
     std::map<const void*, size_t> lds_attr;   // kernels whose dynamic-LDS limit was already raised
@@ -236,22 +240,27 @@ int ensure_dense_ws(rcn_hip_ctx* c, size_t B) {
     return RCN_HIP_OK;
 }
 
-template <typename T>
-int launch_fwd(rcn_hip_ctx* c, bool train, const void* x, const void* y, const int32_t* idx, size_t B, void* out) {
+template <typename T, bool TRAIN, bool VECX, bool STAGED>
+int launch_fwd_v(rcn_hip_ctx* c, const void* x, const void* y, const int32_t* idx, size_t B, void* out) {
     const NetDesc& nd = c->nd;
     const int tiles = (int)((B + kTileS - 1) / kTileS);
     const size_t lds = dense_fwd_lds_elems(nd) * sizeof(T);
-    if (train) {
-        RCN_TRY(set_dyn_lds(c, k_dense_fwd<T, true>, lds));
-        hipLaunchKernelGGL((k_dense_fwd<T, true>), dim3(tiles), dim3(kDenseThreads), lds, c->stream, nd, (const T*)c->params.p,
-                           (const T*)x, (const T*)y, idx, (int)B, (T*)c->acts.p, (T*)c->deltas.p, (T*)c->loss_part.p, (T*)nullptr);
-    } else {
-        RCN_TRY(set_dyn_lds(c, k_dense_fwd<T, false>, lds));
-        hipLaunchKernelGGL((k_dense_fwd<T, false>), dim3(tiles), dim3(kDenseThreads), lds, c->stream, nd, (const T*)c->params.p,
-                           (const T*)x, (const T*)nullptr, idx, (int)B, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)out);
-    }
+    RCN_TRY(set_dyn_lds(c, k_dense_fwd<T, TRAIN, VECX, STAGED>, lds));
+    hipLaunchKernelGGL((k_dense_fwd<T, TRAIN, VECX, STAGED>), dim3(tiles), dim3(kDenseThreads), lds, c->stream, nd, (const T*)c->params.p,
+                       (const T*)x, (const T*)y, idx, (int)B, TRAIN ? (T*)c->acts.p : (T*)nullptr, TRAIN ? (T*)c->deltas.p : (T*)nullptr,
+                       TRAIN ? (T*)c->loss_part.p : (T*)nullptr, (T*)out);
     HIP_TRY(c, hipGetLastError());
     return RCN_HIP_OK;
+}
+
+template <typename T>
+int launch_fwd(rcn_hip_ctx* c, bool train, const void* x, const void* y, const int32_t* idx, size_t B, void* out) {
+    const bool vec = dense_vec_rows(c->nd, sizeof(T)) && ((uintptr_t)x % 16 == 0);
+    const bool st = dense_tail_staged(c->nd);
+#define RCN_FWD(TR, V, S) return launch_fwd_v<T, TR, V, S>(c, x, y, idx, B, out)
+    if (train) { if (vec) { if (st) RCN_FWD(true, true, true); else RCN_FWD(true, true, false); } else { if (st) RCN_FWD(true, false, true); else RCN_FWD(true, false, false); } }
+    else       { if (vec) { if (st) RCN_FWD(false, true, true); else RCN_FWD(false, true, false); } else { if (st) RCN_FWD(false, false, true); else RCN_FWD(false, false, false); } }
+#undef RCN_FWD
 }
 
 template <typename T>
@@ -274,10 +283,112 @@ int launch_wgrad(rcn_hip_ctx* c, bool apply, const void* x, const int32_t* idx, 
     return RCN_HIP_OK;
 }
 
+bool use_pipe(const rcn_hip_ctx* c, size_t B) {
+    if (c->dense_path == 1) return false;
+    if (!pipe_supported(c->nd)) return false;
+    if (c->dense_path == 2) return true;
+    return B <= 1024;                       // beyond that the slabs (G x B x d1) cost more HBM traffic than they save
+}
+
+int ensure_pipe_ws(rcn_hip_ctx* c, size_t B) {
+    const size_t Bp = (B + 15) / 16 * 16;
+    const size_t mp = p2_supported(c->nd, B) ? (size_t)kP2H : (size_t)pipe_mp(c->nd);     // slab row: the specialised kernels pad to 32
+    HIP_TRY(c, c->slab.ensure((size_t)pipe_slices(c->nd) * Bp * mp * c->esz()));
+    HIP_TRY(c, c->loss_part.ensure(((B + kPipeTs - 1) / kPipeTs) * c->esz()));
+    if (p2_supported(c->nd, B)) HIP_TRY(c, c->p2buf.ensure(B * (size_t)(2 * kP2H + kP2C) * c->esz()));
+    return RCN_HIP_OK;
+}
+
+template <typename T>
+int launch_pipe_a(rcn_hip_ctx* c, const void* xp, const void* xn, size_t B, double scale, void* loss_out, double loss_scale, bool do_update, bool do_fwd) {
+    const NetDesc& nd = c->nd;
+    const int G = pipe_slices(nd), grid = G + pipe_extra_wgs(nd);
+    const size_t lds = pipe_a_lds_elems(nd) * sizeof(T);
+    const int n_loss = (int)((B + kPipeTs - 1) / kPipeTs);
+    if (p2_supported(nd, B)) {       // lean specialisation: one hidden layer <= 32, classes <= 16, B % 256 == 0
+        T* a1 = (T*)c->p2buf.p; T* d1 = a1 + B * kP2H; T* d2 = d1 + B * kP2H;
+        hipLaunchKernelGGL((k_p2_a<T>), dim3(grid), dim3(kDenseThreads), p2_a_lds_elems() * sizeof(T), c->stream, nd, (T*)c->params.p, (const T*)xp,
+                           (const T*)xn, (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, G, (const T*)c->loss_part.p, n_loss,
+                           (T)loss_scale, (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0);
+        HIP_TRY(c, hipGetLastError());
+        return RCN_HIP_OK;
+    }
+    RCN_TRY(set_dyn_lds(c, k_pipe_a<T>, lds));
+    hipLaunchKernelGGL((k_pipe_a<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)xp, (const T*)xn, (int)B,
+                       (const T*)c->acts.p, (const T*)c->deltas.p, (T)scale, (T*)c->slab.p, G, (const T*)c->loss_part.p, n_loss, (T)loss_scale,
+                       (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0);
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+template <typename T>
+int launch_pipe_b(rcn_hip_ctx* c, const void* ys, size_t B) {
+    const NetDesc& nd = c->nd;
+    if (p2_supported(nd, B)) {
+        T* a1 = (T*)c->p2buf.p; T* d1 = a1 + B * kP2H; T* d2 = d1 + B * kP2H;
+        hipLaunchKernelGGL((k_p2_b<T>), dim3((unsigned)(B / kP2Ts)), dim3(kP2BThreads), 0, c->stream, nd, (const T*)c->params.p, (const T*)c->slab.p,
+                           pipe_slices(nd), (const T*)ys, (int)B, a1, d1, d2, (T*)c->loss_part.p);
+        HIP_TRY(c, hipGetLastError());
+        return RCN_HIP_OK;
+    }
+    const size_t lds = pipe_b_lds_elems(nd) * sizeof(T);
+    RCN_TRY(set_dyn_lds(c, k_pipe_b<T>, lds));
+    hipLaunchKernelGGL((k_pipe_b<T>), dim3((unsigned)((B + kPipeTs - 1) / kPipeTs)), dim3(kPipeBThreads), lds, c->stream, nd, (const T*)c->params.p,
+                       (const T*)c->slab.p, pipe_slices(nd), (const T*)ys, (int)B, (T*)c->acts.p, (T*)c->deltas.p, (T*)c->loss_part.p);
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+// the shuffled batches of one epoch -> slice-major image (k_pack_epoch), into context-owned scratch
+template <typename T>
+int launch_pack(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb) {
+    const NetDesc& nd = c->nd;
+    const int G = pipe_slices(nd), F = nd.dims[0], Cc = nd.dims[nd.L];
+    if (nb > 65535) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "train_epoch: more than 65535 batches in one call");
+    const bool vec = dense_vec_rows(nd, sizeof(T)) && ((uintptr_t)X % 16 == 0);
+    if (vec) hipLaunchKernelGGL((k_pack_epoch<T, true>), dim3(G + 1, (unsigned)nb), dim3(256), 0, c->stream, (const T*)X, (const T*)Y, perm, (int)B, F, Cc, G,
+                                (T*)c->xpack.p, (T*)c->ypack.p);
+    else hipLaunchKernelGGL((k_pack_epoch<T, false>), dim3(G + 1, (unsigned)nb), dim3(256), 0, c->stream, (const T*)X, (const T*)Y, perm, (int)B, F, Cc, G,
+                            (T*)c->xpack.p, (T*)c->ypack.p);
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+int ensure_pack_ws(rcn_hip_ctx* c, size_t B, size_t nb) {
+    HIP_TRY(c, c->xpack.ensure(nb * (size_t)pipe_slices(c->nd) * B * 16 * c->esz()));
+    HIP_TRY(c, c->ypack.ensure(nb * B * (size_t)c->nd.dims[c->nd.L] * c->esz()));
+    return RCN_HIP_OK;
+}
+
+// nb consecutive train_batch steps through the feature-sliced pipeline: pack, A(F0) B0 A(U0,F1) B1 ... A(U_{nb-1}).
+// perm (nullable) holds nb*B sample indices; without it batch j is rows [jB, (j+1)B) of X / Y.
+template <typename T>
+int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+    const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L], es = c->esz();
+    const double scale = eta / (double)B, loss_scale = 1.0 / (2.0 * (double)B);
+    RCN_TRY(launch_pack<T>(c, X, Y, perm, B, nb));
+    auto xb = [&](size_t j) { return (const void*)((const char*)c->xpack.p + j * G * B * 16 * es); };
+    auto yb = [&](size_t j) { return (const void*)((const char*)c->ypack.p + j * B * Cc * es); };
+    RCN_TRY(launch_pipe_a<T>(c, xb(0), xb(0), B, scale, nullptr, loss_scale, false, true));
+    for (size_t j = 0; j < nb; ++j) {
+        RCN_TRY(launch_pipe_b<T>(c, yb(j), B));
+        const bool more = j + 1 < nb;
+        void* lj = loss_dev ? (char*)loss_dev + j * es : nullptr;
+        RCN_TRY(launch_pipe_a<T>(c, xb(j), more ? xb(j + 1) : xb(j), B, scale, lj, loss_scale, true, more));
+    }
+    return RCN_HIP_OK;
+}
+
 // one train_batch (rcn.rs:176-223) on device-resident data; idx selects the batch's rows (or NULL)
 int enqueue_train_step(rcn_hip_ctx* c, const void* x, const void* y, const int32_t* idx, size_t B, double eta, void* loss_dev) {
     const double scale = eta / (double)B;                       // rcn.rs:214: eta / batch.len() as f64
     const double loss_scale = 1.0 / (2.0 * (double)B);
+    if (use_pipe(c, B)) {
+        RCN_TRY(ensure_pipe_ws(c, B));
+        RCN_TRY(ensure_pack_ws(c, B, 1));
+        return c->dtype == RCN_HIP_F64 ? enqueue_pipe_steps<double>(c, x, y, idx, B, 1, eta, loss_dev)
+                                       : enqueue_pipe_steps<float>(c, x, y, idx, B, 1, eta, loss_dev);
+    }
     if (c->dtype == RCN_HIP_F64) {
         RCN_TRY(launch_fwd<double>(c, true, x, y, idx, B, nullptr));
         RCN_TRY(launch_wgrad<double>(c, true, x, idx, B, scale, nullptr, loss_dev, loss_scale));
@@ -380,7 +491,7 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
         DevGuard g(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         drop_graphs(c);
-        for (DevBuf* b : {&c->params, &c->acts, &c->deltas, &c->loss_part, &c->grad, &c->xstage, &c->ystage, &c->ostage, &c->scratch0,
+        for (DevBuf* b : {&c->slab, &c->xpack, &c->ypack, &c->p2buf, &c->params, &c->acts, &c->deltas, &c->loss_part, &c->grad, &c->xstage, &c->ystage, &c->ostage, &c->scratch0,
                           &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
             b->release();
         if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -397,6 +508,16 @@ int rcn_hip_set_stream(rcn_hip_ctx* c, void* s) {
     if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
     else { HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
+    RCN_TRY(check_ctx(c));
+    if (mode < 0 || mode > 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile) or 2 (feature-sliced)");
+    if (mode == 2 && !pipe_supported(c->nd)) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "feature-sliced path needs >= 2 dense layers whose tail fits LDS");
+    DevGuard g(c->device);
+    drop_graphs(c);
+    c->dense_path = mode;
     return RCN_HIP_OK;
 }
 
@@ -748,9 +869,9 @@ int rcn_hip_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const 
     RCN_TRY(need_params(c));
     DevGuard g(c->device);
     RCN_TRY(ensure_dense_ws(c, B));
-    // make sure LDS attributes are set outside capture
-    const size_t lds = dense_fwd_lds_elems(c->nd) * c->esz();
-    if (c->dtype == RCN_HIP_F64) RCN_TRY(set_dyn_lds(c, k_dense_fwd<double, true>, lds)); else RCN_TRY(set_dyn_lds(c, k_dense_fwd<float, true>, lds));
+    if (use_pipe(c, B)) { RCN_TRY(ensure_pipe_ws(c, B)); RCN_TRY(ensure_pack_ws(c, B, nb)); }
+    // LDS attributes are per kernel variant and cached (set_dyn_lds); hipFuncSetAttribute is not a stream operation,
+    // so the first capture of a variant may set it while capturing.
 
     const EpochKey key{X, Y, perm, B, nb, eta, loss_dev};
     auto it = c->graphs.find(key);
@@ -759,6 +880,10 @@ int rcn_hip_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const 
         hipGraph_t graph = nullptr;
         HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int st = RCN_HIP_OK;
+        if (use_pipe(c, B)) {
+            st = c->dtype == RCN_HIP_F64 ? enqueue_pipe_steps<double>(c, X, Y, perm, B, nb, eta, loss_dev)
+                                         : enqueue_pipe_steps<float>(c, X, Y, perm, B, nb, eta, loss_dev);
+        } else
         for (size_t j = 0; j < nb && st == RCN_HIP_OK; ++j) {
             const void* xb = perm ? X : (const char*)X + j * B * F * es;
             const void* yb = perm ? Y : (const char*)Y + j * B * Cc * es;
@@ -897,17 +1022,35 @@ int rcn_hip_evaluate(rcn_hip_ctx* c, const double* x, const double* y, size_t n,
     return rcn_hip_evaluate_dev(c, c->xstage.p, c->ystage.p, n, accepted);
 }
 
-int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, int reps, double* us_fwd, double* us_wgrad) {
+int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, int reps, double* us_a, double* us_b) {
     RCN_TRY(check_ctx(c));
-    if (!x || !y || !us_fwd || !us_wgrad || reps < 1 || B == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "time_kernels: bad argument");
+    if (!x || !y || !us_a || !us_b || reps < 1 || B == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "time_kernels: bad argument");
     RCN_TRY(need_params(c));
     DevGuard g(c->device);
     RCN_TRY(ensure_dense_ws(c, B));
     HIP_TRY(c, c->grad.ensure((size_t)c->nd.P * c->esz()));
-    const bool f64 = c->dtype == RCN_HIP_F64;
-    // warm both kernels (LDS attribute, code load) outside capture
-    RCN_TRY(f64 ? launch_fwd<double>(c, true, x, y, nullptr, B, nullptr) : launch_fwd<float>(c, true, x, y, nullptr, B, nullptr));
-    RCN_TRY(f64 ? launch_wgrad<double>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0) : launch_wgrad<float>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0));
+    const bool f64 = c->dtype == RCN_HIP_F64, pipe = use_pipe(c, B);
+    if (pipe) RCN_TRY(ensure_pipe_ws(c, B));
+    // which == 0: first kernel of a step (k_dense_fwd | k_pipe_b), which == 1: second (k_dense_wgrad | k_pipe_a).
+    // Updates run with scale 0 / gradient-out so the parameters do not drift while timing.
+    auto launch = [&](int which) -> int {
+        if (pipe) {
+            if (which == 0) return f64 ? launch_pipe_b<double>(c, c->ypack.p, B) : launch_pipe_b<float>(c, c->ypack.p, B);
+            return f64 ? launch_pipe_a<double>(c, c->xpack.p, c->xpack.p, B, 0.0, nullptr, 1.0, true, true)
+                       : launch_pipe_a<float>(c, c->xpack.p, c->xpack.p, B, 0.0, nullptr, 1.0, true, true);
+        }
+        if (which == 0) return f64 ? launch_fwd<double>(c, true, x, y, nullptr, B, nullptr) : launch_fwd<float>(c, true, x, y, nullptr, B, nullptr);
+        return f64 ? launch_wgrad<double>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0) : launch_wgrad<float>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0);
+    };
+    // one complete step's worth of intermediates + warm code / LDS attributes, outside capture
+    if (pipe) {
+        RCN_TRY(ensure_pack_ws(c, B, 1));
+        RCN_TRY(f64 ? launch_pack<double>(c, x, y, nullptr, B, 1) : launch_pack<float>(c, x, y, nullptr, B, 1));
+        RCN_TRY(f64 ? launch_pipe_a<double>(c, c->xpack.p, c->xpack.p, B, 0.0, nullptr, 1.0, false, true)
+                    : launch_pipe_a<float>(c, c->xpack.p, c->xpack.p, B, 0.0, nullptr, 1.0, false, true));
+    }
+    RCN_TRY(launch(0));
+    RCN_TRY(launch(1));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0));
@@ -918,10 +1061,7 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
-        for (int i = 0; i < reps && e == hipSuccess && st == RCN_HIP_OK; ++i) {
-            if (which == 0) st = f64 ? launch_fwd<double>(c, true, x, y, nullptr, B, nullptr) : launch_fwd<float>(c, true, x, y, nullptr, B, nullptr);
-            else st = f64 ? launch_wgrad<double>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0) : launch_wgrad<float>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0);
-        }
+        for (int i = 0; i < reps && e == hipSuccess && st == RCN_HIP_OK; ++i) st = launch(which);
         hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
         if (e == hipSuccess) e = e2;
         if (e == hipSuccess && st == RCN_HIP_OK) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -942,9 +1082,18 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    *us_fwd = res[0]; *us_wgrad = res[1];
+    *us_a = res[0]; *us_b = res[1];
     return st;
 }
+
+#ifdef RCN_STAMPS
+int rcn_hip_debug_read_stamps(rcn_hip_ctx* c, unsigned long long* out) {
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rcn_stamps), sizeof(unsigned long long) * 2 * 512 * 16));
+    return RCN_HIP_OK;
+}
+#endif
 
 int rcn_hip_classify_images(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, int32_t* cls) {
     RCN_TRY(check_ctx(c));

@@ -50,6 +50,9 @@ class DeviceRCN:
     def synchronize(self):
         self.stream.synchronize()
 
+    def set_dense_path(self, mode: int):
+        self.rcn.set_dense_path(mode)
+
     # ---- feature pipeline --------------------------------------------------------------------------------------
     def features(self, imgs_u8: torch.Tensor, standardize: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert imgs_u8.dtype == torch.uint8 and imgs_u8.is_contiguous() and imgs_u8.device == self.device
@@ -125,7 +128,8 @@ class DeviceRCN:
         return int(n.value)
 
     def time_kernels(self, x: torch.Tensor, y: torch.Tensor, reps: int = 200) -> Tuple[float, float]:
-        """Mean microseconds per launch of (k_dense_fwd, k_dense_wgrad) at this batch size, by HIP events."""
+        """Mean microseconds per launch of the two kernels of a step at this batch size, by HIP events:
+        (k_dense_fwd, k_dense_wgrad) on the sample-tile path, (k_pipe_b, k_pipe_a) on the feature-sliced path."""
         a, b = C.c_double(), C.c_double()
         self._ck(self.lib.rcn_hip_time_kernels_dev(self.ctx, _p(x), _p(y), x.shape[0], reps, C.byref(a), C.byref(b)))
         return a.value, b.value

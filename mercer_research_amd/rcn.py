@@ -134,6 +134,10 @@ class RCN:
     def synchronize(self):
         self._ck(self._lib.rcn_hip_synchronize(self._ctx))
 
+    def set_dense_path(self, mode: int):
+        """0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline (include/rcn_hip.h)."""
+        self._ck(self._lib.rcn_hip_set_dense_path(self._ctx, int(mode)))
+
     # ------------------------------------------------------------------ parameters (Weights / Bias)
     def set_params(self, weights: Sequence[np.ndarray], biases: Sequence[np.ndarray]):
         """weights[l]: (out, in) array == Weights.0; biases[l]: (out,) == Bias.0  (rcn.rs:28,31)"""

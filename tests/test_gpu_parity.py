@@ -33,8 +33,10 @@ def _layers(amd, spec):
     return out
 
 
-def _mk(amd, dims, dtype, layers=DEFAULT_LAYERS, shape=(28, 28)):
-    return amd.RCN(dims[-1], _layers(amd, layers), dims[1:-1], input_shape=shape, dtype=dtype)
+def _mk(amd, dims, dtype, layers=DEFAULT_LAYERS, shape=(28, 28), path=0):
+    r = amd.RCN(dims[-1], _layers(amd, layers), dims[1:-1], input_shape=shape, dtype=dtype)
+    r.set_dense_path(path)      # 0 auto, 1 sample-tile kernels (dense.hpp), 2 feature-sliced pipeline (dense_pipe.hpp)
+    return r
 
 
 # ----------------------------------------------------------------------------------------------------- operators
@@ -196,13 +198,14 @@ def _check_params(got, ref, dtype):
             assert np.all(np.abs(a - b) <= F32_PARAM_RTOL * np.abs(b) + F32_PARAM_ATOL), float(np.abs(a - b).max())
 
 
+@pytest.mark.parametrize("path", [1, 2])
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("dims,B", [([784, 30, 10], 32), ([784, 30, 10], 10), ([784, 10, 10, 10], 10), ([784, 30, 10], 1),
-                                    ([784, 30, 10], 17), ([16, 5, 3], 4), ([100, 70, 33, 40, 10], 33), ([48, 8, 6, 10], 255)])
-def test_train_batch_matches_oracle(amd, oracle, dims, B, dtype):
+                                    ([784, 30, 10], 17), ([784, 30, 10], 256), ([784, 12, 7], 512), ([16, 5, 3], 4), ([100, 70, 33, 40, 10], 33), ([48, 8, 6, 10], 255)])
+def test_train_batch_matches_oracle(amd, oracle, dims, B, dtype, path):
     # wscale keeps |z| moderate so that sigmoid' is not identically zero (un-scaled N(0,1) init saturates)
     ws, bs, X, Y = _dense_case(dims, B, seed=B + len(dims), wscale=0.1)
-    r = _dense_rcn(amd, dims, dtype)
+    r = _dense_rcn(amd, dims, dtype, path)
     r.set_params(ws, bs)
     out = r.classify_test(X)
     ref_out = oracle.classify_test(ws, bs, X)
@@ -214,11 +217,11 @@ def test_train_batch_matches_oracle(amd, oracle, dims, B, dtype):
     _check_params(gw + gb, nw + nb, dtype)
 
 
-def _dense_rcn(amd, dims, dtype):
+def _dense_rcn(amd, dims, dtype, path=0):
     """An RCN whose conv/pool stack yields exactly dims[0] features: conv(Same) + pool(Max) on a 2a x 2b image gives
     4*a*b features and satisfies the reference's fan-in formula (one conv, one pool; rcn.rs:443)."""
     if dims[0] == 784:
-        return _mk(amd, dims, dtype)
+        return _mk(amd, dims, dtype, path=path)
     F = dims[0]
     assert F % 4 == 0, "dense test sizes must be 4*a*b with a,b >= 2"
     q = F // 4
@@ -227,18 +230,20 @@ def _dense_rcn(amd, dims, dtype):
     assert a >= 2 and b >= 2
     r = amd.RCN(dims[-1], _layers(amd, ((LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX))), dims[1:-1], input_shape=(2 * a, 2 * b), dtype=dtype)
     assert r.feature_len == F
+    r.set_dense_path(path)
     return r
 
 
+@pytest.mark.parametrize("path", [1, 2])
 @pytest.mark.parametrize("dtype", [0, 1])
-def test_unscaled_n01_init_default_net(amd, oracle, dtype):
+def test_unscaled_n01_init_default_net(amd, oracle, dtype, path):
     """The reference's actual init (N(0,1), un-scaled, rcn.rs:500-523) on the synthetic MNIST-shape workload."""
     imgs, labels = synthetic_images(64, seed=11)
     f = oracle.features(imgs, DEFAULT_LAYERS)
     m, s = oracle.gen_scales(f)
     X, Y = oracle.standardize(f, m, s), one_hot(labels)
     ws, bs = synthetic_params([784, 30, 10], seed=42)
-    r = _mk(amd, [784, 30, 10], dtype)
+    r = _mk(amd, [784, 30, 10], dtype, path=path)
     r.set_params(ws, bs)
     loss = r.train_batch(X, Y, 3.0, want_loss=True)
     nw, nb, cost = oracle.train_batch(ws, bs, X, Y, 3.0)
@@ -314,13 +319,15 @@ def test_evaluate_semantics(amd, oracle):
 
 # ----------------------------------------------------------------------------------------------------- device-resident paths
 
+@pytest.mark.parametrize("path", [1, 2])
 @pytest.mark.parametrize("dtype", [0, 1])
-def test_epoch_graph_matches_sequential_oracle(amd, oracle, dtype):
+def test_epoch_graph_matches_sequential_oracle(amd, oracle, dtype, path):
     import torch
     from mercer_research_amd.device import DeviceRCN
     B, nb, N = 32, 6, 256
     ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=77, wscale=0.1)
     d = DeviceRCN(dtype=dtype)
+    d.set_dense_path(path)
     d.set_params(ws, bs)
     Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
     perm = np.random.default_rng(1).permutation(N).astype(np.int32)
