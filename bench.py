@@ -118,49 +118,37 @@ def main():
     nb_epoch = N_IMAGES // B_PER_GPU
     B = B_PER_GPU
     step_no = [0]
-    # training_set.shuffle (rcn.rs:146): the permutation of epoch e+1 is drawn on a side stream while epoch e trains
-    # (two index buffers, events in both directions), so the epoch loop on the main stream is graph launch after graph
-    # launch.  It is still drawn once per epoch, inside the timed region.
-    perms = [torch.empty(N_IMAGES, dtype=torch.int32, device=d.device) for _ in range(2)]
-    shuf_stream = torch.cuda.Stream(device=d.device)
-    ready = [torch.cuda.Event() for _ in range(2)]
-    consumed = [torch.cuda.Event() for _ in range(2)]
-    epoch_no = [0]
-
-    def draw(buf: int):
-        with torch.cuda.stream(shuf_stream):
-            shuf_stream.wait_event(consumed[buf])                        # the epoch that last read this buffer has finished
-            perms[buf].copy_(torch.randperm(N_IMAGES, device=d.device))
-            ready[buf].record(shuf_stream)
+    # training_set.shuffle (rcn.rs:146): one fresh permutation per pass over the set, drawn ON the device by
+    # rcn_hip_shuffle_dev in-stream (one small kernel per chunk of passes -- a side-stream torch.randperm serialises
+    # against graph replays on this stack and cost 1.8 us/step), inside the timed region.  One hipGraph replay covers
+    # EPG passes; every step sees a fresh batch of a fresh shuffle.
+    EPG = 8                                                          # passes (epochs) per graph replay
+    chunk_steps = EPG * nb_epoch
+    perm = torch.empty(EPG * N_IMAGES, dtype=torch.int32, device=d.device)
+    chunk_no = [0]
 
     if world == 1:
-        for b_ in range(2):
-            consumed[b_].record(d.stream)
-        draw(0)
+        def plan(k: int):
+            """chunk sizes (in steps) that run(k) will issue"""
+            return [min(chunk_steps, k - i) for i in range(0, k, chunk_steps)]
+
+        def prime(k: int):
+            """instantiate the graphs run(k) will replay (set-up, untimed): one per chunk length"""
+            for take in set(plan(k)):
+                d.prepare_epoch(X, Y, perm, B, take, ETA, None)
 
         def run(k: int):
-            """k consecutive train_batch steps; every 64 steps (one pass over the set) a new permutation."""
-            done = 0
-            while done < k:
-                pos = step_no[0] % nb_epoch
-                buf = epoch_no[0] % 2
-                if pos == 0:
-                    d.stream.wait_event(ready[buf])
-                    draw(1 - buf)                                        # next epoch's permutation, off the critical path
-                take = min(k - done, nb_epoch - pos)
-                d.train_epoch(X, Y, perms[buf][pos * B:], B, take, ETA, None)
+            """k consecutive train_batch steps in chunks of up to EPG passes; a new permutation every pass."""
+            for take in plan(k):
+                d.shuffle(perm, N_IMAGES, EPG, seed=0x5DEECE66D + rank * 7919 + chunk_no[0])
+                d.train_epoch(X, Y, perm, B, take, ETA, None)
                 step_no[0] += take
-                done += take
-                if step_no[0] % nb_epoch == 0:
-                    consumed[buf].record(d.stream)
-                    epoch_no[0] += 1
+                chunk_no[0] += 1
     else:
         dp = DataParallelStep(d)
         dp.broadcast_params(0)
         xb = d.empty(B, d.F)
         yb = d.empty(B, d.classes)
-
-        perm = perms[0]
 
         def run(k: int):
             with torch.cuda.stream(d.stream):
@@ -181,7 +169,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world == 1:
+        prime(args.warmup)
     run(args.warmup)
+    if world == 1:
+        prime(args.steps)
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -214,29 +206,44 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events on the stream the kernels run on) ----
-        us_first, us_second = d.time_kernels(X[:B], Y[:B], reps=400)
+        # HIP events on the kernels' own stream: each kernel back to back with itself, and the alternating pair as the epoch
+        # loop issues it (walking the last epoch's packed batches).  A kernel's duration inside the real loop is the pair
+        # time split in the ratio of the two stand-alone times; that is what a profiler's per-dispatch average shows.
+        us_first, us_second, us_pair = d.time_kernels(X[:B], Y[:B], reps=504)
         es = 8 if args.dtype == "f64" else 4
         P, F, H, C = d.P, DIMS[0], DIMS[1], DIMS[2]
-        G = (F + 15) // 16
-        # algorithmic bytes per launch (DESIGN.md "Kernels"), feature-sliced path:
-        #   k_pipe_a: both batches' feature rows once (finish step i-1, start step i), delta_1/delta_2/a_1 of step i-1,
-        #             every parameter read + written once.  (Its slab write is an implementation artefact, excluded.)
-        #   k_pipe_b: the targets, tail parameters + b_0; writes a_1, delta_1, delta_2.  (Slab read excluded likewise.)
-        bytes_a = (2 * B * F + B * (2 * H + C) + 2 * P) * es
-        bytes_b = (B * C + (P - F * H) + B * (2 * H + C)) * es
-        names = ("k_pipe_b", "k_pipe_a") if args.path != 1 else ("k_dense_fwd", "k_dense_wgrad")
+        # Algorithmic bytes per launch = SURVEY.md §8(d)'s per-image figure x the B images one launch processes
+        # (DESIGN.md "Kernels"): features F*es + one-hot C*es + every parameter read and written once per step (2*P*es/B).
+        # The feature rows and the parameters belong to the kernel that owns W_0 (k_p2_a / k_dense_fwd+wgrad); the targets to
+        # the tail kernel.  The second pass over the features, the partial-sum slab and the activation/delta exchange are
+        # implementation traffic: they show up in `traffic` (PMC), not here.
+        per_img_main = F * es + 2 * P * es / B
+        per_img_tail = C * es
         if args.path == 1:
-            sumd = H + C
-            bytes_b = (B * F + B * C + P + B * H + B * sumd) * es          # k_dense_fwd
-            bytes_a = (B * F + B * sumd + B * H + 2 * P) * es              # k_dense_wgrad
-        dom, us, by = (names[0], us_first, bytes_b) if us_first >= us_second else (names[1], us_second, bytes_a)
+            names, by = ("k_dense_fwd", "k_dense_wgrad"), (B * (F * es + C * es + P * es / B), B * (P * es / B))
+        else:
+            names, by = ("k_p2_b", "k_p2_a"), (B * per_img_tail, B * per_img_main)
+        k = 0 if us_first >= us_second else 1
+        if args.path != 1:
+            k = 1                                   # k_p2_a owns the features and W_0; k_p2_b is the small tail kernel
+        us = us_pair * (us_first, us_second)[k] / (us_first + us_second)
         flops_step = 2 * B * ((F * H + H * C) * 2 + H * C)
-        result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(by / us / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(by / us / 1e3 / HBM_PEAK_GBS, 5), "traffic": None,
-                              "algorithmic_bytes_per_launch": by, "us_per_launch_hip_events": round(us, 3),
-                              "us_" + names[0]: round(us_first, 3), "us_" + names[1]: round(us_second, 3),
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(names[k], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "hbm", "kernel": names[k], "achieved": round(by[k] / us / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(by[k] / us / 1e3 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                              "traffic_source": "profiles/r1_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+                              "algorithmic_bytes_per_launch": round(by[k]), "us_per_launch_hip_events": round(us, 3),
+                              "us_alternating_pair": round(us_pair, 3),
+                              "us_standalone_" + names[0]: round(us_first, 3), "us_standalone_" + names[1]: round(us_second, 3),
                               "step_gflops_per_s": round(flops_step / (elapsed / args.steps) / 1e9, 1),
-                              "note": "one train_batch at B=256 moves ~1 MB and ~25 MFLOP: launch/latency-bound, far from either roof"}
+                              "note": "one train_batch at B=256 is ~1 MB and ~25 MFLOP: bound by launch + dependent-latency floors "
+                                      "(1.6 us per dependent launch, >=1 us per global round trip), far from either roof"}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
             result["config"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)

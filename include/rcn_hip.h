@@ -160,6 +160,16 @@ int  rcn_hip_train_batch_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_
  * once into a hipGraph per (pointers, B, n_batches, eta) and replayed. */
 int  rcn_hip_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
                              size_t B, size_t n_batches, double eta, void* loss_dev);
+/* Same arguments: captures and instantiates the hipGraph that rcn_hip_train_epoch_dev would replay for them, without
+ * running it (one-time set-up cost moved out of the loop; perm_dev's CONTENTS may change between replays, the pointers
+ * and sizes may not).  n_batches may span several passes over the set: the caller concatenates one permutation per
+ * pass into perm_dev (each pass is rcn.rs:146-149 once). */
+int  rcn_hip_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
+                               size_t B, size_t n_batches, double eta, void* loss_dev);
+/* training_set.shuffle (rcn.rs:146) on the device: writes `passes` independent pseudo-random permutations of 0..n-1
+ * (pass p at perm_dev[p*n ..]) keyed by `seed` -- ready to be passed to rcn_hip_train_epoch_dev.  Enqueued on the
+ * context's stream (one small kernel); the reference draws from the unseeded thread_rng. */
+int  rcn_hip_shuffle_dev(rcn_hip_ctx* ctx, int32_t* perm_dev, size_t n, size_t passes, uint64_t seed);
 /* Data-parallel halves of train_batch: summed gradients of one shard into a flat buffer laid out like the
  * parameters (no update), and the update from an (all-reduced) flat gradient: p <- p - scale * g. */
 int  rcn_hip_batch_gradient_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t B,
@@ -186,9 +196,14 @@ int  rcn_hip_set_dense_path(rcn_hip_ctx* ctx, int mode);
  * back-to-back launches of each kernel (one hipGraph of `reps` dependent nodes per kernel, so the host launch rate does
  * not bound the result), events recorded immediately before and after each graph.  Returns the mean microseconds per
  * launch.  us_first / us_second are (k_dense_fwd, k_dense_wgrad) on the sample-tile path and (k_pipe_b, k_pipe_a) on
- * the feature-sliced path; updates run with a zero step so the parameters do not drift while timing.  Blocks. */
+ * the feature-sliced path; updates run with a zero step so the parameters do not drift while timing.  On the
+ * feature-sliced path, when the context still holds the packed image of an epoch at this batch size (i.e. right after
+ * rcn_hip_train_epoch_dev), successive launches walk that epoch's batches, so the timing includes the same cold reads as
+ * the real loop.  us_pair (nullable) times `reps` repetitions of (first, second) alternating, as the real loop issues
+ * them: the two kernels of a step cost more alternating than each back to back with itself (+1.7 us per pair measured),
+ * so a profiler's per-dispatch average corresponds to us_pair split in the ratio us_first : us_second.  Blocks. */
 int  rcn_hip_time_kernels_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t B, int reps,
-                              double* us_first, double* us_second);
+                              double* us_first, double* us_second, double* us_pair /* nullable: the two alternating */);
 
 #ifdef __cplusplus
 }

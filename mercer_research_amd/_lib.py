@@ -68,6 +68,8 @@ SIGNATURES = {
     "rcn_hip_train_batch": (_i, [_vp, _dp, _dp, _sz, _d, _dp]),
     "rcn_hip_train_batch_dev": (_i, [_vp, _vp, _vp, _sz, _d, _vp]),
     "rcn_hip_train_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
+    "rcn_hip_prepare_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
+    "rcn_hip_shuffle_dev": (_i, [_vp, _vp, _sz, _sz, C.c_uint64]),
     "rcn_hip_batch_gradient_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "rcn_hip_apply_gradient_dev": (_i, [_vp, _vp, _d]),
     "rcn_hip_forward": (_i, [_vp, _dp, _sz, _dp]),
@@ -77,7 +79,7 @@ SIGNATURES = {
     "rcn_hip_evaluate_dev": (_i, [_vp, _vp, _vp, _sz, _i64p]),
     "rcn_hip_classify_images": (_i, [_vp, _u8p, _sz, _i32p]),
     "rcn_hip_set_dense_path": (_i, [_vp, _i]),
-    "rcn_hip_time_kernels_dev": (_i, [_vp, _vp, _vp, _sz, _i, _dp, _dp]),
+    "rcn_hip_time_kernels_dev": (_i, [_vp, _vp, _vp, _sz, _i, _dp, _dp, _dp]),
 }
 
 _lib = None

@@ -207,6 +207,34 @@ __global__ __launch_bounds__(kDenseThreads) void k_pipe_a(
     RCN_STAMP(0, 5);
 }
 
+// training_set.shuffle (rcn.rs:146) on the device: `passes` independent pseudo-random permutations of 0..n-1, pass p at
+// perm[p*n ..].  Each is a keyed 4-round balanced Feistel network over the next even-bit power of two >= n (a bijection),
+// cycle-walked into [0, n); the key is a hash of (seed, pass).  One thread per element, no sort, no atomics.
+__device__ inline unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__global__ void k_shuffle_indices(int* __restrict__ perm, unsigned n, unsigned passes, unsigned long long seed, int half_bits) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (unsigned long long)n * passes) return;
+    const unsigned p = (unsigned)(gid / n), i = (unsigned)(gid - (unsigned long long)p * n);
+    const unsigned mask = (1u << half_bits) - 1u;
+    unsigned key[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) key[r] = mix32((unsigned)(seed >> (16 * (r & 1))) ^ mix32(p * 0x9e3779b9U + r * 0x85ebca6bU + (unsigned)(seed >> 32)));
+    unsigned x = i;
+    do {
+        unsigned L = x >> half_bits, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned t = L ^ (mix32(R ^ key[r]) & mask);
+            L = R; R = t;
+        }
+        x = (L << half_bits) | R;
+    } while (x >= n);
+    perm[gid] = (int)x;
+}
+
 // Gathers `nb` shuffled batches into the slice-major image described above.  Grid: (G + 1, nb): blockIdx.x < G packs one
 // 16-feature slice of one batch, blockIdx.x == G packs that batch's targets.  perm == NULL: identity (chunks_exact over
 // the set as stored).

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -62,6 +63,8 @@ struct rcn_hip_ctx {
     double mean = 1.0, sd = 1.0;            // scale_set initial value (1,1): rcn.rs:71
     int dense_path = 0;                     // 0 auto, 1 sample-tile kernels (dense.hpp), 2 feature-sliced pipeline (dense_pipe.hpp)
     DevBuf slab, xpack, ypack, p2buf;
+    size_t packed_B = 0, packed_nb = 0;     // what the epoch image currently holds (k_pack_epoch)
+    size_t pack_seg_bytes = (size_t)64 << 20;   // size of one half of the epoch image (env RCN_HIP_PACK_SEGMENT_BYTES, for tests)
     DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
     std::map<EpochKey, hipGraphExec_t> graphs;
     std::map<const void*, size_t> lds_attr;   // kernels whose dynamic-LDS limit was already raised
@@ -339,40 +342,59 @@ int launch_pipe_b(rcn_hip_ctx* c, const void* ys, size_t B) {
     return RCN_HIP_OK;
 }
 
-// the shuffled batches of one epoch -> slice-major image (k_pack_epoch), into context-owned scratch
+// The epoch image is kept to two segments of at most ~64 MB each so that it stays resident in the 256 MB Infinity Cache
+// next to the source set however many batches one call covers (a 411 MB image made the per-step kernels ~15 % slower).
+size_t pack_segment(const rcn_hip_ctx* c, size_t B) {
+    const size_t per_batch = (size_t)pipe_slices(c->nd) * B * 16 * c->esz();
+    const size_t seg = c->pack_seg_bytes / (per_batch ? per_batch : 1);
+    return seg ? seg : 1;
+}
+
+// batches [j0, j0+n) of the call -> slice-major image (k_pack_epoch) in half `half` of the context-owned scratch
 template <typename T>
-int launch_pack(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb) {
+int launch_pack(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t j0, size_t n, int half, size_t seg) {
     const NetDesc& nd = c->nd;
     const int G = pipe_slices(nd), F = nd.dims[0], Cc = nd.dims[nd.L];
-    if (nb > 65535) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "train_epoch: more than 65535 batches in one call");
+    if (n > 65535) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "train_epoch: segment of more than 65535 batches");
     const bool vec = dense_vec_rows(nd, sizeof(T)) && ((uintptr_t)X % 16 == 0);
-    if (vec) hipLaunchKernelGGL((k_pack_epoch<T, true>), dim3(G + 1, (unsigned)nb), dim3(256), 0, c->stream, (const T*)X, (const T*)Y, perm, (int)B, F, Cc, G,
-                                (T*)c->xpack.p, (T*)c->ypack.p);
-    else hipLaunchKernelGGL((k_pack_epoch<T, false>), dim3(G + 1, (unsigned)nb), dim3(256), 0, c->stream, (const T*)X, (const T*)Y, perm, (int)B, F, Cc, G,
-                            (T*)c->xpack.p, (T*)c->ypack.p);
+    // identity order: batch j is rows [jB, (j+1)B) -> shift the base pointers; shuffled: shift the index pointer
+    const T* Xb = perm ? (const T*)X : (const T*)X + j0 * B * (size_t)F;
+    const T* Yb = perm ? (const T*)Y : (const T*)Y + j0 * B * (size_t)Cc;
+    const int32_t* pb = perm ? perm + j0 * B : nullptr;
+    T* xs = (T*)c->xpack.p + (size_t)half * seg * G * B * 16;
+    T* ys = (T*)c->ypack.p + (size_t)half * seg * B * Cc;
+    if (vec) hipLaunchKernelGGL((k_pack_epoch<T, true>), dim3(G + 1, (unsigned)n), dim3(256), 0, c->stream, Xb, Yb, pb, (int)B, F, Cc, G, xs, ys);
+    else hipLaunchKernelGGL((k_pack_epoch<T, false>), dim3(G + 1, (unsigned)n), dim3(256), 0, c->stream, Xb, Yb, pb, (int)B, F, Cc, G, xs, ys);
     HIP_TRY(c, hipGetLastError());
+    if (half == 0) { c->packed_B = B; c->packed_nb = n; }
     return RCN_HIP_OK;
 }
 
 int ensure_pack_ws(rcn_hip_ctx* c, size_t B, size_t nb) {
-    HIP_TRY(c, c->xpack.ensure(nb * (size_t)pipe_slices(c->nd) * B * 16 * c->esz()));
-    HIP_TRY(c, c->ypack.ensure(nb * B * (size_t)c->nd.dims[c->nd.L] * c->esz()));
+    const size_t seg = pack_segment(c, B), cap = nb <= seg ? nb : 2 * seg;
+    HIP_TRY(c, c->xpack.ensure(cap * (size_t)pipe_slices(c->nd) * B * 16 * c->esz()));
+    HIP_TRY(c, c->ypack.ensure(cap * B * (size_t)c->nd.dims[c->nd.L] * c->esz()));
     return RCN_HIP_OK;
 }
 
-// nb consecutive train_batch steps through the feature-sliced pipeline: pack, A(F0) B0 A(U0,F1) B1 ... A(U_{nb-1}).
+// nb consecutive train_batch steps through the feature-sliced pipeline: pack, A(F0) B0 A(U0,F1) B1 ... A(U_{nb-1}),
+// re-packing the next segment (into the other half of the image) just before the step that first needs it.
 // perm (nullable) holds nb*B sample indices; without it batch j is rows [jB, (j+1)B) of X / Y.
 template <typename T>
 int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
     const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L], es = c->esz();
     const double scale = eta / (double)B, loss_scale = 1.0 / (2.0 * (double)B);
-    RCN_TRY(launch_pack<T>(c, X, Y, perm, B, nb));
-    auto xb = [&](size_t j) { return (const void*)((const char*)c->xpack.p + j * G * B * 16 * es); };
-    auto yb = [&](size_t j) { return (const void*)((const char*)c->ypack.p + j * B * Cc * es); };
+    const size_t seg = nb <= pack_segment(c, B) ? nb : pack_segment(c, B);
+    auto slot = [&](size_t j) { return ((j / seg) % 2) * seg + j % seg; };
+    auto xb = [&](size_t j) { return (const void*)((const char*)c->xpack.p + slot(j) * G * B * 16 * es); };
+    auto yb = [&](size_t j) { return (const void*)((const char*)c->ypack.p + slot(j) * B * Cc * es); };
+    auto pack = [&](size_t j0) { return launch_pack<T>(c, X, Y, perm, B, j0, (nb - j0 < seg ? nb - j0 : seg), (int)((j0 / seg) % 2), seg); };
+    RCN_TRY(pack(0));
     RCN_TRY(launch_pipe_a<T>(c, xb(0), xb(0), B, scale, nullptr, loss_scale, false, true));
     for (size_t j = 0; j < nb; ++j) {
         RCN_TRY(launch_pipe_b<T>(c, yb(j), B));
         const bool more = j + 1 < nb;
+        if (more && (j + 1) % seg == 0) RCN_TRY(pack(j + 1));
         void* lj = loss_dev ? (char*)loss_dev + j * es : nullptr;
         RCN_TRY(launch_pipe_a<T>(c, xb(j), more ? xb(j + 1) : xb(j), B, scale, lj, loss_scale, true, more));
     }
@@ -454,6 +476,10 @@ int rcn_hip_create(const rcn_hip_cfg* cfg, rcn_hip_ctx** out) {
     *out = c;                                   // handed back even on failure so the caller can read last_error
     c->device = cfg->device;
     c->dtype = cfg->dtype;
+    if (const char* e = std::getenv("RCN_HIP_PACK_SEGMENT_BYTES")) {
+        const long long v = std::atoll(e);
+        if (v > 0) c->pack_seg_bytes = (size_t)v;
+    }
     RCN_TRY(build_feat_desc(c, cfg));
     // RCN::new itself never fails; a stack whose dense part cannot run in the reference is remembered and
     // reported by the dense entry points (the reference panics inside train, not inside new).
@@ -861,7 +887,7 @@ int rcn_hip_train_batch(rcn_hip_ctx* c, const double* x, const double* y, size_t
     return RCN_HIP_OK;
 }
 
-int rcn_hip_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool launch) {
     RCN_TRY(check_ctx(c));
     if (!X || !Y) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_epoch: NULL pointer");
     if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_epoch: batch size must be in 1..2^30");
@@ -901,7 +927,28 @@ int rcn_hip_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const 
         if (c->graphs.size() >= 16) drop_graphs(c);
         it = c->graphs.emplace(key, exec).first;
     }
-    HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
+    if (launch) HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+    return epoch_impl(c, X, Y, perm, B, nb, eta, loss_dev, true);
+}
+
+int rcn_hip_prepare_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+    return epoch_impl(c, X, Y, perm, B, nb, eta, loss_dev, false);
+}
+
+int rcn_hip_shuffle_dev(rcn_hip_ctx* c, int32_t* perm, size_t n, size_t passes, uint64_t seed) {
+    RCN_TRY(check_ctx(c));
+    if (!perm || n == 0 || n > 0x40000000ULL || passes == 0 || n * passes > 0xffffffffULL) return fail(c, RCN_HIP_ERR_INVALID_ARG, "shuffle: bad argument");
+    DevGuard g(c->device);
+    int bits = 2;
+    while (((size_t)1 << bits) < n) bits += 2;                 // even number of bits: balanced Feistel halves
+    const size_t total = n * passes;
+    hipLaunchKernelGGL(k_shuffle_indices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (int*)perm, (unsigned)n, (unsigned)passes,
+                       (unsigned long long)seed, bits / 2);
+    HIP_TRY(c, hipGetLastError());
     return RCN_HIP_OK;
 }
 
@@ -1022,7 +1069,7 @@ int rcn_hip_evaluate(rcn_hip_ctx* c, const double* x, const double* y, size_t n,
     return rcn_hip_evaluate_dev(c, c->xstage.p, c->ystage.p, n, accepted);
 }
 
-int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, int reps, double* us_a, double* us_b) {
+int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, int reps, double* us_a, double* us_b, double* us_pair) {
     RCN_TRY(check_ctx(c));
     if (!x || !y || !us_a || !us_b || reps < 1 || B == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "time_kernels: bad argument");
     RCN_TRY(need_params(c));
@@ -1033,19 +1080,29 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
     if (pipe) RCN_TRY(ensure_pipe_ws(c, B));
     // which == 0: first kernel of a step (k_dense_fwd | k_pipe_b), which == 1: second (k_dense_wgrad | k_pipe_a).
     // Updates run with scale 0 / gradient-out so the parameters do not drift while timing.
+    // Feature-sliced path: if the context still holds the packed image of a whole epoch at this batch size (the normal
+    // case right after rcn_hip_train_epoch_dev), launch i works on batches i, i+1 of that image, so the timing sees the
+    // same cold slice reads as the real epoch loop; otherwise the given batch is packed and reused.
+    size_t rot = (pipe && c->packed_B == B && c->packed_nb >= 2) ? c->packed_nb : 0;
+    const size_t xstride = (size_t)pipe_slices(c->nd) * B * 16 * c->esz(), ystride = B * (size_t)c->nd.dims[c->nd.L] * c->esz();
+    size_t it = 0;
     auto launch = [&](int which) -> int {
         if (pipe) {
-            if (which == 0) return f64 ? launch_pipe_b<double>(c, c->ypack.p, B) : launch_pipe_b<float>(c, c->ypack.p, B);
-            return f64 ? launch_pipe_a<double>(c, c->xpack.p, c->xpack.p, B, 0.0, nullptr, 1.0, true, true)
-                       : launch_pipe_a<float>(c, c->xpack.p, c->xpack.p, B, 0.0, nullptr, 1.0, true, true);
+            const size_t j = rot ? (it++ % (rot - 1)) : 0;
+            const void* xp = (const char*)c->xpack.p + j * xstride;
+            const void* xn = rot ? (const void*)((const char*)xp + xstride) : xp;
+            if (which == 0) return f64 ? launch_pipe_b<double>(c, (const char*)c->ypack.p + j * ystride, B) : launch_pipe_b<float>(c, (const char*)c->ypack.p + j * ystride, B);
+            return f64 ? launch_pipe_a<double>(c, xp, xn, B, 0.0, nullptr, 1.0, true, true) : launch_pipe_a<float>(c, xp, xn, B, 0.0, nullptr, 1.0, true, true);
         }
         if (which == 0) return f64 ? launch_fwd<double>(c, true, x, y, nullptr, B, nullptr) : launch_fwd<float>(c, true, x, y, nullptr, B, nullptr);
         return f64 ? launch_wgrad<double>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0) : launch_wgrad<float>(c, false, x, nullptr, B, 0.0, c->grad.p, nullptr, 1.0);
     };
     // one complete step's worth of intermediates + warm code / LDS attributes, outside capture
     if (pipe) {
-        RCN_TRY(ensure_pack_ws(c, B, 1));
-        RCN_TRY(f64 ? launch_pack<double>(c, x, y, nullptr, B, 1) : launch_pack<float>(c, x, y, nullptr, B, 1));
+        if (!rot) {
+            RCN_TRY(ensure_pack_ws(c, B, 1));
+            RCN_TRY(f64 ? launch_pack<double>(c, x, y, nullptr, B, 0, 1, 0, 1) : launch_pack<float>(c, x, y, nullptr, B, 0, 1, 0, 1));
+        }
         RCN_TRY(f64 ? launch_pipe_a<double>(c, c->xpack.p, c->xpack.p, B, 0.0, nullptr, 1.0, false, true)
                     : launch_pipe_a<float>(c, c->xpack.p, c->xpack.p, B, 0.0, nullptr, 1.0, false, true));
     }
@@ -1055,13 +1112,18 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
-    double res[2] = {0, 0};
+    double res[3] = {0, 0, 0};
     int st = RCN_HIP_OK;
-    for (int which = 0; which < 2 && st == RCN_HIP_OK; ++which) {
+    // which == 2: the two kernels alternating, as in the real loop (reps pairs)
+    for (int which = 0; which < (us_pair ? 3 : 2) && st == RCN_HIP_OK; ++which) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
-        for (int i = 0; i < reps && e == hipSuccess && st == RCN_HIP_OK; ++i) st = launch(which);
+        it = 0;
+        for (int i = 0; i < reps && e == hipSuccess && st == RCN_HIP_OK; ++i) {
+            if (which < 2) st = launch(which);
+            else { const size_t keep = it; st = launch(0); it = keep; if (st == RCN_HIP_OK) st = launch(1); }
+        }
         hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
         if (e == hipSuccess) e = e2;
         if (e == hipSuccess && st == RCN_HIP_OK) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1083,6 +1145,7 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *us_a = res[0]; *us_b = res[1];
+    if (us_pair) *us_pair = res[2];
     return st;
 }
 

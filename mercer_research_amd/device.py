@@ -108,6 +108,16 @@ class DeviceRCN:
             assert X.shape[0] >= B * n_batches
         self._ck(self.lib.rcn_hip_train_epoch_dev(self.ctx, _p(X), _p(Y), _p(perm), B, n_batches, float(eta), _p(loss)))
 
+    def shuffle(self, perm: torch.Tensor, n: int, passes: int, seed: int):
+        """training_set.shuffle (rcn.rs:146) on the device: `passes` pseudo-random permutations of 0..n-1 into perm."""
+        assert perm.dtype == torch.int32 and perm.numel() >= n * passes
+        self._ck(self.lib.rcn_hip_shuffle_dev(self.ctx, _p(perm), n, passes, seed & 0xFFFFFFFFFFFFFFFF))
+
+    def prepare_epoch(self, X: torch.Tensor, Y: torch.Tensor, perm: Optional[torch.Tensor], B: int, n_batches: int, eta: float,
+                      loss: Optional[torch.Tensor] = None):
+        """Instantiate (do not run) the graph train_epoch will replay for exactly these arguments."""
+        self._ck(self.lib.rcn_hip_prepare_epoch_dev(self.ctx, _p(X), _p(Y), _p(perm), B, n_batches, float(eta), _p(loss)))
+
     def batch_gradient(self, x: torch.Tensor, y: torch.Tensor, grad: Optional[torch.Tensor] = None,
                        loss_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
         grad = grad if grad is not None else self.empty(self.P)
@@ -127,9 +137,10 @@ class DeviceRCN:
         self._ck(self.lib.rcn_hip_evaluate_dev(self.ctx, _p(x), _p(y), x.shape[0], C.byref(n)))
         return int(n.value)
 
-    def time_kernels(self, x: torch.Tensor, y: torch.Tensor, reps: int = 200) -> Tuple[float, float]:
-        """Mean microseconds per launch of the two kernels of a step at this batch size, by HIP events:
-        (k_dense_fwd, k_dense_wgrad) on the sample-tile path, (k_pipe_b, k_pipe_a) on the feature-sliced path."""
-        a, b = C.c_double(), C.c_double()
-        self._ck(self.lib.rcn_hip_time_kernels_dev(self.ctx, _p(x), _p(y), x.shape[0], reps, C.byref(a), C.byref(b)))
-        return a.value, b.value
+    def time_kernels(self, x: torch.Tensor, y: torch.Tensor, reps: int = 200) -> Tuple[float, float, float]:
+        """Mean microseconds per launch, by HIP events on this stream, of the two kernels of a step back to back with
+        themselves -- (k_dense_fwd, k_dense_wgrad) on the sample-tile path, (k_p2_b | k_pipe_b, k_p2_a | k_pipe_a) on the
+        feature-sliced path -- and of the alternating pair as the real loop issues it."""
+        a, b, p = C.c_double(), C.c_double(), C.c_double()
+        self._ck(self.lib.rcn_hip_time_kernels_dev(self.ctx, _p(x), _p(y), x.shape[0], reps, C.byref(a), C.byref(b), C.byref(p)))
+        return a.value, b.value, p.value

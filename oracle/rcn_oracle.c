@@ -488,19 +488,62 @@ static void* mt_worker(void* arg) {
     return NULL;
 }
 
+/* persistent worker pool (rayon keeps its global pool alive between par_iter calls; spawning threads per batch would
+ * charge the baseline for something the reference does not do) */
+static struct {
+    pthread_mutex_t mu; pthread_cond_t start, done;
+    pthread_t* th; int n; unsigned long gen; int remaining; mt_job* job; int init;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, NULL, 0 };
+
+static void* pool_main(void* arg) {
+    (void)arg;
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.start, &g_pool.mu);
+        seen = g_pool.gen;
+        mt_job* job = g_pool.job;
+        pthread_mutex_unlock(&g_pool.mu);
+        if (job) mt_worker(job);
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.remaining == 0) pthread_cond_signal(&g_pool.done);
+        pthread_mutex_unlock(&g_pool.mu);
+    }
+    return NULL;
+}
+
+static void pool_ensure(int n) {
+    if (g_pool.n >= n) return;
+    g_pool.th = (pthread_t*)realloc(g_pool.th, sizeof(pthread_t) * (size_t)n);
+    for (int t = g_pool.n; t < n; ++t) pthread_create(&g_pool.th[t], NULL, pool_main, NULL);
+    g_pool.n = n;
+}
+
 double rcn_o_train_batch_mt(rcn_o_net* net, const double* X, const double* Y, size_t B, double eta, int threads) {
     if (threads < 1) threads = 1;
+    if ((size_t)threads > B) threads = (int)B;                    /* par_iter over B items: at most B tasks */
     double **gW, **gb;
     alloc_grads(net, &gW, &gb);
     size_t next = 0;
     pthread_mutex_t mu;
     pthread_mutex_init(&mu, NULL);
     mt_job job = { net, X, Y, B, &next, &mu, &gW, &gb };
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
-    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, mt_worker, &job);
+    const int helpers = threads - 1;
+    if (helpers > 0) {
+        pool_ensure(helpers);
+        pthread_mutex_lock(&g_pool.mu);
+        /* wake exactly the pool; workers beyond `helpers` find the batch drained immediately */
+        g_pool.job = &job; g_pool.remaining = g_pool.n; g_pool.gen++;
+        pthread_cond_broadcast(&g_pool.start);
+        pthread_mutex_unlock(&g_pool.mu);
+    }
     mt_worker(&job);
-    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
-    free(th);
+    if (helpers > 0) {
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.remaining != 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+        g_pool.job = NULL;
+        pthread_mutex_unlock(&g_pool.mu);
+    }
     pthread_mutex_destroy(&mu);
     sgd_update(net, gW, gb, B, eta);
     free_grads(net, gW, gb);

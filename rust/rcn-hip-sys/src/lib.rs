@@ -1,0 +1,202 @@
+//! Raw FFI declarations for `include/rcn_hip.h` plus a thin safe wrapper.
+//!
+//! **Not compiled or tested here** -- this repository's environment has no Rust toolchain.  The C ABI itself is
+//! exercised through Python `ctypes` (tests/) with the same signatures; keep this file in lock-step with the header.
+//!
+//! Each function names the reference code it replaces (file:line under `rcn/src/`).
+#![allow(non_camel_case_types)]
+
+use std::ffi::{c_char, c_double, c_int, c_void, CStr};
+
+#[repr(C)]
+pub struct rcn_hip_ctx {
+    _private: [u8; 0],
+}
+
+pub const RCN_HIP_OK: c_int = 0;
+pub const RCN_HIP_ERR_SHAPE: c_int = -2; // the reference panics (kernel.rs:127,133,156,200,247; gemv dims)
+pub const RCN_HIP_ERR_UNSUPPORTED: c_int = -3; // Pooling::Average -> panic!("Not implemented")
+
+pub const RCN_HIP_F32: i32 = 0;
+pub const RCN_HIP_F64: i32 = 1;
+
+/// `RCNLayer::Convolve2D(Padding) | RCNLayer::Pool2D(Pooling)` (rcn.rs:35-38); tags = bincode variant indices.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rcn_hip_layer {
+    pub kind: i32, // 0 Convolve2D, 1 Pool2D
+    pub arg: i32,  // Padding: 0 None, 1 Same (kernel.rs:25-28) | Pooling: 0 Average, 1 Max (kernel.rs:32-35)
+}
+
+#[repr(C)]
+pub struct rcn_hip_cfg {
+    pub struct_size: u32,
+    pub device: i32,
+    pub dtype: i32,
+    pub in_h: i32,
+    pub in_w: i32,
+    pub n_convpool: i32,
+    pub convpool: *const rcn_hip_layer,
+    pub n_hidden: i32,
+    pub hidden: *const i32,
+    pub classes: i32,
+    pub stream: *mut c_void,
+}
+
+extern "C" {
+    pub fn rcn_hip_abi_version() -> c_int;
+    pub fn rcn_hip_status_string(status: c_int) -> *const c_char;
+    pub fn rcn_hip_create(cfg: *const rcn_hip_cfg, out: *mut *mut rcn_hip_ctx) -> c_int; // RCN::new, rcn.rs:58-75
+    pub fn rcn_hip_destroy(ctx: *mut rcn_hip_ctx);
+    pub fn rcn_hip_last_error(ctx: *const rcn_hip_ctx) -> *const c_char;
+    pub fn rcn_hip_set_stream(ctx: *mut rcn_hip_ctx, stream: *mut c_void) -> c_int;
+    pub fn rcn_hip_synchronize(ctx: *mut rcn_hip_ctx) -> c_int;
+    pub fn rcn_hip_feature_len(ctx: *const rcn_hip_ctx, out: *mut i64) -> c_int;
+    pub fn rcn_hip_num_layers(ctx: *const rcn_hip_ctx) -> c_int;
+    pub fn rcn_hip_layer_dims(ctx: *const rcn_hip_ctx, layer: c_int, rows: *mut i32, cols: *mut i32) -> c_int;
+    pub fn rcn_hip_param_count(ctx: *const rcn_hip_ctx, out: *mut i64) -> c_int;
+    pub fn rcn_hip_set_params(ctx: *mut rcn_hip_ctx, layer: c_int, w_colmajor: *const c_double, b: *const c_double) -> c_int;
+    pub fn rcn_hip_get_params(ctx: *mut rcn_hip_ctx, layer: c_int, w_colmajor: *mut c_double, b: *mut c_double) -> c_int;
+    pub fn rcn_hip_init_params(ctx: *mut rcn_hip_ctx, seed: u64) -> c_int; // load_weights_and_bias, rcn.rs:425-457
+    pub fn rcn_hip_params_dev(ctx: *mut rcn_hip_ctx, dev_ptr: *mut *mut c_void, count: *mut i64) -> c_int;
+    pub fn rcn_hip_conv_out_shape(r: c_int, c: c_int, kr: c_int, kc: c_int, padding: c_int, or: *mut c_int, oc: *mut c_int) -> c_int;
+    pub fn rcn_hip_pool_out_shape(r: c_int, c: c_int, padding: c_int, or: *mut c_int, oc: *mut c_int) -> c_int;
+    // Convolve2D / Pool2D traits, utils/kernel.rs:110-216, 245-349
+    pub fn rcn_hip_convolve_2d(ctx: *mut rcn_hip_ctx, m: *const c_double, n: c_int, r: c_int, c: c_int, kernel: *const c_double,
+                               kr: c_int, kc: c_int, padding: c_int, out: *mut c_double) -> c_int;
+    pub fn rcn_hip_convolve_2d_separated(ctx: *mut rcn_hip_ctx, m: *const c_double, n: c_int, r: c_int, c: c_int, sep_op: c_int,
+                                         padding: c_int, out: *mut c_double) -> c_int;
+    pub fn rcn_hip_relu(ctx: *mut rcn_hip_ctx, m: *const c_double, count: usize, out: *mut c_double) -> c_int;
+    pub fn rcn_hip_pool_2d(ctx: *mut rcn_hip_ctx, m: *const c_double, n: c_int, r: c_int, c: c_int, padding: c_int, pooling: c_int,
+                           out: *mut c_double) -> c_int;
+    // flatten_feature_set / gen_scales / standardise, rcn.rs:317-356, 230-251, 407-412
+    pub fn rcn_hip_features(ctx: *mut rcn_hip_ctx, imgs: *const u8, n: usize, out: *mut c_double) -> c_int;
+    pub fn rcn_hip_features_dev(ctx: *mut rcn_hip_ctx, imgs_dev: *const u8, n: usize, out_dev: *mut c_void, standardize: c_int) -> c_int;
+    pub fn rcn_hip_gen_scales(ctx: *mut rcn_hip_ctx, feats: *const c_double, n: usize, mean: *mut c_double, sd: *mut c_double) -> c_int;
+    pub fn rcn_hip_gen_scales_dev(ctx: *mut rcn_hip_ctx, feats_dev: *const c_void, n: usize, mean: *mut c_double, sd: *mut c_double) -> c_int;
+    pub fn rcn_hip_set_scale(ctx: *mut rcn_hip_ctx, mean: c_double, sd: c_double) -> c_int;
+    pub fn rcn_hip_get_scale(ctx: *const rcn_hip_ctx, mean: *mut c_double, sd: *mut c_double) -> c_int;
+    pub fn rcn_hip_standardize(ctx: *mut rcn_hip_ctx, feats: *mut c_double, count: usize) -> c_int;
+    pub fn rcn_hip_standardize_dev(ctx: *mut rcn_hip_ctx, feats_dev: *mut c_void, count: usize) -> c_int;
+    // train_batch / classify_test / the epoch loop, rcn.rs:176-223, 105-116, 144-165
+    pub fn rcn_hip_train_batch(ctx: *mut rcn_hip_ctx, x: *const c_double, y: *const c_double, b: usize, eta: c_double, loss_out: *mut c_double) -> c_int;
+    pub fn rcn_hip_train_batch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, b: usize, eta: c_double, loss_dev: *mut c_void) -> c_int;
+    pub fn rcn_hip_train_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b: usize, n_batches: usize,
+                                   eta: c_double, loss_dev: *mut c_void) -> c_int;
+    pub fn rcn_hip_prepare_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b: usize, n_batches: usize,
+                                     eta: c_double, loss_dev: *mut c_void) -> c_int;
+    pub fn rcn_hip_shuffle_dev(ctx: *mut rcn_hip_ctx, perm_dev: *mut i32, n: usize, passes: usize, seed: u64) -> c_int; // rcn.rs:146
+    pub fn rcn_hip_batch_gradient_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, b: usize, grad: *mut c_void, loss_sum: *mut c_void) -> c_int;
+    pub fn rcn_hip_apply_gradient_dev(ctx: *mut rcn_hip_ctx, grad: *const c_void, scale: c_double) -> c_int;
+    pub fn rcn_hip_forward(ctx: *mut rcn_hip_ctx, x: *const c_double, n: usize, out: *mut c_double) -> c_int;
+    pub fn rcn_hip_forward_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, n: usize, out: *mut c_void) -> c_int;
+    pub fn rcn_hip_classify(ctx: *mut rcn_hip_ctx, x: *const c_double, n: usize, class_out: *mut i32) -> c_int;
+    pub fn rcn_hip_evaluate(ctx: *mut rcn_hip_ctx, x: *const c_double, y: *const c_double, n: usize, accepted: *mut i64) -> c_int;
+    pub fn rcn_hip_evaluate_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, n: usize, accepted: *mut i64) -> c_int;
+    pub fn rcn_hip_classify_images(ctx: *mut rcn_hip_ctx, imgs: *const u8, n: usize, class_out: *mut i32) -> c_int;
+    pub fn rcn_hip_set_dense_path(ctx: *mut rcn_hip_ctx, mode: c_int) -> c_int;
+    pub fn rcn_hip_time_kernels_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, b: usize, reps: c_int,
+                                    us_first: *mut c_double, us_second: *mut c_double, us_pair: *mut c_double) -> c_int;
+}
+
+/// Error carrying the status and the library's message.  A `Shape` / `Unsupported` status is where the pure-Rust
+/// reference would have panicked; the wrapper turns it back into a panic so callers observe identical behaviour.
+#[derive(Debug)]
+pub struct HipError {
+    pub status: i32,
+    pub message: String,
+}
+
+/// Safe owner of one context.  `Send` but not `Sync`, like `RCN` behind `&mut self` (rcn.rs:126).
+pub struct Context {
+    raw: *mut rcn_hip_ctx,
+}
+unsafe impl Send for Context {}
+
+impl Context {
+    pub fn new(classes: usize, convpool: &[rcn_hip_layer], hidden: &[usize], in_h: usize, in_w: usize, dtype: i32, device: i32) -> Result<Self, HipError> {
+        let hidden_i32: Vec<i32> = hidden.iter().map(|&h| h as i32).collect();
+        let cfg = rcn_hip_cfg {
+            struct_size: std::mem::size_of::<rcn_hip_cfg>() as u32,
+            device,
+            dtype,
+            in_h: in_h as i32,
+            in_w: in_w as i32,
+            n_convpool: convpool.len() as i32,
+            convpool: convpool.as_ptr(),
+            n_hidden: hidden_i32.len() as i32,
+            hidden: hidden_i32.as_ptr(),
+            classes: classes as i32,
+            stream: std::ptr::null_mut(),
+        };
+        let mut raw = std::ptr::null_mut();
+        let st = unsafe { rcn_hip_create(&cfg, &mut raw) };
+        let ctx = Context { raw };
+        if st != RCN_HIP_OK {
+            return Err(ctx.error(st));
+        }
+        Ok(ctx)
+    }
+
+    fn error(&self, status: i32) -> HipError {
+        let msg = unsafe {
+            let p = if self.raw.is_null() { rcn_hip_status_string(status) } else { rcn_hip_last_error(self.raw) };
+            CStr::from_ptr(p).to_string_lossy().into_owned()
+        };
+        HipError { status, message: msg }
+    }
+
+    /// Maps a status to `Ok`, an `Err`, or -- for the statuses that stand for a reference `panic!` -- a panic.
+    fn check(&self, status: i32) -> Result<(), HipError> {
+        match status {
+            RCN_HIP_OK => Ok(()),
+            RCN_HIP_ERR_SHAPE | RCN_HIP_ERR_UNSUPPORTED => panic!("{}", self.error(status).message),
+            s => Err(self.error(s)),
+        }
+    }
+
+    pub fn feature_len(&self) -> usize {
+        let mut n = 0i64;
+        unsafe { rcn_hip_feature_len(self.raw, &mut n) };
+        n as usize
+    }
+
+    /// `flatten_feature_set` for one decoded grayscale image (row-major pixels as `image::pixels()` yields them).
+    pub fn features(&mut self, pixels: &[u8], out: &mut [f64]) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_features(self.raw, pixels.as_ptr(), 1, out.as_mut_ptr()) };
+        self.check(st)
+    }
+
+    /// `train_batch` (rcn.rs:176-223) on a batch already flattened to sample-major `x` / `y`.
+    pub fn train_batch(&mut self, x: &[f64], y: &[f64], batch: usize, eta: f64) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_train_batch(self.raw, x.as_ptr(), y.as_ptr(), batch, eta, std::ptr::null_mut()) };
+        self.check(st)
+    }
+
+    /// `classify_test` (rcn.rs:105-116).
+    pub fn forward(&mut self, x: &[f64], n: usize, out: &mut [f64]) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_forward(self.raw, x.as_ptr(), n, out.as_mut_ptr()) };
+        self.check(st)
+    }
+
+    /// `Weights.0` / `Bias.0` of layer `l` in nalgebra's own storage order (`DMatrix::as_slice()` is column-major).
+    pub fn set_params(&mut self, layer: usize, w_colmajor: &[f64], b: &[f64]) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_set_params(self.raw, layer as c_int, w_colmajor.as_ptr(), b.as_ptr()) };
+        self.check(st)
+    }
+
+    pub fn get_params(&mut self, layer: usize, w_colmajor: &mut [f64], b: &mut [f64]) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_get_params(self.raw, layer as c_int, w_colmajor.as_mut_ptr(), b.as_mut_ptr()) };
+        self.check(st)
+    }
+
+    pub fn raw(&mut self) -> *mut rcn_hip_ctx {
+        self.raw
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { rcn_hip_destroy(self.raw) }
+    }
+}

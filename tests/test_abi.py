@@ -107,3 +107,12 @@ def test_invalid_cfg_is_rejected(lib):
     assert lib.rcn_hip_create(C.byref(cfg), C.byref(ctx)) == -1
     assert lib.rcn_hip_last_error(None) == b"null context"
     lib.rcn_hip_destroy(None)        # no-op
+
+
+def test_cpp_host_mirror_compiles_and_links(lib, tmp_path):
+    """mercer_research_amd/csrc/host/rcn.hpp (C++ mirror of the Rust RCN API) builds against the C ABI with plain g++."""
+    from mercer_research_amd import _lib
+    exe = tmp_path / "host_demo"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "host_demo.cpp"),
+                    "-L" + os.path.dirname(_lib.LIB_PATH), "-lrcn_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", str(exe)], check=True)
+    assert exe.exists()

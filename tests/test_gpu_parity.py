@@ -439,3 +439,91 @@ def test_full_size_feature_properties(amd, oracle):
     m, s = d.gen_scales(f)
     fo = f.double()
     assert abs(m - fo.mean().item()) <= 1e-9 * m and abs(s - fo.std(unbiased=False).item()) <= 1e-9 * s
+
+
+def test_cpp_host_mirror_trains_on_gpu(tmp_path):
+    """The C++ mirror of RCN::{new, train, classify} (csrc/host/rcn.hpp) end to end: accuracy rises, Average pooling panics."""
+    import subprocess
+    from mercer_research_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "host_demo"
+    subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(root, "tests", "cpp", "host_demo.cpp"), "-L" + os.path.dirname(_lib.LIB_PATH),
+                    "-lrcn_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Epoch 0:" in out.stdout and "host_demo ok" in out.stdout
+
+
+def test_long_epoch_call_repacks_in_segments(amd, oracle, monkeypatch):
+    """One train_epoch call longer than the packed image's segment (forced small here): the image is re-packed in two
+    alternating halves; results must equal sequential oracle steps.  B=256 -> specialised kernels; 3 segments."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 256, 5, 1024
+    dims = [3136, 30, 10]
+    ws, bs = synthetic_params(dims, seed=3)
+    ws = [w * 0.05 for w in ws]
+    rng = np.random.default_rng(3)
+    X = np.maximum(rng.standard_normal((N, dims[0])), 0.0)
+    Y = one_hot(rng.integers(0, 10, N), 10)
+    layers = [amd.RCNLayer.Convolve2D(amd.Padding.SAME), amd.RCNLayer.Pool2D(amd.Pooling.MAX)]
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(2 * 196 * 256 * 16 * 8))      # two batches per half of the image
+    d = DeviceRCN(convpool_cfg=layers, feedforward_cfg=[30], input_shape=(56, 56), dtype=1)
+    assert d.F == 3136
+    d.set_params(ws, bs)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    perm = np.random.default_rng(5).permutation(N).astype(np.int32)
+    perm = np.concatenate([perm, perm[::-1]])[: nb * B].copy()
+    permd = d.to_device(perm)
+    loss = d.empty(nb)
+    d.synchronize()
+    d.train_epoch(Xd, Yd, permd, B, nb, 1.0, loss)
+    gw, gb = d.get_params()
+    rw, rb, costs = ws, bs, []
+    for j in range(nb):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, X[sel], Y[sel], 1.0)
+        costs.append(c)
+    _check_params(gw + gb, rw + rb, 1)
+    np.testing.assert_allclose(loss.cpu().numpy(), costs, rtol=1e-10)
+    # the specialised kernels (F = 784) through the same segmented driver, three batches per half, f32
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(3 * 49 * 256 * 16 * 4))
+    d2 = DeviceRCN(dtype=0)
+    ws2, bs2 = synthetic_params([784, 30, 10], seed=4)
+    ws2 = [w * 0.1 for w in ws2]
+    d2.set_params(ws2, bs2)
+    X2 = X[:, :784].copy()
+    X2d, Y2d = d2.to_device(X2, d2.tdtype), d2.to_device(Y, d2.tdtype)
+    nb2 = 8
+    perm2 = np.concatenate([perm, perm])[: nb2 * B].copy()
+    d2.synchronize()
+    d2.train_epoch(X2d, Y2d, d2.to_device(perm2), B, nb2, 1.0, None)
+    gw, gb = d2.get_params()
+    rw, rb = ws2, bs2
+    for j in range(nb2):
+        sel = perm2[j * B:(j + 1) * B]
+        rw, rb, _ = oracle.train_batch(rw, rb, X2[sel], Y[sel], 1.0)
+    for a, b in zip(gw + gb, rw + rb):
+        assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5)
+
+
+def test_device_shuffle_writes_permutations(amd):
+    """rcn_hip_shuffle_dev (training_set.shuffle, rcn.rs:146): every pass is a permutation of 0..n-1; passes and seeds differ."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    d = DeviceRCN()
+    for n, passes in ((16384, 8), (1000, 3), (7, 5), (1, 2), (65537, 2)):
+        perm = torch.full((n * passes,), -1, dtype=torch.int32, device=d.device)
+        d.synchronize()
+        d.shuffle(perm, n, passes, seed=1234)
+        d.synchronize()
+        p = perm.cpu().numpy().reshape(passes, n)
+        for row in p:
+            assert np.array_equal(np.sort(row), np.arange(n))
+        if n >= 1000:
+            assert not np.array_equal(p[0], p[1]) and not np.array_equal(p[0], np.arange(n))
+            assert abs(np.corrcoef(p[0], np.arange(n))[0, 1]) < 0.1          # not an affine/near-identity map
+            perm2 = torch.empty_like(perm)
+            d.shuffle(perm2, n, passes, seed=1235)
+            d.synchronize()
+            assert not np.array_equal(perm2.cpu().numpy(), perm.cpu().numpy())
