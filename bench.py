@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline")
+    ap.add_argument("--dp", action="store_true", help="use the data-parallel step (gradient -> all-reduce -> apply) even at world size 1")
     args = ap.parse_args()
 
     import torch
@@ -92,10 +93,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dp = world > 1 or args.dp
+    if use_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = max(args.gpus, world) if world > 1 else args.gpus
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
@@ -110,6 +114,8 @@ def main():
     imgs, labels = synthetic_images(N_IMAGES, seed=1234 + rank)          # every rank owns a different shard of data
     ws, bs = synthetic_params(DIMS, seed=42)                             # identical replicas (rcn.rs:500-523 shapes)
     d.set_params(ws, bs)
+    if use_dp:
+        args.path = 1            # the gradient-out form runs on the sample-tile kernels (k_dense_fwd / k_dense_wgrad)
     d.set_dense_path(args.path)
     with torch.cuda.stream(d.stream):
         imgs_d = torch.from_numpy(imgs).to(d.device)
@@ -127,7 +133,7 @@ def main():
     perm = torch.empty(EPG * N_IMAGES, dtype=torch.int32, device=d.device)
     chunk_no = [0]
 
-    if world == 1:
+    if not use_dp:
         def plan(k: int):
             """chunk sizes (in steps) that run(k) will issue"""
             return [min(chunk_steps, k - i) for i in range(0, k, chunk_steps)]
@@ -145,34 +151,32 @@ def main():
                 step_no[0] += take
                 chunk_no[0] += 1
     else:
+        # one process per GPU: every rank shuffles its own resident shard of the data, takes 256 rows per step, and the
+        # summed shard gradients meet in ONE all-reduce of the flat parameter-shaped buffer (RCCL over xGMI)
         dp = DataParallelStep(d)
         dp.broadcast_params(0)
-        xb = d.empty(B, d.F)
-        yb = d.empty(B, d.classes)
 
         def run(k: int):
             with torch.cuda.stream(d.stream):
                 for _ in range(k):
                     pos = step_no[0] % nb_epoch
                     if pos == 0:
-                        perm.copy_(torch.randperm(N_IMAGES, device=d.device))
-                    sel = perm[pos * B:(pos + 1) * B].long()
-                    torch.index_select(X, 0, sel, out=xb)
-                    torch.index_select(Y, 0, sel, out=yb)
-                    dp.train_batch(xb, yb, ETA, B * world)
+                        d.shuffle(perm, N_IMAGES, 1, seed=0x5DEECE66D + rank * 7919 + chunk_no[0])
+                        chunk_no[0] += 1
+                    dp.train_batch(X, Y, ETA, B * world, perm=perm[pos * B:(pos + 1) * B])
                     step_no[0] += 1
 
     def sync():
         d.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dp:
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world == 1:
+    if not use_dp:
         prime(args.warmup)
     run(args.warmup)
-    if world == 1:
+    if not use_dp:
         prime(args.steps)
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -183,7 +187,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if use_dp:
         t = torch.tensor([elapsed], dtype=torch.float64, device=d.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -200,7 +204,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "MNIST-shape 28x28x1, rcn default net conv(Same)-pool-conv(Same)-pool -> 784-30-10 sigmoid/MSE, "
                                "train_batch B=256 per GPU over 16384 resident pre-extracted feature vectors per GPU, eta=3.0",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "images_per_rank": N_IMAGES,
+                   "global_batch": B * world, "parallelism": f"dp{world}", "step_form": "gradient -> all-reduce -> apply" if use_dp else "fused update", "images_per_rank": N_IMAGES,
                    "device_ms_per_step_rank0": round(dev_ms / args.steps, 6), "final_cost_rank0": final_loss},
     }
 
@@ -248,7 +252,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline()
             result["config"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
 

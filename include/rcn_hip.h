@@ -174,6 +174,9 @@ int  rcn_hip_shuffle_dev(rcn_hip_ctx* ctx, int32_t* perm_dev, size_t n, size_t p
  * parameters (no update), and the update from an (all-reduced) flat gradient: p <- p - scale * g. */
 int  rcn_hip_batch_gradient_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t B,
                                 void* grad_dev, void* loss_sum_dev /* nullable: sum ||a_L-y||^2, not normalised */);
+/* same, the shard being rows perm_dev[0..B) of the resident set X_dev / Y_dev (no gather copy) */
+int  rcn_hip_batch_gradient_perm_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev, size_t B,
+                                     void* grad_dev, void* loss_sum_dev);
 int  rcn_hip_apply_gradient_dev(rcn_hip_ctx* ctx, const void* grad_dev, double scale);
 /* classify_test (rcn.rs:105-116) for n samples: a <- sigmoid(W a + b) through every layer. out: n x classes */
 int  rcn_hip_forward(rcn_hip_ctx* ctx, const double* x, size_t n, double* out);

@@ -952,7 +952,7 @@ int rcn_hip_shuffle_dev(rcn_hip_ctx* c, int32_t* perm, size_t n, size_t passes, 
     return RCN_HIP_OK;
 }
 
-int rcn_hip_batch_gradient_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, void* grad, void* loss_sum) {
+static int batch_gradient_impl(rcn_hip_ctx* c, const void* x, const void* y, const int32_t* idx, size_t B, void* grad, void* loss_sum) {
     RCN_TRY(check_ctx(c));
     if (!x || !y || !grad) return fail(c, RCN_HIP_ERR_INVALID_ARG, "batch_gradient: NULL pointer");
     if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "batch_gradient: batch size must be in 1..2^30");
@@ -960,13 +960,22 @@ int rcn_hip_batch_gradient_dev(rcn_hip_ctx* c, const void* x, const void* y, siz
     DevGuard g(c->device);
     RCN_TRY(ensure_dense_ws(c, B));
     if (c->dtype == RCN_HIP_F64) {
-        RCN_TRY(launch_fwd<double>(c, true, x, y, nullptr, B, nullptr));
-        RCN_TRY(launch_wgrad<double>(c, false, x, nullptr, B, 0.0, grad, loss_sum, 1.0));
+        RCN_TRY(launch_fwd<double>(c, true, x, y, idx, B, nullptr));
+        RCN_TRY(launch_wgrad<double>(c, false, x, idx, B, 0.0, grad, loss_sum, 1.0));
     } else {
-        RCN_TRY(launch_fwd<float>(c, true, x, y, nullptr, B, nullptr));
-        RCN_TRY(launch_wgrad<float>(c, false, x, nullptr, B, 0.0, grad, loss_sum, 1.0));
+        RCN_TRY(launch_fwd<float>(c, true, x, y, idx, B, nullptr));
+        RCN_TRY(launch_wgrad<float>(c, false, x, idx, B, 0.0, grad, loss_sum, 1.0));
     }
     return RCN_HIP_OK;
+}
+
+int rcn_hip_batch_gradient_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t B, void* grad, void* loss_sum) {
+    return batch_gradient_impl(c, x, y, nullptr, B, grad, loss_sum);
+}
+
+int rcn_hip_batch_gradient_perm_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, void* grad, void* loss_sum) {
+    if (!perm) return fail(c, RCN_HIP_ERR_INVALID_ARG, "batch_gradient_perm: NULL index pointer");
+    return batch_gradient_impl(c, X, Y, perm, B, grad, loss_sum);
 }
 
 int rcn_hip_apply_gradient_dev(rcn_hip_ctx* c, const void* grad, double scale) {

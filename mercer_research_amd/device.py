@@ -36,6 +36,23 @@ class DeviceRCN:
         self.F, self.classes = self.rcn.feature_len, classes
         self.P = sum(self.rcn.dims[l] * self.rcn.dims[l + 1] + self.rcn.dims[l + 1] for l in range(len(self.rcn.dims) - 1))
 
+    @classmethod
+    def adopt(cls, rcn: RCN) -> "DeviceRCN":
+        """Device-resident driver around an existing context (its kernels move onto a fresh torch side stream)."""
+        self = cls.__new__(cls)
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceRCN needs a GPU; there is no CPU fallback")
+        self.device = torch.device("cuda", 0)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.rcn = rcn
+        rcn._ck(rcn._lib.rcn_hip_set_stream(rcn._ctx, C.c_void_p(self.stream.cuda_stream)))
+        self.tdtype = torch.float64 if rcn.dtype == _lib.F64 else torch.float32
+        self.lib, self.ctx = rcn._lib, rcn._ctx
+        self.F, self.classes = rcn.feature_len, rcn.classes
+        self.P = sum(rcn.dims[l] * rcn.dims[l + 1] + rcn.dims[l + 1] for l in range(len(rcn.dims) - 1))
+        return self
+
     def _ck(self, st):
         _lib.check(self.lib, self.ctx, st)
 
@@ -122,6 +139,13 @@ class DeviceRCN:
                        loss_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
         grad = grad if grad is not None else self.empty(self.P)
         self._ck(self.lib.rcn_hip_batch_gradient_dev(self.ctx, _p(x), _p(y), x.shape[0], _p(grad), _p(loss_sum)))
+        return grad
+
+    def batch_gradient_perm(self, X: torch.Tensor, Y: torch.Tensor, perm: torch.Tensor, B: int, grad: Optional[torch.Tensor] = None,
+                            loss_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Summed gradient of the shard made of rows perm[0..B) of the resident set (no gather copy)."""
+        grad = grad if grad is not None else self.empty(self.P)
+        self._ck(self.lib.rcn_hip_batch_gradient_perm_dev(self.ctx, _p(X), _p(Y), _p(perm), B, _p(grad), _p(loss_sum)))
         return grad
 
     def apply_gradient(self, grad: torch.Tensor, scale: float):

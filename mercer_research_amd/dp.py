@@ -38,9 +38,13 @@ class DataParallelStep:
         if self.world > 1:
             dist.broadcast(self.engine.params_flat(), src=src, group=self.group)
 
-    def train_batch(self, x_shard, y_shard, eta: float, global_batch: int, loss_sum: Optional[torch.Tensor] = None):
-        """One train_batch over a global batch of which this rank holds `x_shard`."""
-        self._grad = self.engine.batch_gradient(x_shard, y_shard, self._grad, loss_sum)
+    def train_batch(self, x_shard, y_shard, eta: float, global_batch: int, loss_sum: Optional[torch.Tensor] = None, perm=None):
+        """One train_batch over a global batch of which this rank holds `x_shard` (or, with `perm`, the rows
+        perm[0..len(perm)) of the resident set x_shard / y_shard)."""
+        if perm is not None:
+            self._grad = self.engine.batch_gradient_perm(x_shard, y_shard, perm, perm.numel(), self._grad, loss_sum)
+        else:
+            self._grad = self.engine.batch_gradient(x_shard, y_shard, self._grad, loss_sum)
         if self.world > 1:
             dist.all_reduce(self._grad, op=dist.ReduceOp.SUM, group=self.group)
             if loss_sum is not None:

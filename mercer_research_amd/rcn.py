@@ -251,6 +251,19 @@ class RCN:
         y[np.arange(len(labels)), np.asarray(labels)] = 1.0
         return x, y
 
+    def train(self, batch_size: int, epochs: int, eta: float, training_class_size_limit: int, testing_class_size_limit: int,
+              rng: Optional[np.random.Generator] = None, log=print) -> List[int]:
+        """RCN::train (rcn.rs:126-133): reads `training_path` / `testing_path` (one directory per class, PNG files),
+        everything after the decode runs on the GPU (mercer_research_amd.data.train_from_directories)."""
+        from .data import train_from_directories
+        return train_from_directories(self, batch_size, epochs, eta, training_class_size_limit, testing_class_size_limit, rng, log)
+
+    def classify_file(self, img_path: str) -> int:
+        """RCN::classify (rcn.rs:82-98) including the PNG decode + grayscale."""
+        from . import png
+        with open(img_path, "rb") as f:
+            return self.classify(png.to_pixel_matrix_u8(f.read()))
+
     def train_arrays(self, train_imgs, train_labels, test_imgs, test_labels, batch_size: int, epochs: int, eta: float,
                      rng: Optional[np.random.Generator] = None, log=print) -> List[int]:
         """RCN::train (rcn.rs:126-167) on decoded images: load both sets (test statistics end up in scale_set,

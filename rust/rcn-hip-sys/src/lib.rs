@@ -87,6 +87,8 @@ extern "C" {
                                      eta: c_double, loss_dev: *mut c_void) -> c_int;
     pub fn rcn_hip_shuffle_dev(ctx: *mut rcn_hip_ctx, perm_dev: *mut i32, n: usize, passes: usize, seed: u64) -> c_int; // rcn.rs:146
     pub fn rcn_hip_batch_gradient_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, b: usize, grad: *mut c_void, loss_sum: *mut c_void) -> c_int;
+    pub fn rcn_hip_batch_gradient_perm_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b: usize, grad: *mut c_void,
+                                           loss_sum: *mut c_void) -> c_int;
     pub fn rcn_hip_apply_gradient_dev(ctx: *mut rcn_hip_ctx, grad: *const c_void, scale: c_double) -> c_int;
     pub fn rcn_hip_forward(ctx: *mut rcn_hip_ctx, x: *const c_double, n: usize, out: *mut c_double) -> c_int;
     pub fn rcn_hip_forward_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, n: usize, out: *mut c_void) -> c_int;

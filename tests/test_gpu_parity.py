@@ -527,3 +527,59 @@ def test_device_shuffle_writes_permutations(amd):
             d.shuffle(perm2, n, passes, seed=1235)
             d.synchronize()
             assert not np.array_equal(perm2.cpu().numpy(), perm.cpu().numpy())
+
+
+def _write_png_set(root, protos, per_class, rng):
+    from mercer_research_amd import png
+    for c, proto in enumerate(protos):
+        os.makedirs(os.path.join(root, str(c)))
+        for i in range(per_class):
+            img = proto.copy()
+            img[rng.random(img.shape) < 0.12] = 0
+            with open(os.path.join(root, str(c), f"{i}.png"), "wb") as f:
+                f.write(png.encode_gray(img))
+
+
+def test_cli_trains_from_png_directories_saves_and_resumes(amd, oracle, tmp_path, capsys):
+    """the reference CLI's flow (rcn/src/main.rs:44-79) on PNG directories: load_data front end, epoch lines,
+    bincode rcn.bin written; a second run resumes from it ("weights non-empty => skip init", rcn.rs:139-141); the saved
+    model classifies a file like RCN::classify and its parameters reproduce the oracle's forward pass."""
+    from mercer_research_amd import checkpoint, cli
+    rng = np.random.default_rng(3)
+    protos = []
+    for _ in range(10):
+        p = np.zeros((28, 28), dtype=np.uint8)
+        p[4:24, 4:24] = np.where(rng.random((20, 20)) < 0.3, rng.integers(80, 256, (20, 20)), 0)
+        protos.append(p)
+    tr, te, model_path = str(tmp_path / "training"), str(tmp_path / "testing"), str(tmp_path / "rcn.bin")
+    _write_png_set(tr, protos, 40, rng)
+    _write_png_set(te, protos, 12, rng)
+    argv = ["--training-path", tr, "--testing-path", te, "--training-class-size", "40", "--testing-class-size", "12", "-b", "10", "-e", "6",
+            "--model-path", model_path, "--seed", "5"]
+    assert cli.main(argv) == 0
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 6 and all(l.startswith(f"Epoch {i}: ") and l.endswith("%]") for i, l in enumerate(out))
+    acc = [int(l.split(": ")[1].split("/")[0]) for l in out]
+    assert out[0].split(": ")[1].split(" ")[0].endswith("/120") and acc[-1] >= 60 and acc[-1] > acc[0]   # un-scaled N(0,1) init learns slowly; chance = 12
+    ck = checkpoint.loads(open(model_path, "rb").read())
+    assert ck.classes == 10 and ck.convpool_cfg == [(0, 1), (1, 1), (0, 1), (1, 1)] and ck.feedforward_cfg == [30]
+    assert [w.shape for w in ck.layer_weights] == [(30, 784), (10, 30)] and ck.training_path == tr
+    # resume: the second run starts from the saved weights, so its first epoch is already accurate
+    argv2 = ["--training-path", tr, "--testing-path", te, "--training-class-size", "40", "--testing-class-size", "12", "-b", "10", "-e", "1",
+             "--model-path", model_path, "--seed", "6"]
+    assert cli.main(argv2) == 0
+    out2 = capsys.readouterr().out.strip().splitlines()
+    assert int(out2[0].split(": ")[1].split("/")[0]) >= acc[-1] - 15     # continues from the saved weights, not from a fresh init
+    # the saved model in a fresh context: RCN::classify on a file, and parity of its forward pass with the oracle
+    m = checkpoint.load_model(model_path)
+    f = os.path.join(te, "7", "0.png")
+    ck2 = checkpoint.loads(open(model_path, "rb").read())
+    from mercer_research_amd import png as _png
+    img = _png.to_pixel_matrix_u8(open(f, "rb").read())
+    feats = oracle.features(img[None], DEFAULT_LAYERS)
+    x = oracle.standardize(feats, ck2.scale_set[0], ck2.scale_set[1])
+    ref = oracle.classify_test(ck2.layer_weights, ck2.layer_bias, x)[0]
+    assert np.abs(m.classify_test(x)[0] - ref).max() <= 2e-6
+    srt = np.sort(ref)
+    if srt[-1] - srt[-2] > 1e-4:
+        assert m.classify_file(f) == oracle.classify_argmax(ref)              # RCN::classify incl. PNG decode == oracle
