@@ -64,6 +64,8 @@ struct rcn_hip_ctx {
     int dense_path = 0;                     // 0 auto, 1 sample-tile kernels (dense.hpp), 2 feature-sliced pipeline (dense_pipe.hpp)
     DevBuf slab, xpack, ypack, p2buf;
     size_t packed_B = 0, packed_nb = 0;     // what the epoch image currently holds (k_pack_epoch)
+    void* pin_host = nullptr;               // small pinned, device-mapped staging block for the serving path (classify)
+    void* pin_dev = nullptr;
     size_t pack_seg_bytes = (size_t)64 << 20;   // size of one half of the epoch image (env RCN_HIP_PACK_SEGMENT_BYTES, for tests)
     DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
     std::map<EpochKey, hipGraphExec_t> graphs;
@@ -520,6 +522,7 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
         for (DevBuf* b : {&c->slab, &c->xpack, &c->ypack, &c->p2buf, &c->params, &c->acts, &c->deltas, &c->loss_part, &c->grad, &c->xstage, &c->ystage, &c->ostage, &c->scratch0,
                           &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
             b->release();
+        if (c->pin_host) (void)hipHostFree(c->pin_host);
         if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -1167,6 +1170,8 @@ int rcn_hip_debug_read_stamps(rcn_hip_ctx* c, unsigned long long* out) {
 }
 #endif
 
+constexpr size_t kPinImgBytes = 64 * 1024, kPinClsBytes = 4096;    // serving path: up to 64 KB of pixels / 1024 classes per call
+
 int rcn_hip_classify_images(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, int32_t* cls) {
     RCN_TRY(check_ctx(c));
     if ((!imgs || !cls) && n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "classify_images: NULL pointer");
@@ -1174,9 +1179,31 @@ int rcn_hip_classify_images(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, int32
     RCN_TRY(need_params(c));
     DevGuard g(c->device);
     const size_t img_b = n * (size_t)c->fd.H * c->fd.W;
-    HIP_TRY(c, c->scratch0.ensure(img_b));
+    const int Cc = c->nd.dims[c->nd.L];
     HIP_TRY(c, c->xstage.ensure(n * (size_t)c->fd.F * c->esz()));
-    HIP_TRY(c, c->ostage.ensure(n * (size_t)c->nd.dims[c->nd.L] * c->esz()));
+    HIP_TRY(c, c->ostage.ensure(n * (size_t)Cc * c->esz()));
+    if (img_b <= kPinImgBytes && n * sizeof(int32_t) <= kPinClsBytes) {
+        // Latency path (one request of the reference's backend, backend/src/main.rs:22-42): pixels are copied by the CPU into
+        // a pinned block the GPU reads in place, the class index is written straight back into it; three small launches and
+        // ONE synchronisation instead of two staged copies around them.
+        if (!c->pin_host) {
+            HIP_TRY(c, hipHostMalloc(&c->pin_host, kPinImgBytes + kPinClsBytes, hipHostMallocMapped));
+            HIP_TRY(c, hipHostGetDevicePointer(&c->pin_dev, c->pin_host, 0));
+        }
+        std::memcpy(c->pin_host, imgs, img_b);
+        int* cls_dev = (int*)((char*)c->pin_dev + kPinImgBytes);
+        RCN_TRY(rcn_hip_features_dev(c, (const uint8_t*)c->pin_dev, n, c->xstage.p, 1));     // rcn.rs:84-89
+        RCN_TRY(rcn_hip_forward_dev(c, c->xstage.p, n, c->ostage.p));                        // rcn.rs:91
+        if (c->dtype == RCN_HIP_F64)
+            hipLaunchKernelGGL((k_argmax_last<double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->ostage.p, (int)n, Cc, cls_dev);
+        else
+            hipLaunchKernelGGL((k_argmax_last<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->ostage.p, (int)n, Cc, cls_dev);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::memcpy(cls, (char*)c->pin_host + kPinImgBytes, n * sizeof(int32_t));           // rcn.rs:92-97
+        return RCN_HIP_OK;
+    }
+    HIP_TRY(c, c->scratch0.ensure(img_b));
     HIP_TRY(c, hipMemcpyAsync(c->scratch0.p, imgs, img_b, hipMemcpyHostToDevice, c->stream));
     RCN_TRY(rcn_hip_features_dev(c, (const uint8_t*)c->scratch0.p, n, c->xstage.p, 1));   // rcn.rs:84-89
     RCN_TRY(rcn_hip_forward_dev(c, c->xstage.p, n, c->ostage.p));                          // rcn.rs:91
