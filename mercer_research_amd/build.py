@@ -32,13 +32,29 @@ def stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not stale():
-        return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+CLI = os.path.join(HERE, "rcn_hip_cli")
+CLI_SRC = os.path.join(CSRC, "host", "rcn_main.cpp")
+CLI_DEPS = [CLI_SRC, os.path.join(CSRC, "host", "rcn.hpp"), os.path.join(CSRC, "host", "formats.hpp")]
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> str:
+    """The C++ host side: rcn_hip_cli = rcn/src/main.rs over the C ABI (plain g++, links librcn_hip.so and zlib)."""
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(f) <= os.path.getmtime(CLI) for f in CLI_DEPS + [LIB]):
+        return CLI
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", CLI_SRC, "-L" + HERE, "-lrcn_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-o", CLI]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    return CLI
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if force or stale():
+        cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    build_cli(force, verbose)
     return LIB
 
 

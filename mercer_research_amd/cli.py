@@ -30,18 +30,17 @@ def main(argv=None) -> int:
     ap.add_argument("--seed", type=int, default=None)
     args = ap.parse_args(argv)
 
-    from . import F32, F64, RCN, checkpoint, default_convpool, png
+    from . import F32, F64, RCN, checkpoint, default_convpool
     kw = dict(input_shape=tuple(args.input_shape), dtype=F64 if args.dtype == "f64" else F32)
     if os.path.exists(args.model_path):                                   # main.rs:47-50
         model = checkpoint.load_model(args.model_path, **kw)
         model.training_path, model.testing_path = args.training_path, args.testing_path
     else:                                                                  # main.rs:51-62
         model = RCN(args.num_classes, default_convpool(), [30], args.training_path, args.testing_path, **kw)
-    try:                                                                   # main.rs:65-74
-        model.train(args.batches, args.epochs, args.learning_rate, args.training_class_size, args.testing_class_size,
-                    rng=np.random.default_rng(args.seed))
-    except (png.PngError, OSError) as e:        # Err(ImageError) is printed and the model still written (main.rs:72-77);
-        print(e, file=sys.stderr)                # panics (RcnPanic) propagate, as in the reference
+    # main.rs:65-74 matches on train's Result, but load_data unwrap()s every I/O / decode error (rcn.rs:369-398): a bad file is
+    # a panic in the reference, so exceptions simply propagate here
+    model.train(args.batches, args.epochs, args.learning_rate, args.training_class_size, args.testing_class_size,
+                rng=np.random.default_rng(args.seed))
     checkpoint.save_model(model, args.model_path)                          # main.rs:77
     return 0
 

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <numeric>
 #include <random>
 #include <stdexcept>
@@ -15,7 +16,10 @@
 #include <utility>
 #include <vector>
 
+#include <filesystem>
+
 #include "../../../include/rcn_hip.h"
+#include "formats.hpp"
 
 namespace rcn {
 namespace host {
@@ -159,6 +163,80 @@ public:
             if (print) std::printf("Epoch %zu: %lld/%zu [%.2f%%]\n", e, (long long)acc, n_test, (double)acc / (double)n_test * 100.0);
         }
         return accepted;
+    }
+
+    // ---- the reference's on-disk model (rcn/src/main.rs:47-50,77): bincode rcn.bin
+    void save(const std::string& path) {
+        Checkpoint c;
+        c.classes = classes_;
+        for (const auto& l : convpool_cfg_) c.convpool_cfg.push_back({(uint32_t)l.kind, (uint32_t)l.arg});
+        c.feedforward_cfg.assign(feedforward_cfg_.begin(), feedforward_cfg_.end());
+        if (weights_loaded_)
+            for (int l = 0; l < rcn_hip_num_layers(ctx_); ++l) {
+                Checkpoint::Matrix m; std::vector<double> b; int32_t r, cc;
+                check(rcn_hip_layer_dims(ctx_, l, &r, &cc));
+                m.rows = r; m.cols = cc;
+                get_params(l, m.data, b);
+                c.layer_weights.push_back(std::move(m)); c.layer_bias.push_back(std::move(b));
+            }
+        auto sc = scale_set(); c.scale_mean = sc.first; c.scale_sd = sc.second;
+        c.training_path = training_path_; c.testing_path = testing_path_;
+        write_file(path, checkpoint_dumps(c));
+    }
+    static std::unique_ptr<RCN> load(const std::string& path, int in_h = 28, int in_w = 28, int dtype = RCN_HIP_F32, int device = 0) {
+        const Checkpoint c = checkpoint_loads(read_file(path));
+        std::vector<RCNLayer> cfg;
+        for (auto& l : c.convpool_cfg) cfg.push_back({(int32_t)l.first, (int32_t)l.second});
+        auto m = std::make_unique<RCN>((size_t)c.classes, cfg, std::vector<size_t>(c.feedforward_cfg.begin(), c.feedforward_cfg.end()),
+                                       c.training_path, c.testing_path, in_h, in_w, dtype, device);
+        for (size_t l = 0; l < c.layer_weights.size(); ++l) m->set_params((int)l, c.layer_weights[l].data, c.layer_bias[l]);   // non-empty => skip init, rcn.rs:139
+        m->check(rcn_hip_set_scale(m->ctx_, c.scale_mean, c.scale_sd));
+        return m;
+    }
+    void set_paths(std::string training, std::string testing) { training_path_ = std::move(training); testing_path_ = std::move(testing); }
+
+    // ---- load_data's file handling (rcn.rs:367-404): class directories in sorted order, `csl` files drawn per class
+    // without replacement; panics if a class holds fewer.  -> pixels [n][h][w] u8, class indices
+    struct ImageSet { std::vector<uint8_t> px; std::vector<int32_t> labels; size_t n = 0, n_classes = 0; };
+    ImageSet read_image_set(const std::string& path, size_t class_size_limit, std::mt19937_64& rng) const {
+        namespace fs = std::filesystem;
+        std::vector<fs::path> classes;
+        for (auto& e : fs::directory_iterator(path)) classes.push_back(e.path());
+        std::sort(classes.begin(), classes.end());                                   // rcn.rs:374
+        ImageSet s; s.n_classes = classes.size();
+        for (size_t i = 0; i < classes.size(); ++i) {
+            std::vector<fs::path> files;
+            for (auto& e : fs::directory_iterator(classes[i])) files.push_back(e.path());
+            if (class_size_limit > files.size())                                          // rcn.rs:383-390
+                throw Panic(RCN_HIP_ERR_SHAPE, "provided class_size_limit for " + path + " too large! expected " + std::to_string(class_size_limit) +
+                                                   " <= " + std::to_string(files.size()));
+            for (size_t k = 0; k < class_size_limit; ++k) {                              // rcn.rs:392-394
+                const size_t idx = std::uniform_int_distribution<size_t>(0, files.size() - 1)(rng);
+                const GrayImage g = png_to_pixel_matrix(read_file(files[idx].string()));
+                files.erase(files.begin() + (long)idx);
+                if (g.h != in_h_ || g.w != in_w_) throw Error(RCN_HIP_ERR_INVALID_ARG, "image shape differs from the context's input shape");
+                s.px.insert(s.px.end(), g.px.begin(), g.px.end());
+                s.labels.push_back((int32_t)i);
+            }
+        }
+        s.n = s.labels.size();
+        return s;
+    }
+    // RCN::train (rcn.rs:126-133) from the two directories
+    std::vector<int64_t> train(size_t batch_size, size_t epochs, double eta, size_t training_class_size_limit, size_t testing_class_size_limit,
+                               uint64_t seed = 0, bool print = true) {
+        std::mt19937_64 rng(seed ? seed : std::random_device{}());
+        const ImageSet tr = read_image_set(training_path_, training_class_size_limit, rng);
+        const ImageSet te = read_image_set(testing_path_, testing_class_size_limit, rng);
+        if (tr.n_classes != classes_ || te.n_classes != classes_)
+            throw Panic(RCN_HIP_ERR_SHAPE, "number of class directories differs from the network's outputs (gemv / vector comparison panics)");
+        return train(tr.px.data(), tr.labels.data(), tr.n, te.px.data(), te.labels.data(), te.n, batch_size, epochs, eta, rng(), print);
+    }
+    // RCN::classify(img_path) (rcn.rs:82-98)
+    size_t classify(const std::string& img_path) {
+        const GrayImage g = png_to_pixel_matrix(read_file(img_path));
+        if (g.h != in_h_ || g.w != in_w_) throw Error(RCN_HIP_ERR_INVALID_ARG, "image shape differs from the context's input shape");
+        return classify(g.px.data());
     }
 
 private:

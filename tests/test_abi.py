@@ -114,5 +114,5 @@ def test_cpp_host_mirror_compiles_and_links(lib, tmp_path):
     from mercer_research_amd import _lib
     exe = tmp_path / "host_demo"
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "host_demo.cpp"),
-                    "-L" + os.path.dirname(_lib.LIB_PATH), "-lrcn_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", str(exe)], check=True)
+                    "-L" + os.path.dirname(_lib.LIB_PATH), "-lrcn_hip", "-lz", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", str(exe)], check=True)
     assert exe.exists()

@@ -161,3 +161,51 @@ def test_scan_and_sample_semantics(tmp_path):
     assert "too large! expected 4 <= 3" in str(e.value)
     imgs, lab, n = data.load_image_set(root, 2, np.random.default_rng(2))
     assert imgs.shape == (8, 6, 6) and imgs.dtype == np.uint8 and lab.tolist() == [0, 0, 1, 1, 2, 2, 3, 3] and n == 4
+
+
+# ------------------------------------------------------------------ the C++ host's codecs agree with the Python ones
+
+@pytest.fixture(scope="module")
+def format_check(tmp_path_factory):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path_factory.mktemp("fc") / "format_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(root, "tests", "cpp", "format_check.cpp"), "-lz", "-o", exe], check=True)
+    return exe
+
+
+def test_cpp_bincode_codec_matches_python(format_check, tmp_path):
+    import subprocess
+    raw, _, _ = _hand_built()
+    src, dst = tmp_path / "a.bin", tmp_path / "b.bin"
+    src.write_bytes(raw)
+    assert subprocess.run([format_check, "bincode", str(src), str(dst)]).returncode == 0
+    assert dst.read_bytes() == raw
+    src.write_bytes(raw[:-5])
+    assert subprocess.run([format_check, "bincode", str(src), str(dst)], capture_output=True).returncode == 4
+
+
+def test_cpp_png_decoder_matches_python(format_check, tmp_path):
+    import subprocess
+    rng = np.random.default_rng(5)
+    cases = []
+    img = rng.integers(0, 256, (28, 28)).astype(np.uint8)
+    cases.append(_png(28, 28, 8, 0, _filter_rows(img, 1, [0, 1, 2, 3, 4])))
+    rgb = rng.integers(0, 256, (5, 7, 3)).astype(np.uint8)
+    cases.append(_png(7, 5, 8, 2, _filter_rows(rgb.reshape(5, 21), 3, [4, 3])))
+    ga = rng.integers(0, 256, (4, 6, 2)).astype(np.uint8)
+    cases.append(_png(6, 4, 8, 4, _filter_rows(ga.reshape(4, 12), 2, [2])))
+    cases.append(_png(4, 1, 1, 0, _filter_rows(np.array([[0b10110000]], dtype=np.uint8), 1, [0])))
+    cases.append(_png(2, 1, 4, 3, _filter_rows(np.array([[0x01]], dtype=np.uint8), 1, [0]), plte=[10, 20, 30, 200, 100, 50]))
+    cases.append(png.encode_gray(img))
+    for i, data_ in enumerate(cases):
+        f = tmp_path / f"c{i}.png"
+        f.write_bytes(data_)
+        out = subprocess.run([format_check, "png", str(f)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout
+        hw, hexpx = out.stdout.strip().split("\n")
+        want = png.to_pixel_matrix_u8(data_)
+        assert hw == f"{want.shape[0]} {want.shape[1]}" and bytes.fromhex(hexpx) == want.tobytes(), i
+    f16 = tmp_path / "g16.png"
+    f16.write_bytes(_png(2, 2, 16, 0, _filter_rows(np.zeros((2, 4), dtype=np.uint8), 2, [0])))
+    assert subprocess.run([format_check, "png", str(f16)], capture_output=True).returncode == 3

@@ -448,7 +448,7 @@ def test_cpp_host_mirror_trains_on_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "host_demo"
     subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(root, "tests", "cpp", "host_demo.cpp"), "-L" + os.path.dirname(_lib.LIB_PATH),
-                    "-lrcn_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", str(exe)], check=True)
+                    "-lrcn_hip", "-lz", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Epoch 0:" in out.stdout and "host_demo ok" in out.stdout
@@ -583,3 +583,35 @@ def test_cli_trains_from_png_directories_saves_and_resumes(amd, oracle, tmp_path
     srt = np.sort(ref)
     if srt[-1] - srt[-2] > 1e-4:
         assert m.classify_file(f) == oracle.classify_argmax(ref)              # RCN::classify incl. PNG decode == oracle
+
+
+def test_cpp_cli_binary_matches_reference_flow(tmp_path):
+    """mercer_research_amd/rcn_hip_cli (C++, = rcn/src/main.rs over the C ABI): PNG directories in, epoch lines out,
+    rcn.bin written in the reference's bincode format and readable by the Python codec; a second run resumes."""
+    import subprocess
+    from mercer_research_amd import build as hb, checkpoint
+    exe = hb.build_cli()
+    rng = np.random.default_rng(4)
+    protos = []
+    for _ in range(10):
+        p = np.zeros((28, 28), dtype=np.uint8)
+        p[4:24, 4:24] = np.where(rng.random((20, 20)) < 0.3, rng.integers(80, 256, (20, 20)), 0)
+        protos.append(p)
+    tr, te, model_path = str(tmp_path / "training"), str(tmp_path / "testing"), str(tmp_path / "rcn.bin")
+    _write_png_set(tr, protos, 30, rng)
+    _write_png_set(te, protos, 10, rng)
+    argv = [exe, "--training-path", tr, "--testing-path", te, "--training-class-size", "30", "--testing-class-size", "10", "-b", "10", "-e", "4",
+            "--model-path", model_path, "--seed", "9"]
+    out = subprocess.run(argv, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 4 and all(l.startswith(f"Epoch {i}: ") and "/100 [" in l and l.endswith("%]") for i, l in enumerate(lines))
+    acc = [int(l.split(": ")[1].split("/")[0]) for l in lines]
+    assert acc[-1] > 30
+    ck = checkpoint.loads(open(model_path, "rb").read())
+    assert ck.classes == 10 and [w.shape for w in ck.layer_weights] == [(30, 784), (10, 30)] and ck.testing_path == te
+    out2 = subprocess.run(argv[:-6] + ["-e", "1", "--model-path", model_path, "--seed", "10"], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0 and int(out2.stdout.split(": ")[1].split("/")[0]) >= acc[-1] - 15
+    bad = subprocess.run(argv[:5] + ["--training-class-size", "31", "--testing-class-size", "10", "--model-path", str(tmp_path / "x.bin")],
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 101 and "too large! expected 31 <= 30" in bad.stderr       # rcn.rs:383-390 panic
