@@ -19,7 +19,7 @@
 
 namespace rcn {
 
-constexpr int kP2H = 32, kP2C = 16, kP2Ts = 8, kP2BThreads = 256, kP2MaxSlices = 64;
+constexpr int kP2H = 32, kP2C = 16, kP2Ts = 8, kP2BThreads = 512, kP2BWaves = kP2BThreads / 64, kP2MaxSlices = 64;
 
 inline bool p2_supported(const NetDesc& nd, size_t B) {
     return nd.L == 2 && nd.dims[1] <= kP2H && nd.dims[2] <= kP2C && B % 256 == 0 && B >= 256 && pipe_slices(nd) <= kP2MaxSlices;
@@ -151,9 +151,9 @@ __global__ __launch_bounds__(kDenseThreads) void k_p2_a(
     RCN_STAMP(0, 5);
 }
 
-// One workgroup per 8 samples, 4 waves.  All four waves sum slabs (slices w, w+4, ...).  Waves 1-3 additionally fetch
-// and mask the tail's operands into LDS as ready-made MFMA fragments, so that wave 0 -- the critical path, ~5.6 cycles
-// per instruction when a wave runs alone on its SIMD -- only reads fragments, issues 16 MFMAs and stores.
+// One workgroup per 8 samples, 8 waves.  All waves sum slabs (slices w, w+8, ...).  Waves 1-7 additionally fetch and
+// mask the tail's operands into LDS as ready-made MFMA fragments (a few loads each), so that wave 0 -- the critical
+// path, ~5.6 cycles per instruction when a wave runs alone on its SIMD -- only reads fragments, issues 16 MFMAs and stores.
 template <typename T>
 __global__ __launch_bounds__(kP2BThreads) void k_p2_b(
     NetDesc nd, const T* __restrict__ params, const T* __restrict__ slab, int G, const T* __restrict__ Ys, int B,
@@ -161,10 +161,11 @@ __global__ __launch_bounds__(kP2BThreads) void k_p2_b(
     using acc_t = typename Mfma16<T>::acc_t;
     using vec4 = typename Vec4<T>::type;
     constexpr int kFrag = 28;                                     // fragment words per lane: wz 8, wd 8, b1 4, y 4, b0 4
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(4 * 64 * 4 + kP2H * kLd + kP2C * kLd + kFrag * 64) * sizeof(T)];
+    constexpr int kPer = kP2MaxSlices / kP2BWaves;                // slab slices per wave (8)
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(kP2BWaves * 64 * 4 + kP2H * kLd + kP2C * kLd + kFrag * 64) * sizeof(T)];
     T* smem = reinterpret_cast<T*>(smem_raw);
-    vec4* zred = reinterpret_cast<vec4*>(smem);                   // [4 waves][64 lanes]
-    T* a1s = smem + 4 * 64 * 4;                                   // a_1 tile  [hidden 32][kLd]  (MFMA B operand image)
+    vec4* zred = reinterpret_cast<vec4*>(smem);                   // [8 waves][64 lanes]
+    T* a1s = smem + kP2BWaves * 64 * 4;                           // a_1 tile  [hidden 32][kLd]  (MFMA B operand image)
     T* d2s = a1s + kP2H * kLd;                                    // delta_2   [class 16][kLd]
     T* frag = d2s + kP2C * kLd;                                   // [word][lane]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
@@ -172,56 +173,64 @@ __global__ __launch_bounds__(kP2BThreads) void k_p2_b(
     const int s0 = blockIdx.x * kP2Ts;
     RCN_STAMP(1, 0);
 
-    // ---- slab loads: 16 slices per wave in flight (G <= 64); lane <- float4 `lane` of the [8][32] slice tile
+    // ---- slab loads: 8 slices per wave in flight (G <= 64); lane <- float4 `lane` of the [8][32] slice tile
     const vec4* sp = reinterpret_cast<const vec4*>(slab + (size_t)blockIdx.x * G * kP2Ts * kP2H) + lane;
-    vec4 t[16];
+    vec4 t[kPer];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int g = wave + 4 * q;
+    for (int q = 0; q < kPer; ++q) {
+        const int g = wave + kP2BWaves * q;
         t[q] = sp[(size_t)(g < G ? g : wave) * 64];
     }
     const T* W1 = params + nd.w_off[1];                           // C x H column-major: (c, h) at h*C + c
-    if (wave == 1) {                                              // z_2 = W_1 a_1:   A[m = c][k = h]
+    if (wave == 1 || wave == 2) {                                 // z_2 = W_1 a_1:   A[m = c][k = h]; 4 k-steps each
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int h = 4 * ks + g4;
+        for (int q = 0; q < 4; ++q) {
+            const int ks = 4 * (wave - 1) + q, h = 4 * ks + g4;
             const T w = W1[(size_t)(h < H ? h : 0) * C + (n < C ? n : 0)];
             frag[ks * 64 + lane] = (h < H && n < C) ? w : (T)0;
         }
-    } else if (wave == 2) {                                       // W_1^T delta_2:  A[m = h][k = c]
+    } else if (wave == 3 || wave == 4) {                          // W_1^T delta_2:  A[m = h][k = c]; one M-tile each
+        const int mt = wave - 3;
 #pragma unroll
-        for (int mt = 0; mt < kMtp; ++mt)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int h = mt * 16 + n, c = 4 * ks + g4;
-                const T w = W1[(size_t)(h < H ? h : 0) * C + (c < C ? c : 0)];
-                frag[(8 + mt * 4 + ks) * 64 + lane] = (h < H && c < C) ? w : (T)0;
-            }
-    } else if (wave == 3) {                                       // b_1, targets (per accumulator element), b_0
+        for (int ks = 0; ks < 4; ++ks) {
+            const int h = mt * 16 + n, c = 4 * ks + g4;
+            const T w = W1[(size_t)(h < H ? h : 0) * C + (c < C ? c : 0)];
+            frag[(8 + mt * 4 + ks) * 64 + lane] = (h < H && c < C) ? w : (T)0;
+        }
+    } else if (wave == 5) {                                       // b_1 per accumulator element
         const T* b1 = W1 + (size_t)C * H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = Mfma16<T>::row(lane, i);
+            const T bb = b1[c < C ? c : 0];
+            frag[(16 + i) * 64 + lane] = c < C ? bb : (T)0;
+        }
+    } else if (wave == 6) {                                       // targets per accumulator element
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = Mfma16<T>::row(lane, i);
+            frag[(20 + i) * 64 + lane] = Ys[(size_t)(s0 + (n & 7)) * C + (c < C ? c : 0)];
+        }
+    } else if (wave == 7) {                                       // b_0 per slab float4 element
         const T* b0 = params + nd.w_off[0] + (size_t)H * F;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = Mfma16<T>::row(lane, i);                // class row of accumulator element i
-            const T bb = b1[c < C ? c : 0];
-            const T yy = Ys[(size_t)(s0 + (n & 7)) * C + (c < C ? c : 0)];
-            const int h = 4 * (lane & 7) + i;                     // hidden unit of slab float4 element i
+            const int h = 4 * (lane & 7) + i;
             const T b = b0[h < H ? h : 0];
-            frag[(16 + i) * 64 + lane] = c < C ? bb : (T)0;
-            frag[(20 + i) * 64 + lane] = yy;
             frag[(24 + i) * 64 + lane] = h < H ? b : (T)0;
         }
     }
     vec4 z = vec4{0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-        if (wave + 4 * q < G) z += t[q];                          // slice order within a wave ...
+    for (int q = 0; q < kPer; ++q)
+        if (wave + kP2BWaves * q < G) z += t[q];                  // slice order within a wave ...
     zred[wave * 64 + lane] = z;
     RCN_STAMP(1, 1);
     __syncthreads();
     RCN_STAMP(1, 2);
     if (wave != 0) return;
-    z = (zred[lane] + zred[64 + lane]) + (zred[128 + lane] + zred[192 + lane]);   // ... and a fixed order across waves
+    z = ((zred[lane] + zred[64 + lane]) + (zred[128 + lane] + zred[192 + lane])) +
+        ((zred[256 + lane] + zred[320 + lane]) + (zred[384 + lane] + zred[448 + lane]));   // ... and a fixed order across waves
 
     // ---- a_1 = sigmoid(z_1 + b_0); lane <- sample lane>>3, hidden 4*(lane&7)+i                       rcn.rs:287-289
     {
