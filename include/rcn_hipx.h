@@ -1,0 +1,65 @@
+/*
+ * rcn_hipx.h -- C ABI of the north-star EXTENSION ("Track X"): a trainable convolution network on gfx950.
+ *
+ * BASELINE.json's north_star asks for trainable Conv2d forward/backward lowered to im2col + MFMA GEMM, dense layers,
+ * softmax / cross-entropy and SGD.  The reference crate has none of these (its "convolution" layers are four fixed
+ * Sobel filters with no backward pass, rcn/src/utils/kernel.rs:38-53, rcn/src/rcn.rs:317-356; its dense part is
+ * sigmoid / MSE, rcn.rs:260-314), so nothing here replaces a reference function and parity is defined against this
+ * repository's own f64 oracle (oracle/convnet_oracle.py) and finite differences -- "parity unpinned" by construction.
+ * The reference-parity hot path lives in rcn_hip.h.
+ *
+ * Data: activations NHWC fp32; a batch is [B][H][W][C] contiguous.  Logical parameters per layer: W[K][Cout] row-major
+ * with K = (kh*3 + kw)*Cin + ci for a 3x3 convolution (pad 1, stride 1) and K = input features for a dense layer
+ * (features of a conv stack are flattened in (h, w, c) order), followed by b[Cout].
+ */
+#ifndef RCN_HIPX_H
+#define RCN_HIPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rcn_hipx_net rcn_hipx_net;
+
+typedef enum {
+    RCN_HIPX_CONV3X3_RELU = 0,   /* 3x3, stride 1, pad 1, + bias, ReLU;  out = output channels (multiple of 32)            */
+    RCN_HIPX_MAXPOOL2 = 1,       /* 2x2 / stride 2 max-pool (even H, W); out ignored                                         */
+    RCN_HIPX_DENSE_RELU = 2,     /* dense + bias + ReLU; out = units (multiple of 32)                                       */
+    RCN_HIPX_DENSE = 3           /* final dense + bias (logits); out = classes (any; padded to 32 internally)               */
+} rcn_hipx_layer_kind;
+
+typedef struct rcn_hipx_layer { int32_t kind; int32_t out; } rcn_hipx_layer;
+
+/* status: 0 ok, -1 invalid argument, -2 shape, -3 unsupported, -4 HIP error, -5 no device, -6 state, -7 out of memory */
+int  rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int max_batch,
+                     void* hip_stream /* NULL: own stream */, rcn_hipx_net** out);
+void rcn_hipx_destroy(rcn_hipx_net* net);
+const char* rcn_hipx_last_error(const rcn_hipx_net* net);
+int  rcn_hipx_synchronize(rcn_hipx_net* net);
+int  rcn_hipx_param_count(const rcn_hipx_net* net, int64_t* logical, int64_t* padded);
+int  rcn_hipx_classes(const rcn_hipx_net* net);
+/* logical layout, host memory, all layers back to back: W_0[K][Cout], b_0[Cout], W_1 ... */
+int  rcn_hipx_set_params(rcn_hipx_net* net, const float* flat);
+int  rcn_hipx_get_params(rcn_hipx_net* net, float* flat);
+int  rcn_hipx_init_params(rcn_hipx_net* net, uint64_t seed);            /* He-normal weights, zero biases */
+/* logits_dev: [B][classes] */
+int  rcn_hipx_forward_dev(rcn_hipx_net* net, const float* x_dev, int B, float* logits_dev);
+/* one SGD step on mean cross-entropy: forward, backward, W <- W - lr * dW.  loss_dev (nullable): mean loss before the step.
+ * Replayed as one hipGraph per (pointers, B, lr). */
+int  rcn_hipx_train_step_dev(rcn_hipx_net* net, const float* x_dev, const int32_t* labels_dev, int B, float lr, float* loss_dev);
+/* data-parallel halves: gradients of the MEAN loss over this shard into the padded flat layout (rcn_hipx_param_count's
+ * `padded`), and p <- p - scale * g from such a buffer. */
+int  rcn_hipx_gradients_dev(rcn_hipx_net* net, const float* x_dev, const int32_t* labels_dev, int B, float* grad_dev, float* loss_dev);
+int  rcn_hipx_apply_dev(rcn_hipx_net* net, const float* grad_dev, float scale);
+/* logical-layout copy of a padded gradient buffer (tests) */
+int  rcn_hipx_unpad_host(rcn_hipx_net* net, const float* padded_dev, float* logical_host);
+/* algorithmic FLOPs of one training step at batch B (2 * MACs; forward + dgrad + wgrad) */
+int  rcn_hipx_step_flops(const rcn_hipx_net* net, int B, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

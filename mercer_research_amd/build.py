@@ -32,6 +32,21 @@ def stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
 
 
+LIBX = os.path.join(HERE, "librcn_hipx.so")          # Track X (trainable conv net; include/rcn_hipx.h)
+LIBX_SRC = os.path.join(CSRC, "rcn_hipx_api.hip")
+LIBX_DEPS = [LIBX_SRC, os.path.join(CSRC, "convnet.hpp"), os.path.join(HERE, "..", "include", "rcn_hipx.h")]
+
+
+def build_x(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(LIBX) and all(os.path.getmtime(f) <= os.path.getmtime(LIBX) for f in LIBX_DEPS):
+        return LIBX
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-result", "-o", LIBX, LIBX_SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIBX
+
+
 CLI = os.path.join(HERE, "rcn_hip_cli")
 CLI_SRC = os.path.join(CSRC, "host", "rcn_main.cpp")
 CLI_DEPS = [CLI_SRC, os.path.join(CSRC, "host", "rcn.hpp"), os.path.join(CSRC, "host", "formats.hpp")]
@@ -55,6 +70,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     build_cli(force, verbose)
+    build_x(force, verbose)
     return LIB
 
 

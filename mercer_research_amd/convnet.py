@@ -1,0 +1,148 @@
+"""ctypes face of librcn_hipx.so (include/rcn_hipx.h): the Track-X trainable convolution network.  No reference
+counterpart (see the header); torch tensors are used only as HBM buffers."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBX_PATH = os.path.join(HERE, "librcn_hipx.so")
+KIND = {"conv": 0, "pool": 1, "dense_relu": 2, "dense": 3}
+
+
+class XLayer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("out", C.c_int32)]
+
+
+_vp, _i = C.c_void_p, C.c_int
+SIGNATURES = {
+    "rcn_hipx_create": (_i, [_i, _i, _i, _i, C.POINTER(XLayer), _i, _i, _vp, C.POINTER(_vp)]),
+    "rcn_hipx_destroy": (None, [_vp]),
+    "rcn_hipx_last_error": (C.c_char_p, [_vp]),
+    "rcn_hipx_synchronize": (_i, [_vp]),
+    "rcn_hipx_param_count": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rcn_hipx_classes": (_i, [_vp]),
+    "rcn_hipx_set_params": (_i, [_vp, C.POINTER(C.c_float)]),
+    "rcn_hipx_get_params": (_i, [_vp, C.POINTER(C.c_float)]),
+    "rcn_hipx_init_params": (_i, [_vp, C.c_uint64]),
+    "rcn_hipx_forward_dev": (_i, [_vp, _vp, _i, _vp]),
+    "rcn_hipx_train_step_dev": (_i, [_vp, _vp, _vp, _i, C.c_float, _vp]),
+    "rcn_hipx_gradients_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "rcn_hipx_apply_dev": (_i, [_vp, _vp, C.c_float]),
+    "rcn_hipx_unpad_host": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+    "rcn_hipx_step_flops": (_i, [_vp, _i, C.POINTER(C.c_double)]),
+}
+_libx = None
+
+
+def load():
+    global _libx
+    if _libx is None:
+        if not os.path.exists(LIBX_PATH):
+            raise ImportError(f"{LIBX_PATH} not found: build it with `python -m mercer_research_amd.build`; there is no CPU fallback")
+        lib = C.CDLL(LIBX_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _libx = lib
+    return _libx
+
+
+class ConvNetError(RuntimeError):
+    pass
+
+
+class ConvNet:
+    """layers: sequence of ("conv", Cout) | ("pool",) | ("dense_relu", units) | ("dense", classes)."""
+
+    def __init__(self, in_shape: Tuple[int, int, int], layers: Sequence[tuple], max_batch: int, device: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("ConvNet needs a GPU; there is no CPU fallback")
+        self.lib = load()
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.in_shape, self.layers, self.max_batch = tuple(in_shape), [tuple(l) for l in layers], max_batch
+        arr = (XLayer * len(layers))()
+        for i, l in enumerate(layers):
+            arr[i].kind, arr[i].out = KIND[l[0]], int(l[1]) if len(l) > 1 else 0
+        self.net = C.c_void_p()
+        st = self.lib.rcn_hipx_create(device, in_shape[0], in_shape[1], in_shape[2], arr, len(layers), max_batch, C.c_void_p(self.stream.cuda_stream), C.byref(self.net))
+        if st != 0:
+            msg = self.lib.rcn_hipx_last_error(self.net).decode() if self.net.value else f"status {st}"
+            if self.net.value:
+                self.lib.rcn_hipx_destroy(self.net)
+            self.net = C.c_void_p()
+            raise ConvNetError(f"rcn_hipx_create: {st}: {msg}")
+        a, b = C.c_int64(), C.c_int64()
+        self.lib.rcn_hipx_param_count(self.net, C.byref(a), C.byref(b))
+        self.n_logical, self.n_padded = int(a.value), int(b.value)
+        self.classes = self.lib.rcn_hipx_classes(self.net)
+
+    def _ck(self, st):
+        if st != 0:
+            raise ConvNetError(f"rcn_hipx status {st}: {self.lib.rcn_hipx_last_error(self.net).decode()}")
+
+    def close(self):
+        if getattr(self, "net", None) is not None and self.net.value:
+            self.lib.rcn_hipx_destroy(self.net)
+            self.net = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._ck(self.lib.rcn_hipx_synchronize(self.net))
+
+    def set_params(self, flat: np.ndarray):
+        f = np.ascontiguousarray(flat, dtype=np.float32)
+        assert f.size == self.n_logical
+        self._ck(self.lib.rcn_hipx_set_params(self.net, f.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def get_params(self) -> np.ndarray:
+        f = np.zeros(self.n_logical, dtype=np.float32)
+        self._ck(self.lib.rcn_hipx_get_params(self.net, f.ctypes.data_as(C.POINTER(C.c_float))))
+        return f
+
+    def init_params(self, seed: int = 1):
+        self._ck(self.lib.rcn_hipx_init_params(self.net, seed))
+
+    def to_device(self, a: np.ndarray):
+        with self.torch.cuda.stream(self.stream):
+            return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def forward(self, x):
+        out = self.torch.empty(x.shape[0], self.classes, dtype=self.torch.float32, device=self.device)
+        self._ck(self.lib.rcn_hipx_forward_dev(self.net, C.c_void_p(x.data_ptr()), x.shape[0], C.c_void_p(out.data_ptr())))
+        return out
+
+    def train_step(self, x, labels, lr: float, loss=None):
+        self._ck(self.lib.rcn_hipx_train_step_dev(self.net, C.c_void_p(x.data_ptr()), C.c_void_p(labels.data_ptr()), x.shape[0], lr,
+                                                  C.c_void_p(loss.data_ptr()) if loss is not None else None))
+
+    def gradients(self, x, labels, grad=None, loss=None):
+        grad = grad if grad is not None else self.torch.empty(self.n_padded, dtype=self.torch.float32, device=self.device)
+        self._ck(self.lib.rcn_hipx_gradients_dev(self.net, C.c_void_p(x.data_ptr()), C.c_void_p(labels.data_ptr()), x.shape[0], C.c_void_p(grad.data_ptr()),
+                                                 C.c_void_p(loss.data_ptr()) if loss is not None else None))
+        return grad
+
+    def apply(self, grad, scale: float):
+        self._ck(self.lib.rcn_hipx_apply_dev(self.net, C.c_void_p(grad.data_ptr()), scale))
+
+    def unpad(self, padded) -> np.ndarray:
+        f = np.zeros(self.n_logical, dtype=np.float32)
+        self._ck(self.lib.rcn_hipx_unpad_host(self.net, C.c_void_p(padded.data_ptr()), f.ctypes.data_as(C.POINTER(C.c_float))))
+        return f
+
+    def step_flops(self, B: int) -> float:
+        f = C.c_double()
+        self._ck(self.lib.rcn_hipx_step_flops(self.net, B, C.byref(f)))
+        return f.value

@@ -1,0 +1,376 @@
+// convnet.hpp -- "Track X": the trainable convolution network BASELINE.json's north_star asks for and the reference
+// does NOT have (its conv layers are four fixed Sobel filters without a backward pass).  No reference
+// counterpart => parity is against this repository's own f64 oracle (oracle/convnet_oracle.py) + finite differences.
+//
+// Layout: activations NHWC fp32 ([N][H][W][C], channels contiguous), so a convolution is an implicit GEMM
+//     Y[m][co] = sum_k A[m][k] * Wk[k][co],   m = (n*H + oh)*W + ow,   k = (kh*KS + kw)*Cin + ci
+// whose A rows are, per filter tap, CONTIGUOUS runs of Cin floats of the input -- the im2col matrix is never written to
+// HBM; the A-tile loader gathers it straight into LDS (zero rows for the padding halo).  Weights are stored K-major
+// (Wk[K][Cout]), which is also the dense layer's [in][out] matrix: a dense layer is the KS = 1 case on a 1x1 image.
+//
+//   k_conv_fwd     128 x BN output tile per workgroup, BK = 32, fp32 MFMA 32x32x2 (exact f32 FMA chains),
+//                  register-staged double buffering, bias + ReLU epilogue.
+//   dgrad          the same kernel on dZ with the tap-flipped, transposed weights Wt[(kh',kw',co)][ci] (k_flip_weights).
+//   k_conv_wgrad   dW[k][co] = sum_m A[m][k] dZ[m][co]: contraction over the output pixels, split over workgroups in
+//                  chunks whose partial tiles go to a slab; k_reduce_update sums the slab in chunk order (bit-
+//                  reproducible) and applies the SGD step.
+//   k_pool_fwd/bwd 2x2/2 max-pool with a 2-bit arg-max image; backward also applies the ReLU mask.
+//   k_softmax_ce   fused softmax + cross-entropy forward and (p - onehot)/B backward.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rcnx {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kBM = 128, kBK = 32, kThreads = 256;
+constexpr int kLdA = kBK + 1;
+
+// D layout of v_mfma_f32_32x32x2_f32: lane l holds col = l & 31, rows (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), r in [0,16)
+__device__ inline int mfma32_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+struct ConvShape {
+    int N, H, W, Cin, Cout;     // stride 1, pad = KS/2, output H x W
+};
+
+// A-tile element source: row m of the implicit im2col matrix, K-tile kt (32 consecutive k)
+template <int KS, bool SMALLC>
+__device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape& s, long long M, long long m0, int kt, int tid, f32x4 (&v)[4]) {
+    // thread t loads rows (t>>3) + 32 q, q = 0..3, columns 4*(t&7) .. +3 of the 128 x 32 tile
+    const int c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long m = m0 + (tid >> 3) + 32 * q;
+        f32x4 val = f32x4{0, 0, 0, 0};
+        if (m < M) {
+            const int ow = (int)(m % s.W);
+            const long long t2 = m / s.W;
+            const int oh = (int)(t2 % s.H);
+            const long long n = t2 / s.H;
+            if (!SMALLC) {
+                const int k0 = kt * kBK + c4;                       // Cin % 32 == 0: the 4 columns share one tap
+                const int tap = k0 / s.Cin, ci = k0 - tap * s.Cin;
+                const int kh = tap / KS, kw = tap - kh * KS;
+                const int ih = oh + kh - KS / 2, iw = ow + kw - KS / 2;
+                if (ih >= 0 && ih < s.H && iw >= 0 && iw < s.W)
+                    val = *reinterpret_cast<const f32x4*>(X + ((n * s.H + ih) * s.W + iw) * (long long)s.Cin + ci);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = c4 + i;                           // whole K (= KS*KS*Cin <= 32) in one tile
+                    if (k < KS * KS * s.Cin) {
+                        const int tap = k / s.Cin, ci = k - tap * s.Cin;
+                        const int kh = tap / KS, kw = tap - kh * KS;
+                        const int ih = oh + kh - KS / 2, iw = ow + kw - KS / 2;
+                        if (ih >= 0 && ih < s.H && iw >= 0 && iw < s.W) val[i] = X[((n * s.H + ih) * s.W + iw) * (long long)s.Cin + ci];
+                    }
+                }
+            }
+        }
+        v[q] = val;
+    }
+}
+
+// EPI: 0 = raw, 1 = + bias, 2 = + bias, ReLU
+template <int KS, bool SMALLC, int BN, int EPI>
+__global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__ X, const float* __restrict__ Wk,
+                                                       const float* __restrict__ bias, float* __restrict__ Y, ConvShape s) {
+    constexpr int kLdB = BN + 1, NT = BN / 32;
+    __shared__ float As[2][kBM * kLdA];
+    __shared__ float Bs[2][kBK * kLdB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long M = (long long)s.N * s.H * s.W;
+    const long long m0 = (long long)blockIdx.x * kBM;
+    const int n0 = blockIdx.y * BN;
+    const int K = KS * KS * s.Cin;
+    const int nkt = SMALLC ? 1 : K / kBK;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    f32x4 av[4];
+    f32x4 bv[BN / 32];                                   // B tile: 32 x BN floats = 8*BN float4 / 256 threads
+    auto load_b = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q) {
+            const int e = tid + kThreads * q;            // float4 index in the 32 x (BN/4) tile
+            const int kr = e / (BN / 4), c4 = (e - kr * (BN / 4)) * 4;
+            const int k = kt * kBK + kr;
+            bv[q] = (k < K) ? *reinterpret_cast<const f32x4*>(Wk + (long long)k * s.Cout + n0 + c4) : f32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        const int c4 = (tid & 7) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* d = &As[buf][((tid >> 3) + 32 * q) * kLdA + c4];
+            d[0] = av[q][0]; d[1] = av[q][1]; d[2] = av[q][2]; d[3] = av[q][3];
+        }
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q) {
+            const int e = tid + kThreads * q;
+            const int kr = e / (BN / 4), c4b = (e - kr * (BN / 4)) * 4;
+            float* d = &Bs[buf][kr * kLdB + c4b];
+            d[0] = bv[q][0]; d[1] = bv[q][1]; d[2] = bv[q][2]; d[3] = bv[q][3];
+        }
+    };
+
+    load_a_regs<KS, SMALLC>(X, s, M, m0, 0, tid, av);
+    load_b(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) {                              // next tile's global loads fly while this tile computes
+            load_a_regs<KS, SMALLC>(X, s, M, m0, kt + 1, tid, av);
+            load_b(kt + 1);
+        }
+        const float* a = &As[cur][(wave * 32 + (lane & 31)) * kLdA + (lane >> 5)];
+        const float* b = &Bs[cur][(lane >> 5) * kLdB + (lane & 31)];
+#pragma unroll
+        for (int ks = 0; ks < kBK / 2; ++ks) {
+            const float af = a[2 * ks];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, b[2 * ks * kLdB + 32 * t], acc[t], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) {
+            store_tiles(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // epilogue: lane holds column co = n0 + 32 t + (lane & 31), 16 rows
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = n0 + 32 * t + (lane & 31);
+        const float bb = (EPI >= 1) ? bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m = m0 + wave * 32 + mfma32_row(lane, r);
+            if (m < M) {
+                float v = acc[t][r] + bb;
+                if (EPI == 2) v = v > 0.f ? v : 0.f;
+                Y[m * s.Cout + co] = v;
+            }
+        }
+    }
+}
+
+// Wt[(kh', kw', co)][ci] = Wk[((2-kh')*KS + (2-kw'))*Cin + ci][co]  (tap-flipped transpose for dgrad); KS = 1: plain transpose
+__global__ void k_flip_weights(const float* __restrict__ Wk, float* __restrict__ Wt, int KS, int Cin, int Cout) {
+    const long long total = (long long)KS * KS * Cin * Cout;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(e % Cin);
+        const long long t = e / Cin;
+        const int co = (int)(t % Cout);
+        const int tap = (int)(t / Cout);
+        const int kh = tap / KS, kw = tap - kh * KS;
+        const int ftap = (KS - 1 - kh) * KS + (KS - 1 - kw);
+        Wt[e] = Wk[((long long)ftap * Cin + ci) * Cout + co];
+    }
+}
+
+// dW partial tiles: workgroup (kb, nb, chunk) computes rows [32 kb, +32) x cols [BN nb, +BN) of dW over the pixels of
+// its chunk and writes them to slab[chunk][K][Cout].
+template <int KS, bool SMALLC, int BN>
+__global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ X, const float* __restrict__ dZ,
+                                                         float* __restrict__ slab, ConvShape s, int pix_per_chunk) {
+    constexpr int kLdD = BN + 1, NT = BN / 32;
+    __shared__ float Xs[32 * 33];                        // [pixel][k]
+    __shared__ float Ds[32 * kLdD];                      // [pixel][co]
+    __shared__ float Red[4 * 32 * kLdD];                 // per-wave partial tiles
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long M = (long long)s.N * s.H * s.W;
+    const int K = KS * KS * s.Cin;
+    const int kb = blockIdx.x, n0 = blockIdx.y * BN;
+    const long long p0 = (long long)blockIdx.z * pix_per_chunk;
+    const long long p1 = p0 + pix_per_chunk < M ? p0 + pix_per_chunk : M;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (long long pb = p0; pb < p1; pb += 32) {
+        // gather 32 pixels x 32 k of the implicit im2col matrix (k-block kb), and 32 pixels x BN of dZ
+        {
+            const int pr = tid >> 3, c4 = (tid & 7) * 4;             // 32 rows x 8 float4
+            const long long m = pb + pr;
+            f32x4 val = f32x4{0, 0, 0, 0};
+            if (m < p1) {
+                const int ow = (int)(m % s.W);
+                const long long t2 = m / s.W;
+                const int oh = (int)(t2 % s.H);
+                const long long n = t2 / s.H;
+                if (!SMALLC) {
+                    const int k0 = kb * 32 + c4;
+                    const int tap = k0 / s.Cin, ci = k0 - tap * s.Cin;
+                    const int kh = tap / KS, kw = tap - kh * KS;
+                    const int ih = oh + kh - KS / 2, iw = ow + kw - KS / 2;
+                    if (ih >= 0 && ih < s.H && iw >= 0 && iw < s.W)
+                        val = *reinterpret_cast<const f32x4*>(X + ((n * s.H + ih) * s.W + iw) * (long long)s.Cin + ci);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = c4 + i;
+                        if (k < K) {
+                            const int tap = k / s.Cin, ci = k - tap * s.Cin;
+                            const int kh = tap / KS, kw = tap - kh * KS;
+                            const int ih = oh + kh - KS / 2, iw = ow + kw - KS / 2;
+                            if (ih >= 0 && ih < s.H && iw >= 0 && iw < s.W) val[i] = X[((n * s.H + ih) * s.W + iw) * (long long)s.Cin + ci];
+                        }
+                    }
+                }
+            }
+            float* d = &Xs[pr * 33 + c4];
+            d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
+        }
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q) {
+            const int e = tid + kThreads * q;
+            const int pr = e / (BN / 4), c4 = (e - pr * (BN / 4)) * 4;
+            const long long m = pb + pr;
+            const f32x4 val = (m < p1) ? *reinterpret_cast<const f32x4*>(dZ + m * s.Cout + n0 + c4) : f32x4{0, 0, 0, 0};
+            float* d = &Ds[pr * kLdD + c4];
+            d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
+        }
+        __syncthreads();
+        // A[m = k][kk = pixel] = Xs[pixel][k];  B[kk = pixel][n = co] = Ds[pixel][co];  wave w takes pixels 8w .. 8w+7
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int px = wave * 8 + 2 * ks + (lane >> 5);
+            const float af = Xs[px * 33 + (lane & 31)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, Ds[px * kLdD + 32 * t + (lane & 31)], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // combine the four waves' partial tiles in wave order, write the chunk's tile
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Red[(wave * 32 + mfma32_row(lane, r)) * kLdD + 32 * t + (lane & 31)] = acc[t][r];
+    __syncthreads();
+    float* out = slab + (long long)blockIdx.z * K * s.Cout;
+    for (int e = tid; e < 32 * BN; e += kThreads) {
+        const int kr = e / BN, c = e - kr * BN;
+        const int k = kb * 32 + kr;
+        if (k < K) {
+            const float v = (Red[(0 * 32 + kr) * kLdD + c] + Red[(1 * 32 + kr) * kLdD + c]) + (Red[(2 * 32 + kr) * kLdD + c] + Red[(3 * 32 + kr) * kLdD + c]);
+            out[(long long)k * s.Cout + n0 + c] = v;
+        }
+    }
+}
+
+// p <- p - lr * sum_chunks slab[c][i]   (or grad out when apply == 0); fixed chunk order
+__global__ void k_reduce_update(float* __restrict__ p, float* __restrict__ grad_out, const float* __restrict__ slab, long long n, int chunks,
+                                float lr, int apply) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float g = 0.f;
+        for (int c = 0; c < chunks; ++c) g += slab[(long long)c * n + i];
+        if (grad_out) grad_out[i] = g;
+        if (apply) p[i] = p[i] - lr * g;
+    }
+}
+
+// db[co] = sum_m dZ[m][co]: one workgroup per 32-column block, rows strided over threads, fixed-order tree
+__global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dZ, long long M, int Cout, float* __restrict__ b, float* __restrict__ grad_out,
+                                                   float lr, int apply) {
+    __shared__ float red[8][33];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rgrp = threadIdx.x >> 5;
+    float acc = 0.f;
+    if (c < Cout)
+        for (long long m = rgrp; m < M; m += 8) acc += dZ[m * Cout + c];
+    red[rgrp][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < Cout) {
+        float g = 0.f;
+        for (int r = 0; r < 8; ++r) g += red[r][threadIdx.x];
+        if (grad_out) grad_out[c] = g;
+        if (apply) b[c] = b[c] - lr * g;
+    }
+}
+
+// 2x2 stride-2 max-pool, NHWC, H and W even; idx = 2-bit position (dy*2+dx) of the first maximum
+__global__ void k_pool_fwd(const float* __restrict__ Y, float* __restrict__ P, uint8_t* __restrict__ idx, int N, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    const long long total = (long long)N * OH * OW * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long t = e / C;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const long long n = t / OH;
+        const float* src = Y + ((n * H + 2 * oh) * W + 2 * ow) * (long long)C + c;
+        float best = src[0]; int bi = 0;
+        const float v1 = src[C], v2 = src[(long long)W * C], v3 = src[(long long)W * C + C];
+        if (v1 > best) { best = v1; bi = 1; }
+        if (v2 > best) { best = v2; bi = 2; }
+        if (v3 > best) { best = v3; bi = 3; }
+        P[e] = best; idx[e] = (uint8_t)bi;
+    }
+}
+
+// dZ[n,h,w,c] = (position is the arg-max of its window && pooled value > 0) ? dP : 0   (max-pool backward + ReLU mask)
+__global__ void k_pool_bwd(const float* __restrict__ dP, const float* __restrict__ P, const uint8_t* __restrict__ idx, float* __restrict__ dZ,
+                           int N, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    const long long total = (long long)N * H * W * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long t = e / C;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const long long n = t / H;
+        const long long pe = ((n * OH + h / 2) * OW + w / 2) * (long long)C + c;
+        const int pos = (h & 1) * 2 + (w & 1);
+        dZ[e] = (idx[pe] == pos && P[pe] > 0.f) ? dP[pe] : 0.f;
+    }
+}
+
+// dZ = dY where the ReLU output is positive (layers without pooling)
+__global__ void k_relu_bwd(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ dZ, long long n) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) dZ[e] = Y[e] > 0.f ? dY[e] : 0.f;
+}
+
+// fused softmax + cross-entropy: one thread per sample (C small); loss_part[block] = sum of -log p[label] over the block
+__global__ __launch_bounds__(256) void k_softmax_ce(const float* __restrict__ logits, const int* __restrict__ labels, int B, int C, int ldl,
+                                                    float* __restrict__ dlogits, float* __restrict__ loss_part, float inv_b) {
+    __shared__ float red[4];
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    float loss = 0.f;
+    if (s < B) {
+        const float* z = logits + (long long)s * ldl;
+        float mx = z[0];
+        for (int c = 1; c < C; ++c) mx = z[c] > mx ? z[c] : mx;
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(z[c] - mx);
+        const int y = labels[s];
+        loss = -(z[y] - mx - logf(sum));
+        if (dlogits) {
+            float* d = dlogits + (long long)s * ldl;
+            for (int c = 0; c < ldl; ++c) d[c] = c < C ? (expf(z[c] - mx) / sum - (c == y ? 1.f : 0.f)) * inv_b : 0.f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) loss += __shfl_down(loss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_part) loss_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void k_sum_small(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < n; ++i) t += part[i];
+        *out = t * scale;
+    }
+}
+
+}  // namespace rcnx

@@ -1,0 +1,395 @@
+// rcn_hipx_api.hip -- C ABI of include/rcn_hipx.h (Track X: trainable conv net; no reference counterpart) over convnet.hpp.
+#include "../../include/rcn_hipx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <new>
+#include <random>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "convnet.hpp"
+
+using namespace rcnx;
+
+namespace {
+
+struct Buf {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes < 4096 ? 4096 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Layer {
+    int kind;
+    int H, W, Cin;          // input of the layer
+    int oH, oW, Cout;       // output (logical Cout)
+    int CoutP;              // padded to a multiple of 32
+    int K;                  // contraction length (3*3*Cin or Cin*H*W for dense)
+    long long w_off = 0, b_off = 0;       // padded flat layout
+    long long lw_off = 0, lb_off = 0;     // logical flat layout
+    bool pool_follows = false;
+    Buf out, idx, dout;     // activation (post-ReLU / pooled), pool arg-max, gradient wrt the layer's OUTPUT
+};
+
+struct Key { const void* x; const void* y; int B; float lr; const void* loss;
+    bool operator<(const Key& o) const { return std::tie(x, y, B, lr, loss) < std::tie(o.x, o.y, o.B, o.lr, o.loss); } };
+
+}  // namespace
+
+struct rcn_hipx_net {
+    int device = 0, in_h = 0, in_w = 0, in_c = 0, max_batch = 0, classes = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    std::vector<Layer> L;
+    long long n_pad = 0, n_log = 0;
+    Buf params, wt, slab, dz, loss_part, grad_tmp, dlogits;
+    std::map<Key, hipGraphExec_t> graphs;
+    std::string err;
+};
+
+namespace {
+
+int fail(rcn_hipx_net* n, int code, const std::string& m) { if (n) n->err = m; return code; }
+#define XTRY(net, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(net, e_ == hipErrorOutOfMemory ? -7 : -4, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define RTRY(expr) do { int s_ = (expr); if (s_ != 0) return s_; } while (0)
+
+struct Dev { int prev = -1; explicit Dev(int d) { (void)hipGetDevice(&prev); if (prev != d) (void)hipSetDevice(d); else prev = -1; } ~Dev() { if (prev >= 0) (void)hipSetDevice(prev); } };
+
+int grid1d(long long total, int block) { long long g = (total + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+// Y = act(conv(X) + b) as implicit GEMM; `ks` = 1 or 3; epi 0 raw / 1 bias / 2 bias + relu
+int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi) {
+    const long long M = (long long)s.N * s.H * s.W;
+    const bool smallc = ks * ks * s.Cin <= 32;
+    if (!smallc && s.Cin % 32) return fail(n, -3, "input channels must be a multiple of 32 (or the whole 3x3xCin patch <= 32)");
+    if (s.Cout % 32) return fail(n, -3, "output channels must be a multiple of 32");
+    const int bn = (s.Cout % 64 == 0) ? 64 : 32;
+    const dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)(s.Cout / bn));
+#define CONV_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, Wk, bias, Y, s)
+#define CONV_EPI(KS_, SM_, BN_) do { if (epi == 0) CONV_CASE(KS_, SM_, BN_, 0); else if (epi == 1) CONV_CASE(KS_, SM_, BN_, 1); else CONV_CASE(KS_, SM_, BN_, 2); } while (0)
+#define CONV_BN(KS_, SM_) do { if (bn == 64) CONV_EPI(KS_, SM_, 64); else CONV_EPI(KS_, SM_, 32); } while (0)
+    if (ks == 3) { if (smallc) CONV_BN(3, true); else CONV_BN(3, false); }
+    else { if (smallc) CONV_BN(1, true); else CONV_BN(1, false); }
+#undef CONV_BN
+#undef CONV_EPI
+#undef CONV_CASE
+    XTRY(n, hipGetLastError());
+    return 0;
+}
+
+constexpr int kPixPerChunk = 1024;
+
+int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, int ks, int* chunks_out) {
+    const long long M = (long long)s.N * s.H * s.W;
+    const int K = ks * ks * s.Cin;
+    const bool smallc = K <= 32;
+    const int bn = (s.Cout % 64 == 0) ? 64 : 32;
+    const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
+    XTRY(n, n->slab.ensure((size_t)chunks * K * s.Cout * sizeof(float)));
+    const dim3 grid((unsigned)(smallc ? 1 : K / 32), (unsigned)(s.Cout / bn), (unsigned)chunks);
+#define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, kPixPerChunk)
+#define WG_BN(KS_, SM_) do { if (bn == 64) WG_CASE(KS_, SM_, 64); else WG_CASE(KS_, SM_, 32); } while (0)
+    if (ks == 3) { if (smallc) WG_BN(3, true); else WG_BN(3, false); }
+    else { if (smallc) WG_BN(1, true); else WG_BN(1, false); }
+#undef WG_BN
+#undef WG_CASE
+    XTRY(n, hipGetLastError());
+    *chunks_out = chunks;
+    return 0;
+}
+
+float* P(rcn_hipx_net* n, long long off) { return (float*)n->params.p + off; }
+
+int ensure_batch(rcn_hipx_net* n, int B) {
+    if (B < 1 || B > n->max_batch) return fail(n, -1, "batch size out of range for this net (max_batch)");
+    return 0;
+}
+
+// forward for batch B; returns pointer to logits (padded rows of CoutP)
+int forward(rcn_hipx_net* n, const float* x, int B) {
+    const float* cur = x;
+    for (size_t i = 0; i < n->L.size(); ++i) {
+        Layer& l = n->L[i];
+        if (l.kind == RCN_HIPX_MAXPOOL2) {
+            const long long tot = (long long)B * l.oH * l.oW * l.Cin;
+            hipLaunchKernelGGL(k_pool_fwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, cur, (float*)l.out.p, (uint8_t*)l.idx.p, B, l.H, l.W, l.Cin);
+            XTRY(n, hipGetLastError());
+        } else if (l.kind == RCN_HIPX_CONV3X3_RELU) {
+            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, ConvShape{B, l.H, l.W, l.Cin, l.CoutP}, 3, 2));
+        } else {
+            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, ConvShape{B, 1, 1, l.K, l.CoutP}, 1, l.kind == RCN_HIPX_DENSE_RELU ? 2 : 1));
+        }
+        cur = (const float*)l.out.p;
+    }
+    return 0;
+}
+
+// backward from dlogits (already in L.back().dout); apply: update parameters with lr, else write gradients to grad (padded layout)
+int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply) {
+    for (int i = (int)n->L.size() - 1; i >= 0; --i) {
+        Layer& l = n->L[i];
+        const float* in = i == 0 ? x : (const float*)n->L[i - 1].out.p;
+        float* din = i == 0 ? nullptr : (float*)n->L[i - 1].dout.p;
+        if (l.kind == RCN_HIPX_MAXPOOL2) {
+            // gradient wrt the pool INPUT, with the preceding conv's ReLU mask folded in (pooled value > 0)
+            const long long tot = (long long)B * l.H * l.W * l.Cin;
+            hipLaunchKernelGGL(k_pool_bwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p,
+                               din, B, l.H, l.W, l.Cin);
+            XTRY(n, hipGetLastError());
+            continue;
+        }
+        const bool conv = l.kind == RCN_HIPX_CONV3X3_RELU;
+        const int ks = conv ? 3 : 1;
+        const ConvShape s = conv ? ConvShape{B, l.H, l.W, l.Cin, l.CoutP} : ConvShape{B, 1, 1, l.K, l.CoutP};
+        const long long M = (long long)s.N * s.H * s.W;
+        // dZ: gradient wrt the pre-activation
+        const float* dZ = (const float*)l.dout.p;
+        if (l.kind != RCN_HIPX_DENSE && !l.pool_follows) {
+            XTRY(n, n->dz.ensure((size_t)M * l.CoutP * sizeof(float)));
+            hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d(M * l.CoutP, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (float*)n->dz.p, M * l.CoutP);
+            XTRY(n, hipGetLastError());
+            dZ = (const float*)n->dz.p;
+        }
+        // dgrad first (needs the weights BEFORE this step's update): dX = conv(dZ, flip(W)^T)
+        if (din) {
+            const long long wn = (long long)ks * ks * s.Cin * s.Cout;
+            XTRY(n, n->wt.ensure((size_t)wn * sizeof(float)));
+            hipLaunchKernelGGL(k_flip_weights, dim3(grid1d(wn, 256)), dim3(256), 0, n->stream, (const float*)P(n, l.w_off), (float*)n->wt.p, ks, s.Cin, s.Cout);
+            XTRY(n, hipGetLastError());
+            RTRY(launch_conv(n, dZ, (const float*)n->wt.p, nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, 0));
+        }
+        int chunks = 0;
+        RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks));
+        const long long wcount = (long long)s.Cin * ks * ks * s.Cout;
+        hipLaunchKernelGGL(k_reduce_update, dim3(grid1d(wcount, 256)), dim3(256), 0, n->stream, P(n, l.w_off), grad ? grad + l.w_off : (float*)nullptr,
+                           (const float*)n->slab.p, wcount, chunks, lr, apply ? 1 : 0);
+        hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)(l.CoutP / 32)), dim3(256), 0, n->stream, dZ, M, l.CoutP, P(n, l.b_off), grad ? grad + l.b_off : (float*)nullptr, lr,
+                           apply ? 1 : 0);
+        XTRY(n, hipGetLastError());
+    }
+    return 0;
+}
+
+int loss_and_dlogits(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, bool want_grad) {
+    Layer& l = n->L.back();
+    const int blocks = (B + 255) / 256;
+    XTRY(n, n->loss_part.ensure(blocks * sizeof(float)));
+    hipLaunchKernelGGL(k_softmax_ce, dim3(blocks), dim3(256), 0, n->stream, (const float*)l.out.p, labels, B, n->classes, l.CoutP, want_grad ? (float*)l.dout.p : (float*)nullptr,
+                       (float*)n->loss_part.p, 1.0f / (float)B);
+    if (loss_dev) hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, n->stream, (const float*)n->loss_part.p, blocks, 1.0f / (float)B, loss_dev);
+    XTRY(n, hipGetLastError());
+    return 0;
+}
+
+void drop_graphs(rcn_hipx_net* n) { for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second); n->graphs.clear(); }
+
+}  // namespace
+
+extern "C" {
+
+int rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int max_batch, void* stream, rcn_hipx_net** out) {
+    if (!out || !layers || n_layers < 1 || in_h < 1 || in_w < 1 || in_c < 1 || max_batch < 1) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -5;
+    rcn_hipx_net* n = new (std::nothrow) rcn_hipx_net();
+    if (!n) return -7;
+    *out = n;
+    n->device = device; n->in_h = in_h; n->in_w = in_w; n->in_c = in_c; n->max_batch = max_batch;
+    int H = in_h, W = in_w, C = in_c;
+    bool flat = false;
+    for (int i = 0; i < n_layers; ++i) {
+        Layer l{};
+        l.kind = layers[i].kind; l.H = H; l.W = W; l.Cin = C;
+        if (l.kind == RCN_HIPX_CONV3X3_RELU) {
+            if (flat) return fail(n, -2, "convolution after a dense layer");
+            if (layers[i].out < 32 || layers[i].out % 32) return fail(n, -3, "conv output channels must be a positive multiple of 32");
+            if (!(9 * C <= 32) && C % 32) return fail(n, -3, "conv input channels must be a multiple of 32 (or 9*Cin <= 32 for the first layer)");
+            l.Cout = l.CoutP = layers[i].out; l.oH = H; l.oW = W; l.K = 9 * C;
+            C = l.Cout;
+        } else if (l.kind == RCN_HIPX_MAXPOOL2) {
+            if (flat || i == 0 || n->L.back().kind != RCN_HIPX_CONV3X3_RELU) return fail(n, -2, "max-pool must follow a convolution");
+            if (H % 2 || W % 2) return fail(n, -3, "max-pool needs even height and width");
+            l.Cout = l.CoutP = C; l.oH = H / 2; l.oW = W / 2; l.K = 0;
+            n->L.back().pool_follows = true;
+            H = l.oH; W = l.oW;
+        } else if (l.kind == RCN_HIPX_DENSE_RELU || l.kind == RCN_HIPX_DENSE) {
+            const long long feat = flat ? C : (long long)H * W * C;
+            if (feat % 32 || feat > 0x7fffffff) return fail(n, -3, "dense input features must be a multiple of 32");
+            if (layers[i].out < 1) return fail(n, -1, "dense units must be positive");
+            if (l.kind == RCN_HIPX_DENSE_RELU && layers[i].out % 32) return fail(n, -3, "hidden dense units must be a multiple of 32");
+            if (l.kind == RCN_HIPX_DENSE && i != n_layers - 1) return fail(n, -2, "the logits layer must be last");
+            l.K = (int)feat; l.H = 1; l.W = 1; l.Cin = (int)feat; l.Cout = layers[i].out; l.CoutP = (l.Cout + 31) / 32 * 32; l.oH = l.oW = 1;
+            C = l.Cout; flat = true; H = W = 1;
+        } else return fail(n, -1, "unknown layer kind");
+        if (l.kind != RCN_HIPX_MAXPOOL2) {
+            l.w_off = n->n_pad; n->n_pad += (long long)l.K * l.CoutP; l.b_off = n->n_pad; n->n_pad += l.CoutP;
+            l.lw_off = n->n_log; n->n_log += (long long)l.K * l.Cout; l.lb_off = n->n_log; n->n_log += l.Cout;
+        }
+        n->L.push_back(l);
+    }
+    if (n->L.back().kind != RCN_HIPX_DENSE) return fail(n, -2, "the last layer must be RCN_HIPX_DENSE (logits)");
+    n->classes = n->L.back().Cout;
+    Dev g(device);
+    if (stream) { n->stream = (hipStream_t)stream; } else { XTRY(n, hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking)); n->own_stream = true; }
+    XTRY(n, n->params.ensure((size_t)n->n_pad * sizeof(float)));
+    XTRY(n, hipMemsetAsync(n->params.p, 0, (size_t)n->n_pad * sizeof(float), n->stream));
+    for (Layer& l : n->L) {
+        const size_t elems = (size_t)max_batch * l.oH * l.oW * l.CoutP;
+        XTRY(n, l.out.ensure(elems * sizeof(float)));
+        XTRY(n, l.dout.ensure(elems * sizeof(float)));
+        if (l.kind == RCN_HIPX_MAXPOOL2) XTRY(n, l.idx.ensure(elems));
+    }
+    XTRY(n, hipStreamSynchronize(n->stream));
+    return 0;
+}
+
+void rcn_hipx_destroy(rcn_hipx_net* n) {
+    if (!n) return;
+    {
+        Dev g(n->device);
+        if (n->stream) (void)hipStreamSynchronize(n->stream);
+        drop_graphs(n);
+        for (Layer& l : n->L) { l.out.release(); l.idx.release(); l.dout.release(); }
+        for (Buf* b : {&n->params, &n->wt, &n->slab, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits}) b->release();
+        if (n->own_stream && n->stream) (void)hipStreamDestroy(n->stream);
+    }
+    delete n;
+}
+
+const char* rcn_hipx_last_error(const rcn_hipx_net* n) { return n ? n->err.c_str() : "null net"; }
+int rcn_hipx_synchronize(rcn_hipx_net* n) { if (!n) return -1; Dev g(n->device); XTRY(n, hipStreamSynchronize(n->stream)); return 0; }
+int rcn_hipx_param_count(const rcn_hipx_net* n, int64_t* logical, int64_t* padded) { if (!n) return -1; if (logical) *logical = n->n_log; if (padded) *padded = n->n_pad; return 0; }
+int rcn_hipx_classes(const rcn_hipx_net* n) { return n ? n->classes : -1; }
+
+int rcn_hipx_set_params(rcn_hipx_net* n, const float* flat) {
+    if (!n || !flat) return -1;
+    Dev g(n->device);
+    std::vector<float> pad((size_t)n->n_pad, 0.f);
+    for (const Layer& l : n->L) {
+        if (l.kind == RCN_HIPX_MAXPOOL2) continue;
+        for (int k = 0; k < l.K; ++k) std::memcpy(&pad[l.w_off + (long long)k * l.CoutP], &flat[l.lw_off + (long long)k * l.Cout], sizeof(float) * l.Cout);
+        std::memcpy(&pad[l.b_off], &flat[l.lb_off], sizeof(float) * l.Cout);
+    }
+    XTRY(n, hipMemcpyAsync(n->params.p, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice, n->stream));
+    XTRY(n, hipStreamSynchronize(n->stream));
+    return 0;
+}
+
+static int unpad(rcn_hipx_net* n, const float* dev, float* flat) {
+    std::vector<float> pad((size_t)n->n_pad);
+    XTRY(n, hipMemcpyAsync(pad.data(), dev, pad.size() * sizeof(float), hipMemcpyDeviceToHost, n->stream));
+    XTRY(n, hipStreamSynchronize(n->stream));
+    for (const Layer& l : n->L) {
+        if (l.kind == RCN_HIPX_MAXPOOL2) continue;
+        for (int k = 0; k < l.K; ++k) std::memcpy(&flat[l.lw_off + (long long)k * l.Cout], &pad[l.w_off + (long long)k * l.CoutP], sizeof(float) * l.Cout);
+        std::memcpy(&flat[l.lb_off], &pad[l.b_off], sizeof(float) * l.Cout);
+    }
+    return 0;
+}
+
+int rcn_hipx_get_params(rcn_hipx_net* n, float* flat) { if (!n || !flat) return -1; Dev g(n->device); return unpad(n, (const float*)n->params.p, flat); }
+int rcn_hipx_unpad_host(rcn_hipx_net* n, const float* padded_dev, float* logical_host) { if (!n || !padded_dev || !logical_host) return -1; Dev g(n->device); return unpad(n, padded_dev, logical_host); }
+
+int rcn_hipx_init_params(rcn_hipx_net* n, uint64_t seed) {
+    if (!n) return -1;
+    std::mt19937_64 gen(seed ? seed : std::random_device{}());
+    std::vector<float> flat((size_t)n->n_log, 0.f);
+    for (const Layer& l : n->L) {
+        if (l.kind == RCN_HIPX_MAXPOOL2) continue;
+        std::normal_distribution<float> nd(0.f, std::sqrt(2.0f / (float)l.K));
+        for (long long i = 0; i < (long long)l.K * l.Cout; ++i) flat[l.lw_off + i] = nd(gen);
+    }
+    return rcn_hipx_set_params(n, flat.data());
+}
+
+int rcn_hipx_forward_dev(rcn_hipx_net* n, const float* x, int B, float* logits) {
+    if (!n || !x || !logits) return -1;
+    RTRY(ensure_batch(n, B));
+    Dev g(n->device);
+    RTRY(forward(n, x, B));
+    const Layer& l = n->L.back();
+    XTRY(n, hipMemcpy2DAsync(logits, (size_t)n->classes * sizeof(float), l.out.p, (size_t)l.CoutP * sizeof(float), (size_t)n->classes * sizeof(float), (size_t)B,
+                             hipMemcpyDeviceToDevice, n->stream));
+    return 0;
+}
+
+int rcn_hipx_train_step_dev(rcn_hipx_net* n, const float* x, const int32_t* labels, int B, float lr, float* loss_dev) {
+    if (!n || !x || !labels) return -1;
+    RTRY(ensure_batch(n, B));
+    Dev g(n->device);
+    const Key key{x, labels, B, lr, loss_dev};
+    auto it = n->graphs.find(key);
+    if (it == n->graphs.end()) {
+        // one eager step first: sizes every scratch buffer outside capture (hipMalloc is illegal while capturing)
+        RTRY(forward(n, x, B));
+        RTRY(loss_and_dlogits(n, labels, B, loss_dev, true));
+        RTRY(backward(n, x, B, lr, nullptr, true));
+        hipGraph_t graph = nullptr;
+        XTRY(n, hipStreamBeginCapture(n->stream, hipStreamCaptureModeThreadLocal));
+        int st = forward(n, x, B);
+        if (st == 0) st = loss_and_dlogits(n, labels, B, loss_dev, true);
+        if (st == 0) st = backward(n, x, B, lr, nullptr, true);
+        hipError_t e = hipStreamEndCapture(n->stream, &graph);
+        if (st != 0) { if (graph) (void)hipGraphDestroy(graph); return st; }
+        XTRY(n, e);
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        XTRY(n, e);
+        if (n->graphs.size() >= 8) drop_graphs(n);
+        n->graphs.emplace(key, exec);
+        return 0;                                       // the eager step above WAS this call's step
+    }
+    XTRY(n, hipGraphLaunch(it->second, n->stream));
+    return 0;
+}
+
+int rcn_hipx_gradients_dev(rcn_hipx_net* n, const float* x, const int32_t* labels, int B, float* grad, float* loss_dev) {
+    if (!n || !x || !labels || !grad) return -1;
+    RTRY(ensure_batch(n, B));
+    Dev g(n->device);
+    XTRY(n, hipMemsetAsync(grad, 0, (size_t)n->n_pad * sizeof(float), n->stream));
+    RTRY(forward(n, x, B));
+    RTRY(loss_and_dlogits(n, labels, B, loss_dev, true));
+    return backward(n, x, B, 0.f, grad, false);
+}
+
+__global__ void k_axpy(float* __restrict__ p, const float* __restrict__ g, float scale, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = p[i] - scale * g[i];
+}
+
+int rcn_hipx_apply_dev(rcn_hipx_net* n, const float* grad, float scale) {
+    if (!n || !grad) return -1;
+    Dev g(n->device);
+    hipLaunchKernelGGL(k_axpy, dim3(grid1d(n->n_pad, 256)), dim3(256), 0, n->stream, (float*)n->params.p, grad, scale, n->n_pad);
+    XTRY(n, hipGetLastError());
+    return 0;
+}
+
+int rcn_hipx_step_flops(const rcn_hipx_net* n, int B, double* flops) {
+    if (!n || !flops) return -1;
+    double f = 0;
+    for (size_t i = 0; i < n->L.size(); ++i) {
+        const Layer& l = n->L[i];
+        if (l.kind == RCN_HIPX_MAXPOOL2) continue;
+        const double macs = (double)B * l.oH * l.oW * (double)l.K * l.Cout * (l.kind == RCN_HIPX_CONV3X3_RELU ? 1.0 : 1.0);
+        f += 2.0 * macs * (i == 0 ? 2.0 : 3.0);         // forward + wgrad (+ dgrad except for the first layer)
+    }
+    *flops = f;
+    return 0;
+}
+
+}  // extern "C"

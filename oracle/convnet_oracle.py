@@ -1,0 +1,132 @@
+"""f64 NumPy oracle for the Track-X convolution network (mercer_research_amd/csrc/convnet.hpp) -- TEST INFRASTRUCTURE ONLY.
+
+There is NO reference counterpart: the reference's conv layers are fixed Sobel filters without a backward pass
+(rcn/src/utils/kernel.rs:38-53, rcn/src/rcn.rs:317-356), and it has no softmax / cross-entropy.  This oracle is therefore
+pinned only by its own finite-difference gradient check (tests/test_convnet_oracle.py): "parity unpinned".
+
+Layers: ("conv", Cout) 3x3 stride 1 pad 1 + bias + ReLU | ("pool",) 2x2/2 max | ("dense_relu", units) | ("dense", classes).
+Activations NHWC; conv weights W[K][Cout] with K = (kh*3 + kw)*Cin + ci; dense weights W[features][units] with features
+flattened in (h, w, c) order; loss = mean cross-entropy of softmax(logits)."""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+def param_shapes(in_shape: Tuple[int, int, int], layers: Sequence[tuple]) -> List[Tuple[Tuple[int, int], int]]:
+    H, W, C = in_shape
+    out = []
+    for l in layers:
+        if l[0] == "conv":
+            out.append(((9 * C, l[1]), l[1])); C = l[1]
+        elif l[0] == "pool":
+            H, W = H // 2, W // 2
+        else:
+            feat = H * W * C
+            out.append(((feat, l[1]), l[1])); H, W, C = 1, 1, l[1]
+    return out
+
+
+def unflatten(flat: np.ndarray, in_shape, layers):
+    ws, bs, o = [], [], 0
+    for (k, c), nb in param_shapes(in_shape, layers):
+        ws.append(np.asarray(flat[o:o + k * c], dtype=np.float64).reshape(k, c)); o += k * c
+        bs.append(np.asarray(flat[o:o + nb], dtype=np.float64)); o += nb
+    assert o == len(flat)
+    return ws, bs
+
+
+def flatten(ws, bs) -> np.ndarray:
+    return np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in zip(ws, bs)])
+
+
+def _im2col(x: np.ndarray) -> np.ndarray:
+    """[N,H,W,C] -> [N*H*W, 9*C] with k = (kh*3+kw)*C + ci (zero padding 1)."""
+    N, H, W, C = x.shape
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    cols = [xp[:, kh:kh + H, kw:kw + W, :] for kh in range(3) for kw in range(3)]
+    return np.concatenate(cols, axis=-1).reshape(N * H * W, 9 * C)
+
+
+def forward(x, ws, bs, layers, cache=None):
+    a = np.asarray(x, dtype=np.float64)
+    pi = 0
+    for l in layers:
+        if l[0] == "conv":
+            N, H, W, C = a.shape
+            cols = _im2col(a)
+            z = cols @ ws[pi] + bs[pi]
+            y = np.maximum(z, 0).reshape(N, H, W, -1)
+            if cache is not None:
+                cache.append(("conv", cols, y, a.shape))
+            a = y; pi += 1
+        elif l[0] == "pool":
+            N, H, W, C = a.shape
+            win = a.reshape(N, H // 2, 2, W // 2, 2, C).transpose(0, 1, 3, 2, 4, 5).reshape(N, H // 2, W // 2, 4, C)
+            idx = win.argmax(axis=3)                      # first maximum, positions ordered (dy, dx) = 00, 01, 10, 11
+            p = np.take_along_axis(win, idx[:, :, :, None, :], axis=3)[:, :, :, 0, :]
+            if cache is not None:
+                cache.append(("pool", idx, a.shape))
+            a = p
+        else:
+            f = a.reshape(a.shape[0], -1)
+            z = f @ ws[pi] + bs[pi]
+            y = np.maximum(z, 0) if l[0] == "dense_relu" else z
+            if cache is not None:
+                cache.append((l[0], f, y, a.shape))
+            a = y; pi += 1
+    return a
+
+
+def loss_and_grads(x, labels, ws, bs, layers):
+    cache = []
+    logits = forward(x, ws, bs, layers, cache)
+    B = logits.shape[0]
+    z = logits - logits.max(axis=1, keepdims=True)
+    p = np.exp(z); p /= p.sum(axis=1, keepdims=True)
+    loss = float(-np.log(p[np.arange(B), labels]).mean())
+    d = p.copy(); d[np.arange(B), labels] -= 1.0; d /= B
+    gws, gbs = [None] * len(ws), [None] * len(bs)
+    pi = len(ws) - 1
+    for l, c in zip(reversed(layers), reversed(cache)):
+        if c[0] == "pool":
+            _, idx, shp = c
+            N, H, W, C = shp
+            g = np.zeros((N, H // 2, W // 2, 4, C))
+            np.put_along_axis(g, idx[:, :, :, None, :], d[:, :, :, None, :], axis=3)
+            d = g.reshape(N, H // 2, W // 2, 2, 2, C).transpose(0, 1, 3, 2, 4, 5).reshape(N, H, W, C)
+        elif c[0] == "conv":
+            _, cols, y, shp = c
+            N, H, W, C = shp
+            dz = (d * (y > 0)).reshape(N * H * W, -1)
+            gws[pi] = cols.T @ dz; gbs[pi] = dz.sum(axis=0)
+            dcols = (dz @ ws[pi].T).reshape(N, H, W, 9, C)
+            dxp = np.zeros((N, H + 2, W + 2, C))
+            t = 0
+            for kh in range(3):
+                for kw in range(3):
+                    dxp[:, kh:kh + H, kw:kw + W, :] += dcols[:, :, :, t, :]; t += 1
+            d = dxp[:, 1:-1, 1:-1, :]
+            pi -= 1
+        else:
+            kind, f, y, shp = c
+            dz = d * (y > 0) if kind == "dense_relu" else d
+            gws[pi] = f.T @ dz; gbs[pi] = dz.sum(axis=0)
+            d = (dz @ ws[pi].T).reshape(shp)
+            pi -= 1
+    return loss, logits, gws, gbs
+
+
+def sgd_step(x, labels, ws, bs, layers, lr):
+    loss, logits, gws, gbs = loss_and_grads(x, labels, ws, bs, layers)
+    return [w - lr * g for w, g in zip(ws, gws)], [b - lr * g for b, g in zip(bs, gbs)], loss
+
+
+def numeric_grad(x, labels, ws, bs, layers, which: int, idx, eps=1e-6, bias=False):
+    arr = bs[which] if bias else ws[which]
+    old = arr[idx]
+    arr[idx] = old + eps; lp = loss_and_grads(x, labels, ws, bs, layers)[0]
+    arr[idx] = old - eps; lm = loss_and_grads(x, labels, ws, bs, layers)[0]
+    arr[idx] = old
+    return (lp - lm) / (2 * eps)

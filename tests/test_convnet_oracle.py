@@ -1,0 +1,41 @@
+"""CPU test of the Track-X oracle (oracle/convnet_oracle.py): its analytic gradients against central finite differences.
+This is the ONLY pin the trainable-conv path can have -- the reference has no trainable convolution."""
+import numpy as np
+
+from oracle import convnet_oracle as co
+
+LAYERS = (("conv", 4), ("pool",), ("conv", 6), ("pool",), ("dense_relu", 8), ("dense", 5))
+
+
+def test_gradients_match_finite_differences():
+    rng = np.random.default_rng(0)
+    in_shape = (8, 8, 3)
+    x = rng.standard_normal((3,) + in_shape)
+    y = rng.integers(0, 5, 3)
+    ws = [rng.standard_normal(k) * 0.3 for k, _ in co.param_shapes(in_shape, LAYERS)]
+    bs = [rng.standard_normal(n) * 0.1 for _, n in co.param_shapes(in_shape, LAYERS)]
+    loss, logits, gws, gbs = co.loss_and_grads(x, y, ws, bs, LAYERS)
+    assert logits.shape == (3, 5) and loss > 0
+    for li in range(len(ws)):
+        for _ in range(6):
+            idx = tuple(rng.integers(0, s) for s in ws[li].shape)
+            num = co.numeric_grad(x, y, ws, bs, LAYERS, li, idx)
+            assert abs(num - gws[li][idx]) <= 1e-6 * max(1.0, abs(num)), (li, idx, num, gws[li][idx])
+        j = int(rng.integers(0, bs[li].size))
+        num = co.numeric_grad(x, y, ws, bs, LAYERS, li, j, bias=True)
+        assert abs(num - gbs[li][j]) <= 1e-6 * max(1.0, abs(num))
+
+
+def test_flatten_roundtrip_and_step():
+    rng = np.random.default_rng(1)
+    in_shape = (4, 4, 2)
+    layers = (("conv", 3), ("pool",), ("dense", 4))
+    shapes = co.param_shapes(in_shape, layers)
+    flat = rng.standard_normal(sum(k * c + n for (k, c), n in shapes))
+    ws, bs = co.unflatten(flat, in_shape, layers)
+    assert np.array_equal(co.flatten(ws, bs), flat)
+    x = rng.standard_normal((2,) + in_shape); y = np.array([1, 3])
+    l0 = co.loss_and_grads(x, y, ws, bs, layers)[0]
+    for _ in range(20):
+        ws, bs, _ = co.sgd_step(x, y, ws, bs, layers, 0.2)
+    assert co.loss_and_grads(x, y, ws, bs, layers)[0] < l0

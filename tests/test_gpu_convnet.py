@@ -1,0 +1,108 @@
+"""GPU tests of the Track-X trainable convolution network (include/rcn_hipx.h) against its f64 oracle.
+No reference counterpart exists ("parity unpinned"); tolerance: fp32 MFMA vs f64, |d| <= 2e-4 * scale + 1e-6."""
+import numpy as np
+import pytest
+
+from oracle import convnet_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(in_shape, layers, B):
+    from mercer_research_amd.convnet import ConvNet
+    return ConvNet(in_shape, layers, B)
+
+
+def _close(a, b, rtol=2e-4):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(1e-3, float(np.abs(b).max()))
+    assert np.abs(a - b).max() <= rtol * scale + 1e-6, (float(np.abs(a - b).max()), scale)
+
+
+@pytest.mark.parametrize("in_shape,layers,B", [
+    ((8, 8, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 32), ("dense", 10)), 5),
+    ((6, 6, 1), (("conv", 32), ("conv", 32), ("pool",), ("dense", 7)), 3),
+    ((4, 8, 3), (("conv", 64), ("pool",), ("dense_relu", 64), ("dense_relu", 32), ("dense", 3)), 130),
+    ((8, 8, 32), (("conv", 32), ("pool",), ("dense", 10)), 4),
+])
+def test_forward_gradients_and_step_match_oracle(in_shape, layers, B):
+    rng = np.random.default_rng(B)
+    net = _net(in_shape, layers, B)
+    shapes = co.param_shapes(in_shape, layers)
+    ws = [rng.standard_normal(k) * np.sqrt(2.0 / k[0]) for k, _ in shapes]
+    bs = [rng.standard_normal(n) * 0.1 for _, n in shapes]
+    flat = co.flatten(ws, bs)
+    assert flat.size == net.n_logical
+    net.set_params(flat)
+    assert np.array_equal(net.get_params(), flat.astype(np.float32))
+    x = rng.standard_normal((B,) + in_shape)
+    y = rng.integers(0, layers[-1][1], B).astype(np.int32)
+    xd, yd = net.to_device(x.astype(np.float32)), net.to_device(y)
+    x64 = x.astype(np.float32).astype(np.float64)
+    w32 = [w.astype(np.float32).astype(np.float64) for w in ws]
+    b32 = [b.astype(np.float32).astype(np.float64) for b in bs]
+    loss_ref, logits_ref, gws, gbs = co.loss_and_grads(x64, y, w32, b32, layers)
+    net.synchronize()
+    import torch
+    with torch.cuda.stream(net.stream):
+        logits = net.forward(xd)
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        grad = net.gradients(xd, yd, loss=loss)
+    net.synchronize()
+    _close(logits.cpu().numpy(), logits_ref)
+    assert abs(loss.item() - loss_ref) <= 2e-4 * max(1.0, loss_ref)
+    _close(net.unpad(grad), co.flatten(gws, gbs))
+    # one SGD step (eager first call, then the cached graph for the second)
+    lr = 0.05
+    with torch.cuda.stream(net.stream):
+        net.train_step(xd, yd, lr, loss)
+    net.synchronize()
+    nw, nb, _ = co.sgd_step(x64, y, w32, b32, layers, lr)
+    _close(net.get_params(), co.flatten(nw, nb))
+    with torch.cuda.stream(net.stream):
+        net.train_step(xd, yd, lr, loss)            # graph replay
+    net.synchronize()
+    nw2, nb2, l2 = co.sgd_step(x64, y, nw, nb, layers, lr)
+    _close(net.get_params(), co.flatten(nw2, nb2), rtol=4e-4)
+    assert abs(loss.item() - l2) <= 4e-4 * max(1.0, l2)
+    # data-parallel halves: apply(gradients) == train_step
+    net.set_params(flat)
+    with torch.cuda.stream(net.stream):
+        g = net.gradients(xd, yd)
+        net.apply(g, lr)
+    net.synchronize()
+    _close(net.get_params(), co.flatten(nw, nb))
+
+
+def test_training_reduces_loss_on_cifar_shape():
+    """CIFAR-10 shape net of SURVEY.md §8(d): 32x32x3, conv 3->32, pool, 32->64, pool, 64->128, pool -> 2048 -> 256 -> 10."""
+    import torch
+    layers = (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("conv", 128), ("pool",), ("dense_relu", 256), ("dense", 10))
+    B = 64
+    net = _net((32, 32, 3), layers, B)
+    net.init_params(3)
+    rng = np.random.default_rng(0)
+    protos = rng.standard_normal((10, 32, 32, 3)).astype(np.float32)
+    y = rng.integers(0, 10, B).astype(np.int32)
+    x = protos[y] + 0.3 * rng.standard_normal((B, 32, 32, 3)).astype(np.float32)
+    xd, yd = net.to_device(x), net.to_device(y)
+    loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+    net.synchronize()
+    losses = []
+    for _ in range(30):
+        with torch.cuda.stream(net.stream):
+            net.train_step(xd, yd, 0.02, loss)
+        net.synchronize()
+        losses.append(loss.item())
+    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses[::5]
+    assert net.step_flops(B) > 0
+
+
+def test_unsupported_shapes_are_rejected():
+    from mercer_research_amd.convnet import ConvNetError
+    with pytest.raises(ConvNetError):
+        _net((8, 8, 3), (("conv", 30), ("dense", 10)), 4)            # channels not a multiple of 32
+    with pytest.raises(ConvNetError):
+        _net((7, 8, 3), (("conv", 32), ("pool",), ("dense", 10)), 4)   # odd height under the pool
+    with pytest.raises(ConvNetError):
+        _net((8, 8, 3), (("conv", 32), ("pool",), ("dense_relu", 32)), 4)   # no logits layer
