@@ -86,7 +86,11 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__
     const long long m0 = (long long)blockIdx.x * kBM;
     const int n0 = blockIdx.y * BN;
     const int K = KS * KS * s.Cin;
-    const int nkt = SMALLC ? 1 : K / kBK;
+    const int nkt_all = SMALLC ? 1 : K / kBK;
+    // split-K: workgroup z of gridDim.z contracts K-tiles [kt0, kt1) and writes a raw partial tile to Y + z * M * Cout
+    const int kt0 = (int)((long long)nkt_all * blockIdx.z / gridDim.z), kt1 = (int)((long long)nkt_all * (blockIdx.z + 1) / gridDim.z);
+    const int nkt = kt1 - kt0;
+    Y += (long long)blockIdx.z * M * s.Cout;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -121,15 +125,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__
         }
     };
 
-    load_a_regs<KS, SMALLC>(X, s, M, m0, 0, tid, av);
-    load_b(0);
+    load_a_regs<KS, SMALLC>(X, s, M, m0, kt0, tid, av);
+    load_b(kt0);
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) {                              // next tile's global loads fly while this tile computes
-            load_a_regs<KS, SMALLC>(X, s, M, m0, kt + 1, tid, av);
-            load_b(kt + 1);
+            load_a_regs<KS, SMALLC>(X, s, M, m0, kt0 + kt + 1, tid, av);
+            load_b(kt0 + kt + 1);
         }
         const float* a = &As[cur][(wave * 32 + (lane & 31)) * kLdA + (lane >> 5)];
         const float* b = &Bs[cur][(lane >> 5) * kLdB + (lane & 31)];
@@ -176,14 +180,19 @@ __global__ void k_flip_weights(const float* __restrict__ Wk, float* __restrict__
 }
 
 // dW partial tiles: workgroup (kb, nb, chunk) computes rows [32 kb, +32) x cols [BN nb, +BN) of dW over the pixels of
-// its chunk and writes them to slab[chunk][K][Cout].
+// its chunk and writes them to slab[chunk][K + 1][Cout]; row K is the chunk's partial bias gradient (column sums of dZ,
+// taken by the kb == 0 workgroups from the dZ tiles they stage anyway).  [W | b] is contiguous in the parameter buffer,
+// so ONE k_reduce_update over (K + 1) * Cout elements finishes both.
 template <int KS, bool SMALLC, int BN>
 __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ X, const float* __restrict__ dZ,
                                                          float* __restrict__ slab, ConvShape s, int pix_per_chunk) {
-    constexpr int kLdD = BN + 1, NT = BN / 32;
-    __shared__ float Xs[32 * 33];                        // [pixel][k]
-    __shared__ float Ds[32 * kLdD];                      // [pixel][co]
-    __shared__ float Red[4 * 32 * kLdD];                 // per-wave partial tiles
+    // Both MFMA operands are read along a staged row (A[m = k][kk = pixel] = Xs[pixel][k], B[kk = pixel][n] = Ds[pixel][n]:
+    // a half-wave reads 32 consecutive floats of one row), so the LDS images need no padding and are filled with 16-byte
+    // stores.  64 pixels per iteration, double-buffered (49 KB at BN = 64 -> three workgroups per CU).
+    constexpr int NT = BN / 32, kPT = 64;
+    __shared__ __attribute__((aligned(16))) float smem[2 * kPT * 32 + 2 * kPT * BN];
+    float (*Xs)[kPT * 32] = reinterpret_cast<float (*)[kPT * 32]>(smem);                    // [buffer][pixel][k]
+    float (*Ds)[kPT * BN] = reinterpret_cast<float (*)[kPT * BN]>(smem + 2 * kPT * 32);      // [buffer][pixel][co]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long M = (long long)s.N * s.H * s.W;
     const int K = KS * KS * s.Cin;
@@ -196,12 +205,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float colsum = 0.f;                                  // bias partial: thread c < BN of the kb == 0 workgroups
 
-    for (long long pb = p0; pb < p1; pb += 32) {
-        // gather 32 pixels x 32 k of the implicit im2col matrix (k-block kb), and 32 pixels x BN of dZ
-        {
-            const int pr = tid >> 3, c4 = (tid & 7) * 4;             // 32 rows x 8 float4
-            const long long m = pb + pr;
+    f32x4 xv[2], dv[BN / 16];                            // 64 x 32 floats / 256 thr = 2 float4; 64 x BN / 256 = BN/16 float4
+    auto gload = [&](long long pb) {
+        const int c4 = (tid & 7) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long long m = pb + (tid >> 3) + 32 * q;
             f32x4 val = f32x4{0, 0, 0, 0};
             if (m < p1) {
                 const int ow = (int)(m % s.W);
@@ -228,43 +239,97 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
                     }
                 }
             }
-            float* d = &Xs[pr * 33 + c4];
-            d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
+            xv[q] = val;
         }
 #pragma unroll
-        for (int q = 0; q < BN / 32; ++q) {
+        for (int q = 0; q < BN / 16; ++q) {
             const int e = tid + kThreads * q;
-            const int pr = e / (BN / 4), c4 = (e - pr * (BN / 4)) * 4;
+            const int pr = e / (BN / 4), c4b = (e - pr * (BN / 4)) * 4;
             const long long m = pb + pr;
-            const f32x4 val = (m < p1) ? *reinterpret_cast<const f32x4*>(dZ + m * s.Cout + n0 + c4) : f32x4{0, 0, 0, 0};
-            float* d = &Ds[pr * kLdD + c4];
-            d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
+            dv[q] = (m < p1) ? *reinterpret_cast<const f32x4*>(dZ + m * s.Cout + n0 + c4b) : f32x4{0, 0, 0, 0};
         }
-        __syncthreads();
-        // A[m = k][kk = pixel] = Xs[pixel][k];  B[kk = pixel][n = co] = Ds[pixel][co];  wave w takes pixels 8w .. 8w+7
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int px = wave * 8 + 2 * ks + (lane >> 5);
-            const float af = Xs[px * 33 + (lane & 31)];
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(&Xs[buf][((tid >> 3) + 32 * q) * 32 + (tid & 7) * 4]) = xv[q];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, Ds[px * kLdD + 32 * t + (lane & 31)], acc[t], 0, 0, 0);
+        for (int q = 0; q < BN / 16; ++q) *reinterpret_cast<f32x4*>(&Ds[buf][(tid + kThreads * q) * 4]) = dv[q];
+    };
+
+    gload(p0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (long long pb = p0; pb < p1; pb += kPT) {
+        const bool more = pb + kPT < p1;
+        if (more) gload(pb + kPT);                       // next 64 pixels fly while these are contracted
+        if (kb == 0 && tid < BN) {
+#pragma unroll 8
+            for (int px = 0; px < kPT; ++px) colsum += Ds[cur][px * BN + tid];
         }
-        __syncthreads();
+        // wave w contracts pixels 16w .. 16w+15 of the staged 64
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int px = wave * 16 + 2 * ks + (lane >> 5);
+            const float af = Xs[cur][px * 32 + (lane & 31)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, Ds[cur][px * BN + 32 * t + (lane & 31)], acc[t], 0, 0, 0);
+        }
+        if (more) {
+            lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
-    // combine the four waves' partial tiles in wave order, write the chunk's tile
+    // combine the four waves' partial tiles in wave order (through the now idle staging memory), write the chunk's tile
+    __syncthreads();
+    constexpr int kLdR = BN + 1;
+    static_assert(4 * 32 * kLdR <= 2 * kPT * 32 + 2 * kPT * BN, "partial tiles must fit the staging memory");
+    float* Red = smem;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Red[(wave * 32 + mfma32_row(lane, r)) * kLdD + 32 * t + (lane & 31)] = acc[t][r];
+        for (int r = 0; r < 16; ++r) Red[(wave * 32 + mfma32_row(lane, r)) * kLdR + 32 * t + (lane & 31)] = acc[t][r];
     __syncthreads();
-    float* out = slab + (long long)blockIdx.z * K * s.Cout;
+    float* out = slab + (long long)blockIdx.z * (K + 1) * s.Cout;
+    if (kb == 0 && tid < BN) out[(long long)K * s.Cout + n0 + tid] = colsum;
     for (int e = tid; e < 32 * BN; e += kThreads) {
         const int kr = e / BN, c = e - kr * BN;
         const int k = kb * 32 + kr;
         if (k < K) {
-            const float v = (Red[(0 * 32 + kr) * kLdD + c] + Red[(1 * 32 + kr) * kLdD + c]) + (Red[(2 * 32 + kr) * kLdD + c] + Red[(3 * 32 + kr) * kLdD + c]);
+            const float v = (Red[(0 * 32 + kr) * kLdR + c] + Red[(1 * 32 + kr) * kLdR + c]) + (Red[(2 * 32 + kr) * kLdR + c] + Red[(3 * 32 + kr) * kLdR + c]);
             out[(long long)k * s.Cout + n0 + c] = v;
         }
+    }
+}
+
+// split-K epilogue: Y[m][co] = act(bias[co] + sum_z part[z][m][co]), z in order
+__global__ void k_splitk_epilogue(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ Y, long long MN, int Cout, int Z, int epi) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < MN; e += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < Z; ++z) v += part[(long long)z * MN + e];
+        if (epi >= 1) v += bias[(int)(e % Cout)];
+        if (epi == 2) v = v > 0.f ? v : 0.f;
+        Y[e] = v;
+    }
+}
+
+// slab reduction for many chunks and few elements: 8 chunk-groups x 32 elements per workgroup, groups combined in order
+__global__ __launch_bounds__(256) void k_reduce_update_wide(float* __restrict__ p, float* __restrict__ grad_out, const float* __restrict__ slab, long long n,
+                                                            int chunks, float lr, int apply) {
+    __shared__ float red[8][33];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + el;
+    float g = 0.f;
+    if (i < n)
+        for (int c = grp; c < chunks; c += 8) g += slab[(long long)c * n + i];
+    red[grp][el] = g;
+    __syncthreads();
+    if (threadIdx.x < 32 && i < n) {
+        float t = 0.f;
+        for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+        if (grad_out) grad_out[i] = t;
+        if (apply) p[i] = p[i] - lr * t;
     }
 }
 
@@ -297,40 +362,58 @@ __global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dZ,
     }
 }
 
-// 2x2 stride-2 max-pool, NHWC, H and W even; idx = 2-bit position (dy*2+dx) of the first maximum
+// 2x2 stride-2 max-pool, NHWC, H and W even, C % 4 == 0; idx = 2-bit position (dy*2+dx) of the first maximum.
+// One thread per 4 channels (16-byte accesses; the index arithmetic is paid once per 4 elements).
 __global__ void k_pool_fwd(const float* __restrict__ Y, float* __restrict__ P, uint8_t* __restrict__ idx, int N, int H, int W, int C) {
-    const int OH = H / 2, OW = W / 2;
-    const long long total = (long long)N * OH * OW * C;
+    const int OH = H / 2, OW = W / 2, C4 = C / 4;
+    const long long total = (long long)N * OH * OW * C4;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        long long t = e / C;
+        const int c = (int)(e % C4) * 4;
+        long long t = e / C4;
         const int ow = (int)(t % OW); t /= OW;
         const int oh = (int)(t % OH);
         const long long n = t / OH;
         const float* src = Y + ((n * H + 2 * oh) * W + 2 * ow) * (long long)C + c;
-        float best = src[0]; int bi = 0;
-        const float v1 = src[C], v2 = src[(long long)W * C], v3 = src[(long long)W * C + C];
-        if (v1 > best) { best = v1; bi = 1; }
-        if (v2 > best) { best = v2; bi = 2; }
-        if (v3 > best) { best = v3; bi = 3; }
-        P[e] = best; idx[e] = (uint8_t)bi;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + C);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (long long)W * C), v3 = *reinterpret_cast<const f32x4*>(src + (long long)W * C + C);
+        f32x4 best; uint8_t bi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float b = v0[i]; int k = 0;
+            if (v1[i] > b) { b = v1[i]; k = 1; }
+            if (v2[i] > b) { b = v2[i]; k = 2; }
+            if (v3[i] > b) { b = v3[i]; k = 3; }
+            best[i] = b; bi[i] = (uint8_t)k;
+        }
+        const long long o = e * 4;
+        *reinterpret_cast<f32x4*>(P + o) = best;
+        *reinterpret_cast<uint32_t*>(idx + o) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
 }
 
-// dZ[n,h,w,c] = (position is the arg-max of its window && pooled value > 0) ? dP : 0   (max-pool backward + ReLU mask)
+// dZ[n,h,w,c] = (position is the arg-max of its window && pooled value > 0) ? dP : 0   (max-pool backward + ReLU mask).
+// One thread per pooled element group of 4 channels writes all four window positions.
 __global__ void k_pool_bwd(const float* __restrict__ dP, const float* __restrict__ P, const uint8_t* __restrict__ idx, float* __restrict__ dZ,
                            int N, int H, int W, int C) {
-    const int OH = H / 2, OW = W / 2;
-    const long long total = (long long)N * H * W * C;
+    const int OH = H / 2, OW = W / 2, C4 = C / 4;
+    const long long total = (long long)N * OH * OW * C4;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        long long t = e / C;
-        const int w = (int)(t % W); t /= W;
-        const int h = (int)(t % H);
-        const long long n = t / H;
-        const long long pe = ((n * OH + h / 2) * OW + w / 2) * (long long)C + c;
-        const int pos = (h & 1) * 2 + (w & 1);
-        dZ[e] = (idx[pe] == pos && P[pe] > 0.f) ? dP[pe] : 0.f;
+        const int c = (int)(e % C4) * 4;
+        long long t = e / C4;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const long long n = t / OH;
+        const long long o = e * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dP + o), pv = *reinterpret_cast<const f32x4*>(P + o);
+        const uint32_t ii = *reinterpret_cast<const uint32_t*>(idx + o);
+        float* dst = dZ + ((n * H + 2 * oh) * W + 2 * ow) * (long long)C + c;
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (((ii >> (8 * i)) & 3u) == (uint32_t)pos && pv[i] > 0.f) ? g[i] : 0.f;
+            *reinterpret_cast<f32x4*>(dst + (long long)(pos >> 1) * W * C + (pos & 1) * C) = v;
+        }
     }
 }
 

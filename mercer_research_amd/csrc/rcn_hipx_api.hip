@@ -54,7 +54,7 @@ struct rcn_hipx_net {
     hipStream_t stream = nullptr; bool own_stream = false;
     std::vector<Layer> L;
     long long n_pad = 0, n_log = 0;
-    Buf params, wt, slab, dz, loss_part, grad_tmp, dlogits;
+    Buf params, wt, slab, dz, loss_part, grad_tmp, dlogits, skbuf;
     std::map<Key, hipGraphExec_t> graphs;
     std::string err;
 };
@@ -69,16 +69,28 @@ struct Dev { int prev = -1; explicit Dev(int d) { (void)hipGetDevice(&prev); if 
 
 int grid1d(long long total, int block) { long long g = (total + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
-// Y = act(conv(X) + b) as implicit GEMM; `ks` = 1 or 3; epi 0 raw / 1 bias / 2 bias + relu
+// Y = act(conv(X) + b) as implicit GEMM; `ks` = 1 or 3; epi 0 raw / 1 bias / 2 bias + relu.
+// Few output tiles and a long contraction (the dense layers: M = batch) -> split-K over gridDim.z into raw partial tiles
+// (slab `skbuf`) that k_splitk_epilogue sums in order.
 int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi) {
     const long long M = (long long)s.N * s.H * s.W;
     const bool smallc = ks * ks * s.Cin <= 32;
     if (!smallc && s.Cin % 32) return fail(n, -3, "input channels must be a multiple of 32 (or the whole 3x3xCin patch <= 32)");
     if (s.Cout % 32) return fail(n, -3, "output channels must be a multiple of 32");
     const int bn = (s.Cout % 64 == 0) ? 64 : 32;
-    const dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)(s.Cout / bn));
-#define CONV_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, Wk, bias, Y, s)
-#define CONV_EPI(KS_, SM_, BN_) do { if (epi == 0) CONV_CASE(KS_, SM_, BN_, 0); else if (epi == 1) CONV_CASE(KS_, SM_, BN_, 1); else CONV_CASE(KS_, SM_, BN_, 2); } while (0)
+    const long long tiles = ((M + kBM - 1) / kBM) * (s.Cout / bn);
+    const int nkt = smallc ? 1 : ks * ks * s.Cin / 32;
+    int Z = 1;
+    if (tiles < 256 && nkt >= 8) { Z = (int)(512 / tiles); if (Z > nkt / 4) Z = nkt / 4; if (Z < 1) Z = 1; }
+    float* out = Y;
+    int kepi = epi;
+    if (Z > 1) {
+        XTRY(n, n->skbuf.ensure((size_t)Z * M * s.Cout * sizeof(float)));
+        out = (float*)n->skbuf.p; kepi = 0;
+    }
+    const dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)(s.Cout / bn), (unsigned)Z);
+#define CONV_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, Wk, bias, out, s)
+#define CONV_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONV_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONV_CASE(KS_, SM_, BN_, 1); else CONV_CASE(KS_, SM_, BN_, 2); } while (0)
 #define CONV_BN(KS_, SM_) do { if (bn == 64) CONV_EPI(KS_, SM_, 64); else CONV_EPI(KS_, SM_, 32); } while (0)
     if (ks == 3) { if (smallc) CONV_BN(3, true); else CONV_BN(3, false); }
     else { if (smallc) CONV_BN(1, true); else CONV_BN(1, false); }
@@ -86,6 +98,10 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #undef CONV_EPI
 #undef CONV_CASE
     XTRY(n, hipGetLastError());
+    if (Z > 1) {
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3(grid1d(M * s.Cout, 256)), dim3(256), 0, n->stream, (const float*)n->skbuf.p, bias, Y, M * s.Cout, s.Cout, Z, epi);
+        XTRY(n, hipGetLastError());
+    }
     return 0;
 }
 
@@ -97,7 +113,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const bool smallc = K <= 32;
     const int bn = (s.Cout % 64 == 0) ? 64 : 32;
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
-    XTRY(n, n->slab.ensure((size_t)chunks * K * s.Cout * sizeof(float)));
+    XTRY(n, n->slab.ensure((size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
     const dim3 grid((unsigned)(smallc ? 1 : K / 32), (unsigned)(s.Cout / bn), (unsigned)chunks);
 #define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, kPixPerChunk)
 #define WG_BN(KS_, SM_) do { if (bn == 64) WG_CASE(KS_, SM_, 64); else WG_CASE(KS_, SM_, 32); } while (0)
@@ -123,7 +139,7 @@ int forward(rcn_hipx_net* n, const float* x, int B) {
     for (size_t i = 0; i < n->L.size(); ++i) {
         Layer& l = n->L[i];
         if (l.kind == RCN_HIPX_MAXPOOL2) {
-            const long long tot = (long long)B * l.oH * l.oW * l.Cin;
+            const long long tot = (long long)B * l.oH * l.oW * (l.Cin / 4);
             hipLaunchKernelGGL(k_pool_fwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, cur, (float*)l.out.p, (uint8_t*)l.idx.p, B, l.H, l.W, l.Cin);
             XTRY(n, hipGetLastError());
         } else if (l.kind == RCN_HIPX_CONV3X3_RELU) {
@@ -144,7 +160,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         float* din = i == 0 ? nullptr : (float*)n->L[i - 1].dout.p;
         if (l.kind == RCN_HIPX_MAXPOOL2) {
             // gradient wrt the pool INPUT, with the preceding conv's ReLU mask folded in (pooled value > 0)
-            const long long tot = (long long)B * l.H * l.W * l.Cin;
+            const long long tot = (long long)B * l.oH * l.oW * (l.Cin / 4);
             hipLaunchKernelGGL(k_pool_bwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p,
                                din, B, l.H, l.W, l.Cin);
             XTRY(n, hipGetLastError());
@@ -172,11 +188,14 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         }
         int chunks = 0;
         RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks));
-        const long long wcount = (long long)s.Cin * ks * ks * s.Cout;
-        hipLaunchKernelGGL(k_reduce_update, dim3(grid1d(wcount, 256)), dim3(256), 0, n->stream, P(n, l.w_off), grad ? grad + l.w_off : (float*)nullptr,
-                           (const float*)n->slab.p, wcount, chunks, lr, apply ? 1 : 0);
-        hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)(l.CoutP / 32)), dim3(256), 0, n->stream, dZ, M, l.CoutP, P(n, l.b_off), grad ? grad + l.b_off : (float*)nullptr, lr,
-                           apply ? 1 : 0);
+        // [W | b] is contiguous (b_off == w_off + K * CoutP): one pass reduces the slab (incl. its bias row) and updates both
+        const long long wcount = ((long long)s.Cin * ks * ks + 1) * s.Cout;
+        if (chunks >= 8)
+            hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32)), dim3(256), 0, n->stream, P(n, l.w_off), grad ? grad + l.w_off : (float*)nullptr,
+                               (const float*)n->slab.p, wcount, chunks, lr, apply ? 1 : 0);
+        else
+            hipLaunchKernelGGL(k_reduce_update, dim3(grid1d(wcount, 256)), dim3(256), 0, n->stream, P(n, l.w_off), grad ? grad + l.w_off : (float*)nullptr,
+                               (const float*)n->slab.p, wcount, chunks, lr, apply ? 1 : 0);
         XTRY(n, hipGetLastError());
     }
     return 0;
@@ -263,7 +282,7 @@ void rcn_hipx_destroy(rcn_hipx_net* n) {
         if (n->stream) (void)hipStreamSynchronize(n->stream);
         drop_graphs(n);
         for (Layer& l : n->L) { l.out.release(); l.idx.release(); l.dout.release(); }
-        for (Buf* b : {&n->params, &n->wt, &n->slab, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits}) b->release();
+        for (Buf* b : {&n->params, &n->wt, &n->slab, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf}) b->release();
         if (n->own_stream && n->stream) (void)hipStreamDestroy(n->stream);
     }
     delete n;
