@@ -36,41 +36,63 @@ struct ConvShape {
     int N, H, W, Cin, Cout;     // stride 1, pad = KS/2, output H x W
 };
 
-// A-tile element source: row m of the implicit im2col matrix, K-tile kt (32 consecutive k)
-template <int KS, bool SMALLC>
-__device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape& s, long long M, long long m0, int kt, int tid, f32x4 (&v)[4]) {
-    // thread t loads rows (t>>3) + 32 q, q = 0..3, columns 4*(t&7) .. +3 of the 128 x 32 tile
-    const int c4 = (tid & 7) * 4;
+// Per-thread description of the 4 rows of the 128 x 32 A tile it stages: decoded ONCE per workgroup (the pixel of a row does
+// not change along K), so that per K-tile only the tap offset -- uniform over the workgroup -- is applied.
+struct ARows {
+    long long base[4];      // element offset of the row's own pixel, channel 0 (or -1: row past M)
+    int oh[4], ow[4];
+};
+
+__device__ inline ARows decode_rows(const ConvShape& s, long long M, long long m0, int tid) {
+    ARows r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const long long m = m0 + (tid >> 3) + 32 * q;
-        f32x4 val = f32x4{0, 0, 0, 0};
         if (m < M) {
             const int ow = (int)(m % s.W);
             const long long t2 = m / s.W;
             const int oh = (int)(t2 % s.H);
-            const long long n = t2 / s.H;
-            if (!SMALLC) {
-                const int k0 = kt * kBK + c4;                       // Cin % 32 == 0: the 4 columns share one tap
-                const int tap = k0 / s.Cin, ci = k0 - tap * s.Cin;
-                const int kh = tap / KS, kw = tap - kh * KS;
-                const int ih = oh + kh - KS / 2, iw = ow + kw - KS / 2;
-                if (ih >= 0 && ih < s.H && iw >= 0 && iw < s.W)
-                    val = *reinterpret_cast<const f32x4*>(X + ((n * s.H + ih) * s.W + iw) * (long long)s.Cin + ci);
-            } else {
+            r.base[q] = m * (long long)s.Cin;          // ((n*H + oh)*W + ow) * Cin == m * Cin
+            r.oh[q] = oh; r.ow[q] = ow;
+        } else { r.base[q] = -1; r.oh[q] = 0; r.ow[q] = 0; }
+    }
+    return r;
+}
+
+// A-tile element source: row m of the implicit im2col matrix, K-tile kt (32 consecutive k)
+template <int KS, bool SMALLC>
+__device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape& s, const ARows& rows, int kt, int tid, f32x4 (&v)[4]) {
+    // thread t loads rows (t>>3) + 32 q, q = 0..3, columns 4*(t&7) .. +3 of the 128 x 32 tile
+    const int c4 = (tid & 7) * 4;
+    if (!SMALLC) {
+        const int k0 = kt * kBK;                                    // Cin % 32 == 0: the whole K-tile lies in one tap
+        const int tap = k0 / s.Cin, ci = k0 - tap * s.Cin + c4;
+        const int dh = tap / KS - KS / 2, dw = tap % KS - KS / 2;
+        const long long toff = ((long long)dh * s.W + dw) * s.Cin + ci;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = rows.base[q] >= 0 && (unsigned)(rows.oh[q] + dh) < (unsigned)s.H && (unsigned)(rows.ow[q] + dw) < (unsigned)s.W;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(X + (ok ? rows.base[q] + toff : 0));     // unconditional load, masked by value
+            v[q] = ok ? val : f32x4{0, 0, 0, 0};
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 val = f32x4{0, 0, 0, 0};
+            if (rows.base[q] >= 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k = c4 + i;                           // whole K (= KS*KS*Cin <= 32) in one tile
                     if (k < KS * KS * s.Cin) {
                         const int tap = k / s.Cin, ci = k - tap * s.Cin;
-                        const int kh = tap / KS, kw = tap - kh * KS;
-                        const int ih = oh + kh - KS / 2, iw = ow + kw - KS / 2;
-                        if (ih >= 0 && ih < s.H && iw >= 0 && iw < s.W) val[i] = X[((n * s.H + ih) * s.W + iw) * (long long)s.Cin + ci];
+                        const int dh = tap / KS - KS / 2, dw = tap % KS - KS / 2;
+                        if ((unsigned)(rows.oh[q] + dh) < (unsigned)s.H && (unsigned)(rows.ow[q] + dw) < (unsigned)s.W)
+                            val[i] = X[rows.base[q] + ((long long)dh * s.W + dw) * s.Cin + ci];
                     }
                 }
             }
+            v[q] = val;
         }
-        v[q] = val;
     }
 }
 
@@ -125,14 +147,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__
         }
     };
 
-    load_a_regs<KS, SMALLC>(X, s, M, m0, kt0, tid, av);
+    const ARows rows = decode_rows(s, M, m0, tid);
+    load_a_regs<KS, SMALLC>(X, s, rows, kt0, tid, av);
     load_b(kt0);
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) {                              // next tile's global loads fly while this tile computes
-            load_a_regs<KS, SMALLC>(X, s, M, m0, kt0 + kt + 1, tid, av);
+            load_a_regs<KS, SMALLC>(X, s, rows, kt0 + kt + 1, tid, av);
             load_b(kt0 + kt + 1);
         }
         const float* a = &As[cur][(wave * 32 + (lane & 31)) * kLdA + (lane >> 5)];
