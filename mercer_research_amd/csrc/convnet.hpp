@@ -211,11 +211,12 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
                                                          float* __restrict__ slab, ConvShape s, int pix_per_chunk) {
     // Both MFMA operands are read along a staged row (A[m = k][kk = pixel] = Xs[pixel][k], B[kk = pixel][n] = Ds[pixel][n]:
     // a half-wave reads 32 consecutive floats of one row), so the LDS images need no padding and are filled with 16-byte
-    // stores.  64 pixels per iteration, double-buffered (49 KB at BN = 64 -> three workgroups per CU).
-    constexpr int NT = BN / 32, kPT = 64;
-    __shared__ __attribute__((aligned(16))) float smem[2 * kPT * 32 + 2 * kPT * BN];
-    float (*Xs)[kPT * 32] = reinterpret_cast<float (*)[kPT * 32]>(smem);                    // [buffer][pixel][k]
-    float (*Ds)[kPT * BN] = reinterpret_cast<float (*)[kPT * BN]>(smem + 2 * kPT * 32);      // [buffer][pixel][co]
+    // stores.  128 pixels per iteration in ONE LDS buffer (48 KB at BN = 64 -> three workgroups per CU); the next 128 are
+    // prefetched into registers while the current ones are contracted (32 MFMAs per wave between barriers).
+    constexpr int NT = BN / 32, kPT = 128;
+    __shared__ __attribute__((aligned(16))) float smem[kPT * 32 + kPT * BN];
+    float* Xs = smem;                                    // [pixel][k]
+    float* Ds = smem + kPT * 32;                         // [pixel][co]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long M = (long long)s.N * s.H * s.W;
     const int K = KS * KS * s.Cin;
@@ -230,84 +231,84 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float colsum = 0.f;                                  // bias partial: thread c < BN of the kb == 0 workgroups
 
-    f32x4 xv[2], dv[BN / 16];                            // 64 x 32 floats / 256 thr = 2 float4; 64 x BN / 256 = BN/16 float4
+    // tap of this k-block: uniform over the workgroup
+    const int c4 = (tid & 7) * 4;
+    int dh = 0, dw = 0; long long toff = 0;
+    if (!SMALLC) {
+        const int k0 = kb * 32, tap = k0 / s.Cin;
+        dh = tap / KS - KS / 2; dw = tap % KS - KS / 2;
+        toff = ((long long)dh * s.W + dw) * s.Cin + (k0 - tap * s.Cin) + c4;
+    }
+    f32x4 xv[4], dv[BN / 8];                             // 128 x 32 floats / 256 thr = 4 float4; 128 x BN / 256 = BN/8 float4
     auto gload = [&](long long pb) {
-        const int c4 = (tid & 7) * 4;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             const long long m = pb + (tid >> 3) + 32 * q;
-            f32x4 val = f32x4{0, 0, 0, 0};
-            if (m < p1) {
-                const int ow = (int)(m % s.W);
-                const long long t2 = m / s.W;
-                const int oh = (int)(t2 % s.H);
-                const long long n = t2 / s.H;
-                if (!SMALLC) {
-                    const int k0 = kb * 32 + c4;
-                    const int tap = k0 / s.Cin, ci = k0 - tap * s.Cin;
-                    const int kh = tap / KS, kw = tap - kh * KS;
-                    const int ih = oh + kh - KS / 2, iw = ow + kw - KS / 2;
-                    if (ih >= 0 && ih < s.H && iw >= 0 && iw < s.W)
-                        val = *reinterpret_cast<const f32x4*>(X + ((n * s.H + ih) * s.W + iw) * (long long)s.Cin + ci);
-                } else {
+            const bool in = m < p1;
+            const long long mc = in ? m : p0;
+            const int ow = (int)(mc % s.W);
+            const int oh = (int)((mc / s.W) % s.H);
+            if (!SMALLC) {
+                const bool ok = in && (unsigned)(oh + dh) < (unsigned)s.H && (unsigned)(ow + dw) < (unsigned)s.W;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(X + (ok ? mc * (long long)s.Cin + toff : 0));
+                xv[q] = ok ? val : f32x4{0, 0, 0, 0};
+            } else {
+                f32x4 val = f32x4{0, 0, 0, 0};
+                if (in) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int k = c4 + i;
                         if (k < K) {
                             const int tap = k / s.Cin, ci = k - tap * s.Cin;
-                            const int kh = tap / KS, kw = tap - kh * KS;
-                            const int ih = oh + kh - KS / 2, iw = ow + kw - KS / 2;
-                            if (ih >= 0 && ih < s.H && iw >= 0 && iw < s.W) val[i] = X[((n * s.H + ih) * s.W + iw) * (long long)s.Cin + ci];
+                            const int eh = tap / KS - KS / 2, ew = tap % KS - KS / 2;
+                            if ((unsigned)(oh + eh) < (unsigned)s.H && (unsigned)(ow + ew) < (unsigned)s.W)
+                                val[i] = X[mc * (long long)s.Cin + ((long long)eh * s.W + ew) * s.Cin + ci];
                         }
                     }
                 }
+                xv[q] = val;
             }
-            xv[q] = val;
         }
 #pragma unroll
-        for (int q = 0; q < BN / 16; ++q) {
+        for (int q = 0; q < BN / 8; ++q) {
             const int e = tid + kThreads * q;
             const int pr = e / (BN / 4), c4b = (e - pr * (BN / 4)) * 4;
             const long long m = pb + pr;
-            dv[q] = (m < p1) ? *reinterpret_cast<const f32x4*>(dZ + m * s.Cout + n0 + c4b) : f32x4{0, 0, 0, 0};
+            const f32x4 val = *reinterpret_cast<const f32x4*>(dZ + (m < p1 ? m : p0) * s.Cout + n0 + c4b);
+            dv[q] = (m < p1) ? val : f32x4{0, 0, 0, 0};
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&]() {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(&Xs[buf][((tid >> 3) + 32 * q) * 32 + (tid & 7) * 4]) = xv[q];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&Xs[((tid >> 3) + 32 * q) * 32 + c4]) = xv[q];
 #pragma unroll
-        for (int q = 0; q < BN / 16; ++q) *reinterpret_cast<f32x4*>(&Ds[buf][(tid + kThreads * q) * 4]) = dv[q];
+        for (int q = 0; q < BN / 8; ++q) *reinterpret_cast<f32x4*>(&Ds[(tid + kThreads * q) * 4]) = dv[q];
     };
 
     gload(p0);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
     for (long long pb = p0; pb < p1; pb += kPT) {
-        const bool more = pb + kPT < p1;
-        if (more) gload(pb + kPT);                       // next 64 pixels fly while these are contracted
-        if (kb == 0 && tid < BN) {
+        lstore();
+        __syncthreads();
+        if (pb + kPT < p1) gload(pb + kPT);              // next 128 pixels fly while these are contracted
+        if (kb == 0) {                                   // bias partial: thread (column tid % BN, pixel part tid / BN)
+            constexpr int kParts = kThreads / BN;
+            const int col = tid % BN, part = tid / BN;
 #pragma unroll 8
-            for (int px = 0; px < kPT; ++px) colsum += Ds[cur][px * BN + tid];
+            for (int px = part * (kPT / kParts); px < (part + 1) * (kPT / kParts); ++px) colsum += Ds[px * BN + col];
         }
-        // wave w contracts pixels 16w .. 16w+15 of the staged 64
+        // wave w contracts pixels 32w .. 32w+31 of the staged 128
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int px = wave * 16 + 2 * ks + (lane >> 5);
-            const float af = Xs[cur][px * 32 + (lane & 31)];
+        for (int ks = 0; ks < 16; ++ks) {
+            const int px = wave * 32 + 2 * ks + (lane >> 5);
+            const float af = Xs[px * 32 + (lane & 31)];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, Ds[cur][px * BN + 32 * t + (lane & 31)], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, Ds[px * BN + 32 * t + (lane & 31)], acc[t], 0, 0, 0);
         }
-        if (more) {
-            lstore(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-        }
+        __syncthreads();                                 // everyone is done reading before the next store
     }
     // combine the four waves' partial tiles in wave order (through the now idle staging memory), write the chunk's tile
-    __syncthreads();
     constexpr int kLdR = BN + 1;
-    static_assert(4 * 32 * kLdR <= 2 * kPT * 32 + 2 * kPT * BN, "partial tiles must fit the staging memory");
+    static_assert(4 * 32 * kLdR <= kPT * 32 + kPT * BN, "partial tiles must fit the staging memory");
     float* Red = smem;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -315,13 +316,22 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
         for (int r = 0; r < 16; ++r) Red[(wave * 32 + mfma32_row(lane, r)) * kLdR + 32 * t + (lane & 31)] = acc[t][r];
     __syncthreads();
     float* out = slab + (long long)blockIdx.z * (K + 1) * s.Cout;
-    if (kb == 0 && tid < BN) out[(long long)K * s.Cout + n0 + tid] = colsum;
     for (int e = tid; e < 32 * BN; e += kThreads) {
         const int kr = e / BN, c = e - kr * BN;
         const int k = kb * 32 + kr;
         if (k < K) {
             const float v = (Red[(0 * 32 + kr) * kLdR + c] + Red[(1 * 32 + kr) * kLdR + c]) + (Red[(2 * 32 + kr) * kLdR + c] + Red[(3 * 32 + kr) * kLdR + c]);
             out[(long long)k * s.Cout + n0 + c] = v;
+        }
+    }
+    if (kb == 0) {
+        __syncthreads();
+        smem[tid] = colsum;
+        __syncthreads();
+        if (tid < BN) {
+            float t = 0.f;
+            for (int part = 0; part < kThreads / BN; ++part) t += smem[part * BN + tid];
+            out[(long long)K * s.Cout + n0 + tid] = t;
         }
     }
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -105,7 +106,8 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     return 0;
 }
 
-constexpr int kPixPerChunk = 1024;
+static int pix_per_chunk() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_PIX_PER_CHUNK"); const int x = e ? std::atoi(e) : 0; return x >= 128 ? x / 128 * 128 : 1024; }(); return v; }
+#define kPixPerChunk (pix_per_chunk())
 
 int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, int ks, int* chunks_out) {
     const long long M = (long long)s.N * s.H * s.W;
