@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline")
+    ap.add_argument("--dp-impl", choices=["native", "torch"], default="native",
+                    help="data-parallel loop: native = RCCL calls inside librcn_hip (rcn_hip_dp_*), torch = torch.distributed all_reduce per step")
     ap.add_argument("--dp", action="store_true", help="use the data-parallel step (gradient -> all-reduce -> apply) even at world size 1")
     args = ap.parse_args()
 
@@ -153,18 +155,47 @@ def main():
     else:
         # one process per GPU: every rank shuffles its own resident shard of the data, takes 256 rows per step, and the
         # summed shard gradients meet in ONE all-reduce of the flat parameter-shaped buffer (RCCL over xGMI)
-        dp = DataParallelStep(d)
-        dp.broadcast_params(0)
+        native = args.dp_impl == "native"
+        if native:
+            try:
+                d.dp_init()                   # RCCL communicator owned by the library; torch only carried its 128-byte id
+                ok = 1
+            except Exception as e:            # e.g. librccl not loadable: every rank falls back together
+                print(f"[bench] native RCCL loop unavailable on rank {rank}: {e}", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native = bool(flag.item())
+            args.dp_impl = "native" if native else "torch"
+        if native:
+            d.dp_broadcast_params(0)
 
-        def run(k: int):
-            with torch.cuda.stream(d.stream):
-                for _ in range(k):
+            def run(k: int):
+                # the whole loop is native: per step gradient kernels -> ncclAllReduce -> update, enqueued by
+                # rcn_hip_dp_train_epoch_dev; Python only starts each pass (one in-stream shuffle + one call per 64 steps)
+                done = 0
+                while done < k:
                     pos = step_no[0] % nb_epoch
                     if pos == 0:
                         d.shuffle(perm, N_IMAGES, 1, seed=0x5DEECE66D + rank * 7919 + chunk_no[0])
                         chunk_no[0] += 1
-                    dp.train_batch(X, Y, ETA, B * world, perm=perm[pos * B:(pos + 1) * B])
-                    step_no[0] += 1
+                    take = min(nb_epoch - pos, k - done)
+                    d.dp_train_epoch(X, Y, perm[pos * B:], B, take, ETA, None)
+                    step_no[0] += take
+                    done += take
+        else:
+            dp = DataParallelStep(d)
+            dp.broadcast_params(0)
+
+            def run(k: int):
+                with torch.cuda.stream(d.stream):
+                    for _ in range(k):
+                        pos = step_no[0] % nb_epoch
+                        if pos == 0:
+                            d.shuffle(perm, N_IMAGES, 1, seed=0x5DEECE66D + rank * 7919 + chunk_no[0])
+                            chunk_no[0] += 1
+                        dp.train_batch(X, Y, ETA, B * world, perm=perm[pos * B:(pos + 1) * B])
+                        step_no[0] += 1
 
     def sync():
         d.synchronize()
@@ -204,7 +235,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "MNIST-shape 28x28x1, rcn default net conv(Same)-pool-conv(Same)-pool -> 784-30-10 sigmoid/MSE, "
                                "train_batch B=256 per GPU over 16384 resident pre-extracted feature vectors per GPU, eta=3.0",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "step_form": "gradient -> all-reduce -> apply" if use_dp else "fused update", "images_per_rank": N_IMAGES,
+                   "global_batch": B * world, "parallelism": f"dp{world}", "step_form": f"gradient -> all-reduce -> apply ({args.dp_impl} loop)" if use_dp else "fused update", "images_per_rank": N_IMAGES,
                    "device_ms_per_step_rank0": round(dev_ms / args.steps, 6), "final_cost_rank0": final_loss},
     }
 

@@ -178,6 +178,25 @@ int  rcn_hip_batch_gradient_dev(rcn_hip_ctx* ctx, const void* x_dev, const void*
 int  rcn_hip_batch_gradient_perm_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev, size_t B,
                                      void* grad_dev, void* loss_sum_dev);
 int  rcn_hip_apply_gradient_dev(rcn_hip_ctx* ctx, const void* grad_dev, double scale);
+/* The same data-parallel step as a native loop over RCCL (xGMI), one rank per context / GPU / process.  The reference
+ * has no multi-device mode; this is its train_batch (rcn.rs:176-223) with the batch split over ranks: per step each
+ * rank runs the gradient kernels on its B_shard rows, one ncclAllReduce(sum) combines the flat gradient (and the loss),
+ * and every rank applies W <- W - eta / (B_shard * world) * sum dW.  Bootstrap: rank 0 calls rcn_hip_dp_unique_id and
+ * ships the RCN_HIP_DP_ID_BYTES bytes to the other ranks by any out-of-band channel (MPI, a socket, a file); every
+ * rank then calls rcn_hip_dp_init (collective).  RCCL is loaded with dlopen at the first of these calls;
+ * RCN_HIP_ERR_UNSUPPORTED if it cannot be found. */
+#define RCN_HIP_DP_ID_BYTES 128
+int  rcn_hip_dp_unique_id(void* id_out /* RCN_HIP_DP_ID_BYTES */);
+int  rcn_hip_dp_init(rcn_hip_ctx* ctx, const void* id, int rank, int world);       /* collective */
+int  rcn_hip_dp_finalize(rcn_hip_ctx* ctx);                                         /* also done by rcn_hip_destroy */
+int  rcn_hip_dp_world(const rcn_hip_ctx* ctx);
+int  rcn_hip_dp_rank(const rcn_hip_ctx* ctx);
+int  rcn_hip_dp_broadcast_params(rcn_hip_ctx* ctx, int root);                       /* collective: one model (rcn.rs:139-141) */
+/* n_batches global steps; this rank's shard of step j is rows perm_dev[j*B_shard ..] of ITS resident X_dev / Y_dev
+ * (perm_dev NULL: consecutive rows).  loss_dev (nullable): n_batches GLOBAL costs sum ||a-y||^2 / (2 B_global).
+ * Collective; asynchronous on the context's stream. */
+int  rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
+                                size_t B_shard, size_t n_batches, double eta, void* loss_dev);
 /* classify_test (rcn.rs:105-116) for n samples: a <- sigmoid(W a + b) through every layer. out: n x classes */
 int  rcn_hip_forward(rcn_hip_ctx* ctx, const double* x, size_t n, double* out);
 int  rcn_hip_forward_dev(rcn_hip_ctx* ctx, const void* x_dev, size_t n, void* out_dev);

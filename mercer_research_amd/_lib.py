@@ -73,6 +73,13 @@ SIGNATURES = {
     "rcn_hip_batch_gradient_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "rcn_hip_batch_gradient_perm_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "rcn_hip_apply_gradient_dev": (_i, [_vp, _vp, _d]),
+    "rcn_hip_dp_unique_id": (_i, [_vp]),
+    "rcn_hip_dp_init": (_i, [_vp, _vp, _i, _i]),
+    "rcn_hip_dp_finalize": (_i, [_vp]),
+    "rcn_hip_dp_world": (_i, [_vp]),
+    "rcn_hip_dp_rank": (_i, [_vp]),
+    "rcn_hip_dp_broadcast_params": (_i, [_vp, _i]),
+    "rcn_hip_dp_train_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
     "rcn_hip_forward": (_i, [_vp, _dp, _sz, _dp]),
     "rcn_hip_forward_dev": (_i, [_vp, _vp, _sz, _vp]),
     "rcn_hip_classify": (_i, [_vp, _dp, _sz, _i32p]),

@@ -22,6 +22,7 @@
 #include "dense_p2.hpp"
 #include "features.hpp"
 #include "ops.hpp"
+#include "dp_rccl.hpp"
 
 using namespace rcn;
 
@@ -69,6 +70,8 @@ struct rcn_hip_ctx {
     size_t pack_seg_bytes = (size_t)64 << 20;   // size of one half of the epoch image (env RCN_HIP_PACK_SEGMENT_BYTES, for tests)
     DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
     std::map<EpochKey, hipGraphExec_t> graphs;
+    ncclComm_t comm = nullptr;              // data-parallel group (rcn_hip_dp_init); one rank per context
+    int dp_rank = 0, dp_world = 1;
     std::map<const void*, size_t> lds_attr;   // kernels whose dynamic-LDS limit was already raised
     std::string err;
     size_t esz() const { return dtype == RCN_HIP_F64 ? 8 : 4; }
@@ -519,6 +522,7 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
         DevGuard g(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         drop_graphs(c);
+        if (c->comm) { (void)rcn::Rccl::get().CommDestroy(c->comm); c->comm = nullptr; }
         for (DevBuf* b : {&c->slab, &c->xpack, &c->ypack, &c->p2buf, &c->params, &c->acts, &c->deltas, &c->loss_part, &c->grad, &c->xstage, &c->ystage, &c->ostage, &c->scratch0,
                           &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
             b->release();
@@ -992,6 +996,113 @@ int rcn_hip_apply_gradient_dev(rcn_hip_ctx* c, const void* grad, double scale) {
     else
         hipLaunchKernelGGL((k_apply_gradient<float>), dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (float*)c->params.p, (const float*)grad, (float)scale, n);
     HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+// ---------------------------------------------------------------- data-parallel training over RCCL
+// The sum over samples of rcn.rs:190-205 is split over ranks: every rank computes the summed gradient of its shard of
+// each global batch, ONE ncclAllReduce(sum) of the flat gradient (+ the loss in its last element) combines them over
+// xGMI, and every rank applies the identical update W <- W - (eta / B_global) * sum dW (rcn.rs:214,221 with the global
+// batch length), so replicas stay bit-identical without a broadcast.  The whole loop is enqueued from here on the
+// context's stream -- no host round trip, no Python between steps.
+#define NCCL_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess)                                                                               \
+            return fail(ctx, RCN_HIP_ERR_HIP, std::string(#expr) + ": " + rcn::Rccl::get().GetErrorString(r_)); \
+    } while (0)
+
+int rcn_hip_dp_unique_id(void* id_out) {
+    if (!id_out) return RCN_HIP_ERR_INVALID_ARG;
+    rcn::Rccl& r = rcn::Rccl::get();
+    if (!r.ok) return RCN_HIP_ERR_UNSUPPORTED;
+    static_assert(sizeof(ncclUniqueId) == RCN_HIP_DP_ID_BYTES, "rcn_hip.h: RCN_HIP_DP_ID_BYTES");
+    ncclUniqueId id;
+    if (r.GetUniqueId(&id) != ncclSuccess) return RCN_HIP_ERR_HIP;
+    std::memcpy(id_out, &id, sizeof id);
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_dp_init(rcn_hip_ctx* c, const void* id_bytes, int rank, int world) {
+    RCN_TRY(check_ctx(c));
+    if (!id_bytes || world < 1 || rank < 0 || rank >= world) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_init: bad id / rank / world");
+    rcn::Rccl& r = rcn::Rccl::get();
+    if (!r.ok) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "dp_init: " + r.err);
+    DevGuard g(c->device);
+    if (c->comm) { HIP_TRY(c, hipStreamSynchronize(c->stream)); NCCL_TRY(c, r.CommDestroy(c->comm)); c->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof id);
+    NCCL_TRY(c, r.CommInitRank(&c->comm, world, id, rank));
+    c->dp_rank = rank;
+    c->dp_world = world;
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_dp_finalize(rcn_hip_ctx* c) {
+    RCN_TRY(check_ctx(c));
+    if (!c->comm) return RCN_HIP_OK;
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    NCCL_TRY(c, rcn::Rccl::get().CommDestroy(c->comm));
+    c->comm = nullptr;
+    c->dp_rank = 0;
+    c->dp_world = 1;
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_dp_world(const rcn_hip_ctx* c) { return c ? c->dp_world : 0; }
+int rcn_hip_dp_rank(const rcn_hip_ctx* c) { return c ? c->dp_rank : -1; }
+
+int rcn_hip_dp_broadcast_params(rcn_hip_ctx* c, int root) {
+    RCN_TRY(check_ctx(c));
+    if (!c->comm) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_broadcast_params: rcn_hip_dp_init was not called");
+    if (root < 0 || root >= c->dp_world) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_broadcast_params: bad root");
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    NCCL_TRY(c, rcn::Rccl::get().Broadcast(c->params.p, c->params.p, (size_t)c->nd.P, c->dtype == RCN_HIP_F64 ? ncclDouble : ncclFloat, root,
+                                           c->comm, c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta,
+                               void* loss_dev) {
+    RCN_TRY(check_ctx(c));
+    if (!c->comm) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_train_epoch: rcn_hip_dp_init was not called");
+    if (!X || !Y) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_train_epoch: NULL pointer");
+    if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_train_epoch: shard batch size must be in 1..2^30");
+    if (nb == 0) return RCN_HIP_OK;
+    RCN_TRY(need_params(c));
+    DevGuard g(c->device);
+    RCN_TRY(ensure_dense_ws(c, B));
+    const size_t es = c->esz(), P = (size_t)c->nd.P, F = c->nd.dims[0], Cc = c->nd.dims[c->nd.L];
+    HIP_TRY(c, c->grad.ensure((P + 1) * es));                 // [gradient | loss]: one all-reduce carries both
+    rcn::Rccl& r = rcn::Rccl::get();
+    const double Bg = (double)B * (double)c->dp_world;          // the global batch.len() of rcn.rs:214
+    const double scale = eta / Bg, loss_scale = 1.0 / (2.0 * Bg);
+    char* gbuf = (char*)c->grad.p;
+    void* lslot = gbuf + P * es;
+    const bool f64 = c->dtype == RCN_HIP_F64;
+    for (size_t j = 0; j < nb; ++j) {
+        const void* xb = perm ? X : (const char*)X + j * B * F * es;
+        const void* yb = perm ? Y : (const char*)Y + j * B * Cc * es;
+        const int32_t* ib = perm ? perm + j * B : nullptr;
+        if (f64) {
+            RCN_TRY(launch_fwd<double>(c, true, xb, yb, ib, B, nullptr));
+            RCN_TRY(launch_wgrad<double>(c, false, xb, ib, B, 0.0, gbuf, lslot, loss_scale));
+        } else {
+            RCN_TRY(launch_fwd<float>(c, true, xb, yb, ib, B, nullptr));
+            RCN_TRY(launch_wgrad<float>(c, false, xb, ib, B, 0.0, gbuf, lslot, loss_scale));
+        }
+        NCCL_TRY(c, r.AllReduce(gbuf, gbuf, P + 1, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream));
+        if (f64)
+            hipLaunchKernelGGL((k_apply_gradient<double>), dim3(grid_for((int)P, 256)), dim3(256), 0, c->stream, (double*)c->params.p,
+                               (const double*)gbuf, scale, (int)P);
+        else
+            hipLaunchKernelGGL((k_apply_gradient<float>), dim3(grid_for((int)P, 256)), dim3(256), 0, c->stream, (float*)c->params.p,
+                               (const float*)gbuf, (float)scale, (int)P);
+        HIP_TRY(c, hipGetLastError());
+        if (loss_dev) HIP_TRY(c, hipMemcpyAsync((char*)loss_dev + j * es, lslot, es, hipMemcpyDeviceToDevice, c->stream));
+    }
     return RCN_HIP_OK;
 }
 

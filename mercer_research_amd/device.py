@@ -151,6 +151,40 @@ class DeviceRCN:
     def apply_gradient(self, grad: torch.Tensor, scale: float):
         self._ck(self.lib.rcn_hip_apply_gradient_dev(self.ctx, _p(grad), float(scale)))
 
+    # ---- native data-parallel loop (RCCL inside the library; rcn_hip.h "rcn_hip_dp_*") ------------------------------
+    def dp_init(self, group=None):
+        """Collective.  Creates this context's RCCL communicator: rank 0 draws the unique id, torch.distributed (any
+        backend) only carries those 128 bytes to the other ranks; the training loop itself never goes through torch."""
+        import torch.distributed as dist
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            st = self.lib.rcn_hip_dp_unique_id(buf)
+            if st != 0:
+                raise RuntimeError(f"rcn_hip_dp_unique_id failed with status {st} (is librccl loadable?)")
+        box = [bytes(buf.raw)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self._ck(self.lib.rcn_hip_dp_init(self.ctx, box[0], rank, world))
+        return rank, world
+
+    def dp_finalize(self):
+        self._ck(self.lib.rcn_hip_dp_finalize(self.ctx))
+
+    def dp_broadcast_params(self, root: int = 0):
+        self._ck(self.lib.rcn_hip_dp_broadcast_params(self.ctx, root))
+
+    def dp_train_epoch(self, X: torch.Tensor, Y: torch.Tensor, perm: Optional[torch.Tensor], B_shard: int, n_batches: int, eta: float,
+                       loss: Optional[torch.Tensor] = None):
+        """n_batches global train_batch steps; this rank contributes rows perm[j*B_shard ..] of its resident X / Y to
+        step j.  Enqueued natively: gradient kernels -> ncclAllReduce -> update, per step, on this stream."""
+        if perm is not None:
+            assert perm.dtype == torch.int32 and perm.numel() >= B_shard * n_batches
+        else:
+            assert X.shape[0] >= B_shard * n_batches
+        self._ck(self.lib.rcn_hip_dp_train_epoch_dev(self.ctx, _p(X), _p(Y), _p(perm), B_shard, n_batches, float(eta), _p(loss)))
+
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = out if out is not None else self.empty(x.shape[0], self.classes)
         self._ck(self.lib.rcn_hip_forward_dev(self.ctx, _p(x), x.shape[0], _p(out)))

@@ -90,6 +90,14 @@ extern "C" {
     pub fn rcn_hip_batch_gradient_perm_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b: usize, grad: *mut c_void,
                                            loss_sum: *mut c_void) -> c_int;
     pub fn rcn_hip_apply_gradient_dev(ctx: *mut rcn_hip_ctx, grad: *const c_void, scale: c_double) -> c_int;
+    pub fn rcn_hip_dp_unique_id(id_out: *mut c_void) -> c_int;
+    pub fn rcn_hip_dp_init(ctx: *mut rcn_hip_ctx, id: *const c_void, rank: c_int, world: c_int) -> c_int;
+    pub fn rcn_hip_dp_finalize(ctx: *mut rcn_hip_ctx) -> c_int;
+    pub fn rcn_hip_dp_world(ctx: *const rcn_hip_ctx) -> c_int;
+    pub fn rcn_hip_dp_rank(ctx: *const rcn_hip_ctx) -> c_int;
+    pub fn rcn_hip_dp_broadcast_params(ctx: *mut rcn_hip_ctx, root: c_int) -> c_int;
+    pub fn rcn_hip_dp_train_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b_shard: usize, n_batches: usize,
+                                      eta: c_double, loss: *mut c_void) -> c_int;
     pub fn rcn_hip_forward(ctx: *mut rcn_hip_ctx, x: *const c_double, n: usize, out: *mut c_double) -> c_int;
     pub fn rcn_hip_forward_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, n: usize, out: *mut c_void) -> c_int;
     pub fn rcn_hip_classify(ctx: *mut rcn_hip_ctx, x: *const c_double, n: usize, class_out: *mut i32) -> c_int;

@@ -363,6 +363,45 @@ def test_epoch_graph_matches_sequential_oracle(amd, oracle, dtype, path):
         _check_params(gw + gb, rw + rb, 1)
 
 
+@pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
+def test_native_rccl_epoch_world1_matches_oracle(amd, oracle, dtype):
+    """rcn_hip_dp_train_epoch_dev (gradient kernels -> ncclAllReduce -> update, all enqueued natively) with a
+    one-rank RCCL communicator must be the reference's sequential train_batch loop (rcn.rs:147-149, 176-223)."""
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 32, 5, 256
+    ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=78, wscale=0.1)
+    d = DeviceRCN(dtype=dtype)
+    d.set_params(ws, bs)
+    assert d.dp_init() == (0, 1)
+    assert d.lib.rcn_hip_dp_world(d.ctx) == 1 and d.lib.rcn_hip_dp_rank(d.ctx) == 0
+    d.dp_broadcast_params(0)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    perm = np.random.default_rng(2).permutation(N).astype(np.int32)
+    permd = d.to_device(perm)
+    loss = d.empty(nb)
+    d.dp_train_epoch(Xd, Yd, permd, B, nb, 3.0, loss)
+    gw, gb = d.get_params()
+    losses = loss.cpu().numpy()
+    rw, rb, costs = ws, bs, []
+    for j in range(nb):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, X[sel], Y[sel], 3.0)
+        costs.append(c)
+    if dtype == 1:
+        _check_params(gw + gb, rw + rb, 1)
+        np.testing.assert_allclose(losses, costs, rtol=1e-10)
+    else:
+        for a, b in zip(gw + gb, rw + rb):
+            assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)
+        np.testing.assert_allclose(losses, costs, rtol=1e-3)
+    # identity order, and the uninitialised / finalised states fail loudly
+    d.dp_train_epoch(Xd, Yd, None, B, 2, 3.0, None)
+    d.dp_finalize()
+    with pytest.raises(Exception):
+        d.dp_train_epoch(Xd, Yd, None, B, 1, 3.0, None)
+    d.rcn.close()
+
+
 def test_data_parallel_halves_equal_full_batch(amd, oracle):
     """Shard gradients + sum + one update == train_batch on the concatenated batch, single GPU."""
     from mercer_research_amd.device import DeviceRCN
