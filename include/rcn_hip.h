@@ -213,6 +213,10 @@ int  rcn_hip_classify_images(rcn_hip_ctx* ctx, const uint8_t* imgs, size_t n, in
  * the layer stack allows it, sample-tile kernels otherwise), 1 = always the sample-tile kernels, 2 = always the
  * feature-sliced pipeline.  Both compute the same step (summation grouping differs, within the stated tolerances). */
 int  rcn_hip_set_dense_path(rcn_hip_ctx* ctx, int mode);
+/* Which kernel implements flatten_feature_set: 0 = automatic (the fused conv+pool kernel specialised for the default
+ * stack conv(Same),pool(Max),conv(Same),pool(Max) on 28x28 input when the configuration is exactly that, the generic
+ * layer-walking kernel otherwise), 1 = always the generic kernel.  Both are bit-identical (integer-valued arithmetic). */
+int  rcn_hip_set_feature_kernel(rcn_hip_ctx* ctx, int mode);
 
 /* Times the two kernels of one train_batch at batch size B with HIP events on the context's stream: `reps`
  * back-to-back launches of each kernel (one hipGraph of `reps` dependent nodes per kernel, so the host launch rate does

@@ -3,7 +3,9 @@ this raises -- the product path never computes on the CPU."""
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librcn_hip.so")
@@ -87,10 +89,38 @@ SIGNATURES = {
     "rcn_hip_evaluate_dev": (_i, [_vp, _vp, _vp, _sz, _i64p]),
     "rcn_hip_classify_images": (_i, [_vp, _u8p, _sz, _i32p]),
     "rcn_hip_set_dense_path": (_i, [_vp, _i]),
+    "rcn_hip_set_feature_kernel": (_i, [_vp, _i]),
     "rcn_hip_time_kernels_dev": (_i, [_vp, _vp, _vp, _sz, _i, _dp, _dp, _dp]),
 }
 
 _lib = None
+_hip_preloaded = False
+
+
+def preload_hip_runtime() -> None:
+    """One HIP runtime per process.  librcn_hip.so asks the loader for libamdhip64 by SONAME; PyTorch ships its own copy
+    under the same SONAME.  Whichever is mapped first wins for both, and a process that mapped the system copy first
+    (ctypes-only use of this package) and imports torch later ends up with a runtime torch cannot initialise
+    (`torch.cuda.is_available()` turns False).  So: when torch is installed, map ITS copy before ours -- without
+    importing torch -- and the order of use no longer matters.  Without torch the system copy is used."""
+    global _hip_preloaded
+    if _hip_preloaded:
+        return
+    _hip_preloaded = True
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
 
 
 def load(path: str | None = None) -> C.CDLL:
@@ -102,6 +132,7 @@ def load(path: str | None = None) -> C.CDLL:
     if not os.path.exists(p):
         raise ImportError(f"{p} not found: build it with `python -m mercer_research_amd.build` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    preload_hip_runtime()
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

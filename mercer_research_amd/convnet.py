@@ -8,6 +8,8 @@ from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import _lib
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBX_PATH = os.path.join(HERE, "librcn_hipx.so")
 KIND = {"conv": 0, "pool": 1, "dense_relu": 2, "dense": 3}
@@ -43,6 +45,7 @@ def load():
     if _libx is None:
         if not os.path.exists(LIBX_PATH):
             raise ImportError(f"{LIBX_PATH} not found: build it with `python -m mercer_research_amd.build`; there is no CPU fallback")
+        _lib.preload_hip_runtime()
         lib = C.CDLL(LIBX_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -120,6 +120,153 @@ __global__ __launch_bounds__(kFeatThreads) void k_features(
     }
 }
 
+// ---- specialisation: the default stack conv(Same), pool(Max), conv(Same), pool(Max) (rcn/src/main.rs:53-59) on an
+// H x W image with H, W multiples of 4 known at compile time (MNIST: 28 x 28).
+//
+// Same arithmetic as k_features (integer-valued f32, exact), restructured for throughput:
+//  * one WAVE owns one image at a time (workgroup = 1 wave: barriers are free, no cross-wave coupling), ~20 waves per
+//    CU resident, 8 KB of LDS each;
+//  * each conv+pool pair is fused: one work item produces one POOLED pixel of all four operator maps from a 4x4 input
+//    window (the four 3x3 neighbourhoods of its 2x2 pooling cell share column sums / differences);
+//  * the Padding::Same quirk masks (kernel.rs:154-158: a row/column of zeros ends up top/left and the last input
+//    column is never read; output row 0 is zero) become LAYOUT: maps sit in LDS inside a frame of zeros (two rows
+//    above, two columns left) with their last column stored as zero, so the stencil runs with no per-element
+//    predicates and every window row is two aligned ds_read_b64;
+//  * ReLU followed by max-pool is max(+0, max4(.)); Right = -Left and Bottom = -Top come from the negated operands;
+//  * all index arithmetic divides by compile-time constants.
+// HBM traffic is the algorithmic minimum: H*W bytes in, F*sizeof(TO) out.
+template <int H, int W, typename TO>
+__global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, int standardize,
+                                                      TO mean, TO sd) {
+    static_assert(H % 4 == 0 && W % 4 == 0, "two exact 2x2 poolings and 4-pixel word loads");
+    constexpr int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4;
+    constexpr int PW0 = W + 4, PW1 = W1 + 2;                 // padded row strides (frame: 2 left; right slack keeps windows in range)
+    constexpr int N0 = (H + 2) * PW0, N1 = (H1 + 2) * PW1;
+    constexpr int WORDS = H * W / 4, ROWW = W / 4;
+    constexpr int I1 = H1 * W1, I2 = 4 * H2 * W2, SZ2 = H2 * W2, F = 16 * SZ2;
+    __shared__ __attribute__((aligned(16))) float P0[N0];
+    __shared__ __attribute__((aligned(16))) float P1[4 * N1];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < N0; e += 64) P0[e] = 0.f;
+    for (int e = lane; e < 4 * N1; e += 64) P1[e] = 0.f;
+    __syncthreads();
+
+    for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
+        // get_pixel_matrix (lib.rs:27-41): 4 pixels of one row per 32-bit word; image pixel (r,c) -> P0[(r+2)*PW0 + c+2]
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(imgs + (size_t)img * (H * W));
+#pragma unroll
+        for (int k = 0; k < (WORDS + 63) / 64; ++k) {
+            const int wd = lane + 64 * k;
+            const int wc = wd < WORDS ? wd : WORDS - 1;
+            const uint32_t v = src[wc];
+            const int r = wc / ROWW, c0 = (wc - r * ROWW) * 4;
+            float2 lo, hi;
+            lo.x = (float)(v & 255u); lo.y = (float)((v >> 8) & 255u);
+            hi.x = (float)((v >> 16) & 255u); hi.y = c0 + 3 == W - 1 ? 0.f : (float)(v >> 24);     // last column: never read (quirk)
+            float* dst = &P0[(r + 2) * PW0 + c0 + 2];
+            if (wd < WORDS) {
+                *reinterpret_cast<float2*>(dst) = lo;
+                *reinterpret_cast<float2*>(dst + 2) = hi;
+            }
+        }
+        __syncthreads();
+
+        // conv1 + pool1: item = pooled pixel (py,px) of the H1 x W1 maps
+#pragma unroll
+        for (int k = 0; k < (I1 + 63) / 64; ++k) {
+            const int t = lane + 64 * k;
+            const int tc = t < I1 ? t : I1 - 1;
+            const int py = tc / W1, px = tc - py * W1;
+            float w[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* row = &P0[(2 * py + r) * PW0 + 2 * px];
+                const float2 a = *reinterpret_cast<const float2*>(row), b = *reinterpret_cast<const float2*>(row + 2);
+                w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
+            }
+            float tmax = 0.f, bmax = 0.f, lmax = 0.f, rmax = 0.f;      // the +0 is the ReLU floor; Bottom = -Top, Right = -Left
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                float d[4], sm[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    d[c] = w[dy][c] - w[dy + 2][c];                          // column kernel [1,0,-1]   kernel.rs:47
+                    sm[c] = (w[dy][c] + w[dy + 2][c]) + 2.f * w[dy + 1][c];   // column kernel [1,2,1]    kernel.rs:48
+                }
+                const bool live = dy == 1 || py > 0;                          // output row 0 is zero (quirk)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float top = (d[dx] + d[dx + 2]) + 2.f * d[dx + 1];        // row kernel [1,2,1]
+                    float left = sm[dx] - sm[dx + 2];                         // row kernel [1,0,-1]
+                    top = live ? top : 0.f; left = live ? left : 0.f;
+                    tmax = fmaxf(tmax, top); bmax = fmaxf(bmax, -top);
+                    lmax = fmaxf(lmax, left); rmax = fmaxf(rmax, -left);
+                }
+            }
+            if (t < I1) {
+                const bool lastc = px == W1 - 1;                              // conv2 never reads a map's last column
+                float* q = &P1[(py + 2) * PW1 + px + 2];
+                q[0 * N1] = lastc ? 0.f : tmax;                               // Top      (SEP_OPS order rcn.rs:41-46)
+                q[1 * N1] = lastc ? 0.f : lmax;                               // Left
+                q[2 * N1] = lastc ? 0.f : rmax;                              // Right  = relu(-left)
+                q[3 * N1] = lastc ? 0.f : bmax;                              // Bottom = relu(-top)
+            }
+        }
+        __syncthreads();
+
+        // conv2 + pool2 + flatten: item = (input map i, pooled pixel) ordered column-major within the map (rcn.rs:350-355)
+        TO* dst = out + (size_t)img * F;
+#pragma unroll
+        for (int k = 0; k < (I2 + 63) / 64; ++k) {
+            const int t = lane + 64 * k;
+            const int tc = t < I2 ? t : I2 - 1;
+            const int i = tc / SZ2, q = tc - i * SZ2, px = q / H2, py = q - px * H2;
+            float w[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* row = &P1[i * N1 + (2 * py + r) * PW1 + 2 * px];
+                const float2 a = *reinterpret_cast<const float2*>(row), b = *reinterpret_cast<const float2*>(row + 2);
+                w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
+            }
+            float tmax = 0.f, bmax = 0.f, lmax = 0.f, rmax = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                float d[4], sm[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    d[c] = w[dy][c] - w[dy + 2][c];
+                    sm[c] = (w[dy][c] + w[dy + 2][c]) + 2.f * w[dy + 1][c];
+                }
+                const bool live = dy == 1 || py > 0;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float top = (d[dx] + d[dx + 2]) + 2.f * d[dx + 1];
+                    float left = sm[dx] - sm[dx + 2];
+                    top = live ? top : 0.f; left = live ? left : 0.f;
+                    tmax = fmaxf(tmax, top); bmax = fmaxf(bmax, -top);
+                    lmax = fmaxf(lmax, left); rmax = fmaxf(rmax, -left);
+                }
+            }
+            TO v[4] = {(TO)tmax, (TO)lmax, (TO)rmax, (TO)bmax};
+            if (standardize) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const TO dd = (v[o] - mean) / sd;                          // rcn.rs:407-412
+                    v[o] = dd >= (TO)0 ? dd : (TO)0;
+                }
+            }
+            if (t < I2) {
+                // slots after the second conv layer (rcn.rs:323-340): Bottom stays in slot i, T/L/R are pushed to 4+3i+o
+                dst[(4 + 3 * i + 0) * SZ2 + q] = v[0];
+                dst[(4 + 3 * i + 1) * SZ2 + q] = v[1];
+                dst[(4 + 3 * i + 2) * SZ2 + q] = v[2];
+                dst[i * SZ2 + q] = v[3];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- gen_scales (rcn.rs:230-251): two-pass population mean / sd, f64 accumulation, per-block partials that
 // the host sums in block order (deterministic).
 template <typename T, bool SQDEV>

@@ -62,6 +62,7 @@ struct rcn_hip_ctx {
     bool params_set = false;
     std::string dense_err;                  // non-empty: every dense call panics in the reference (see rcn_hip_create)
     double mean = 1.0, sd = 1.0;            // scale_set initial value (1,1): rcn.rs:71
+    int feat_kernel = 0;                    // 0 auto, 1 always the generic k_features (tests compare the two)
     int dense_path = 0;                     // 0 auto, 1 sample-tile kernels (dense.hpp), 2 feature-sliced pipeline (dense_pipe.hpp)
     DevBuf slab, xpack, ypack, p2buf;
     size_t packed_B = 0, packed_nb = 0;     // what the epoch image currently holds (k_pack_epoch)
@@ -544,6 +545,13 @@ int rcn_hip_set_stream(rcn_hip_ctx* c, void* s) {
     return RCN_HIP_OK;
 }
 
+int rcn_hip_set_feature_kernel(rcn_hip_ctx* c, int mode) {
+    RCN_TRY(check_ctx(c));
+    if (mode < 0 || mode > 1) return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_feature_kernel: mode must be 0 or 1");
+    c->feat_kernel = mode;
+    return RCN_HIP_OK;
+}
+
 int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
     RCN_TRY(check_ctx(c));
     if (mode < 0 || mode > 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile) or 2 (feature-sliced)");
@@ -748,6 +756,20 @@ int rcn_hip_features_dev(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, void* ou
     if (n == 0 || c->fd.F == 0) return RCN_HIP_OK;          // an empty feature_set flattens to an empty vector (rcn.rs:350)
     if (n > 0x7fffffffULL) return fail(c, RCN_HIP_ERR_INVALID_ARG, "features: too many images in one call");
     DevGuard g(c->device);
+    // the default stack on MNIST-shaped input has its own kernel (features.hpp: k_features_cpcp)
+    const FeatDesc& fd = c->fd;
+    if (c->feat_kernel != 1 && fd.n == 4 && fd.H == 28 && fd.W == 28 && fd.kind[0] == 0 && fd.arg[0] == RCN_HIP_PAD_SAME && fd.kind[1] == 1 &&
+        fd.kind[2] == 0 && fd.arg[2] == RCN_HIP_PAD_SAME && fd.kind[3] == 1 && ((uintptr_t)imgs & 3) == 0) {
+        const int grid = (int)(n < 4096 ? n : 4096);
+        if (c->dtype == RCN_HIP_F64)
+            hipLaunchKernelGGL((k_features_cpcp<28, 28, double>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (double*)out, standardize,
+                               c->mean, c->sd);
+        else
+            hipLaunchKernelGGL((k_features_cpcp<28, 28, float>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (float*)out, standardize,
+                               (float)c->mean, (float)c->sd);
+        HIP_TRY(c, hipGetLastError());
+        return RCN_HIP_OK;
+    }
     const bool wide = c->n_conv > 5;             // |v| <= 255*8^n stays below 2^24 only up to 5 conv layers
     const size_t lds = 2 * (size_t)c->fd.max_elems * (wide ? 8 : 4);
     const int grid = (int)(n < 4096 ? n : 4096);

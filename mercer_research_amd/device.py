@@ -70,6 +70,9 @@ class DeviceRCN:
     def set_dense_path(self, mode: int):
         self.rcn.set_dense_path(mode)
 
+    def set_feature_kernel(self, mode: int):
+        self.rcn.set_feature_kernel(mode)
+
     # ---- feature pipeline --------------------------------------------------------------------------------------
     def features(self, imgs_u8: torch.Tensor, standardize: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert imgs_u8.dtype == torch.uint8 and imgs_u8.is_contiguous() and imgs_u8.device == self.device

@@ -138,6 +138,10 @@ class RCN:
         """0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline (include/rcn_hip.h)."""
         self._ck(self._lib.rcn_hip_set_dense_path(self._ctx, int(mode)))
 
+    def set_feature_kernel(self, mode: int):
+        """0 auto (specialised fused kernel for the default stack on 28x28), 1 always the generic kernel."""
+        self._ck(self._lib.rcn_hip_set_feature_kernel(self._ctx, int(mode)))
+
     # ------------------------------------------------------------------ parameters (Weights / Bias)
     def set_params(self, weights: Sequence[np.ndarray], biases: Sequence[np.ndarray]):
         """weights[l]: (out, in) array == Weights.0; biases[l]: (out,) == Bias.0  (rcn.rs:28,31)"""

@@ -110,6 +110,51 @@ def test_features_default_net_bit_exact(amd, oracle, dtype):
     assert 2040 < got.max() <= 16320.0      # bound of SURVEY §8c: 255 * 8^2
 
 
+@pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
+def test_features_specialised_and_generic_kernels_agree(amd, oracle, dtype):
+    """The fused conv+pool kernel for the default stack (k_features_cpcp) and the generic layer-walking kernel are both
+    the reference's flatten_feature_set (rcn.rs:317-356): bit-identical to each other and to the oracle, with and
+    without the fused standardisation, on inputs that light every border (quirk Q1) and every pixel individually."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    rng = np.random.default_rng(99)
+    imgs = rng.integers(0, 256, (1200, 28, 28)).astype(np.uint8)
+    imgs[0] = 255
+    imgs[1] = 0
+    imgs[2, ::2] = 255; imgs[2, 1::2] = 0
+    imgs[3, :, ::2] = 255; imgs[3, :, 1::2] = 0
+    hot = np.zeros((784, 28, 28), np.uint8)                       # one image per single hot pixel
+    hot.reshape(784, 784)[np.arange(784), np.arange(784)] = 255
+    imgs[100:884] = hot
+    ref = oracle.features(imgs, DEFAULT_LAYERS)
+    d = DeviceRCN(dtype=dtype)
+    dev = d.to_device(imgs)
+
+    def feats(x, **kw):
+        t = d.features(x, **kw)
+        d.synchronize()                 # the kernels run on the context's stream, .cpu() on torch's
+        return t.cpu().numpy()
+
+    fast = feats(dev)
+    d.set_feature_kernel(1)
+    slow = feats(dev)
+    assert np.array_equal(fast, ref) and np.array_equal(slow, ref)
+    assert not np.signbit(fast).any()                             # relu(-x) of x == 0 is +0, as in the reference
+    d.rcn.scale_set = (37.5, 211.0)
+    slow_s = feats(dev, standardize=True)
+    d.set_feature_kernel(0)
+    fast_s = feats(dev, standardize=True)
+    assert np.array_equal(fast_s, slow_s)
+    want = oracle.standardize(ref, 37.5, 211.0)
+    np.testing.assert_allclose(fast_s, want, rtol=1e-12 if dtype == 1 else 1e-6, atol=0 if dtype == 1 else 1e-7)
+    # an image count that is not a multiple of the grid, and a single image
+    for n in (1, 4097):
+        big = np.tile(imgs, (4, 1, 1))[:n]
+        got = feats(d.to_device(big))
+        assert np.array_equal(got, np.tile(ref, (4, 1))[:n])
+    d.rcn.close()
+
+
 @pytest.mark.parametrize("spec,shape", [
     (((LAYER_CONV, PAD_NONE), (LAYER_POOL, POOL_MAX)), (9, 11)),
     (((LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX)), (9, 11)),
