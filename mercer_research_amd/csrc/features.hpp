@@ -135,28 +135,61 @@ __global__ __launch_bounds__(kFeatThreads) void k_features(
 //  * ReLU followed by max-pool is max(+0, max4(.)); Right = -Left and Bottom = -Top come from the negated operands;
 //  * all index arithmetic divides by compile-time constants.
 // HBM traffic is the algorithmic minimum: H*W bytes in, F*sizeof(TO) out.
-template <int H, int W, typename TO>
-__global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, int standardize,
-                                                      TO mean, TO sd) {
+template <int H, int W>
+struct Cpcp {
     static_assert(H % 4 == 0 && W % 4 == 0, "two exact 2x2 poolings and 4-pixel word loads");
-    constexpr int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4;
-    constexpr int PW0 = W + 4, PW1 = W1 + 2;                 // padded row strides (frame: 2 left; right slack keeps windows in range)
-    constexpr int N0 = (H + 2) * PW0, N1 = (H1 + 2) * PW1;
-    constexpr int WORDS = H * W / 4, ROWW = W / 4;
-    constexpr int I1 = H1 * W1, I2 = 4 * H2 * W2, SZ2 = H2 * W2, F = 16 * SZ2;
-    __shared__ __attribute__((aligned(16))) float P0[N0];
-    __shared__ __attribute__((aligned(16))) float P1[4 * N1];
-    const int lane = threadIdx.x;
-    for (int e = lane; e < N0; e += 64) P0[e] = 0.f;
-    for (int e = lane; e < 4 * N1; e += 64) P1[e] = 0.f;
-    __syncthreads();
+    static constexpr int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4;
+    static constexpr int PW0 = W + 4, PW1 = W1 + 2;          // padded row strides (frame: 2 left; right slack keeps windows in range)
+    static constexpr int N0 = (H + 2) * PW0, N1 = (H1 + 2) * PW1;
+    static constexpr int WORDS = H * W / 4, ROWW = W / 4;
+    static constexpr int I1 = H1 * W1, I2 = 4 * H2 * W2, SZ2 = H2 * W2, F = 16 * SZ2;
+    static constexpr int LDS_FLOATS = N0 + 4 * N1;
 
-    for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
-        // get_pixel_matrix (lib.rs:27-41): 4 pixels of one row per 32-bit word; image pixel (r,c) -> P0[(r+2)*PW0 + c+2]
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(imgs + (size_t)img * (H * W));
+    // the frame of zeros; once per workgroup (image writes never touch it)
+    template <int NT>
+    __device__ static inline void init(float* P0, float* P1, int tid) {
+        for (int e = tid; e < N0; e += NT) P0[e] = 0.f;
+        for (int e = tid; e < 4 * N1; e += NT) P1[e] = 0.f;
+    }
+
+    // one 4x4 window -> the four pooled operator responses (Top, Left, Right, Bottom) of its 2x2 cell
+    __device__ static inline void cell(const float* win, int stride, bool row0, float& tmax, float& lmax, float& rmax, float& bmax) {
+        float w[4][4];
 #pragma unroll
-        for (int k = 0; k < (WORDS + 63) / 64; ++k) {
-            const int wd = lane + 64 * k;
+        for (int r = 0; r < 4; ++r) {
+            const float2 a = *reinterpret_cast<const float2*>(win + r * stride), b = *reinterpret_cast<const float2*>(win + r * stride + 2);
+            w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
+        }
+        tmax = 0.f; bmax = 0.f; lmax = 0.f; rmax = 0.f;          // the +0 is the ReLU floor; Bottom = -Top, Right = -Left
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            float d[4], sm[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d[c] = w[dy][c] - w[dy + 2][c];                          // column kernel [1,0,-1]   kernel.rs:47
+                sm[c] = (w[dy][c] + w[dy + 2][c]) + 2.f * w[dy + 1][c];   // column kernel [1,2,1]    kernel.rs:48
+            }
+            const bool live = dy == 1 || !row0;                          // output row 0 is zero (quirk)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float top = (d[dx] + d[dx + 2]) + 2.f * d[dx + 1];        // row kernel [1,2,1]
+                float left = sm[dx] - sm[dx + 2];                         // row kernel [1,0,-1]
+                top = live ? top : 0.f; left = live ? left : 0.f;
+                tmax = fmaxf(tmax, top); bmax = fmaxf(bmax, -top);
+                lmax = fmaxf(lmax, left); rmax = fmaxf(rmax, -left);
+            }
+        }
+    }
+
+    // One image through conv,pool,conv,pool by NT threads (a whole workgroup: contains barriers).  emit(e, v): feature e
+    // of the flattened vector (rcn.rs:350-355 order) has the integer value v.
+    template <int NT, typename Emit>
+    __device__ static inline void image(float* P0, float* P1, const uint8_t* img, int tid, Emit emit) {
+        // get_pixel_matrix (lib.rs:27-41): 4 pixels of one row per 32-bit word; image pixel (r,c) -> P0[(r+2)*PW0 + c+2]
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
+#pragma unroll
+        for (int k = 0; k < (WORDS + NT - 1) / NT; ++k) {
+            const int wd = tid + NT * k;
             const int wc = wd < WORDS ? wd : WORDS - 1;
             const uint32_t v = src[wc];
             const int r = wc / ROWW, c0 = (wc - r * ROWW) * 4;
@@ -170,99 +203,62 @@ __global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict_
             }
         }
         __syncthreads();
-
         // conv1 + pool1: item = pooled pixel (py,px) of the H1 x W1 maps
 #pragma unroll
-        for (int k = 0; k < (I1 + 63) / 64; ++k) {
-            const int t = lane + 64 * k;
+        for (int k = 0; k < (I1 + NT - 1) / NT; ++k) {
+            const int t = tid + NT * k;
             const int tc = t < I1 ? t : I1 - 1;
             const int py = tc / W1, px = tc - py * W1;
-            float w[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* row = &P0[(2 * py + r) * PW0 + 2 * px];
-                const float2 a = *reinterpret_cast<const float2*>(row), b = *reinterpret_cast<const float2*>(row + 2);
-                w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
-            }
-            float tmax = 0.f, bmax = 0.f, lmax = 0.f, rmax = 0.f;      // the +0 is the ReLU floor; Bottom = -Top, Right = -Left
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                float d[4], sm[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    d[c] = w[dy][c] - w[dy + 2][c];                          // column kernel [1,0,-1]   kernel.rs:47
-                    sm[c] = (w[dy][c] + w[dy + 2][c]) + 2.f * w[dy + 1][c];   // column kernel [1,2,1]    kernel.rs:48
-                }
-                const bool live = dy == 1 || py > 0;                          // output row 0 is zero (quirk)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    float top = (d[dx] + d[dx + 2]) + 2.f * d[dx + 1];        // row kernel [1,2,1]
-                    float left = sm[dx] - sm[dx + 2];                         // row kernel [1,0,-1]
-                    top = live ? top : 0.f; left = live ? left : 0.f;
-                    tmax = fmaxf(tmax, top); bmax = fmaxf(bmax, -top);
-                    lmax = fmaxf(lmax, left); rmax = fmaxf(rmax, -left);
-                }
-            }
+            float tmax, lmax, rmax, bmax;
+            cell(&P0[2 * py * PW0 + 2 * px], PW0, py == 0, tmax, lmax, rmax, bmax);
             if (t < I1) {
                 const bool lastc = px == W1 - 1;                              // conv2 never reads a map's last column
                 float* q = &P1[(py + 2) * PW1 + px + 2];
                 q[0 * N1] = lastc ? 0.f : tmax;                               // Top      (SEP_OPS order rcn.rs:41-46)
                 q[1 * N1] = lastc ? 0.f : lmax;                               // Left
-                q[2 * N1] = lastc ? 0.f : rmax;                              // Right  = relu(-left)
-                q[3 * N1] = lastc ? 0.f : bmax;                              // Bottom = relu(-top)
+                q[2 * N1] = lastc ? 0.f : rmax;                               // Right
+                q[3 * N1] = lastc ? 0.f : bmax;                               // Bottom
             }
         }
         __syncthreads();
-
         // conv2 + pool2 + flatten: item = (input map i, pooled pixel) ordered column-major within the map (rcn.rs:350-355)
-        TO* dst = out + (size_t)img * F;
 #pragma unroll
-        for (int k = 0; k < (I2 + 63) / 64; ++k) {
-            const int t = lane + 64 * k;
+        for (int k = 0; k < (I2 + NT - 1) / NT; ++k) {
+            const int t = tid + NT * k;
             const int tc = t < I2 ? t : I2 - 1;
             const int i = tc / SZ2, q = tc - i * SZ2, px = q / H2, py = q - px * H2;
-            float w[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* row = &P1[i * N1 + (2 * py + r) * PW1 + 2 * px];
-                const float2 a = *reinterpret_cast<const float2*>(row), b = *reinterpret_cast<const float2*>(row + 2);
-                w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
-            }
-            float tmax = 0.f, bmax = 0.f, lmax = 0.f, rmax = 0.f;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                float d[4], sm[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    d[c] = w[dy][c] - w[dy + 2][c];
-                    sm[c] = (w[dy][c] + w[dy + 2][c]) + 2.f * w[dy + 1][c];
-                }
-                const bool live = dy == 1 || py > 0;
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    float top = (d[dx] + d[dx + 2]) + 2.f * d[dx + 1];
-                    float left = sm[dx] - sm[dx + 2];
-                    top = live ? top : 0.f; left = live ? left : 0.f;
-                    tmax = fmaxf(tmax, top); bmax = fmaxf(bmax, -top);
-                    lmax = fmaxf(lmax, left); rmax = fmaxf(rmax, -left);
-                }
-            }
-            TO v[4] = {(TO)tmax, (TO)lmax, (TO)rmax, (TO)bmax};
-            if (standardize) {
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const TO dd = (v[o] - mean) / sd;                          // rcn.rs:407-412
-                    v[o] = dd >= (TO)0 ? dd : (TO)0;
-                }
-            }
+            float tmax, lmax, rmax, bmax;
+            cell(&P1[i * N1 + 2 * py * PW1 + 2 * px], PW1, py == 0, tmax, lmax, rmax, bmax);
             if (t < I2) {
                 // slots after the second conv layer (rcn.rs:323-340): Bottom stays in slot i, T/L/R are pushed to 4+3i+o
-                dst[(4 + 3 * i + 0) * SZ2 + q] = v[0];
-                dst[(4 + 3 * i + 1) * SZ2 + q] = v[1];
-                dst[(4 + 3 * i + 2) * SZ2 + q] = v[2];
-                dst[i * SZ2 + q] = v[3];
+                emit((4 + 3 * i + 0) * SZ2 + q, tmax);
+                emit((4 + 3 * i + 1) * SZ2 + q, lmax);
+                emit((4 + 3 * i + 2) * SZ2 + q, rmax);
+                emit(i * SZ2 + q, bmax);
             }
         }
+    }
+};
+
+template <int H, int W, typename TO>
+__global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, int standardize,
+                                                      TO mean, TO sd) {
+    using K = Cpcp<H, W>;
+    __shared__ __attribute__((aligned(16))) float P0[K::N0];
+    __shared__ __attribute__((aligned(16))) float P1[4 * K::N1];
+    const int lane = threadIdx.x;
+    K::template init<64>(P0, P1, lane);
+    __syncthreads();
+    for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
+        TO* dst = out + (size_t)img * K::F;
+        K::template image<64>(P0, P1, imgs + (size_t)img * (H * W), lane, [&](int e, float fv) {
+            TO v = (TO)fv;
+            if (standardize) {
+                const TO dd = (v - mean) / sd;                               // rcn.rs:407-412
+                v = dd >= (TO)0 ? dd : (TO)0;
+            }
+            dst[e] = v;
+        });
         __syncthreads();
     }
 }

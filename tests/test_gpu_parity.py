@@ -224,6 +224,35 @@ def test_classify_images_path(amd, oracle):
         assert r.classify(imgs[int(np.argmax(clear))]) == expect[int(np.argmax(clear))]
 
 
+@pytest.mark.parametrize("dims", [[784, 30, 10], [784, 10, 10, 10], [784, 40, 7], [784, 64, 10]],
+                         ids=["default", "suite-variant", "widest-fused", "fallback-3-launch"])
+def test_classify_single_launch_kernel_matches_staged_path_and_oracle(amd, oracle, dims):
+    """The one-launch serving kernel (serve.hpp: features -> standardise -> all layers -> arg-max) must return the classes
+    of the staged path (feature kernel, forward kernel, arg-max kernel) and of the oracle's RCN::classify (rcn.rs:82-98),
+    for single requests and for small batches; nets it does not cover take the staged path."""
+    imgs, _ = synthetic_images(70, seed=19)
+    ws, bs = synthetic_params(dims, seed=4)
+    ws = [w * 0.05 for w in ws]
+    f = oracle.features(imgs, DEFAULT_LAYERS)
+    mo, so = oracle.gen_scales(f)
+    out = oracle.classify_test(ws, bs, oracle.standardize(f, mo, so))
+    srt = np.sort(out, axis=1)
+    expect = np.array([oracle.classify_argmax(o) for o in out])
+    for dtype in (1, 0):
+        clear = (srt[:, -1] - srt[:, -2]) > (1e-9 if dtype == 1 else 1e-4)
+        r = _mk(amd, dims, dtype)
+        r.set_params(ws, bs)
+        r.scale_set = (mo, so)
+        fused = r.classify_many(imgs)
+        singles = np.array([r.classify(imgs[i]) for i in range(12)])
+        r.set_feature_kernel(1)                                       # forces the generic feature kernel and the staged path
+        staged = r.classify_many(imgs)
+        assert clear.sum() > 35
+        assert np.array_equal(fused[clear], expect[clear]) and np.array_equal(staged[clear], expect[clear])
+        assert np.array_equal(singles[clear[:12]], expect[:12][clear[:12]])
+        r.close()
+
+
 # ----------------------------------------------------------------------------------------------------- dense path
 
 def _dense_case(dims, B, seed, wscale=1.0):
