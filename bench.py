@@ -170,6 +170,9 @@ def main():
             args.dp_impl = "native" if native else "torch"
         if native:
             d.dp_broadcast_params(0)
+            allreduce_kind = "xgmi peer-read kernel (csrc/dp_p2p.hpp), fused with the update" if d.dp_p2p_active() else "ncclAllReduce (RCCL)"
+        else:
+            allreduce_kind = "torch.distributed all_reduce (RCCL)"
 
             def run(k: int):
                 # the whole loop is native: per step gradient kernels -> ncclAllReduce -> update, enqueued by
@@ -263,7 +266,8 @@ def main():
                                "train_batch B=256 per GPU over 16384 resident pre-extracted feature vectors per GPU, eta=3.0",
                    "global_batch": B * world, "parallelism": f"dp{world}", "step_form": f"gradient -> all-reduce -> apply ({args.dp_impl} loop)" if use_dp else "fused update", "images_per_rank": N_IMAGES,
                    "device_ms_per_step_rank0": round(dev_ms / args.steps, 6), "final_cost_rank0": final_loss,
-                   "end_to_end_images_per_s": round(e2e, 1) if e2e else None},
+                   "end_to_end_images_per_s": round(e2e, 1) if e2e else None,
+                   "allreduce": allreduce_kind if use_dp else None},
     }
 
     if rank == 0:

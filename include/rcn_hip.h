@@ -197,6 +197,20 @@ int  rcn_hip_dp_broadcast_params(rcn_hip_ctx* ctx, int root);                   
  * Collective; asynchronous on the context's stream. */
 int  rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
                                 size_t B_shard, size_t n_batches, double eta, void* loss_dev);
+/* The all-reduce of that loop.  For 2..8 ranks of one node rcn_hip_dp_init also sets up a one-shot PEER-READ all-reduce
+ * over xGMI (every rank reads all ranks' gradient buffers through hipIpc mappings, adds them in rank order and applies
+ * the update in the same kernel; csrc/dp_p2p.hpp) and keeps it only if every rank mapped every peer and a known-answer
+ * exchange came back exact on every rank; otherwise, or with RCN_HIP_DP_P2P=0 in the environment, the loop uses
+ * ncclAllReduce (RCN_HIP_DP_P2P=2 also sets it up for a single rank, for tests).  rcn_hip_dp_p2p_active tells which.  The three calls below are the same set-up with the handle exchange
+ * done by the caller instead of RCCL (any transport; used by the tests): export -> gather every rank's
+ * RCN_HIP_DP_P2P_HANDLE_BYTES in rank order -> attach (collective; after it rcn_hip_dp_train_epoch_dev uses the peer
+ * all-reduce and needs no RCCL communicator) -> optionally selftest (collective; counts wrong sums over `iters` exchanges
+ * of a known pattern, *timed_out != 0 if a wait expired). */
+#define RCN_HIP_DP_P2P_HANDLE_BYTES 128
+int  rcn_hip_dp_p2p_export(rcn_hip_ctx* ctx, void* handles_out /* RCN_HIP_DP_P2P_HANDLE_BYTES */);
+int  rcn_hip_dp_p2p_attach(rcn_hip_ctx* ctx, const void* all_handles /* world x RCN_HIP_DP_P2P_HANDLE_BYTES */, int rank, int world);
+int  rcn_hip_dp_p2p_selftest(rcn_hip_ctx* ctx, int iters, unsigned* mismatches, unsigned* timed_out);
+int  rcn_hip_dp_p2p_active(const rcn_hip_ctx* ctx);
 /* classify_test (rcn.rs:105-116) for n samples: a <- sigmoid(W a + b) through every layer. out: n x classes */
 int  rcn_hip_forward(rcn_hip_ctx* ctx, const double* x, size_t n, double* out);
 int  rcn_hip_forward_dev(rcn_hip_ctx* ctx, const void* x_dev, size_t n, void* out_dev);

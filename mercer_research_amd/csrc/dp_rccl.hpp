@@ -17,6 +17,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
     bool ok = false;
@@ -46,6 +47,7 @@ struct Rccl {
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         ok = err.empty();
     }

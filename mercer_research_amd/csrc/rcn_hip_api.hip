@@ -24,6 +24,7 @@
 #include "ops.hpp"
 #include "dp_rccl.hpp"
 #include "serve.hpp"
+#include "dp_p2p.hpp"
 #include <chrono>
 
 using namespace rcn;
@@ -75,6 +76,18 @@ struct rcn_hip_ctx {
     std::map<EpochKey, hipGraphExec_t> graphs;
     ncclComm_t comm = nullptr;              // data-parallel group (rcn_hip_dp_init); one rank per context
     int dp_rank = 0, dp_world = 1;
+    struct P2P {                            // peer-read all-reduce over xGMI (dp_p2p.hpp)
+        bool exported = false, attached = false, on = false;
+        void* local_buf = nullptr;          // [2][stride] values, ordinary device memory
+        unsigned* local_flags = nullptr;    // [kP2PMaxWorld], uncached device memory
+        void* peer_buf[rcn::kP2PMaxWorld] = {};
+        unsigned* peer_flags[rcn::kP2PMaxWorld] = {};
+        size_t stride = 0;                  // values per slot (>= P+1, multiple of 4)
+        unsigned seq = 0;                   // step sequence number, identical on every rank
+        unsigned* err_dev = nullptr;        // sticky: 1 + rank that timed out
+        unsigned* err_host = nullptr;       // pinned copy, refreshed after every epoch call
+        DevBuf raw, mism;
+    } p2p;
     std::map<const void*, size_t> lds_attr;   // kernels whose dynamic-LDS limit was already raised
     std::string err;
     size_t esz() const { return dtype == RCN_HIP_F64 ? 8 : 4; }
@@ -442,6 +455,126 @@ int need_params(rcn_hip_ctx* c) {
     return RCN_HIP_OK;
 }
 
+// ---- peer-read all-reduce plumbing (dp_p2p.hpp) ------------------------------------------------------------------
+void p2p_release(rcn_hip_ctx* c) {
+    auto& q = c->p2p;
+    for (int r = 0; r < kP2PMaxWorld; ++r) {
+        if (q.attached && r != c->dp_rank) {
+            if (q.peer_buf[r]) (void)hipIpcCloseMemHandle(q.peer_buf[r]);
+            if (q.peer_flags[r]) (void)hipIpcCloseMemHandle(q.peer_flags[r]);
+        }
+        q.peer_buf[r] = nullptr;
+        q.peer_flags[r] = nullptr;
+    }
+    if (q.local_buf) (void)hipFree(q.local_buf);
+    if (q.local_flags) (void)hipFree(q.local_flags);
+    if (q.err_dev) (void)hipFree(q.err_dev);
+    if (q.err_host) (void)hipHostFree(q.err_host);
+    q.raw.release();
+    q.mism.release();
+    q = rcn_hip_ctx::P2P{};
+}
+
+constexpr size_t kP2PHandleBytes = 2 * sizeof(hipIpcMemHandle_t);       // [data buffer | flag array]
+
+int p2p_export(rcn_hip_ctx* c, void* out) {
+    RCN_TRY(need_dense(c));
+    auto& q = c->p2p;
+    if (q.exported) p2p_release(c);
+    q.stride = (((size_t)c->nd.P + 1) + 3) & ~(size_t)3;
+    const size_t bytes = 2 * q.stride * c->esz();
+    HIP_TRY(c, hipMalloc(&q.local_buf, bytes));
+    HIP_TRY(c, hipExtMallocWithFlags((void**)&q.local_flags, 4096, hipDeviceMallocUncached));
+    HIP_TRY(c, hipMalloc((void**)&q.err_dev, 256));
+    HIP_TRY(c, hipHostMalloc((void**)&q.err_host, 64, hipHostMallocDefault));
+    *q.err_host = 0;
+    HIP_TRY(c, hipMemset(q.local_buf, 0, bytes));
+    HIP_TRY(c, hipMemset(q.local_flags, 0, 4096));
+    HIP_TRY(c, hipMemset(q.err_dev, 0, 256));
+    HIP_TRY(c, hipDeviceSynchronize());
+    hipIpcMemHandle_t h[2];
+    HIP_TRY(c, hipIpcGetMemHandle(&h[0], q.local_buf));
+    HIP_TRY(c, hipIpcGetMemHandle(&h[1], q.local_flags));
+    std::memcpy(out, h, sizeof h);
+    q.exported = true;
+    return RCN_HIP_OK;
+}
+
+int p2p_attach(rcn_hip_ctx* c, const void* all, int rank, int world) {
+    auto& q = c->p2p;
+    if (!q.exported) return fail(c, RCN_HIP_ERR_STATE, "p2p_attach: export first");
+    if (world < 1 || world > kP2PMaxWorld || rank < 0 || rank >= world) return fail(c, RCN_HIP_ERR_INVALID_ARG, "p2p_attach: world must be 1..8");
+    c->dp_rank = rank;
+    c->dp_world = world;
+    q.attached = true;
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) { q.peer_buf[r] = q.local_buf; q.peer_flags[r] = q.local_flags; continue; }
+        hipIpcMemHandle_t h[2];
+        std::memcpy(h, (const char*)all + (size_t)r * kP2PHandleBytes, sizeof h);
+        HIP_TRY(c, hipIpcOpenMemHandle(&q.peer_buf[r], h[0], hipIpcMemLazyEnablePeerAccess));
+        HIP_TRY(c, hipIpcOpenMemHandle((void**)&q.peer_flags[r], h[1], hipIpcMemLazyEnablePeerAccess));
+    }
+    return RCN_HIP_OK;
+}
+
+P2PDesc p2p_desc(const rcn_hip_ctx* c) {
+    P2PDesc d{};
+    d.world = c->dp_world;
+    d.rank = c->dp_rank;
+    for (int r = 0; r < kP2PMaxWorld; ++r) { d.buf[r] = c->p2p.peer_buf[r < d.world ? r : 0]; d.flags[r] = c->p2p.peer_flags[r < d.world ? r : 0]; }
+    return d;
+}
+
+constexpr long long kP2PTimeoutTicks = 100000000LL;        // 1 s of the 100 MHz wall clock
+
+// one all-reduce step on the context's stream; mode 0 applies the update, mode 1 writes the raw sums to p2p.raw
+template <typename T>
+int p2p_step(rcn_hip_ctx* c, int mode, double scale, void* loss_out, long long timeout) {
+    auto& q = c->p2p;
+    const unsigned seq = ++q.seq;
+    const size_t words = q.stride / P2PWord<T>::per;
+    int grid = (int)((words + kP2PThreads - 1) / kP2PThreads);
+    if (grid > 96) grid = 96;
+    hipLaunchKernelGGL((k_p2p_allreduce<T>), dim3(grid), dim3(kP2PThreads), 0, c->stream, p2p_desc(c), seq, q.stride, c->nd.P, (T*)c->params.p,
+                       (T)scale, (T*)loss_out, (T*)q.raw.p, mode, q.err_dev, timeout);
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+// `iters` exchanges of a known integer pattern; counts wrong sums and reads the timeout word.  Collective.
+int p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* err) {
+    auto& q = c->p2p;
+    if (!q.attached) return fail(c, RCN_HIP_ERR_STATE, "p2p_selftest: not attached");
+    const size_t es = c->esz();
+    HIP_TRY(c, q.raw.ensure(q.stride * es));
+    HIP_TRY(c, q.mism.ensure(64));
+    HIP_TRY(c, hipMemsetAsync(q.mism.p, 0, 64, c->stream));
+    for (int it = 0; it < iters; ++it) {
+        const unsigned seq = q.seq + 1;
+        char* slot = (char*)q.local_buf + (size_t)(seq & 1u) * q.stride * es;
+        const long long to = it == 0 ? 10 * kP2PTimeoutTicks : kP2PTimeoutTicks;      // the first exchange absorbs start-up skew
+        if (c->dtype == RCN_HIP_F64) {
+            hipLaunchKernelGGL((k_p2p_fill<double>), dim3(48), dim3(256), 0, c->stream, (double*)slot, q.stride, c->dp_rank, seq);
+            RCN_TRY(p2p_step<double>(c, 1, 0.0, nullptr, to));
+            hipLaunchKernelGGL((k_p2p_check<double>), dim3(48), dim3(256), 0, c->stream, (const double*)q.raw.p, q.stride, c->dp_world, seq, (unsigned*)q.mism.p);
+        } else {
+            hipLaunchKernelGGL((k_p2p_fill<float>), dim3(48), dim3(256), 0, c->stream, (float*)slot, q.stride, c->dp_rank, seq);
+            RCN_TRY(p2p_step<float>(c, 1, 0.0, nullptr, to));
+            hipLaunchKernelGGL((k_p2p_check<float>), dim3(48), dim3(256), 0, c->stream, (const float*)q.raw.p, q.stride, c->dp_world, seq, (unsigned*)q.mism.p);
+        }
+        HIP_TRY(c, hipGetLastError());
+    }
+    unsigned host[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&host[0], q.mism.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&host[1], q.err_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // The slots keep the last patterns: peers may still be reading them, and nothing depends on their contents -- the
+    // gradient kernels overwrite [0, P] every step and the reduce ignores the padding beyond P.
+    *mismatches = host[0];
+    *err = host[1];
+    return RCN_HIP_OK;
+}
+
 void drop_graphs(rcn_hip_ctx* c) {
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
@@ -526,6 +659,7 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         drop_graphs(c);
         if (c->comm) { (void)rcn::Rccl::get().CommDestroy(c->comm); c->comm = nullptr; }
+        p2p_release(c);
         for (DevBuf* b : {&c->slab, &c->xpack, &c->ypack, &c->p2buf, &c->params, &c->acts, &c->deltas, &c->loss_part, &c->grad, &c->xstage, &c->ystage, &c->ostage, &c->scratch0,
                           &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
             b->release();
@@ -1041,6 +1175,53 @@ int rcn_hip_apply_gradient_dev(rcn_hip_ctx* c, const void* grad, double scale) {
             return fail(ctx, RCN_HIP_ERR_HIP, std::string(#expr) + ": " + rcn::Rccl::get().GetErrorString(r_)); \
     } while (0)
 
+// Sets up the peer-read all-reduce behind an existing RCCL communicator, and keeps it only if EVERY rank could map every
+// peer and a known-answer exchange came back exact on every rank.  Every rank executes the same collectives whatever
+// fails locally (a failure only lowers its vote), so a rank that cannot use xGMI peer reads makes the whole group stay
+// on ncclAllReduce instead of deadlocking it.
+static int p2p_bootstrap_over_rccl(rcn_hip_ctx* c) {
+    rcn::Rccl& r = rcn::Rccl::get();
+    const int world = c->dp_world, rank = c->dp_rank;
+    DevBuf xch;
+    HIP_TRY(c, xch.ensure((size_t)(world + 1) * kP2PHandleBytes + 64));
+    char* d_all = (char*)xch.p;
+    char* d_mine = d_all + (size_t)world * kP2PHandleBytes;
+    int* d_vote = (int*)(d_mine + kP2PHandleBytes);
+    char mine[kP2PHandleBytes] = {};
+    int ok = p2p_export(c, mine) == RCN_HIP_OK ? 1 : 0;
+    std::vector<char> all((size_t)world * kP2PHandleBytes);
+    auto vote = [&](int& v) -> int {          // v <- min over ranks
+        HIP_TRY(c, hipMemcpyAsync(d_vote, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+        NCCL_TRY(c, r.AllReduce(d_vote, d_vote, 1, ncclInt, ncclMin, c->comm, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&v, d_vote, sizeof v, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return RCN_HIP_OK;
+    };
+    int st = RCN_HIP_OK;
+    do {
+        if ((st = [&]() -> int {
+                HIP_TRY(c, hipMemcpyAsync(d_mine, mine, kP2PHandleBytes, hipMemcpyHostToDevice, c->stream));
+                NCCL_TRY(c, r.AllGather(d_mine, d_all, kP2PHandleBytes, ncclChar, c->comm, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                return RCN_HIP_OK;
+            }()) != RCN_HIP_OK) break;
+        if ((st = vote(ok)) != RCN_HIP_OK) break;            // did every rank export?
+        if (!ok) break;
+        ok = p2p_attach(c, all.data(), rank, world) == RCN_HIP_OK ? 1 : 0;
+        if ((st = vote(ok)) != RCN_HIP_OK) break;            // did every rank map every peer?
+        if (!ok) break;
+        unsigned bad = 0, err = 0;
+        ok = (p2p_selftest(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0) ? 1 : 0;
+        if ((st = vote(ok)) != RCN_HIP_OK) break;            // did every rank see exact sums, without a timeout?
+        if (ok) c->p2p.on = true;
+    } while (0);
+    xch.release();
+    if (!c->p2p.on) { const int rk = c->dp_rank, w = c->dp_world; p2p_release(c); c->dp_rank = rk; c->dp_world = w; }
+    c->err.clear();                                          // a failed attempt is not an error: the loop runs on ncclAllReduce
+    return st;
+}
+
 int rcn_hip_dp_unique_id(void* id_out) {
     if (!id_out) return RCN_HIP_ERR_INVALID_ARG;
     rcn::Rccl& r = rcn::Rccl::get();
@@ -1064,20 +1245,55 @@ int rcn_hip_dp_init(rcn_hip_ctx* c, const void* id_bytes, int rank, int world) {
     NCCL_TRY(c, r.CommInitRank(&c->comm, world, id, rank));
     c->dp_rank = rank;
     c->dp_world = world;
+    p2p_release(c);
+    const char* env = std::getenv("RCN_HIP_DP_P2P");
+    const bool force = env && env[0] == '2';          // "2": also at world size 1 (exercises the whole set-up path on one GPU)
+    if ((world > 1 || force) && world <= kP2PMaxWorld && !(env && env[0] == '0') && c->dense_err.empty()) RCN_TRY(p2p_bootstrap_over_rccl(c));
     return RCN_HIP_OK;
 }
 
 int rcn_hip_dp_finalize(rcn_hip_ctx* c) {
     RCN_TRY(check_ctx(c));
-    if (!c->comm) return RCN_HIP_OK;
     DevGuard g(c->device);
+    if (!c->comm) {
+        if (c->p2p.exported) { HIP_TRY(c, hipStreamSynchronize(c->stream)); p2p_release(c); c->dp_rank = 0; c->dp_world = 1; }
+        return RCN_HIP_OK;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     NCCL_TRY(c, rcn::Rccl::get().CommDestroy(c->comm));
     c->comm = nullptr;
+    p2p_release(c);
     c->dp_rank = 0;
     c->dp_world = 1;
     return RCN_HIP_OK;
 }
+
+/* ---- the peer all-reduce without RCCL: explicit handle exchange (what rcn_hip_dp_init does internally over RCCL) ---- */
+int rcn_hip_dp_p2p_export(rcn_hip_ctx* c, void* handles_out) {
+    RCN_TRY(check_ctx(c));
+    if (!handles_out) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_p2p_export: NULL pointer");
+    static_assert(kP2PHandleBytes == RCN_HIP_DP_P2P_HANDLE_BYTES, "rcn_hip.h: RCN_HIP_DP_P2P_HANDLE_BYTES");
+    DevGuard g(c->device);
+    return p2p_export(c, handles_out);
+}
+
+int rcn_hip_dp_p2p_attach(rcn_hip_ctx* c, const void* all_handles, int rank, int world) {
+    RCN_TRY(check_ctx(c));
+    if (!all_handles) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_p2p_attach: NULL pointer");
+    DevGuard g(c->device);
+    RCN_TRY(p2p_attach(c, all_handles, rank, world));
+    c->p2p.on = world > 1;
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_dp_p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* timed_out) {
+    RCN_TRY(check_ctx(c));
+    if (!mismatches || !timed_out || iters < 1) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_p2p_selftest: bad arguments");
+    DevGuard g(c->device);
+    return p2p_selftest(c, iters, mismatches, timed_out);
+}
+
+int rcn_hip_dp_p2p_active(const rcn_hip_ctx* c) { return c && c->p2p.on ? 1 : 0; }
 
 int rcn_hip_dp_world(const rcn_hip_ctx* c) { return c ? c->dp_world : 0; }
 int rcn_hip_dp_rank(const rcn_hip_ctx* c) { return c ? c->dp_rank : -1; }
@@ -1096,7 +1312,10 @@ int rcn_hip_dp_broadcast_params(rcn_hip_ctx* c, int root) {
 int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta,
                                void* loss_dev) {
     RCN_TRY(check_ctx(c));
-    if (!c->comm) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_train_epoch: rcn_hip_dp_init was not called");
+    if (!c->comm && !c->p2p.on) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_train_epoch: rcn_hip_dp_init was not called");
+    if (c->p2p.on && *c->p2p.err_host != 0)
+        return fail(c, RCN_HIP_ERR_HIP, "dp_train_epoch: the peer all-reduce timed out waiting for rank " + std::to_string((int)*c->p2p.err_host - 1) +
+                                            "'s peers in an earlier call; the replicas are no longer in step");
     if (!X || !Y) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_train_epoch: NULL pointer");
     if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_train_epoch: shard batch size must be in 1..2^30");
     if (nb == 0) return RCN_HIP_OK;
@@ -1111,6 +1330,28 @@ int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, con
     char* gbuf = (char*)c->grad.p;
     void* lslot = gbuf + P * es;
     const bool f64 = c->dtype == RCN_HIP_F64;
+    if (c->p2p.on) {
+        // gradient kernels write straight into this rank's exported slot; ONE kernel then waits for the peers' flags, reads
+        // all `world` slots over xGMI, adds them in rank order and applies the update (dp_p2p.hpp)
+        for (size_t j = 0; j < nb; ++j) {
+            const void* xb = perm ? X : (const char*)X + j * B * F * es;
+            const void* yb = perm ? Y : (const char*)Y + j * B * Cc * es;
+            const int32_t* ib = perm ? perm + j * B : nullptr;
+            char* slot = (char*)c->p2p.local_buf + (size_t)((c->p2p.seq + 1) & 1u) * c->p2p.stride * es;
+            void* lj = loss_dev ? (char*)loss_dev + j * es : nullptr;
+            if (f64) {
+                RCN_TRY(launch_fwd<double>(c, true, xb, yb, ib, B, nullptr));
+                RCN_TRY(launch_wgrad<double>(c, false, xb, ib, B, 0.0, slot, slot + P * es, loss_scale));
+                RCN_TRY(p2p_step<double>(c, 0, scale, lj, kP2PTimeoutTicks));
+            } else {
+                RCN_TRY(launch_fwd<float>(c, true, xb, yb, ib, B, nullptr));
+                RCN_TRY(launch_wgrad<float>(c, false, xb, ib, B, 0.0, slot, slot + P * es, loss_scale));
+                RCN_TRY(p2p_step<float>(c, 0, scale, lj, kP2PTimeoutTicks));
+            }
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->p2p.err_host, c->p2p.err_dev, 4, hipMemcpyDeviceToHost, c->stream));   // read at the next call
+        return RCN_HIP_OK;
+    }
     for (size_t j = 0; j < nb; ++j) {
         const void* xb = perm ? X : (const char*)X + j * B * F * es;
         const void* yb = perm ? Y : (const char*)Y + j * B * Cc * es;

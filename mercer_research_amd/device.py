@@ -172,6 +172,24 @@ class DeviceRCN:
         self._ck(self.lib.rcn_hip_dp_init(self.ctx, box[0], rank, world))
         return rank, world
 
+    def dp_p2p_active(self) -> bool:
+        """True when the loop's all-reduce is the one-shot xGMI peer-read kernel (csrc/dp_p2p.hpp), False on ncclAllReduce."""
+        return bool(self.lib.rcn_hip_dp_p2p_active(self.ctx))
+
+    def dp_p2p_setup(self, group=None, selftest_iters: int = 8):
+        """The peer all-reduce with the handle exchange carried by torch.distributed (any backend, e.g. gloo) instead of
+        RCCL: export -> all_gather -> attach -> known-answer self-test.  Collective.  Returns (mismatches, timed_out)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = C.create_string_buffer(128)
+        self._ck(self.lib.rcn_hip_dp_p2p_export(self.ctx, buf))
+        box = [None] * world
+        dist.all_gather_object(box, bytes(buf.raw), group=group)
+        self._ck(self.lib.rcn_hip_dp_p2p_attach(self.ctx, b"".join(box), rank, world))
+        bad, to = C.c_uint(), C.c_uint()
+        self._ck(self.lib.rcn_hip_dp_p2p_selftest(self.ctx, selftest_iters, C.byref(bad), C.byref(to)))
+        return int(bad.value), int(to.value)
+
     def dp_finalize(self):
         self._ck(self.lib.rcn_hip_dp_finalize(self.ctx))
 

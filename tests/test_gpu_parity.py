@@ -476,6 +476,89 @@ def test_native_rccl_epoch_world1_matches_oracle(amd, oracle, dtype):
     d.rcn.close()
 
 
+@pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
+def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, tmp_path):
+    """The xGMI peer-read all-reduce (csrc/dp_p2p.hpp) between two PROCESSES (hipIpc handles carried by gloo), both on this
+    box's one GPU: the known-answer self-test is exact, both replicas end bit-identical, and two epochs of the sharded
+    loop equal the oracle's sequential train_batch on the concatenated global batches."""
+    import socket
+    import subprocess
+    import sys
+    dims, Bs, nb, world = [784, 30, 10], 16, 4, 2
+    rng = np.random.default_rng(31)
+    Xs = [np.maximum(rng.standard_normal((Bs * nb, dims[0])), 0.0) for _ in range(world)]
+    Ys = [one_hot(rng.integers(0, dims[-1], Bs * nb), dims[-1]) for _ in range(world)]
+    np.savez(tmp_path / "case.npz", dims=dims, Bs=Bs, nb=nb, seed=17, X0=Xs[0], X1=Xs[1], Y0=Ys[0], Y1=Ys[1])
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_p2p_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(dtype), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, _ = pr.communicate()
+        logs.append(out.decode(errors="replace")[-3000:])
+    assert all(pr.returncode == 0 for pr in procs), "\n----\n".join(logs)
+    outs = [np.load(tmp_path / f"out{r}.npz") for r in range(world)]
+    for o in outs:
+        assert int(o["bad"]) == 0 and int(o["timed_out"]) == 0 and int(o["active"]) == 1
+    for k in ("w0", "w1", "b0", "b1", "loss"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k            # rank-order sums: replicas are bit-identical
+    ws, bs = synthetic_params(dims, seed=17)
+    rw, rb = [w * 0.1 for w in ws], bs
+    costs = []
+    for ep in range(2):
+        for j in range(nb):
+            xb = np.concatenate([X[j * Bs:(j + 1) * Bs] for X in Xs])
+            yb = np.concatenate([Y[j * Bs:(j + 1) * Bs] for Y in Ys])
+            rw, rb, c = oracle.train_batch(rw, rb, xb, yb, 3.0)
+            if ep == 0:
+                costs.append(c)
+    got = [outs[0]["w0"], outs[0]["w1"], outs[0]["b0"], outs[0]["b1"]]
+    want = [rw[0], rw[1], rb[0], rb[1]]
+    if dtype == 1:
+        _check_params(got, want, 1)
+        np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-10)
+    else:
+        for a, b in zip(got, want):
+            assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)
+        np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-3)
+
+
+def test_peer_allreduce_bootstrap_over_rccl_world1(amd, oracle, monkeypatch):
+    """rcn_hip_dp_init's own set-up of the peer all-reduce (export -> ncclAllGather of the handles -> attach -> known-answer
+    vote) forced on at world size 1: every line of the bootstrap except the peer mappings runs, and the epoch loop on the
+    peer-read kernel is the oracle's loop."""
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_DP_P2P", "2")
+    B, nb, N = 32, 5, 256
+    ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=79, wscale=0.1)
+    d = DeviceRCN(dtype=1)
+    d.set_params(ws, bs)
+    assert d.dp_init() == (0, 1) and d.dp_p2p_active()
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    loss = d.empty(nb)
+    d.dp_train_epoch(Xd, Yd, None, B, nb, 3.0, loss)
+    gw, gb = d.get_params()
+    rw, rb, costs = ws, bs, []
+    for j in range(nb):
+        rw, rb, c = oracle.train_batch(rw, rb, X[j * B:(j + 1) * B], Y[j * B:(j + 1) * B], 3.0)
+        costs.append(c)
+    _check_params(gw + gb, rw + rb, 1)
+    np.testing.assert_allclose(loss.cpu().numpy(), costs, rtol=1e-10)
+    monkeypatch.setenv("RCN_HIP_DP_P2P", "0")
+    d.dp_init()
+    assert not d.dp_p2p_active()
+    d.dp_finalize()
+    d.rcn.close()
+
+
 def test_data_parallel_halves_equal_full_batch(amd, oracle):
     """Shard gradients + sum + one update == train_batch on the concatenated batch, single GPU."""
     from mercer_research_amd.device import DeviceRCN
