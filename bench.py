@@ -171,8 +171,6 @@ def main():
         if native:
             d.dp_broadcast_params(0)
             allreduce_kind = "xgmi peer-read kernel (csrc/dp_p2p.hpp), fused with the update" if d.dp_p2p_active() else "ncclAllReduce (RCCL)"
-        else:
-            allreduce_kind = "torch.distributed all_reduce (RCCL)"
 
             def run(k: int):
                 # the whole loop is native: per step gradient kernels -> ncclAllReduce -> update, enqueued by
@@ -188,6 +186,7 @@ def main():
                     step_no[0] += take
                     done += take
         else:
+            allreduce_kind = "torch.distributed all_reduce (RCCL)"
             dp = DataParallelStep(d)
             dp.broadcast_params(0)
 
