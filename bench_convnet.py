@@ -3,6 +3,7 @@
 network BASELINE.json's north_star asks for, on the configs SURVEY.md §8(d) fixes:
 
   cifar   CIFAR-10 shape 32x32x3: conv3x3 3->32, pool, 32->64, pool, 64->128, pool -> 2048 -> 256 -> 10, B = 512   (configs[2])
+  synth224  synthetic 224x224x3, 8 conv layers, 128 images per GPU (global batch 1024 on 8 GPUs)                    (configs[3])
   mnist   MNIST shape 28x28x1 LeNet-style: conv 1->32, pool, conv 32->64, pool -> 3136 -> 128 -> 10, B = 256      (configs[1], trainable form)
 
 fp32 activations / weights, fp32 MFMA (v_mfma_f32_32x32x2_f32; peak 157.3 TFLOP/s).  Reports achieved TFLOP/s of the whole
@@ -16,6 +17,10 @@ import numpy as np
 CONFIGS = {
     "cifar": ((32, 32, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("conv", 128), ("pool",), ("dense_relu", 256), ("dense", 10)), 512),
     "mnist": ((28, 28, 1), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 128), ("dense", 10)), 256),
+    # configs[3]: synthetic 224x224x3, 8 conv layers (3->32->32 | 64->64 | 128->128 | 256->256, pool after each pair) -> 10;
+    # global batch 1024 over 8 GPUs = 128 images per GPU (the per-GPU batch below; --gpus N runs N such shards)
+    "synth224": ((224, 224, 3), (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("conv", 64), ("pool",), ("conv", 128), ("conv", 128), ("pool",),
+                                 ("conv", 256), ("conv", 256), ("pool",), ("dense", 10)), 128),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3
 
@@ -25,34 +30,72 @@ def main():
     ap.add_argument("--config", choices=list(CONFIGS), default="cifar")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU")
+    ap.add_argument("--gpus", type=int, default=1)
     args = ap.parse_args()
     import torch
+    import torch.distributed as dist
     from mercer_research_amd.convnet import ConvNet
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     in_shape, layers, B = CONFIGS[args.config]
-    B = args.batch or B
-    net = ConvNet(in_shape, layers, B)
-    net.init_params(1)
-    rng = np.random.default_rng(0)
-    nbuf = 8                                               # rotate over several resident batches
+    B = args.batch or B                                    # per GPU (weak scaling)
+    net = ConvNet(in_shape, layers, B, device=local_rank)
+    net.init_params(1)                                     # same seed on every rank: identical replicas
+    rng = np.random.default_rng(rank)
+    nbuf = 8 if args.config != "synth224" else 2           # rotate over several resident batches
     xs = [net.to_device(rng.standard_normal((B,) + in_shape).astype(np.float32)) for _ in range(nbuf)]
     ys = [net.to_device(rng.integers(0, 10, B).astype(np.int32)) for _ in range(nbuf)]
     loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+    lr = 0.01 if args.config != "synth224" else 1e-6     # the un-normalised 8-conv stack on noise diverges at larger steps (speed does not depend on it)
+    if world > 1:
+        # one process per GPU: shard gradients of the mean loss -> ONE all-reduce (RCCL over xGMI) of the flat padded
+        # gradient buffer -> identical update on every rank with lr / world (mean over the global batch)
+        grad = torch.empty(net.n_padded, dtype=torch.float32, device=net.device)
+
+        def step(i):
+            with torch.cuda.stream(net.stream):
+                net.gradients(xs[i % nbuf], ys[i % nbuf], grad, loss)
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                net.apply(grad, lr / world)
+    else:
+        def step(i):
+            net.train_step(xs[i % nbuf], ys[i % nbuf], lr, loss)
     net.synchronize()
     for i in range(max(args.warmup, 2 * nbuf)):            # first use of each (x, y) pair instantiates its graph
-        net.train_step(xs[i % nbuf], ys[i % nbuf], 0.01, loss)
+        step(i)
     net.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        net.train_step(xs[i % nbuf], ys[i % nbuf], 0.01, loss)
+        step(i)
     net.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=net.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
     flops = net.step_flops(B)
-    tf = flops * args.steps / el / 1e12
-    print(json.dumps({"metric": "training images/sec (Track X, trainable conv net; not the BASELINE metric)", "config": args.config, "batch": B,
-                      "value": round(B * args.steps / el, 1), "unit": "images/s", "ms_per_step": round(el / args.steps * 1e3, 4),
-                      "step_gflop": round(flops / 1e9, 3), "achieved_tflops": round(tf, 2), "mfma_fp32_peak_tflops": F32_MFMA_PEAK_TFLOPS,
-                      "frac_of_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "dtype": "f32", "data": "synthetic", "final_loss": round(loss.item(), 4)}))
+    tf = flops * args.steps / el / 1e12                    # per GPU
+    if rank == 0:
+        print(json.dumps({"metric": "training images/sec (Track X, trainable conv net; not the BASELINE metric)", "config": args.config, "batch_per_gpu": B, "n_gpus": world,
+                          "scaling": "weak", "value": round(world * B * args.steps / el, 1), "unit": "images/s", "ms_per_step": round(el / args.steps * 1e3, 4),
+                          "step_gflop_per_gpu": round(flops / 1e9, 3), "achieved_tflops_per_gpu": round(tf, 2), "mfma_fp32_peak_tflops": F32_MFMA_PEAK_TFLOPS,
+                          "frac_of_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "dtype": "f32", "data": "synthetic", "final_loss": round(loss.item(), 4)}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -24,6 +24,9 @@ def _close(a, b, rtol=2e-4):
     ((6, 6, 1), (("conv", 32), ("conv", 32), ("pool",), ("dense", 7)), 3),
     ((4, 8, 3), (("conv", 64), ("pool",), ("dense_relu", 64), ("dense_relu", 32), ("dense", 3)), 130),
     ((8, 8, 32), (("conv", 32), ("pool",), ("dense", 10)), 4),
+    # the layer stack of the synthetic 224x224x3 config (BASELINE configs[3]) at 16x16: 8 conv layers, pool after each pair
+    ((16, 16, 3), (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("conv", 64), ("pool",), ("conv", 128), ("conv", 128), ("pool",),
+                   ("conv", 256), ("conv", 256), ("pool",), ("dense", 10)), 3),
 ])
 def test_forward_gradients_and_step_match_oracle(in_shape, layers, B):
     rng = np.random.default_rng(B)
