@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="GEMM operand precision of forward / dgrad: fp32 MFMA, or bf16 MFMA with fp32 accumulate / storage / update")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -49,6 +51,7 @@ def main():
     B = args.batch or B                                    # per GPU (weak scaling)
     net = ConvNet(in_shape, layers, B, device=local_rank)
     net.init_params(1)                                     # same seed on every rank: identical replicas
+    net.set_precision(args.precision)
     rng = np.random.default_rng(rank)
     nbuf = 8 if args.config != "synth224" else 2           # rotate over several resident batches
     xs = [net.to_device(rng.standard_normal((B,) + in_shape).astype(np.float32)) for _ in range(nbuf)]
@@ -93,7 +96,7 @@ def main():
         print(json.dumps({"metric": "training images/sec (Track X, trainable conv net; not the BASELINE metric)", "config": args.config, "batch_per_gpu": B, "n_gpus": world,
                           "scaling": "weak", "value": round(world * B * args.steps / el, 1), "unit": "images/s", "ms_per_step": round(el / args.steps * 1e3, 4),
                           "step_gflop_per_gpu": round(flops / 1e9, 3), "achieved_tflops_per_gpu": round(tf, 2), "mfma_fp32_peak_tflops": F32_MFMA_PEAK_TFLOPS,
-                          "frac_of_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "dtype": "f32", "data": "synthetic", "final_loss": round(loss.item(), 4)}))
+                          "frac_of_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands (fwd, dgrad), f32 accumulate/storage/update", "data": "synthetic", "final_loss": round(loss.item(), 4)}))
     if world > 1:
         dist.destroy_process_group()
 

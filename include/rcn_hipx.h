@@ -41,6 +41,12 @@ const char* rcn_hipx_last_error(const rcn_hipx_net* net);
 int  rcn_hipx_synchronize(rcn_hipx_net* net);
 int  rcn_hipx_param_count(const rcn_hipx_net* net, int64_t* logical, int64_t* padded);
 int  rcn_hipx_classes(const rcn_hipx_net* net);
+/* GEMM operand precision of the forward and input-gradient convolutions / dense layers.  RCN_HIPX_FP32 (default): fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), exact fp32 products.  RCN_HIPX_BF16: operands rounded to bf16 on their way into LDS,
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations, gradients, parameters and the SGD update stay fp32 in HBM.
+ * Results then agree with an f64 evaluation to ~1e-2 relative instead of ~1e-4. */
+enum { RCN_HIPX_FP32 = 0, RCN_HIPX_BF16 = 1 };
+int  rcn_hipx_set_precision(rcn_hipx_net* net, int mode);
 /* logical layout, host memory, all layers back to back: W_0[K][Cout], b_0[Cout], W_1 ... */
 int  rcn_hipx_set_params(rcn_hipx_net* net, const float* flat);
 int  rcn_hipx_get_params(rcn_hipx_net* net, float* flat);

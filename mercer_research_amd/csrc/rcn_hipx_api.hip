@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "convnet.hpp"
+#include "convnet_bf16.hpp"
 
 using namespace rcnx;
 
@@ -55,7 +56,8 @@ struct rcn_hipx_net {
     hipStream_t stream = nullptr; bool own_stream = false;
     std::vector<Layer> L;
     long long n_pad = 0, n_log = 0;
-    Buf params, wt, slab, dz, loss_part, grad_tmp, dlogits, skbuf;
+    Buf params, wt, slab, dz, loss_part, grad_tmp, dlogits, skbuf, wb;
+    int precision = RCN_HIPX_FP32;          // GEMM operand precision of forward / dgrad (rcn_hipx_set_precision)
     std::map<Key, hipGraphExec_t> graphs;
     std::string err;
 };
@@ -78,7 +80,8 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     const bool smallc = ks * ks * s.Cin <= 32;
     if (!smallc && s.Cin % 32) return fail(n, -3, "input channels must be a multiple of 32 (or the whole 3x3xCin patch <= 32)");
     if (s.Cout % 32) return fail(n, -3, "output channels must be a multiple of 32");
-    const int bn = (s.Cout % 64 == 0) ? 64 : 32;
+    const bool bf16 = n->precision == RCN_HIPX_BF16;
+    const int bn = (bf16 && s.Cout % 128 == 0) ? 128 : (s.Cout % 64 == 0) ? 64 : 32;
     const long long tiles = ((M + kBM - 1) / kBM) * (s.Cout / bn);
     const int nkt = smallc ? 1 : ks * ks * s.Cin / 32;
     int Z = 1;
@@ -90,14 +93,30 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
         out = (float*)n->skbuf.p; kepi = 0;
     }
     const dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)(s.Cout / bn), (unsigned)Z);
+    if (bf16) {
+        // operands rounded to bf16: the weights once here, transposed to [Cout][Kp]; the activations inside the kernel
+        const int K = ks * ks * s.Cin, Kp = (K + 31) / 32 * 32;
+        XTRY(n, n->wb.ensure((size_t)s.Cout * Kp * sizeof(__bf16)));
+        hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
+        const __bf16* WB = (const __bf16*)n->wb.p;
+#define CONVB_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd_bf16<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s)
+#define CONVB_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONVB_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONVB_CASE(KS_, SM_, BN_, 1); else CONVB_CASE(KS_, SM_, BN_, 2); } while (0)
+#define CONVB_BN(KS_, SM_) do { if (bn == 128) CONVB_EPI(KS_, SM_, 128); else if (bn == 64) CONVB_EPI(KS_, SM_, 64); else CONVB_EPI(KS_, SM_, 32); } while (0)
+        if (ks == 3) { if (smallc) CONVB_BN(3, true); else CONVB_BN(3, false); }
+        else { if (smallc) CONVB_BN(1, true); else CONVB_BN(1, false); }
+#undef CONVB_BN
+#undef CONVB_EPI
+#undef CONVB_CASE
+    } else {
 #define CONV_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, Wk, bias, out, s)
 #define CONV_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONV_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONV_CASE(KS_, SM_, BN_, 1); else CONV_CASE(KS_, SM_, BN_, 2); } while (0)
 #define CONV_BN(KS_, SM_) do { if (bn == 64) CONV_EPI(KS_, SM_, 64); else CONV_EPI(KS_, SM_, 32); } while (0)
-    if (ks == 3) { if (smallc) CONV_BN(3, true); else CONV_BN(3, false); }
-    else { if (smallc) CONV_BN(1, true); else CONV_BN(1, false); }
+        if (ks == 3) { if (smallc) CONV_BN(3, true); else CONV_BN(3, false); }
+        else { if (smallc) CONV_BN(1, true); else CONV_BN(1, false); }
 #undef CONV_BN
 #undef CONV_EPI
 #undef CONV_CASE
+    }
     XTRY(n, hipGetLastError());
     if (Z > 1) {
         hipLaunchKernelGGL(k_splitk_epilogue, dim3(grid1d(M * s.Cout, 256)), dim3(256), 0, n->stream, (const float*)n->skbuf.p, bias, Y, M * s.Cout, s.Cout, Z, epi);
@@ -284,7 +303,7 @@ void rcn_hipx_destroy(rcn_hipx_net* n) {
         if (n->stream) (void)hipStreamSynchronize(n->stream);
         drop_graphs(n);
         for (Layer& l : n->L) { l.out.release(); l.idx.release(); l.dout.release(); }
-        for (Buf* b : {&n->params, &n->wt, &n->slab, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf}) b->release();
+        for (Buf* b : {&n->params, &n->wt, &n->slab, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf, &n->wb}) b->release();
         if (n->own_stream && n->stream) (void)hipStreamDestroy(n->stream);
     }
     delete n;
@@ -294,6 +313,15 @@ const char* rcn_hipx_last_error(const rcn_hipx_net* n) { return n ? n->err.c_str
 int rcn_hipx_synchronize(rcn_hipx_net* n) { if (!n) return -1; Dev g(n->device); XTRY(n, hipStreamSynchronize(n->stream)); return 0; }
 int rcn_hipx_param_count(const rcn_hipx_net* n, int64_t* logical, int64_t* padded) { if (!n) return -1; if (logical) *logical = n->n_log; if (padded) *padded = n->n_pad; return 0; }
 int rcn_hipx_classes(const rcn_hipx_net* n) { return n ? n->classes : -1; }
+
+int rcn_hipx_set_precision(rcn_hipx_net* n, int mode) {
+    if (!n) return -1;
+    if (mode != RCN_HIPX_FP32 && mode != RCN_HIPX_BF16) return fail(n, -1, "set_precision: mode must be RCN_HIPX_FP32 or RCN_HIPX_BF16");
+    Dev g(n->device);
+    if (mode != n->precision) { XTRY(n, hipStreamSynchronize(n->stream)); drop_graphs(n); }
+    n->precision = mode;
+    return 0;
+}
 
 int rcn_hipx_set_params(rcn_hipx_net* n, const float* flat) {
     if (!n || !flat) return -1;

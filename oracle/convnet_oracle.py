@@ -41,6 +41,18 @@ def flatten(ws, bs) -> np.ndarray:
     return np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in zip(ws, bs)])
 
 
+def round_bf16(a: np.ndarray) -> np.ndarray:
+    """Round to the nearest bfloat16 (ties to even), returned as f64 -- what v_cvt_pk_bf16_f32 does to a GEMM operand in
+    the bf16 MFMA path (csrc/convnet_bf16.hpp).  Input goes through fp32 first, as on the device."""
+    u = np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64).reshape(np.shape(a))
+
+
+def _op(a: np.ndarray, operand: str) -> np.ndarray:
+    return round_bf16(a) if operand == "bf16" else a
+
+
 def _im2col(x: np.ndarray) -> np.ndarray:
     """[N,H,W,C] -> [N*H*W, 9*C] with k = (kh*3+kw)*C + ci (zero padding 1)."""
     N, H, W, C = x.shape
@@ -49,14 +61,15 @@ def _im2col(x: np.ndarray) -> np.ndarray:
     return np.concatenate(cols, axis=-1).reshape(N * H * W, 9 * C)
 
 
-def forward(x, ws, bs, layers, cache=None):
+def forward(x, ws, bs, layers, cache=None, operand="f64"):
+    """operand="bf16": both operands of every forward GEMM are rounded to bf16 first (products and sums stay f64)."""
     a = np.asarray(x, dtype=np.float64)
     pi = 0
     for l in layers:
         if l[0] == "conv":
             N, H, W, C = a.shape
             cols = _im2col(a)
-            z = cols @ ws[pi] + bs[pi]
+            z = _op(cols, operand) @ _op(ws[pi], operand) + bs[pi]
             y = np.maximum(z, 0).reshape(N, H, W, -1)
             if cache is not None:
                 cache.append(("conv", cols, y, a.shape))
@@ -71,7 +84,7 @@ def forward(x, ws, bs, layers, cache=None):
             a = p
         else:
             f = a.reshape(a.shape[0], -1)
-            z = f @ ws[pi] + bs[pi]
+            z = _op(f, operand) @ _op(ws[pi], operand) + bs[pi]
             y = np.maximum(z, 0) if l[0] == "dense_relu" else z
             if cache is not None:
                 cache.append((l[0], f, y, a.shape))
@@ -79,9 +92,11 @@ def forward(x, ws, bs, layers, cache=None):
     return a
 
 
-def loss_and_grads(x, labels, ws, bs, layers):
+def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
+    """operand="bf16": forward and input-gradient GEMMs take bf16-rounded operands; the weight-gradient GEMM does not
+    (it runs on the fp32 MFMA path on the device)."""
     cache = []
-    logits = forward(x, ws, bs, layers, cache)
+    logits = forward(x, ws, bs, layers, cache, operand)
     B = logits.shape[0]
     z = logits - logits.max(axis=1, keepdims=True)
     p = np.exp(z); p /= p.sum(axis=1, keepdims=True)
@@ -101,7 +116,7 @@ def loss_and_grads(x, labels, ws, bs, layers):
             N, H, W, C = shp
             dz = (d * (y > 0)).reshape(N * H * W, -1)
             gws[pi] = cols.T @ dz; gbs[pi] = dz.sum(axis=0)
-            dcols = (dz @ ws[pi].T).reshape(N, H, W, 9, C)
+            dcols = (_op(dz, operand) @ _op(ws[pi], operand).T).reshape(N, H, W, 9, C)
             dxp = np.zeros((N, H + 2, W + 2, C))
             t = 0
             for kh in range(3):
@@ -113,13 +128,13 @@ def loss_and_grads(x, labels, ws, bs, layers):
             kind, f, y, shp = c
             dz = d * (y > 0) if kind == "dense_relu" else d
             gws[pi] = f.T @ dz; gbs[pi] = dz.sum(axis=0)
-            d = (dz @ ws[pi].T).reshape(shp)
+            d = (_op(dz, operand) @ _op(ws[pi], operand).T).reshape(shp)
             pi -= 1
     return loss, logits, gws, gbs
 
 
-def sgd_step(x, labels, ws, bs, layers, lr):
-    loss, logits, gws, gbs = loss_and_grads(x, labels, ws, bs, layers)
+def sgd_step(x, labels, ws, bs, layers, lr, operand="f64"):
+    loss, logits, gws, gbs = loss_and_grads(x, labels, ws, bs, layers, operand)
     return [w - lr * g for w, g in zip(ws, gws)], [b - lr * g for b, g in zip(bs, gbs)], loss
 
 

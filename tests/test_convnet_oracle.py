@@ -39,3 +39,13 @@ def test_flatten_roundtrip_and_step():
     for _ in range(20):
         ws, bs, _ = co.sgd_step(x, y, ws, bs, layers, 0.2)
     assert co.loss_and_grads(x, y, ws, bs, layers)[0] < l0
+
+
+def test_round_bf16_is_round_to_nearest_even():
+    """oracle.round_bf16 models v_cvt_pk_bf16_f32: 8 significant bits, ties to even, sign preserved, exact values fixed."""
+    a = np.array([1.0, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, 1.0 + 2.0 ** -8 + 2.0 ** -20, -3.14159, 0.0, 256.0, 257.0, 259.0])
+    want = np.array([1.0, 1.0, 1.0 + 2.0 ** -6, 1.0 + 2.0 ** -7, -3.140625, 0.0, 256.0, 256.0, 260.0])
+    assert np.array_equal(co.round_bf16(a), want)
+    r = np.random.default_rng(0).standard_normal(1000)
+    q = co.round_bf16(r)
+    assert np.all(np.abs(q - r) <= np.abs(r) * 2.0 ** -8) and np.array_equal(co.round_bf16(q), q)

@@ -77,6 +77,63 @@ def test_forward_gradients_and_step_match_oracle(in_shape, layers, B):
     _close(net.get_params(), co.flatten(nw, nb))
 
 
+@pytest.mark.parametrize("in_shape,layers,B", [
+    ((8, 8, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 32), ("dense", 10)), 5),
+    ((6, 6, 1), (("conv", 32), ("conv", 32), ("pool",), ("dense", 7)), 3),
+    ((4, 8, 3), (("conv", 128), ("pool",), ("dense_relu", 128), ("dense_relu", 32), ("dense", 3)), 130),
+    ((16, 16, 3), (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("conv", 64), ("pool",), ("conv", 128), ("conv", 128), ("pool",),
+                   ("conv", 256), ("conv", 256), ("pool",), ("dense", 10)), 3),
+])
+def test_bf16_mfma_path_matches_bf16_operand_oracle(in_shape, layers, B):
+    """rcn_hipx_set_precision(BF16): GEMM operands of forward and dgrad rounded to bf16 (RNE), fp32 accumulation and storage,
+    wgrad on the fp32 path.  Checked against the oracle evaluated with the SAME operand rounding (oracle.round_bf16; f64
+    products and sums): 5e-3 of each tensor's scale -- what is left is accumulation precision and the rare operand that
+    rounds the other way because its fp32 value differs in the last bit.  Against the unrounded f64 oracle the logits sit
+    within 3e-2 (the price of 8-bit mantissas), and switching back to fp32 restores the 2e-4 agreement."""
+    import torch
+    rng = np.random.default_rng(B + 1)
+    net = _net(in_shape, layers, B)
+    shapes = co.param_shapes(in_shape, layers)
+    ws = [rng.standard_normal(k) * np.sqrt(2.0 / k[0]) for k, _ in shapes]
+    bs = [rng.standard_normal(n) * 0.1 for _, n in shapes]
+    flat = co.flatten(ws, bs)
+    net.set_params(flat)
+    x = rng.standard_normal((B,) + in_shape)
+    y = rng.integers(0, layers[-1][1], B).astype(np.int32)
+    xd, yd = net.to_device(x.astype(np.float32)), net.to_device(y)
+    x64 = x.astype(np.float32).astype(np.float64)
+    w32 = [w.astype(np.float32).astype(np.float64) for w in ws]
+    b32 = [b.astype(np.float32).astype(np.float64) for b in bs]
+    loss_ref, logits_ref, gws, gbs = co.loss_and_grads(x64, y, w32, b32, layers, operand="bf16")
+    logits_f64 = co.forward(x64, w32, b32, layers)
+    net.set_precision("bf16")
+    with torch.cuda.stream(net.stream):
+        logits = net.forward(xd)
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        grad = net.gradients(xd, yd, loss=loss)
+    net.synchronize()
+    _close(logits.cpu().numpy(), logits_ref, rtol=5e-3)
+    _close(logits.cpu().numpy(), logits_f64, rtol=3e-2)
+    assert abs(loss.item() - loss_ref) <= 5e-3 * max(1.0, loss_ref)
+    _close(net.unpad(grad), co.flatten(gws, gbs), rtol=5e-3)
+    # it really is a different arithmetic: not bit-equal to the fp32 path, which still holds its own tolerance
+    net.set_precision("fp32")
+    with torch.cuda.stream(net.stream):
+        logits32 = net.forward(xd)
+    net.synchronize()
+    _close(logits32.cpu().numpy(), logits_f64)
+    assert not np.array_equal(logits32.cpu().numpy(), logits.cpu().numpy())
+    # two training steps in bf16 mode (eager, then the cached graph) follow the bf16-operand oracle's steps
+    net.set_precision("bf16")
+    with torch.cuda.stream(net.stream):
+        net.train_step(xd, yd, 0.05, loss)
+        net.train_step(xd, yd, 0.05, loss)
+    net.synchronize()
+    nw, nb, _ = co.sgd_step(x64, y, w32, b32, layers, 0.05, operand="bf16")
+    nw, nb, _ = co.sgd_step(x64, y, nw, nb, layers, 0.05, operand="bf16")
+    _close(net.get_params(), co.flatten(nw, nb), rtol=1e-2)
+
+
 def test_training_reduces_loss_on_cifar_shape():
     """CIFAR-10 shape net of SURVEY.md §8(d): 32x32x3, conv 3->32, pool, 32->64, pool, 64->128, pool -> 2048 -> 256 -> 10."""
     import torch
