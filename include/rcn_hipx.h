@@ -41,7 +41,8 @@ const char* rcn_hipx_last_error(const rcn_hipx_net* net);
 int  rcn_hipx_synchronize(rcn_hipx_net* net);
 int  rcn_hipx_param_count(const rcn_hipx_net* net, int64_t* logical, int64_t* padded);
 int  rcn_hipx_classes(const rcn_hipx_net* net);
-/* GEMM operand precision of the forward and input-gradient convolutions / dense layers.  RCN_HIPX_FP32 (default): fp32 MFMA
+/* GEMM operand precision of the forward, input-gradient and weight-gradient convolutions / dense layers (the weight gradient
+ * of a first layer with 9*Cin <= 32 stays fp32).  RCN_HIPX_FP32 (default): fp32 MFMA
  * (v_mfma_f32_32x32x2_f32), exact fp32 products.  RCN_HIPX_BF16: operands rounded to bf16 on their way into LDS,
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations, gradients, parameters and the SGD update stay fp32 in HBM.
  * Results then agree with an f64 evaluation to ~1e-2 relative instead of ~1e-4. */

@@ -202,13 +202,32 @@ __global__ void k_flip_weights(const float* __restrict__ Wk, float* __restrict__
     }
 }
 
+// XCD-aware workgroup -> (k-tile, n-tile, pixel chunk) map for the weight-gradient kernels.  All tiles of one pixel chunk
+// read the same rows of X (nine shifted views, one per filter tap) and of dZ; hardware deals consecutive workgroup ids
+// round-robin over the 8 XCDs, each with its own L2, so a plain 3-D grid scatters a chunk's tiles over all eight L2s and
+// every one of them fetches the chunk again.  Here workgroup id L runs on XCD L % 8 and works on chunk 8 (L / (8 T)) + L % 8,
+// tile (L / 8) % T: the T tiles of a chunk are consecutive ON ONE XCD and share its L2.
+struct WgradGrid {
+    int tiles_x, tiles_y, nchunks, xcd_aware;
+    __host__ __device__ int tiles() const { return tiles_x * tiles_y; }
+    __host__ unsigned launch_blocks() const { return (unsigned)(tiles() * (xcd_aware ? (nchunks + 7) / 8 * 8 : nchunks)); }
+    __device__ bool decode(int L, int& tx, int& ty, int& chunk) const {
+        const int T = tiles();
+        int inner;
+        if (xcd_aware) { const int j = L >> 3; inner = j % T; chunk = (j / T) * 8 + (L & 7); }
+        else { inner = L % T; chunk = L / T; }
+        tx = inner % tiles_x; ty = inner / tiles_x;
+        return chunk < nchunks;
+    }
+};
+
 // dW partial tiles: workgroup (kb, nb, chunk) computes rows [32 kb, +32) x cols [BN nb, +BN) of dW over the pixels of
 // its chunk and writes them to slab[chunk][K + 1][Cout]; row K is the chunk's partial bias gradient (column sums of dZ,
 // taken by the kb == 0 workgroups from the dZ tiles they stage anyway).  [W | b] is contiguous in the parameter buffer,
 // so ONE k_reduce_update over (K + 1) * Cout elements finishes both.
 template <int KS, bool SMALLC, int BN>
 __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ X, const float* __restrict__ dZ,
-                                                         float* __restrict__ slab, ConvShape s, int pix_per_chunk) {
+                                                         float* __restrict__ slab, ConvShape s, int pix_per_chunk, WgradGrid gd) {
     // Both MFMA operands are read along a staged row (A[m = k][kk = pixel] = Xs[pixel][k], B[kk = pixel][n] = Ds[pixel][n]:
     // a half-wave reads 32 consecutive floats of one row), so the LDS images need no padding and are filled with 16-byte
     // stores.  128 pixels per iteration in ONE LDS buffer (48 KB at BN = 64 -> three workgroups per CU); the next 128 are
@@ -220,8 +239,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long M = (long long)s.N * s.H * s.W;
     const int K = KS * KS * s.Cin;
-    const int kb = blockIdx.x, n0 = blockIdx.y * BN;
-    const long long p0 = (long long)blockIdx.z * pix_per_chunk;
+    int kb, nby, chunk;
+    if (!gd.decode((int)blockIdx.x, kb, nby, chunk)) return;             // padding of the XCD-aware grid (uniform per workgroup)
+    const int n0 = nby * BN;
+    const long long p0 = (long long)chunk * pix_per_chunk;
     const long long p1 = p0 + pix_per_chunk < M ? p0 + pix_per_chunk : M;
 
     f32x16 acc[NT];
@@ -240,14 +261,20 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
         toff = ((long long)dh * s.W + dw) * s.Cin + (k0 - tap * s.Cin) + c4;
     }
     f32x4 xv[4], dv[BN / 8];                             // 128 x 32 floats / 256 thr = 4 float4; 128 x BN / 256 = BN/8 float4
+    // The thread's X rows are pixels m_first, m_first + 32, ... across q AND across stages (128 = 4 * 32): (oh, ow) of the next
+    // row is running state advanced by 32 pixels per load -- one 32-bit division per kernel instead of two 64-bit ones per load.
+    int row_m = (int)p0 + (tid >> 3);
+    int row_ow = row_m % s.W, row_oh = (row_m / s.W) % s.H;
+    const int adv_h = 32 / s.W, adv_w = 32 % s.W;
     auto gload = [&](long long pb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const long long m = pb + (tid >> 3) + 32 * q;
-            const bool in = m < p1;
-            const long long mc = in ? m : p0;
-            const int ow = (int)(mc % s.W);
-            const int oh = (int)((mc / s.W) % s.H);
+            const bool in = row_m < (int)p1;
+            const long long mc = in ? row_m : p0;
+            const int ow = row_ow, oh = row_oh;
+            row_m += 32; row_ow += adv_w; row_oh += adv_h;
+            if (row_ow >= s.W) { row_ow -= s.W; ++row_oh; }
+            if (row_oh >= s.H) row_oh %= s.H;
             if (!SMALLC) {
                 const bool ok = in && (unsigned)(oh + dh) < (unsigned)s.H && (unsigned)(ow + dw) < (unsigned)s.W;
                 const f32x4 val = *reinterpret_cast<const f32x4*>(X + (ok ? mc * (long long)s.Cin + toff : 0));
@@ -315,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) Red[(wave * 32 + mfma32_row(lane, r)) * kLdR + 32 * t + (lane & 31)] = acc[t][r];
     __syncthreads();
-    float* out = slab + (long long)blockIdx.z * (K + 1) * s.Cout;
+    float* out = slab + (long long)chunk * (K + 1) * s.Cout;
     for (int e = tid; e < 32 * BN; e += kThreads) {
         const int kr = e / BN, c = e - kr * BN;
         const int k = kb * 32 + kr;

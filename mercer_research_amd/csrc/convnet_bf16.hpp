@@ -131,3 +131,154 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
 }
 
 }  // namespace rcnx
+
+namespace rcnx {
+
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16-lane group a 4-row x 16-column block of 16-bit elements comes
+// back column-major -- lane i of the group receives column i of the 4 rows.  Lane 4q+p supplies the address of row q,
+// columns 4p..4p+3.  EXEC must be all ones; addresses 8-byte aligned.
+__device__ inline s16x4 lds_read_tr16(const __bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// One 32x32x16 operand fragment whose CONTRACTION index runs along the rows of a row-major LDS image: rows = pixels
+// px0 .. px0+15, columns = col0 .. col0+31 (the operand's M or N index).  MFMA lane l (r = l & 31, h = l >> 5) needs rows
+// px0 + 8h + j, j = 0..7, of column col0 + r: two transposed 4-row reads.
+__device__ inline bf16x8 tr_fragment(const __bf16* img, int ld, int px0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const __bf16* a = img + (px0 + 8 * (g >> 1) + q) * ld + col0 + 16 * (g & 1) + 4 * p;
+    const s16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + 4 * ld);
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = lo; u.s[1] = hi;
+    return u.v;
+}
+
+// dW partial tiles with bf16 operands: workgroup (kg, nb, chunk) of NKB waves computes rows [32 NKB kg, +32 NKB) x cols
+// [BN nb, +BN) of dW over its pixel chunk -- wave w owns k-block NKB kg + w (a 32 x BN tile, no cross-wave reduction) --
+// and writes slab[chunk][K + 1][Cout] exactly like k_conv_wgrad (row K = the chunk's bias gradient, summed in fp32 from
+// the unrounded dZ values as they pass through registers).
+//
+// The contraction runs over PIXELS, which are the rows of both staged images (Xs[pixel][k], Ds[pixel][co], filled with
+// plain 8-byte stores of converted fp32 rows); the MFMA wants 8 consecutive contraction indices per lane, i.e. a column of
+// those images -- the hardware transposed read delivers exactly that, so no operand is ever transposed by software.
+// A k-block lies inside one filter tap (Cin % 32 == 0), different waves' blocks may be different taps.
+template <int KS, int BN, int NKB>
+__global__ __launch_bounds__(64 * NKB) void k_conv_wgrad_bf16(const float* __restrict__ X, const float* __restrict__ dZ,
+                                                              float* __restrict__ slab, ConvShape s, int pix_per_chunk, WgradGrid gd) {
+    constexpr int NT = BN / 32, kPT = 128, NTHR = 64 * NKB;
+    constexpr int LDX = 32 * NKB + 8, LDD = BN + 8;
+    constexpr int XCH = kPT * 8 * NKB / NTHR;                              // f32x4 chunks of the X tile per thread (= 16)
+    constexpr int DCH = (kPT * (BN / 4) + NTHR - 1) / NTHR;               // ... of the dZ tile
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[kPT * LDX];
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[kPT * LDD];
+    __shared__ __attribute__((aligned(16))) float red[NTHR * 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long M = (long long)s.N * s.H * s.W;
+    const int K = KS * KS * s.Cin, nkb = K / 32;
+    int kgx, nby, chunk;
+    if (!gd.decode((int)blockIdx.x, kgx, nby, chunk)) return;            // padding of the XCD-aware grid (uniform per workgroup)
+    const int kb0 = kgx * NKB, n0 = nby * BN;
+    const long long p0 = (long long)chunk * pix_per_chunk;
+    const long long p1 = p0 + pix_per_chunk < M ? p0 + pix_per_chunk : M;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+
+    // X loader: chunk e = tid + NTHR q -> pixel row e / (8 NKB), 4 floats at tile column 4 (e % (8 NKB)).  NTHR is a multiple
+    // of 8 NKB, so a thread's tile column -- hence its k-block and filter tap -- is the same for all its chunks.
+    const int xcol = (tid % (8 * NKB)) * 4;
+    const int xkb = kb0 + xcol / 32;
+    const bool xlive = xkb < nkb;
+    const int k0 = (xlive ? xkb : 0) * 32, tap = k0 / s.Cin;
+    const int dh = tap / KS - KS / 2, dw = tap % KS - KS / 2;
+    const long long toff = ((long long)dh * s.W + dw) * s.Cin + (k0 - tap * s.Cin) + (xcol & 31);
+    f32x4 xv[XCH], dv[DCH];
+    // The thread's X rows are pixels m_first, m_first + 8, m_first + 16, ... across q AND across stages (128 = 16 * 8), so
+    // the (oh, ow) of its next row is kept as running state and advanced by 8 pixels per load -- one 32-bit division per
+    // kernel instead of two 64-bit ones per load (which used to cost more than the MFMAs).
+    int row_m = (int)p0 + tid / (8 * NKB);
+    int row_ow = row_m % s.W, row_oh = (row_m / s.W) % s.H;
+    const int adv_h = 8 / s.W, adv_w = 8 % s.W;
+    auto gload = [&](long long pb) {
+#pragma unroll
+        for (int q = 0; q < XCH; ++q) {
+            const bool in = xlive && row_m < (int)p1;
+            const bool ok = in && (unsigned)(row_oh + dh) < (unsigned)s.H && (unsigned)(row_ow + dw) < (unsigned)s.W;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(X + (ok ? (long long)row_m * s.Cin + toff : 0));   // unconditional, masked by value
+            xv[q] = ok ? val : f32x4{0, 0, 0, 0};
+            row_m += 8; row_ow += adv_w; row_oh += adv_h;
+            if (row_ow >= s.W) { row_ow -= s.W; ++row_oh; }
+            if (row_oh >= s.H) row_oh %= s.H;
+        }
+#pragma unroll
+        for (int q = 0; q < DCH; ++q) {
+            const int e = tid + NTHR * q;
+            const int ec = e < kPT * (BN / 4) ? e : 0;
+            const int pr = ec / (BN / 4), c4b = (ec - pr * (BN / 4)) * 4;
+            const long long m = pb + pr;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(dZ + (m < p1 ? m : p0) * s.Cout + n0 + c4b);
+            dv[q] = (m < p1 && e < kPT * (BN / 4)) ? val : f32x4{0, 0, 0, 0};
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < XCH; ++q)
+            *reinterpret_cast<bf16x4*>(&Xs[((tid + NTHR * q) / (8 * NKB)) * LDX + xcol]) = to_bf16x4(xv[q]);
+#pragma unroll
+        for (int q = 0; q < DCH; ++q) {
+            const int e = tid + NTHR * q;
+            if (e < kPT * (BN / 4)) {
+                const int pr = e / (BN / 4), c4b = (e - pr * (BN / 4)) * 4;
+                *reinterpret_cast<bf16x4*>(&Ds[pr * LDD + c4b]) = to_bf16x4(dv[q]);
+                colsum += dv[q];                                             // fp32, unrounded: the bias gradient
+            }
+        }
+    };
+
+    const bool wlive = kb0 + wave < nkb;                                    // wave-uniform
+    gload(p0);
+    for (long long pb = p0; pb < p1; pb += kPT) {
+        lstore();
+        __syncthreads();
+        if (pb + kPT < p1) gload(pb + kPT);                                 // next 128 pixels fly while these are contracted
+        if (wlive) {
+#pragma unroll
+            for (int st = 0; st < kPT / 16; ++st) {
+                const bf16x8 af = tr_fragment(Xs, LDX, 16 * st, 32 * wave, lane);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 bf = tr_fragment(Ds, LDD, 16 * st, 32 * t, lane);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = slab + (long long)chunk * (K + 1) * s.Cout;
+    if (wlive) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(long long)((kb0 + wave) * 32 + mfma32_row(lane, r)) * s.Cout + n0 + 32 * t + (lane & 31)] = acc[t][r];
+    }
+    if (kgx == 0) {
+        // bias row: thread's four columns are c4b = 4 (tid % (BN/4)) (NTHR is a multiple of BN/4); add the threads in fixed order
+        *reinterpret_cast<f32x4*>(&red[tid * 4]) = colsum;
+        __syncthreads();
+        if (tid < BN) {
+            const int grp = tid >> 2, comp = tid & 3;
+            float t = 0.f;
+            for (int u = grp; u < NTHR; u += BN / 4) t += red[u * 4 + comp];
+            out[(long long)K * s.Cout + n0 + tid] = t;
+        }
+    }
+}
+
+}  // namespace rcnx

@@ -125,6 +125,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     return 0;
 }
 
+static int xcd_remap() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_XCD_REMAP"); return e ? std::atoi(e) : 0; }(); return v; }
 static int pix_per_chunk() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_PIX_PER_CHUNK"); const int x = e ? std::atoi(e) : 0; return x >= 128 ? x / 128 * 128 : 1024; }(); return v; }
 #define kPixPerChunk (pix_per_chunk())
 
@@ -133,10 +134,29 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const int K = ks * ks * s.Cin;
     const bool smallc = K <= 32;
     const int bn = (s.Cout % 64 == 0) ? 64 : 32;
+    if (M > 0x7fff0000LL) return fail(n, -3, "too many output pixels in one layer (N*H*W must stay below 2^31)");
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
     XTRY(n, n->slab.ensure((size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
-    const dim3 grid((unsigned)(smallc ? 1 : K / 32), (unsigned)(s.Cout / bn), (unsigned)chunks);
-#define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, kPixPerChunk)
+    if (n->precision == RCN_HIPX_BF16 && !smallc) {
+        // bf16 operands, transposed LDS reads (convnet_bf16.hpp); NKB waves per workgroup, one 32-row k-block each
+        const int nkb = K / 32;
+        const int nk = nkb % 4 == 0 ? 4 : nkb % 3 == 0 ? 3 : nkb % 2 == 0 ? 2 : 1;
+        const WgradGrid gdb{nkb / nk, s.Cout / bn, chunks, xcd_remap()};
+        const dim3 gridb(gdb.launch_blocks());
+#define WGB_CASE(KS_, BN_, NK_) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)n->slab.p, s, kPixPerChunk, gdb)
+#define WGB_NK(KS_, BN_) do { if (nk == 4) WGB_CASE(KS_, BN_, 4); else if (nk == 3) WGB_CASE(KS_, BN_, 3); else if (nk == 2) WGB_CASE(KS_, BN_, 2); else WGB_CASE(KS_, BN_, 1); } while (0)
+#define WGB_BN(KS_) do { if (bn == 64) WGB_NK(KS_, 64); else WGB_NK(KS_, 32); } while (0)
+        if (ks == 3) WGB_BN(3); else WGB_BN(1);
+#undef WGB_BN
+#undef WGB_NK
+#undef WGB_CASE
+        XTRY(n, hipGetLastError());
+        *chunks_out = chunks;
+        return 0;
+    }
+    const WgradGrid gd{smallc ? 1 : K / 32, s.Cout / bn, chunks, xcd_remap()};
+    const dim3 grid(gd.launch_blocks());
+#define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, kPixPerChunk, gd)
 #define WG_BN(KS_, SM_) do { if (bn == 64) WG_CASE(KS_, SM_, 64); else WG_CASE(KS_, SM_, 32); } while (0)
     if (ks == 3) { if (smallc) WG_BN(3, true); else WG_BN(3, false); }
     else { if (smallc) WG_BN(1, true); else WG_BN(1, false); }

@@ -93,8 +93,9 @@ def forward(x, ws, bs, layers, cache=None, operand="f64"):
 
 
 def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
-    """operand="bf16": forward and input-gradient GEMMs take bf16-rounded operands; the weight-gradient GEMM does not
-    (it runs on the fp32 MFMA path on the device)."""
+    """operand="bf16": every GEMM takes bf16-rounded operands -- forward, input gradient and weight gradient -- except the
+    weight gradient of a first layer whose whole patch fits one K-tile (9*Cin <= 32), which stays on the fp32 path on the
+    device.  Bias gradients are plain sums of the unrounded dZ."""
     cache = []
     logits = forward(x, ws, bs, layers, cache, operand)
     B = logits.shape[0]
@@ -115,7 +116,8 @@ def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
             _, cols, y, shp = c
             N, H, W, C = shp
             dz = (d * (y > 0)).reshape(N * H * W, -1)
-            gws[pi] = cols.T @ dz; gbs[pi] = dz.sum(axis=0)
+            small = cols.shape[1] <= 32
+            gws[pi] = cols.T @ dz if small else _op(cols, operand).T @ _op(dz, operand); gbs[pi] = dz.sum(axis=0)
             dcols = (_op(dz, operand) @ _op(ws[pi], operand).T).reshape(N, H, W, 9, C)
             dxp = np.zeros((N, H + 2, W + 2, C))
             t = 0
@@ -127,7 +129,7 @@ def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
         else:
             kind, f, y, shp = c
             dz = d * (y > 0) if kind == "dense_relu" else d
-            gws[pi] = f.T @ dz; gbs[pi] = dz.sum(axis=0)
+            gws[pi] = _op(f, operand).T @ _op(dz, operand); gbs[pi] = dz.sum(axis=0)
             d = (_op(dz, operand) @ _op(ws[pi], operand).T).reshape(shp)
             pi -= 1
     return loss, logits, gws, gbs
