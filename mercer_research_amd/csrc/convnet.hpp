@@ -96,7 +96,8 @@ __device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape&
     }
 }
 
-// EPI: 0 = raw, 1 = + bias, 2 = + bias, ReLU
+// EPI: 0 = raw, 1 = + bias, 2 = + bias, ReLU, 3 = raw gated by (G > 0) where `bias` points at a tensor G shaped like Y (the
+// input-gradient pass writes dZ of the layer below directly: G = that layer's post-ReLU output)
 template <int KS, bool SMALLC, int BN, int EPI>
 __global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__ X, const float* __restrict__ Wk,
                                                        const float* __restrict__ bias, float* __restrict__ Y, ConvShape s) {
@@ -175,13 +176,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int co = n0 + 32 * t + (lane & 31);
-        const float bb = (EPI >= 1) ? bias[co] : 0.f;
+        const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long long m = m0 + wave * 32 + mfma32_row(lane, r);
             if (m < M) {
                 float v = acc[t][r] + bb;
                 if (EPI == 2) v = v > 0.f ? v : 0.f;
+                if (EPI == 3) v = bias[m * s.Cout + co] > 0.f ? v : 0.f;      // dgrad: ReLU mask of the layer below, `bias` = its output
                 Y[m * s.Cout + co] = v;
             }
         }
@@ -368,8 +370,9 @@ __global__ void k_splitk_epilogue(const float* __restrict__ part, const float* _
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < MN; e += (long long)gridDim.x * blockDim.x) {
         float v = 0.f;
         for (int z = 0; z < Z; ++z) v += part[(long long)z * MN + e];
-        if (epi >= 1) v += bias[(int)(e % Cout)];
+        if (epi == 1 || epi == 2) v += bias[(int)(e % Cout)];
         if (epi == 2) v = v > 0.f ? v : 0.f;
+        if (epi == 3) v = bias[e] > 0.f ? v : 0.f;
         Y[e] = v;
     }
 }

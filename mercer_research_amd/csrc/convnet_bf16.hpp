@@ -117,13 +117,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int co = n0 + 32 * t + (lane & 31);
-        const float bb = (EPI >= 1) ? bias[co] : 0.f;
+        const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long long m = m0 + wave * 32 + mfma32_row(lane, r);
             if (m < M) {
                 float v = acc[t][r] + bb;
                 if (EPI == 2) v = v > 0.f ? v : 0.f;
+                if (EPI == 3) v = bias[m * s.Cout + co] > 0.f ? v : 0.f;      // dgrad: ReLU mask of the layer below, `bias` = its output
                 Y[m * s.Cout + co] = v;
             }
         }

@@ -100,7 +100,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
         hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
         const __bf16* WB = (const __bf16*)n->wb.p;
 #define CONVB_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd_bf16<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s)
-#define CONVB_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONVB_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONVB_CASE(KS_, SM_, BN_, 1); else CONVB_CASE(KS_, SM_, BN_, 2); } while (0)
+#define CONVB_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONVB_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONVB_CASE(KS_, SM_, BN_, 1); else if (kepi == 2) CONVB_CASE(KS_, SM_, BN_, 2); else CONVB_CASE(KS_, SM_, BN_, 3); } while (0)
 #define CONVB_BN(KS_, SM_) do { if (bn == 128) CONVB_EPI(KS_, SM_, 128); else if (bn == 64) CONVB_EPI(KS_, SM_, 64); else CONVB_EPI(KS_, SM_, 32); } while (0)
         if (ks == 3) { if (smallc) CONVB_BN(3, true); else CONVB_BN(3, false); }
         else { if (smallc) CONVB_BN(1, true); else CONVB_BN(1, false); }
@@ -109,7 +109,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #undef CONVB_CASE
     } else {
 #define CONV_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, Wk, bias, out, s)
-#define CONV_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONV_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONV_CASE(KS_, SM_, BN_, 1); else CONV_CASE(KS_, SM_, BN_, 2); } while (0)
+#define CONV_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONV_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONV_CASE(KS_, SM_, BN_, 1); else if (kepi == 2) CONV_CASE(KS_, SM_, BN_, 2); else CONV_CASE(KS_, SM_, BN_, 3); } while (0)
 #define CONV_BN(KS_, SM_) do { if (bn == 64) CONV_EPI(KS_, SM_, 64); else CONV_EPI(KS_, SM_, 32); } while (0)
         if (ks == 3) { if (smallc) CONV_BN(3, true); else CONV_BN(3, false); }
         else { if (smallc) CONV_BN(1, true); else CONV_BN(1, false); }
@@ -126,8 +126,16 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 }
 
 static int xcd_remap() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_XCD_REMAP"); return e ? std::atoi(e) : 0; }(); return v; }
-static int pix_per_chunk() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_PIX_PER_CHUNK"); const int x = e ? std::atoi(e) : 0; return x >= 128 ? x / 128 * 128 : 1024; }(); return v; }
-#define kPixPerChunk (pix_per_chunk())
+// Pixels per weight-gradient chunk: 1024 (measured best on the CIFAR/MNIST nets: parallelism matters there), grown for very
+// large layers so that the slab of partial tiles -- written once, read once by k_reduce_update_wide -- stays near 2048 chunks.
+static int pix_per_chunk(long long M) {
+    static const int v = [] { const char* e = std::getenv("RCN_HIPX_PIX_PER_CHUNK"); const int x = e ? std::atoi(e) : 0; return x >= 128 ? x / 128 * 128 : 0; }();
+    if (v) return v;
+    long long pix = 1024;
+    if (M / pix > 2048) { pix = (M / 2048 + 127) / 128 * 128; if (pix > 16384) pix = 16384; }
+    return (int)pix;
+}
+#define kPixPerChunk (pix_per_chunk(M))
 
 int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, int ks, int* chunks_out) {
     const long long M = (long long)s.N * s.H * s.W;
@@ -195,6 +203,7 @@ int forward(rcn_hipx_net* n, const float* x, int B) {
 
 // backward from dlogits (already in L.back().dout); apply: update parameters with lr, else write gradients to grad (padded layout)
 int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply) {
+    std::vector<char> gated(n->L.size(), 0);       // layer's dout already holds dZ (ReLU gate applied by the producer)
     for (int i = (int)n->L.size() - 1; i >= 0; --i) {
         Layer& l = n->L[i];
         const float* in = i == 0 ? x : (const float*)n->L[i - 1].out.p;
@@ -213,7 +222,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         const long long M = (long long)s.N * s.H * s.W;
         // dZ: gradient wrt the pre-activation
         const float* dZ = (const float*)l.dout.p;
-        if (l.kind != RCN_HIPX_DENSE && !l.pool_follows) {
+        if (l.kind != RCN_HIPX_DENSE && !l.pool_follows && !gated[i]) {
             XTRY(n, n->dz.ensure((size_t)M * l.CoutP * sizeof(float)));
             hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d(M * l.CoutP, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (float*)n->dz.p, M * l.CoutP);
             XTRY(n, hipGetLastError());
@@ -225,7 +234,12 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
             XTRY(n, n->wt.ensure((size_t)wn * sizeof(float)));
             hipLaunchKernelGGL(k_flip_weights, dim3(grid1d(wn, 256)), dim3(256), 0, n->stream, (const float*)P(n, l.w_off), (float*)n->wt.p, ks, s.Cin, s.Cout);
             XTRY(n, hipGetLastError());
-            RTRY(launch_conv(n, dZ, (const float*)n->wt.p, nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, 0));
+            // the layer below is a ReLU layer feeding this one directly (no pool in between): gate the gradient with its output in
+            // this kernel's epilogue, so that layer finds its dZ ready instead of running a k_relu_bwd pass over the tensor
+            const Layer& below = n->L[i - 1];
+            const bool gate = below.kind == RCN_HIPX_CONV3X3_RELU || below.kind == RCN_HIPX_DENSE_RELU;
+            RTRY(launch_conv(n, dZ, (const float*)n->wt.p, gate ? (const float*)below.out.p : nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, gate ? 3 : 0));
+            gated[i - 1] = gate;
         }
         int chunks = 0;
         RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks));
