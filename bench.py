@@ -117,8 +117,8 @@ def main():
     imgs, labels = synthetic_images(N_IMAGES, seed=1234 + rank)          # every rank owns a different shard of data
     ws, bs = synthetic_params(DIMS, seed=42)                             # identical replicas (rcn.rs:500-523 shapes)
     d.set_params(ws, bs)
-    if use_dp:
-        args.path = 1            # the gradient-out form runs on the sample-tile kernels (k_dense_fwd / k_dense_wgrad)
+    # data-parallel: with the peer-read exchange the step runs on the feature-sliced pipeline (k_p2_b, k_p2_dp_grad,
+    # k_p2_dp_apply); on the RCCL fallback the gradient-out form runs on the sample-tile kernels (--path 1 forces those)
     d.set_dense_path(args.path)
     with torch.cuda.stream(d.stream):
         imgs_d = torch.from_numpy(imgs).to(d.device)
@@ -255,6 +255,19 @@ def main():
         d.synchronize()
         e2e = reps * N_IMAGES / (ea.elapsed_time(eb) * 1e-3)
 
+    # data-parallel runs: every rank must hold bit-identical parameters (identical update from rank-ordered sums); a stale or
+    # torn read in the exchange would show up here as diverged replicas
+    replicas_identical = None
+    if use_dp:
+        with torch.cuda.stream(d.stream):
+            pf = d.params_flat().to(torch.float64)
+            chk = torch.stack([pf.sum(), (pf * pf).sum(), pf.abs().max()])
+        d.synchronize()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi)) and bool(torch.isfinite(chk).all())
+
     images = args.steps * B * world
     result = {
         "metric": "training images/sec, MNIST-shape 28x28x1 batch=256, at 1/2/4/8 MI355X",
@@ -266,7 +279,7 @@ def main():
                    "global_batch": B * world, "parallelism": f"dp{world}", "step_form": f"gradient -> all-reduce -> apply ({args.dp_impl} loop)" if use_dp else "fused update", "images_per_rank": N_IMAGES,
                    "device_ms_per_step_rank0": round(dev_ms / args.steps, 6), "final_cost_rank0": final_loss,
                    "end_to_end_images_per_s": round(e2e, 1) if e2e else None,
-                   "allreduce": allreduce_kind if use_dp else None},
+                   "allreduce": allreduce_kind if use_dp else None, "replicas_identical": replicas_identical},
     }
 
     if rank == 0:

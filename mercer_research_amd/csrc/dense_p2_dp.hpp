@@ -1,0 +1,210 @@
+// dense_p2_dp.hpp -- the feature-sliced pipeline (dense_p2.hpp) for the data-parallel step, on the peer-read exchange of
+// dp_p2p.hpp.  Single-GPU step: k_p2_b, k_p2_a (update + next partials).  Data-parallel step, per rank:
+//
+//   k_p2_b            unchanged: slab -> a_1, layer 2, loss parts, delta_2, delta_1 of this rank's shard
+//   k_p2_dp_grad      the U half of k_p2_a with the gradient going OUT: every feature slice's sum_s delta_1 (x) x (and the
+//                     tail tiles db_0, d[W_1|b_1], and the shard's loss in element P) is written, unscaled, into this
+//                     rank's exported slot -- at its parameter index, so the slot is laid out like the parameters
+//   k_p2_dp_apply     the exchange + the rest of k_p2_a: signal "my slot is ready" (the data was written by the PREVIOUS
+//                     kernel, so the end-of-kernel release already made it visible), wait for every peer's flag, then each
+//                     thread adds ITS OWN parameter's gradient over all ranks in rank order (system-scope loads straight
+//                     from the peers' HBM over xGMI), applies w <- w - eta/B_global * sum, keeps the updated W_0 slice in
+//                     LDS and computes the next batch's partial z_1 from it -- so the all-reduce costs no kernel of its own
+//                     and no rank ever materialises the reduced gradient.
+//
+// Same protocol, sequence numbers, double buffering and bounded waits as k_p2p_allreduce; the sums are in rank order on
+// every rank, so replicas stay bit-identical.  The copies of k_p2_a's two loops below are deliberate: the single-GPU kernel
+// is tuned at instruction level and is not touched.
+#pragma once
+
+#include "dense_p2.hpp"
+#include "dp_p2p.hpp"
+
+namespace rcn {
+
+template <typename T> struct SysWord;
+template <> struct SysWord<float> { using type = unsigned; };
+template <> struct SysWord<double> { using type = unsigned long long; };
+
+// one value of a (possibly remote) buffer, never served from a stale local cache line
+template <typename T>
+__device__ inline T load_sys(const T* p) {
+    using W = typename SysWord<T>::type;
+    const W w = __hip_atomic_load(reinterpret_cast<const W*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    T v;
+    __builtin_memcpy(&v, &w, sizeof v);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kDenseThreads) void k_p2_dp_grad(
+    NetDesc nd, const T* __restrict__ Xp, int B, const T* __restrict__ a1, const T* __restrict__ d1, const T* __restrict__ d2,
+    T* __restrict__ gbuf, size_t stride, const unsigned* __restrict__ seq_base, unsigned seq_off, int G, const T* __restrict__ loss_part,
+    int n_loss, T loss_scale) {
+    using acc_t = typename Mfma16<T>::acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
+    const int F = nd.dims[0], H = nd.dims[1];
+    // step sequence number = *seq_base + seq_off: inside a replayed hipGraph the offset is baked in and the base is a device
+    // word the host sets before every replay; launched eagerly, seq_base is null and seq_off is the number itself
+    const unsigned seq = (seq_base ? *seq_base : 0u) + seq_off;
+    T* __restrict__ gslot = gbuf + (size_t)(seq & 1u) * stride;
+    if ((int)blockIdx.x >= G) {
+        const int e = (int)blockIdx.x - G;
+        if (e == 0 && tid == 0) finish_loss<T>(loss_part, n_loss, loss_scale, gslot + nd.P);     // this shard's part of the global cost
+        if (e == 0) wgrad_tile_ld<T, false>(nd, 0, F, (T*)nullptr, gslot, (const T*)nullptr, 0, (const int*)nullptr, d1, kP2H, B, (T)0, red);
+        else        wgrad_tile_ld<T, false>(nd, 1, (e - 1) * 16, (T*)nullptr, gslot, a1, kP2H, (const int*)nullptr, d2, kP2C, B, (T)0, red);
+        return;
+    }
+    const int f0 = (int)blockIdx.x * 16;
+    const int nf = F - f0 < 16 ? F - f0 : 16;
+    const T* __restrict__ cp = Xp + (size_t)blockIdx.x * B * 16;
+    const int ml = tid & 15, cl = (tid >> 4) & 15, mt = tid >> 8;
+    const int m = mt * 16 + ml;
+    const bool wvalid = m < H && cl < nf;
+    acc_t acc[kMtp];
+#pragma unroll
+    for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
+    const int kw = B >> 3;
+    for (int kc = wave * kw; kc < (wave + 1) * kw; kc += 32) {
+        const T* xb = cp + (size_t)(kc + g4) * 16 + n;
+        const T* db = d1 + (size_t)(kc + g4) * kP2H + n;
+        T bv[8], av[8][kMtp];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            bv[q] = xb[q * 64];
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) av[q][t] = db[q * 4 * kP2H + t * 16];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(av[q][t], bv[q], acc[t]);
+    }
+    store_partials<T>(red, wave, lane, acc);
+    __syncthreads();
+    const T gsum = sum_partials<T>(red, mt, cl, ml);
+    if (wvalid) gslot[(size_t)nd.w_off[0] + (size_t)(f0 + cl) * H + m] = gsum;                    // rcn.rs:310 summed over the shard
+}
+
+template <typename T>
+__global__ __launch_bounds__(kDenseThreads) void k_p2_dp_apply(
+    NetDesc nd, T* __restrict__ params, const T* __restrict__ Xn, int B, T scale, T* __restrict__ slab, int G, T* __restrict__ loss_out,
+    int do_fwd, P2PDesc d, const unsigned* __restrict__ seq_base, unsigned seq_off, size_t stride, unsigned* __restrict__ err,
+    long long timeout_ticks) {
+    using acc_t = typename Mfma16<T>::acc_t;
+    using vec4 = typename Vec4<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);
+    int& s_bad = *reinterpret_cast<int*>(red + kDenseWaves * kMtp * kRedTile + 16 * kP2H);      // in the slack behind the slice image
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
+    const int F = nd.dims[0], H = nd.dims[1];
+    const bool feat = (int)blockIdx.x < G;
+    const unsigned seq = (seq_base ? *seq_base : 0u) + seq_off;
+    const int f0 = (int)blockIdx.x * 16;
+    const T* __restrict__ cn = Xn + (size_t)blockIdx.x * B * 16;
+
+    // the next batch's rows do not depend on the exchange: issue them first
+    vec4 xn[2];
+    if (feat && do_fwd) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xn[u] = *reinterpret_cast<const vec4*>(cn + (size_t)(16 * (wave + 8 * u) + n) * 16 + 4 * g4);
+    }
+
+    // ---- exchange: signal, then wait (dp_p2p.hpp)
+    if (tid == 0) s_bad = *err != 0u ? 2 : 0;
+    __syncthreads();
+    if (s_bad == 2) return;
+    if (blockIdx.x == 0 && tid < d.world) __hip_atomic_store(d.flags[tid] + d.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < d.world && tid != d.rank) {                  // own slot: complete by stream order, nothing to wait for
+        const unsigned* mine = d.flags[d.rank] + tid;
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (wall_clock64() - t0 > timeout_ticks) { s_bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) *err = 1u + (unsigned)d.rank;
+        return;
+    }
+    const size_t slot = (size_t)(seq & 1u) * stride;
+
+    if (!feat) {
+        // tail parameters b_0 | W_1 | b_1 (everything after W_0), spread over the tail workgroups; element P is the loss
+        const int e = (int)blockIdx.x - G, ntw = (int)gridDim.x - G;
+        const int t_begin = nd.w_off[0] + F * H;
+        for (int p = t_begin + e * kDenseThreads + tid; p < nd.P; p += ntw * kDenseThreads) {
+            T g = 0;
+#pragma unroll
+            for (int q = 0; q < kP2PMaxWorld; ++q) {
+                const T v = load_sys<T>((const T*)d.buf[q < d.world ? q : 0] + slot + p);
+                g += q < d.world ? v : (T)0;
+            }
+            params[p] = params[p] - scale * g;                                                    // rcn.rs:214,221
+        }
+        if (e == 0 && tid == 0 && loss_out) {
+            T g = 0;
+            for (int q = 0; q < d.world; ++q) g += load_sys<T>((const T*)d.buf[q] + slot + nd.P);
+            *loss_out = g;
+        }
+        return;
+    }
+
+    // ---- this thread's element of the W_0 slice: gradient summed over ranks in rank order, update, keep the slice in LDS
+    const int nf = F - f0 < 16 ? F - f0 : 16;
+    T* wsl = red + kDenseWaves * kMtp * kRedTile;
+    T* W0 = params + nd.w_off[0];
+    {
+        const int ml = tid & 15, cl = (tid >> 4) & 15, mt = tid >> 8;
+        const int m = mt * 16 + ml;
+        const bool wvalid = m < H && cl < nf;
+        const size_t off = (size_t)(f0 + (cl < nf ? cl : 0)) * H + (m < H ? m : 0);
+        const T wold = W0[off];
+        T g = 0;
+#pragma unroll
+        for (int q = 0; q < kP2PMaxWorld; ++q) {
+            const T v = load_sys<T>((const T*)d.buf[q < d.world ? q : 0] + slot + nd.w_off[0] + off);   // unconditional, masked by value
+            g += q < d.world ? v : (T)0;
+        }
+        const T w = wold - scale * g;
+        if (wvalid) W0[off] = w;
+        wsl[cl * kP2H + m] = wvalid ? w : (T)0;
+    }
+    __syncthreads();
+    if (!do_fwd) return;
+
+    // ---- F: partial z_1 of the new batch from the slice in LDS (k_p2_a's F half)
+    const int ntile = B >> 4;
+    T wf[4][kMtp];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < kMtp; ++t) wf[i][t] = wsl[(4 * g4 + i) * kP2H + t * 16 + n];
+    for (int tb = 0; tb < ntile; tb += 16) {
+        if (tb > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) xn[u] = *reinterpret_cast<const vec4*>(cn + (size_t)(16 * (tb + wave + 8 * u) + n) * 16 + 4 * g4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = 16 * (tb + wave + 8 * u) + n;
+            acc_t acc[kMtp];
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(wf[i][t], xn[u][i], acc[t]);
+            T* dst = slab + (((size_t)(s >> 3) * G + blockIdx.x) * kP2Ts + (s & 7)) * kP2H;
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) store4<T>(dst + t * 16, lane, acc[t]);
+        }
+    }
+}
+
+__global__ void k_set_u32(unsigned* p, unsigned v) { *p = v; }
+
+}  // namespace rcn

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kP2PThreads) void k_p2p_allreduce(P2PDesc d, unsign
     if (s_bad == 2) return;
     if (blockIdx.x == 0 && tid < d.world)
         __hip_atomic_store(d.flags[tid] + d.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (tid < d.world) {
+    if (tid < d.world && tid != d.rank) {                  // own slot: complete by stream order, nothing to wait for
         const unsigned* mine = d.flags[d.rank] + tid;
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {

@@ -25,6 +25,7 @@
 #include "dp_rccl.hpp"
 #include "serve.hpp"
 #include "dp_p2p.hpp"
+#include "dense_p2_dp.hpp"
 #include <chrono>
 
 using namespace rcn;
@@ -73,7 +74,7 @@ struct rcn_hip_ctx {
     void* pin_dev = nullptr;
     size_t pack_seg_bytes = (size_t)64 << 20;   // size of one half of the epoch image (env RCN_HIP_PACK_SEGMENT_BYTES, for tests)
     DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
-    std::map<EpochKey, hipGraphExec_t> graphs;
+    std::map<EpochKey, hipGraphExec_t> graphs, dp_graphs;
     ncclComm_t comm = nullptr;              // data-parallel group (rcn_hip_dp_init); one rank per context
     int dp_rank = 0, dp_world = 1;
     struct P2P {                            // peer-read all-reduce over xGMI (dp_p2p.hpp)
@@ -84,7 +85,7 @@ struct rcn_hip_ctx {
         unsigned* peer_flags[rcn::kP2PMaxWorld] = {};
         size_t stride = 0;                  // values per slot (>= P+1, multiple of 4)
         unsigned seq = 0;                   // step sequence number, identical on every rank
-        unsigned* err_dev = nullptr;        // sticky: 1 + rank that timed out
+        unsigned* err_dev = nullptr;        // sticky: 1 + rank that timed out; err_dev[16] = sequence base read by replayed graphs
         unsigned* err_host = nullptr;       // pinned copy, refreshed after every epoch call
         DevBuf raw, mism;
     } p2p;
@@ -458,6 +459,8 @@ int need_params(rcn_hip_ctx* c) {
 // ---- peer-read all-reduce plumbing (dp_p2p.hpp) ------------------------------------------------------------------
 void p2p_release(rcn_hip_ctx* c) {
     auto& q = c->p2p;
+    for (auto& kv : c->dp_graphs) (void)hipGraphExecDestroy(kv.second);      // they hold pointers into the buffers freed below
+    c->dp_graphs.clear();
     for (int r = 0; r < kP2PMaxWorld; ++r) {
         if (q.attached && r != c->dp_rank) {
             if (q.peer_buf[r]) (void)hipIpcCloseMemHandle(q.peer_buf[r]);
@@ -541,6 +544,44 @@ int p2p_step(rcn_hip_ctx* c, int mode, double scale, void* loss_out, long long t
     return RCN_HIP_OK;
 }
 
+// The data-parallel epoch on the feature-sliced pipeline (dense_p2_dp.hpp): per step k_p2_b, k_p2_dp_grad, k_p2_dp_apply --
+// the exchange happens inside the third kernel, which also computes the next batch's partial z_1.
+template <typename T>
+int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev,
+                          bool in_graph) {
+    auto& q = c->p2p;
+    const unsigned* seq_base = in_graph ? q.err_dev + 16 : nullptr;     // set by the caller before each replay
+    const NetDesc& nd = c->nd;
+    const size_t G = pipe_slices(nd), Cc = nd.dims[nd.L], es = c->esz();
+    const double Bg = (double)B * (double)c->dp_world;
+    const double scale = eta / Bg, loss_scale = 1.0 / (2.0 * Bg);
+    const size_t seg = nb <= pack_segment(c, B) ? nb : pack_segment(c, B);
+    auto slot = [&](size_t j) { return ((j / seg) % 2) * seg + j % seg; };
+    auto xb = [&](size_t j) { return (const void*)((const char*)c->xpack.p + slot(j) * G * B * 16 * es); };
+    auto yb = [&](size_t j) { return (const void*)((const char*)c->ypack.p + slot(j) * B * Cc * es); };
+    auto pack = [&](size_t j0) { return launch_pack<T>(c, X, Y, perm, B, j0, (nb - j0 < seg ? nb - j0 : seg), (int)((j0 / seg) % 2), seg); };
+    const int grid = (int)G + pipe_extra_wgs(nd);
+    const size_t lds = p2_a_lds_elems() * sizeof(T);
+    const int n_loss = (int)((B + kPipeTs - 1) / kPipeTs);
+    T* a1 = (T*)c->p2buf.p; T* d1 = a1 + B * kP2H; T* d2 = d1 + B * kP2H;
+    RCN_TRY(pack(0));
+    RCN_TRY(launch_pipe_a<T>(c, xb(0), xb(0), B, 0.0, nullptr, 0.0, false, true));      // partial z_1 of the first batch, current W_0
+    for (size_t j = 0; j < nb; ++j) {
+        RCN_TRY(launch_pipe_b<T>(c, yb(j), B));
+        const bool more = j + 1 < nb;
+        if (more && (j + 1) % seg == 0) RCN_TRY(pack(j + 1));
+        const unsigned seq = in_graph ? (unsigned)(j + 1) : ++q.seq;       // offset from the base, or the number itself
+        hipLaunchKernelGGL((k_p2_dp_grad<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (const T*)xb(j), (int)B, (const T*)a1, (const T*)d1,
+                           (const T*)d2, (T*)q.local_buf, q.stride, seq_base, seq, (int)G, (const T*)c->loss_part.p, n_loss, (T)loss_scale);
+        HIP_TRY(c, hipGetLastError());
+        T* lj = loss_dev ? (T*)loss_dev + j : nullptr;
+        hipLaunchKernelGGL((k_p2_dp_apply<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)(more ? xb(j + 1) : xb(j)),
+                           (int)B, (T)scale, (T*)c->slab.p, (int)G, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev, kP2PTimeoutTicks);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return RCN_HIP_OK;
+}
+
 // `iters` exchanges of a known integer pattern; counts wrong sums and reads the timeout word.  Collective.
 int p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* err) {
     auto& q = c->p2p;
@@ -578,6 +619,8 @@ int p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* err)
 void drop_graphs(rcn_hip_ctx* c) {
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
+    for (auto& kv : c->dp_graphs) (void)hipGraphExecDestroy(kv.second);
+    c->dp_graphs.clear();
 }
 
 }  // namespace
@@ -1330,6 +1373,42 @@ int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, con
     char* gbuf = (char*)c->grad.p;
     void* lslot = gbuf + P * es;
     const bool f64 = c->dtype == RCN_HIP_F64;
+    if (c->p2p.on && c->dense_path != 1 && p2_supported(c->nd, B)) {
+        // the lean pipeline with the exchange inside its third kernel (dense_p2_dp.hpp)
+        RCN_TRY(ensure_pipe_ws(c, B));
+        RCN_TRY(ensure_pack_ws(c, B, nb));
+        // captured once per (pointers, B, n_batches, eta) and replayed: three launches per step would otherwise be bound by the
+        // host's launch rate (~6 us each), not by the GPU.  Sequence numbers inside the graph are offsets from a device word.
+        const char* ge = std::getenv("RCN_HIP_DP_GRAPH");
+        if (ge && ge[0] == '0') {
+            RCN_TRY(f64 ? enqueue_pipe_steps_dp<double>(c, X, Y, perm, B, nb, eta, loss_dev, false)
+                        : enqueue_pipe_steps_dp<float>(c, X, Y, perm, B, nb, eta, loss_dev, false));
+        } else {
+            const EpochKey key{X, Y, perm, B, nb, eta, loss_dev};
+            auto it = c->dp_graphs.find(key);
+            if (it == c->dp_graphs.end()) {
+                hipGraph_t graph = nullptr;
+                HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                const int st = f64 ? enqueue_pipe_steps_dp<double>(c, X, Y, perm, B, nb, eta, loss_dev, true)
+                                   : enqueue_pipe_steps_dp<float>(c, X, Y, perm, B, nb, eta, loss_dev, true);
+                hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (st != RCN_HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+                HIP_TRY(c, e);
+                hipGraphExec_t exec = nullptr;
+                e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                HIP_TRY(c, e);
+                if (c->dp_graphs.size() >= 16) drop_graphs(c);
+                it = c->dp_graphs.emplace(key, exec).first;
+            }
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, c->stream, c->p2p.err_dev + 16, c->p2p.seq);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
+            c->p2p.seq += (unsigned)nb;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->p2p.err_host, c->p2p.err_dev, 4, hipMemcpyDeviceToHost, c->stream));   // read at the next call
+        return RCN_HIP_OK;
+    }
     if (c->p2p.on) {
         // gradient kernels write straight into this rank's exported slot; ONE kernel then waits for the peers' flags, reads
         // all `world` slots over xGMI, adds them in rank order and applies the update (dp_p2p.hpp)

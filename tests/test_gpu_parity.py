@@ -476,15 +476,18 @@ def test_native_rccl_epoch_world1_matches_oracle(amd, oracle, dtype):
     d.rcn.close()
 
 
-@pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
-def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, tmp_path):
+@pytest.mark.parametrize("dtype,Bs,nb", [(1, 16, 4), (0, 16, 4), (1, 256, 3), (0, 256, 3)],
+                         ids=["f64-sample-tile", "f32-sample-tile", "f64-pipeline", "f32-pipeline"])
+def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, tmp_path):
     """The xGMI peer-read all-reduce (csrc/dp_p2p.hpp) between two PROCESSES (hipIpc handles carried by gloo), both on this
     box's one GPU: the known-answer self-test is exact, both replicas end bit-identical, and two epochs of the sharded
     loop equal the oracle's sequential train_batch on the concatenated global batches."""
     import socket
     import subprocess
     import sys
-    dims, Bs, nb, world = [784, 30, 10], 16, 4, 2
+    # shard batch 16: sample-tile gradient kernels + k_p2p_allreduce; shard batch 256: the feature-sliced pipeline with the
+    # exchange inside its third kernel (dense_p2_dp.hpp)
+    dims, world = [784, 30, 10], 2
     rng = np.random.default_rng(31)
     Xs = [np.maximum(rng.standard_normal((Bs * nb, dims[0])), 0.0) for _ in range(world)]
     Ys = [one_hot(rng.integers(0, dims[-1], Bs * nb), dims[-1]) for _ in range(world)]
