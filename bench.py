@@ -110,7 +110,7 @@ def main():
     import mercer_research_amd as amd
     from mercer_research_amd.device import DeviceRCN
     from mercer_research_amd.dp import DataParallelStep
-    from oracle.rcn_oracle import synthetic_images, synthetic_params   # data generator only (shared with the tests)
+    from mercer_research_amd.synth import synthetic_images, synthetic_params
 
     dtype = amd.F64 if args.dtype == "f64" else amd.F32
     d = DeviceRCN(classes=10, feedforward_cfg=[30], input_shape=(28, 28), dtype=dtype, device=local_rank)

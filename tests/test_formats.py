@@ -209,3 +209,15 @@ def test_cpp_png_decoder_matches_python(format_check, tmp_path):
     f16 = tmp_path / "g16.png"
     f16.write_bytes(_png(2, 2, 16, 0, _filter_rows(np.zeros((2, 4), dtype=np.uint8), 2, [0])))
     assert subprocess.run([format_check, "png", str(f16)], capture_output=True).returncode == 3
+
+
+def test_product_and_oracle_synthetic_generators_agree():
+    """bench.py draws its workload from mercer_research_amd.synth (the product never imports oracle/); the tests draw from the
+    oracle's copy.  Same seeds must give the same arrays."""
+    from mercer_research_amd import synth
+    from oracle import rcn_oracle as ro
+    a, la = synth.synthetic_images(50, seed=7)
+    b, lb = ro.synthetic_images(50, seed=7)
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
+    for (wa, ba), (wb, bb) in [(synth.synthetic_params([784, 30, 10], seed=3), ro.synthetic_params([784, 30, 10], seed=3))]:
+        assert all(np.array_equal(x, y) for x, y in zip(wa + ba, wb + bb))

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from mercer_research_amd.device import DeviceRCN
-from oracle.rcn_oracle import synthetic_params
+from mercer_research_amd.synth import synthetic_params
 d = DeviceRCN()
 ws, bs = synthetic_params([784, 30, 10], seed=42)
 d.set_params(ws, bs)

@@ -16,7 +16,7 @@ def worker(rank, world, port):
     import torch
     import torch.distributed as dist
     from mercer_research_amd.device import DeviceRCN
-    from oracle.rcn_oracle import synthetic_images, synthetic_params   # data generator only
+    from mercer_research_amd.synth import synthetic_images, synthetic_params
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     N, B = 16384, 256
     d = DeviceRCN(dtype=0)

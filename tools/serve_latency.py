@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import mercer_research_amd as amd
-from oracle.rcn_oracle import synthetic_images, synthetic_params
+from mercer_research_amd.synth import synthetic_images, synthetic_params
 imgs, _ = synthetic_images(256, seed=3)
 ws, bs = synthetic_params([784, 30, 10], seed=42)
 for dtype, name in ((amd.F32, "f32"), (amd.F64, "f64")):

@@ -12,7 +12,7 @@ subprocess.run([hb.hipcc()] + hb.FLAGS + ["-DRCN_STAMPS", "-o", out, os.path.joi
 _lib.LIB_PATH = out
 import torch
 from mercer_research_amd.device import DeviceRCN
-from oracle.rcn_oracle import synthetic_params
+from mercer_research_amd.synth import synthetic_params
 d = DeviceRCN()
 lib = d.lib
 lib.rcn_hip_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
