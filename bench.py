@@ -170,7 +170,8 @@ def main():
             args.dp_impl = "native" if native else "torch"
         if native:
             d.dp_broadcast_params(0)
-            allreduce_kind = "xgmi peer-read kernel (csrc/dp_p2p.hpp), fused with the update" if d.dp_p2p_active() else "ncclAllReduce (RCCL)"
+            allreduce_kind = {0: "ncclAllReduce (RCCL)", 1: "xgmi peer reads between kernels, fused with the update (csrc/dense_p2_dp.hpp, 3 kernels/step)",
+                              2: "xgmi peer reads inside the gradient kernel (csrc/dense_p2_dp.hpp, 2 kernels/step)"}[d.dp_p2p_mode()]
 
             def run(k: int):
                 # the whole loop is native: per step gradient kernels -> ncclAllReduce -> update, enqueued by

@@ -210,7 +210,7 @@ int  rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void*
 int  rcn_hip_dp_p2p_export(rcn_hip_ctx* ctx, void* handles_out /* RCN_HIP_DP_P2P_HANDLE_BYTES */);
 int  rcn_hip_dp_p2p_attach(rcn_hip_ctx* ctx, const void* all_handles /* world x RCN_HIP_DP_P2P_HANDLE_BYTES */, int rank, int world);
 int  rcn_hip_dp_p2p_selftest(rcn_hip_ctx* ctx, int iters, unsigned* mismatches, unsigned* timed_out);
-int  rcn_hip_dp_p2p_active(const rcn_hip_ctx* ctx);
+int  rcn_hip_dp_p2p_active(const rcn_hip_ctx* ctx);   /* 0 ncclAllReduce, 1 peer exchange at kernel boundaries, 2 also inside the gradient kernel */
 /* classify_test (rcn.rs:105-116) for n samples: a <- sigmoid(W a + b) through every layer. out: n x classes */
 int  rcn_hip_forward(rcn_hip_ctx* ctx, const double* x, size_t n, double* out);
 int  rcn_hip_forward_dev(rcn_hip_ctx* ctx, const void* x_dev, size_t n, void* out_dev);

@@ -205,6 +205,224 @@ __global__ __launch_bounds__(kDenseThreads) void k_p2_dp_apply(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two kernels per step: the exchange INSIDE the gradient kernel, on self-validating words.
+//
+// k_p2_dp_fused = k_p2_a with the peer exchange between its two halves.  Every thread owns one parameter; it needs from
+// each peer exactly that parameter's partial gradient, produced by the peer's thread of the same index.  Flags plus
+// fences would make that a release/acquire problem across GPUs inside a running kernel (tried: __threadfence_system
+// costs an L2 write-back per workgroup, +8 us per step).  Instead each value travels WITH its step number in one 8-byte
+// word -- {value bits, seq} for f32, two words {half, seq} for f64 -- written by one system-scope atomic store and polled
+// by the consumer until the tag equals the step it is in (the "LL" idea of NCCL's low-latency protocol).  A word is
+// single-copy atomic, so tag == seq implies the value is this step's; there is no flag, no fence and no barrier in the
+// exchange, and its latency is one store propagation plus one load.  Slots alternate by step parity exactly like the
+// kernel-boundary protocol (a word is next overwritten at step s+2, which its writer reaches only after every peer has
+// produced step s+1, i.e. finished consuming step s), tags never repeat, every poll is bounded by the wall clock.
+// rcn_hip_dp_init gives this form its own known-answer exchange (k_p2p_ll_selftest: same primitives) and its own vote.
+using u64 = unsigned long long;
+template <typename T> struct LLWords;
+template <> struct LLWords<float> { static constexpr int n = 1; };
+template <> struct LLWords<double> { static constexpr int n = 2; };
+
+template <typename T>
+__device__ inline u64* ll_region(void* rank_buf, size_t stride) { return reinterpret_cast<u64*>(reinterpret_cast<T*>(rank_buf) + 2 * stride); }   // behind the plain slots
+
+__device__ inline void ll_store(u64* words, size_t idx, float v, unsigned seq) {
+    unsigned b; __builtin_memcpy(&b, &v, 4);
+    __hip_atomic_store(words + idx, ((u64)seq << 32) | b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline void ll_store(u64* words, size_t idx, double v, unsigned seq) {
+    u64 b; __builtin_memcpy(&b, &v, 8);
+    __hip_atomic_store(words + 2 * idx, ((u64)seq << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(words + 2 * idx + 1, ((u64)seq << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline bool ll_poll(const u64* words, size_t idx, unsigned seq, float& out) {
+    const u64 w = __hip_atomic_load(words + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned b = (unsigned)w;
+    __builtin_memcpy(&out, &b, 4);
+    return (unsigned)(w >> 32) == seq;
+}
+__device__ inline bool ll_poll(const u64* words, size_t idx, unsigned seq, double& out) {
+    const u64 lo = __hip_atomic_load(words + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const u64 hi = __hip_atomic_load(words + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const u64 b = (lo & 0xffffffffull) | (hi << 32);
+    __builtin_memcpy(&out, &b, 8);
+    return (unsigned)(lo >> 32) == seq && (unsigned)(hi >> 32) == seq;
+}
+
+// value `idx` of slot `seq & 1` summed over the ranks in rank order: own from the register, the peers' polled out of their
+// HBM.  false: a peer's word did not arrive within the timeout.
+template <typename T>
+__device__ inline bool ll_gather_sum(const P2PDesc& d, size_t stride, size_t idx, unsigned seq, T own, long long timeout_ticks, T& sum) {
+    T v[kP2PMaxWorld];
+    unsigned ready = 1u << d.rank;
+    const unsigned all = (1u << d.world) - 1u;
+    const size_t at = (size_t)(seq & 1u) * stride + idx;
+    const long long t0 = wall_clock64();
+    while (ready != all) {
+#pragma unroll
+        for (int q = 0; q < kP2PMaxWorld; ++q)
+            if (q < d.world && !((ready >> q) & 1u)) {
+                T x;
+                if (ll_poll(ll_region<T>(d.buf[q], stride), at, seq, x)) { v[q] = x; ready |= 1u << q; }
+            }
+        if (ready != all && wall_clock64() - t0 > timeout_ticks) return false;
+    }
+    T g = 0;
+#pragma unroll
+    for (int q = 0; q < kP2PMaxWorld; ++q) g += q < d.world ? (q == d.rank ? own : v[q]) : (T)0;
+    sum = g;
+    return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kDenseThreads) void k_p2_dp_fused(
+    NetDesc nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B, const T* __restrict__ a1,
+    const T* __restrict__ d1, const T* __restrict__ d2, T scale, T* __restrict__ slab, int G, const T* __restrict__ loss_part, int n_loss,
+    T loss_scale, T* __restrict__ loss_out, int do_fwd, P2PDesc d, const unsigned* __restrict__ seq_base, unsigned seq_off, size_t stride,
+    unsigned* __restrict__ err, long long timeout_ticks, T* __restrict__ tail_scratch) {
+    using acc_t = typename Mfma16<T>::acc_t;
+    using vec4 = typename Vec4<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);
+    int& s_bad = *reinterpret_cast<int*>(red + kDenseWaves * kMtp * kRedTile + 16 * kP2H);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
+    const int F = nd.dims[0], H = nd.dims[1];
+    const unsigned seq = (seq_base ? *seq_base : 0u) + seq_off;
+    u64* __restrict__ mine = ll_region<T>(d.buf[d.rank], stride) + (size_t)(seq & 1u) * stride * LLWords<T>::n;
+    if (tid == 0) s_bad = *err != 0u ? 2 : 0;
+    __syncthreads();
+    if (s_bad == 2) return;
+
+    if ((int)blockIdx.x >= G) {
+        // tail tile e: db_0 (e == 0) or 16 columns of [W_1 | b_1]; its parameters are one contiguous run.  The tile's sums go
+        // through a local scratch image (wgrad_tile_ld ends on a barrier), from where each thread publishes and consumes its own
+        const int e = (int)blockIdx.x - G;
+        const int j = e == 0 ? 0 : 1, n0 = e == 0 ? F : (e - 1) * 16;
+        if (e == 0) wgrad_tile_ld<T, false>(nd, 0, F, (T*)nullptr, tail_scratch, (const T*)nullptr, 0, (const int*)nullptr, d1, kP2H, B, (T)0, red);
+        else        wgrad_tile_ld<T, false>(nd, 1, n0, (T*)nullptr, tail_scratch, a1, kP2H, (const int*)nullptr, d2, kP2C, B, (T)0, red);
+        const int Kin = nd.dims[j], M = nd.dims[j + 1];
+        const int c1 = n0 + 16 < Kin + 1 ? n0 + 16 : Kin + 1;                    // columns n0 .. c1-1 of [W_j | b_j] (bias = column Kin)
+        const int p0 = nd.w_off[j] + n0 * M, cnt = (c1 - n0) * M;
+        bool ok = true;
+        for (int i = tid; i < cnt; i += kDenseThreads) ll_store(mine, (size_t)(p0 + i), tail_scratch[p0 + i], seq);
+        T own_loss = 0;
+        if (e == 0 && tid == 0) { finish_loss<T>(loss_part, n_loss, loss_scale, &own_loss); ll_store(mine, (size_t)nd.P, own_loss, seq); }
+        for (int i = tid; i < cnt; i += kDenseThreads) {
+            T g;
+            if (ll_gather_sum<T>(d, stride, (size_t)(p0 + i), seq, tail_scratch[p0 + i], timeout_ticks, g)) params[p0 + i] = params[p0 + i] - scale * g;   // rcn.rs:214,221
+            else ok = false;
+        }
+        if (e == 0 && tid == 0) {
+            T g;
+            if (ll_gather_sum<T>(d, stride, (size_t)nd.P, seq, own_loss, timeout_ticks, g)) { if (loss_out) *loss_out = g; }
+            else ok = false;
+        }
+        if (!ok) *err = 1u + (unsigned)d.rank;
+        return;
+    }
+
+    const int f0 = (int)blockIdx.x * 16;
+    const int nf = F - f0 < 16 ? F - f0 : 16;
+    T* wsl = red + kDenseWaves * kMtp * kRedTile;
+    T* W0 = params + nd.w_off[0];
+    const T* __restrict__ cp = Xp + (size_t)blockIdx.x * B * 16;
+    const T* __restrict__ cn = Xn + (size_t)blockIdx.x * B * 16;
+    const int ntile = B >> 4;
+    vec4 xn[2];
+    if (do_fwd) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xn[u] = *reinterpret_cast<const vec4*>(cn + (size_t)(16 * (wave + 8 * u) + n) * 16 + 4 * g4);
+    }
+    {
+        // ---- U: this shard's dW_0[:, slice]                                                      rcn.rs:310
+        const int ml = tid & 15, cl = (tid >> 4) & 15, mt = tid >> 8;
+        const int m = mt * 16 + ml;
+        const bool wvalid = m < H && cl < nf;
+        const size_t off = (size_t)(f0 + (cl < nf ? cl : 0)) * H + (m < H ? m : 0);
+        const T wold = W0[off];
+        acc_t acc[kMtp];
+#pragma unroll
+        for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
+        const int kw = B >> 3;
+        for (int kc = wave * kw; kc < (wave + 1) * kw; kc += 32) {
+            const T* xb = cp + (size_t)(kc + g4) * 16 + n;
+            const T* db = d1 + (size_t)(kc + g4) * kP2H + n;
+            T bv[8], av[8][kMtp];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                bv[q] = xb[q * 64];
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) av[q][t] = db[q * 4 * kP2H + t * 16];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(av[q][t], bv[q], acc[t]);
+        }
+        store_partials<T>(red, wave, lane, acc);
+        __syncthreads();
+        const T gsum = sum_partials<T>(red, mt, cl, ml);
+        // ---- publish, gather, W_0 <- W_0 - (eta / B_global) * sum over ranks                        rcn.rs:214
+        T g = gsum;
+        bool ok = true;
+        if (wvalid) {
+            ll_store(mine, (size_t)nd.w_off[0] + off, gsum, seq);
+            ok = ll_gather_sum<T>(d, stride, (size_t)nd.w_off[0] + off, seq, gsum, timeout_ticks, g);
+        }
+        if (!ok) { s_bad = 1; *err = 1u + (unsigned)d.rank; }
+        __syncthreads();
+        if (s_bad) return;
+        const T w = wold - scale * g;
+        if (wvalid) W0[off] = w;
+        wsl[cl * kP2H + m] = wvalid ? w : (T)0;
+    }
+    __syncthreads();
+    if (!do_fwd) return;
+    // ---- F: partial z_1 of the new batch (k_p2_a's F half)
+    T wf[4][kMtp];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < kMtp; ++t) wf[i][t] = wsl[(4 * g4 + i) * kP2H + t * 16 + n];
+    for (int tb = 0; tb < ntile; tb += 16) {
+        if (tb > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) xn[u] = *reinterpret_cast<const vec4*>(cn + (size_t)(16 * (tb + wave + 8 * u) + n) * 16 + 4 * g4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = 16 * (tb + wave + 8 * u) + n;
+            acc_t acc[kMtp];
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(wf[i][t], xn[u][i], acc[t]);
+            T* dst = slab + (((size_t)(s >> 3) * G + blockIdx.x) * kP2Ts + (s & 7)) * kP2H;
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) store4<T>(dst + t * 16, lane, acc[t]);
+        }
+    }
+}
+
+// known-answer exchange on exactly these primitives: every thread publishes one pattern value and gathers the sum
+template <typename T>
+__global__ __launch_bounds__(256) void k_p2p_ll_selftest(P2PDesc d, unsigned seq, size_t stride, unsigned* __restrict__ err,
+                                                         long long timeout_ticks, unsigned* __restrict__ mismatches) {
+    if (*err != 0u) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= stride) return;
+    const T own = (T)p2p_pattern(d.rank, seq, i);
+    ll_store(ll_region<T>(d.buf[d.rank], stride) + (size_t)(seq & 1u) * stride * LLWords<T>::n, i, own, seq);
+    T got;
+    if (!ll_gather_sum<T>(d, stride, i, seq, own, timeout_ticks, got)) { *err = 1u + (unsigned)d.rank; return; }
+    T want = 0;
+    for (int q = 0; q < d.world; ++q) want += (T)p2p_pattern(q, seq, i);
+    if (got != want) atomicAdd(mismatches, 1u);
+}
+
 __global__ void k_set_u32(unsigned* p, unsigned v) { *p = v; }
 
 }  // namespace rcn

@@ -79,7 +79,8 @@ struct rcn_hip_ctx {
     int dp_rank = 0, dp_world = 1;
     struct P2P {                            // peer-read all-reduce over xGMI (dp_p2p.hpp)
         bool exported = false, attached = false, on = false;
-        void* local_buf = nullptr;          // [2][stride] values, ordinary device memory
+        bool fused = false;                 // the exchange may run inside the gradient kernel (passed its own known-answer vote)
+        void* local_buf = nullptr;          // [2][stride] values + [2][stride] tagged words, ordinary device memory
         unsigned* local_flags = nullptr;    // [kP2PMaxWorld], uncached device memory
         void* peer_buf[rcn::kP2PMaxWorld] = {};
         unsigned* peer_flags[rcn::kP2PMaxWorld] = {};
@@ -485,7 +486,8 @@ int p2p_export(rcn_hip_ctx* c, void* out) {
     auto& q = c->p2p;
     if (q.exported) p2p_release(c);
     q.stride = (((size_t)c->nd.P + 1) + 3) & ~(size_t)3;
-    const size_t bytes = 2 * q.stride * c->esz();
+    // [2 plain slots | 2 slots of self-validating words, 2 * esz bytes per value]  (dp_p2p.hpp / dense_p2_dp.hpp)
+    const size_t bytes = 6 * q.stride * c->esz();
     HIP_TRY(c, hipMalloc(&q.local_buf, bytes));
     HIP_TRY(c, hipExtMallocWithFlags((void**)&q.local_flags, 4096, hipDeviceMallocUncached));
     HIP_TRY(c, hipMalloc((void**)&q.err_dev, 256));
@@ -548,7 +550,7 @@ int p2p_step(rcn_hip_ctx* c, int mode, double scale, void* loss_out, long long t
 // the exchange happens inside the third kernel, which also computes the next batch's partial z_1.
 template <typename T>
 int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev,
-                          bool in_graph) {
+                          bool in_graph, bool fused) {
     auto& q = c->p2p;
     const unsigned* seq_base = in_graph ? q.err_dev + 16 : nullptr;     // set by the caller before each replay
     const NetDesc& nd = c->nd;
@@ -571,10 +573,18 @@ int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const in
         const bool more = j + 1 < nb;
         if (more && (j + 1) % seg == 0) RCN_TRY(pack(j + 1));
         const unsigned seq = in_graph ? (unsigned)(j + 1) : ++q.seq;       // offset from the base, or the number itself
+        T* lj = loss_dev ? (T*)loss_dev + j : nullptr;
+        if (fused) {
+            hipLaunchKernelGGL((k_p2_dp_fused<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)xb(j),
+                               (const T*)(more ? xb(j + 1) : xb(j)), (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, (int)G,
+                               (const T*)c->loss_part.p, n_loss, (T)loss_scale, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev,
+                               kP2PTimeoutTicks, (T*)c->grad.p);
+            HIP_TRY(c, hipGetLastError());
+            continue;
+        }
         hipLaunchKernelGGL((k_p2_dp_grad<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (const T*)xb(j), (int)B, (const T*)a1, (const T*)d1,
                            (const T*)d2, (T*)q.local_buf, q.stride, seq_base, seq, (int)G, (const T*)c->loss_part.p, n_loss, (T)loss_scale);
         HIP_TRY(c, hipGetLastError());
-        T* lj = loss_dev ? (T*)loss_dev + j : nullptr;
         hipLaunchKernelGGL((k_p2_dp_apply<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)(more ? xb(j + 1) : xb(j)),
                            (int)B, (T)scale, (T*)c->slab.p, (int)G, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev, kP2PTimeoutTicks);
         HIP_TRY(c, hipGetLastError());
@@ -611,6 +621,30 @@ int p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* err)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // The slots keep the last patterns: peers may still be reading them, and nothing depends on their contents -- the
     // gradient kernels overwrite [0, P] every step and the reduce ignores the padding beyond P.
+    *mismatches = host[0];
+    *err = host[1];
+    return RCN_HIP_OK;
+}
+
+// the same for the in-kernel exchange of k_p2_dp_fused (self-validating tagged words).  Collective.
+int p2p_selftest_fused(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* err) {
+    auto& q = c->p2p;
+    if (!q.attached) return fail(c, RCN_HIP_ERR_STATE, "p2p_selftest: not attached");
+    HIP_TRY(c, q.mism.ensure(64));
+    HIP_TRY(c, hipMemsetAsync(q.mism.p, 0, 64, c->stream));
+    const int wgs = (int)((q.stride + 255) / 256);
+    for (int it = 0; it < iters; ++it) {
+        const unsigned seq = ++q.seq;
+        if (c->dtype == RCN_HIP_F64)
+            hipLaunchKernelGGL((k_p2p_ll_selftest<double>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, kP2PTimeoutTicks, (unsigned*)q.mism.p);
+        else
+            hipLaunchKernelGGL((k_p2p_ll_selftest<float>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, kP2PTimeoutTicks, (unsigned*)q.mism.p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    unsigned host[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&host[0], q.mism.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&host[1], q.err_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     *mismatches = host[0];
     *err = host[1];
     return RCN_HIP_OK;
@@ -1257,7 +1291,19 @@ static int p2p_bootstrap_over_rccl(rcn_hip_ctx* c) {
         unsigned bad = 0, err = 0;
         ok = (p2p_selftest(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0) ? 1 : 0;
         if ((st = vote(ok)) != RCN_HIP_OK) break;            // did every rank see exact sums, without a timeout?
-        if (ok) c->p2p.on = true;
+        if (!ok) break;
+        c->p2p.on = true;
+        // second, independent question: may the exchange also run INSIDE the gradient kernel (tagged words, no flags)?  A failed
+        // wait here leaves the sticky error word set, which would disable the kernel-boundary protocol too, so it is cleared
+        // (after every rank has drained: the vote synchronises) when only this stage failed.
+        const char* fe = std::getenv("RCN_HIP_DP_FUSED");
+        int okf = (fe && fe[0] == '0') ? 0 : 1;
+        if ((st = vote(okf)) != RCN_HIP_OK) break;           // every rank must want it (same environment everywhere, normally)
+        if (!okf) break;
+        okf = (p2p_selftest_fused(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0) ? 1 : 0;
+        if ((st = vote(okf)) != RCN_HIP_OK) break;
+        if (okf) c->p2p.fused = true;
+        else if (hipMemsetAsync(c->p2p.err_dev, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) c->p2p.on = false;
     } while (0);
     xch.release();
     if (!c->p2p.on) { const int rk = c->dp_rank, w = c->dp_world; p2p_release(c); c->dp_rank = rk; c->dp_world = w; }
@@ -1333,10 +1379,21 @@ int rcn_hip_dp_p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, uns
     RCN_TRY(check_ctx(c));
     if (!mismatches || !timed_out || iters < 1) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_p2p_selftest: bad arguments");
     DevGuard g(c->device);
-    return p2p_selftest(c, iters, mismatches, timed_out);
+    RCN_TRY(p2p_selftest(c, iters, mismatches, timed_out));
+    if (*mismatches || *timed_out) { c->p2p.on = false; return RCN_HIP_OK; }
+    // the in-kernel form of the exchange, same verdict rule (the caller's ranks see the same result and decide alike)
+    const char* fe = std::getenv("RCN_HIP_DP_FUSED");
+    unsigned bad2 = 0, to2 = 0;
+    if (!(fe && fe[0] == '0')) {
+        RCN_TRY(p2p_selftest_fused(c, iters, &bad2, &to2));
+        c->p2p.fused = bad2 == 0 && to2 == 0;
+    }
+    *mismatches += bad2;
+    *timed_out |= to2;
+    return RCN_HIP_OK;
 }
 
-int rcn_hip_dp_p2p_active(const rcn_hip_ctx* c) { return c && c->p2p.on ? 1 : 0; }
+int rcn_hip_dp_p2p_active(const rcn_hip_ctx* c) { return c && c->p2p.on ? (c->p2p.fused ? 2 : 1) : 0; }
 
 int rcn_hip_dp_world(const rcn_hip_ctx* c) { return c ? c->dp_world : 0; }
 int rcn_hip_dp_rank(const rcn_hip_ctx* c) { return c ? c->dp_rank : -1; }
@@ -1381,16 +1438,16 @@ int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, con
         // host's launch rate (~6 us each), not by the GPU.  Sequence numbers inside the graph are offsets from a device word.
         const char* ge = std::getenv("RCN_HIP_DP_GRAPH");
         if (ge && ge[0] == '0') {
-            RCN_TRY(f64 ? enqueue_pipe_steps_dp<double>(c, X, Y, perm, B, nb, eta, loss_dev, false)
-                        : enqueue_pipe_steps_dp<float>(c, X, Y, perm, B, nb, eta, loss_dev, false));
+            RCN_TRY(f64 ? enqueue_pipe_steps_dp<double>(c, X, Y, perm, B, nb, eta, loss_dev, false, c->p2p.fused)
+                        : enqueue_pipe_steps_dp<float>(c, X, Y, perm, B, nb, eta, loss_dev, false, c->p2p.fused));
         } else {
             const EpochKey key{X, Y, perm, B, nb, eta, loss_dev};
             auto it = c->dp_graphs.find(key);
             if (it == c->dp_graphs.end()) {
                 hipGraph_t graph = nullptr;
                 HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                const int st = f64 ? enqueue_pipe_steps_dp<double>(c, X, Y, perm, B, nb, eta, loss_dev, true)
-                                   : enqueue_pipe_steps_dp<float>(c, X, Y, perm, B, nb, eta, loss_dev, true);
+                const int st = f64 ? enqueue_pipe_steps_dp<double>(c, X, Y, perm, B, nb, eta, loss_dev, true, c->p2p.fused)
+                                   : enqueue_pipe_steps_dp<float>(c, X, Y, perm, B, nb, eta, loss_dev, true, c->p2p.fused);
                 hipError_t e = hipStreamEndCapture(c->stream, &graph);
                 if (st != RCN_HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
                 HIP_TRY(c, e);

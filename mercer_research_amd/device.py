@@ -176,6 +176,10 @@ class DeviceRCN:
         """True when the loop's all-reduce is the one-shot xGMI peer-read kernel (csrc/dp_p2p.hpp), False on ncclAllReduce."""
         return bool(self.lib.rcn_hip_dp_p2p_active(self.ctx))
 
+    def dp_p2p_mode(self) -> int:
+        """0 ncclAllReduce; 1 peer exchange between kernels; 2 peer exchange inside the gradient kernel (two kernels per step)."""
+        return int(self.lib.rcn_hip_dp_p2p_active(self.ctx))
+
     def dp_p2p_setup(self, group=None, selftest_iters: int = 8):
         """The peer all-reduce with the handle exchange carried by torch.distributed (any backend, e.g. gloo) instead of
         RCCL: export -> all_gather -> attach -> known-answer self-test.  Collective.  Returns (mismatches, timed_out)."""

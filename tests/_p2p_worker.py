@@ -31,7 +31,7 @@ def main():
     d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, None)           # a second call: sequence numbers carry over
     gw, gb = d.get_params()
     d.synchronize()
-    np.savez(os.path.join(outdir, f"out{rank}.npz"), bad=bad, timed_out=timed_out, active=int(d.dp_p2p_active()), loss=loss.cpu().numpy(),
+    np.savez(os.path.join(outdir, f"out{rank}.npz"), bad=bad, timed_out=timed_out, active=d.dp_p2p_mode(), loss=loss.cpu().numpy(),
              **{f"w{i}": w for i, w in enumerate(gw)}, **{f"b{i}": b for i, b in enumerate(gb)})
     dist.barrier()                                             # nobody unmaps while a peer may still read
     d.dp_finalize()

@@ -476,9 +476,10 @@ def test_native_rccl_epoch_world1_matches_oracle(amd, oracle, dtype):
     d.rcn.close()
 
 
-@pytest.mark.parametrize("dtype,Bs,nb", [(1, 16, 4), (0, 16, 4), (1, 256, 3), (0, 256, 3)],
-                         ids=["f64-sample-tile", "f32-sample-tile", "f64-pipeline", "f32-pipeline"])
-def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, tmp_path):
+@pytest.mark.parametrize("dtype,Bs,nb,fused", [(1, 16, 4, 1), (0, 16, 4, 1), (1, 256, 3, 0), (0, 256, 3, 0), (1, 256, 3, 1), (0, 256, 3, 1)],
+                         ids=["f64-sample-tile", "f32-sample-tile", "f64-pipeline-3-kernels", "f32-pipeline-3-kernels",
+                              "f64-pipeline-exchange-in-kernel", "f32-pipeline-exchange-in-kernel"])
+def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused, tmp_path):
     """The xGMI peer-read all-reduce (csrc/dp_p2p.hpp) between two PROCESSES (hipIpc handles carried by gloo), both on this
     box's one GPU: the known-answer self-test is exact, both replicas end bit-identical, and two epochs of the sharded
     loop equal the oracle's sequential train_batch on the concatenated global batches."""
@@ -486,7 +487,7 @@ def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, tmp_pa
     import subprocess
     import sys
     # shard batch 16: sample-tile gradient kernels + k_p2p_allreduce; shard batch 256: the feature-sliced pipeline with the
-    # exchange inside its third kernel (dense_p2_dp.hpp)
+    # exchange either in a third kernel (k_p2_dp_grad / k_p2_dp_apply) or inside the gradient kernel (k_p2_dp_fused)
     dims, world = [784, 30, 10], 2
     rng = np.random.default_rng(31)
     Xs = [np.maximum(rng.standard_normal((Bs * nb, dims[0])), 0.0) for _ in range(world)]
@@ -496,7 +497,7 @@ def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, tmp_pa
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_p2p_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RCN_HIP_DP_FUSED=str(fused))
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(dtype), str(tmp_path)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
@@ -510,7 +511,7 @@ def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, tmp_pa
     assert all(pr.returncode == 0 for pr in procs), "\n----\n".join(logs)
     outs = [np.load(tmp_path / f"out{r}.npz") for r in range(world)]
     for o in outs:
-        assert int(o["bad"]) == 0 and int(o["timed_out"]) == 0 and int(o["active"]) == 1
+        assert int(o["bad"]) == 0 and int(o["timed_out"]) == 0 and int(o["active"]) == (2 if fused else 1)
     for k in ("w0", "w1", "b0", "b1", "loss"):
         assert np.array_equal(outs[0][k], outs[1][k]), k            # rank-order sums: replicas are bit-identical
     ws, bs = synthetic_params(dims, seed=17)
