@@ -173,6 +173,17 @@ def main():
             allreduce_kind = {0: "ncclAllReduce (RCCL)", 1: "xgmi peer reads between kernels, fused with the update (csrc/dense_p2_dp.hpp, 3 kernels/step)",
                               2: "xgmi peer reads inside the gradient kernel (csrc/dense_p2_dp.hpp, 2 kernels/step)"}[d.dp_p2p_mode()]
 
+            def prime(k: int):
+                """instantiate the graphs run(k) will replay from the current position (set-up, untimed, not collective)"""
+                pos, done, seen = step_no[0] % nb_epoch, 0, set()
+                while done < k:
+                    take = min(nb_epoch - pos, k - done)
+                    if (pos, take) not in seen:
+                        seen.add((pos, take))
+                        d.dp_prepare_epoch(X, Y, perm[pos * B:], B, take, ETA, None)
+                    done += take
+                    pos = (pos + take) % nb_epoch
+
             def run(k: int):
                 # the whole loop is native: per step gradient kernels -> ncclAllReduce -> update, enqueued by
                 # rcn_hip_dp_train_epoch_dev; Python only starts each pass (one in-stream shuffle + one call per 64 steps)
@@ -208,10 +219,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if not use_dp:
+    can_prime = (not use_dp) or (use_dp and args.dp_impl == "native")
+    if can_prime:
         prime(args.warmup)
     run(args.warmup)
-    if not use_dp:
+    if can_prime:
         prime(args.steps)
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -328,7 +340,9 @@ def main():
             result["config"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(result), flush=True)
     if use_dp:
-        dist.barrier()
+        dist.barrier()                     # nobody unmaps its buffers while a peer may still read them
+        if args.dp_impl == "native":
+            d.dp_finalize()
         dist.destroy_process_group()
 
 

@@ -197,6 +197,10 @@ int  rcn_hip_dp_broadcast_params(rcn_hip_ctx* ctx, int root);                   
  * Collective; asynchronous on the context's stream. */
 int  rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
                                 size_t B_shard, size_t n_batches, double eta, void* loss_dev);
+/* Same arguments: instantiates (does not run) the hipGraph rcn_hip_dp_train_epoch_dev would replay for them, when the loop
+ * is one that replays a graph (the peer-exchange pipeline); a no-op otherwise.  Not collective. */
+int  rcn_hip_dp_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
+                                  size_t B_shard, size_t n_batches, double eta, void* loss_dev);
 /* The all-reduce of that loop.  For 2..8 ranks of one node rcn_hip_dp_init also sets up a one-shot PEER-READ all-reduce
  * over xGMI (every rank reads all ranks' gradient buffers through hipIpc mappings, adds them in rank order and applies
  * the update in the same kernel; csrc/dp_p2p.hpp) and keeps it only if every rank mapped every peer and a known-answer

@@ -1409,8 +1409,7 @@ int rcn_hip_dp_broadcast_params(rcn_hip_ctx* c, int root) {
     return RCN_HIP_OK;
 }
 
-int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta,
-                               void* loss_dev) {
+static int dp_epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool launch) {
     RCN_TRY(check_ctx(c));
     if (!c->comm && !c->p2p.on) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_train_epoch: rcn_hip_dp_init was not called");
     if (c->p2p.on && *c->p2p.err_host != 0)
@@ -1438,6 +1437,7 @@ int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, con
         // host's launch rate (~6 us each), not by the GPU.  Sequence numbers inside the graph are offsets from a device word.
         const char* ge = std::getenv("RCN_HIP_DP_GRAPH");
         if (ge && ge[0] == '0') {
+            if (!launch) return RCN_HIP_OK;
             RCN_TRY(f64 ? enqueue_pipe_steps_dp<double>(c, X, Y, perm, B, nb, eta, loss_dev, false, c->p2p.fused)
                         : enqueue_pipe_steps_dp<float>(c, X, Y, perm, B, nb, eta, loss_dev, false, c->p2p.fused));
         } else {
@@ -1458,6 +1458,7 @@ int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, con
                 if (c->dp_graphs.size() >= 16) drop_graphs(c);
                 it = c->dp_graphs.emplace(key, exec).first;
             }
+            if (!launch) return RCN_HIP_OK;                   // rcn_hip_dp_prepare_epoch_dev: instantiated, not run
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, c->stream, c->p2p.err_dev + 16, c->p2p.seq);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
@@ -1466,6 +1467,7 @@ int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, con
         HIP_TRY(c, hipMemcpyAsync(c->p2p.err_host, c->p2p.err_dev, 4, hipMemcpyDeviceToHost, c->stream));   // read at the next call
         return RCN_HIP_OK;
     }
+    if (!launch) return RCN_HIP_OK;                           // nothing to prepare on the eager paths
     if (c->p2p.on) {
         // gradient kernels write straight into this rank's exported slot; ONE kernel then waits for the peers' flags, reads
         // all `world` slots over xGMI, adds them in rank order and applies the update (dp_p2p.hpp)
@@ -1510,6 +1512,16 @@ int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, con
         if (loss_dev) HIP_TRY(c, hipMemcpyAsync((char*)loss_dev + j * es, lslot, es, hipMemcpyDeviceToDevice, c->stream));
     }
     return RCN_HIP_OK;
+}
+
+int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta,
+                               void* loss_dev) {
+    return dp_epoch_impl(c, X, Y, perm, B, nb, eta, loss_dev, true);
+}
+
+int rcn_hip_dp_prepare_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta,
+                                 void* loss_dev) {
+    return dp_epoch_impl(c, X, Y, perm, B, nb, eta, loss_dev, false);
 }
 
 int rcn_hip_forward_dev(rcn_hip_ctx* c, const void* x, size_t n, void* out) {

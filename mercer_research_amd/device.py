@@ -200,6 +200,11 @@ class DeviceRCN:
     def dp_broadcast_params(self, root: int = 0):
         self._ck(self.lib.rcn_hip_dp_broadcast_params(self.ctx, root))
 
+    def dp_prepare_epoch(self, X: torch.Tensor, Y: torch.Tensor, perm: Optional[torch.Tensor], B_shard: int, n_batches: int, eta: float,
+                         loss: Optional[torch.Tensor] = None):
+        """Instantiate (do not run) the graph dp_train_epoch will replay for exactly these arguments.  Not collective."""
+        self._ck(self.lib.rcn_hip_dp_prepare_epoch_dev(self.ctx, _p(X), _p(Y), _p(perm), B_shard, n_batches, float(eta), _p(loss)))
+
     def dp_train_epoch(self, X: torch.Tensor, Y: torch.Tensor, perm: Optional[torch.Tensor], B_shard: int, n_batches: int, eta: float,
                        loss: Optional[torch.Tensor] = None):
         """n_batches global train_batch steps; this rank contributes rows perm[j*B_shard ..] of its resident X / Y to

@@ -101,6 +101,8 @@ extern "C" {
     pub fn rcn_hip_dp_p2p_selftest(ctx: *mut rcn_hip_ctx, iters: c_int, mismatches: *mut u32, timed_out: *mut u32) -> c_int;
     pub fn rcn_hip_dp_p2p_active(ctx: *const rcn_hip_ctx) -> c_int;
     pub fn rcn_hip_set_feature_kernel(ctx: *mut rcn_hip_ctx, mode: c_int) -> c_int;
+    pub fn rcn_hip_dp_prepare_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b_shard: usize, n_batches: usize,
+                                        eta: c_double, loss: *mut c_void) -> c_int;
     pub fn rcn_hip_dp_train_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b_shard: usize, n_batches: usize,
                                       eta: c_double, loss: *mut c_void) -> c_int;
     pub fn rcn_hip_forward(ctx: *mut rcn_hip_ctx, x: *const c_double, n: usize, out: *mut c_double) -> c_int;
