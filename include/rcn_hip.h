@@ -229,7 +229,10 @@ int  rcn_hip_classify_images(rcn_hip_ctx* ctx, const uint8_t* imgs, size_t n, in
 /* ---------------------------------------------------------------- tuning / measurement aids */
 /* Which kernels implement train_batch / train_epoch: 0 = automatic (feature-sliced pipeline for batches <= 1024 when
  * the layer stack allows it, sample-tile kernels otherwise), 1 = always the sample-tile kernels, 2 = always the
- * feature-sliced pipeline.  Both compute the same step (summation grouping differs, within the stated tolerances). */
+ * feature-sliced pipeline, 3 = experimental: one resident kernel per epoch segment whose workgroups exchange results through
+ * tagged words (f32, default shape class only; needs all its workgroups on the GPU at once -- a device shared with another
+ * process can make a call fail with RCN_HIP_ERR_HIP instead; currently slower than mode 2).  All compute the
+ * same step (summation grouping differs, within the stated tolerances). */
 int  rcn_hip_set_dense_path(rcn_hip_ctx* ctx, int mode);
 /* Which kernel implements flatten_feature_set: 0 = automatic (the fused conv+pool kernel specialised for the default
  * stack conv(Same),pool(Max),conv(Same),pool(Max) on 28x28 input when the configuration is exactly that, the generic

@@ -26,6 +26,7 @@
 #include "serve.hpp"
 #include "dp_p2p.hpp"
 #include "dense_p2_dp.hpp"
+#include "dense_p2_persist.hpp"
 #include <chrono>
 
 using namespace rcn;
@@ -67,6 +68,11 @@ struct rcn_hip_ctx {
     std::string dense_err;                  // non-empty: every dense call panics in the reference (see rcn_hip_create)
     double mean = 1.0, sd = 1.0;            // scale_set initial value (1,1): rcn.rs:71
     int feat_kernel = 0;                    // 0 auto, 1 always the generic k_features (tests compare the two)
+    DevBuf pll;                             // persistent epoch kernel: tagged-word exchange buffers (dense_p2_persist.hpp)
+    size_t pll_B = 0;
+    unsigned ptag = 0;                      // last tag handed out; monotonic for the life of the context
+    unsigned* perr_dev = nullptr;           // sticky timeout word of the persistent kernel, and its pinned mirror
+    unsigned* perr_host = nullptr;
     int dense_path = 0;                     // 0 auto, 1 sample-tile kernels (dense.hpp), 2 feature-sliced pipeline (dense_pipe.hpp)
     DevBuf slab, xpack, ypack, p2buf;
     size_t packed_B = 0, packed_nb = 0;     // what the epoch image currently holds (k_pack_epoch)
@@ -424,6 +430,62 @@ int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32
     return RCN_HIP_OK;
 }
 
+// ---- one resident kernel per epoch segment (dense_p2_persist.hpp) ------------------------------------------------
+bool use_persist(const rcn_hip_ctx* c, size_t B) {
+    if (c->dtype != RCN_HIP_F32 || !persist_supported(c->nd, B)) return false;
+    if (c->dense_path == 3) return true;
+    if (c->dense_path != 0) return false;
+    static const int auto_on = [] { const char* e = std::getenv("RCN_HIP_PERSIST"); return e ? std::atoi(e) : 0; }();
+    return auto_on != 0;
+}
+
+constexpr long long kPersistTimeoutTicks = 5000000LL;        // 50 ms of the 100 MHz wall clock per wait
+
+int enqueue_persist_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+    const NetDesc& nd = c->nd;
+    const size_t G = pipe_slices(nd), Cc = nd.dims[nd.L];
+    if (!c->perr_dev) {
+        HIP_TRY(c, hipMalloc((void**)&c->perr_dev, 256));
+        HIP_TRY(c, hipHostMalloc((void**)&c->perr_host, 64, hipHostMallocDefault));
+        *c->perr_host = 0;
+        HIP_TRY(c, hipMemsetAsync(c->perr_dev, 0, 256, c->stream));
+    }
+    if (*c->perr_host != 0)
+        return fail(c, RCN_HIP_ERR_HIP, "train_epoch: a resident epoch kernel timed out in an earlier call (its workgroups were not all on the GPU at "
+                                        "once -- is the device shared?); the parameters are no longer consistent.  rcn_hip_set_dense_path(ctx, 2) avoids this kernel");
+    const size_t words = persist_words(B, G);
+    if (c->pll_B != B || c->pll.cap < words * sizeof(pw_t)) {
+        HIP_TRY(c, c->pll.ensure(words * sizeof(pw_t)));
+        HIP_TRY(c, hipMemsetAsync(c->pll.p, 0, c->pll.cap, c->stream));      // tag 0 never matches (tags start at 1)
+        c->pll_B = B;
+    }
+    const size_t NS = B / kP2Ts;
+    PersistBufs pb;
+    pw_t* w = (pw_t*)c->pll.p;
+    pb.slab = w; w += 2 * NS * G * kP2Ts * kP2H;
+    pb.d1 = w;   w += 2 * B * kP2H;
+    pb.a1 = w;   w += 2 * B * kP2H;
+    pb.d2 = w;   w += 2 * B * kP2C;
+    pb.tail = w; w += 2 * kPersistTailPad;
+    pb.loss = w;
+    const size_t seg = nb <= pack_segment(c, B) ? nb : pack_segment(c, B);
+    const float scale = (float)(eta / (double)B), loss_scale = (float)(1.0 / (2.0 * (double)B));
+    const int grid = persist_grid(nd, B);
+    for (size_t j0 = 0; j0 < nb; j0 += seg) {
+        const size_t n = nb - j0 < seg ? nb - j0 : seg;
+        const int half = (int)((j0 / seg) % 2);
+        RCN_TRY(launch_pack<float>(c, X, Y, perm, B, j0, n, half, seg));
+        const float* xs = (const float*)c->xpack.p + (size_t)half * seg * G * B * 16;
+        const float* ys = (const float*)c->ypack.p + (size_t)half * seg * B * Cc;
+        hipLaunchKernelGGL(k_p2_epoch, dim3(grid), dim3(kPersistThreads), 0, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)n, (int)G, scale,
+                           loss_scale, loss_dev ? (float*)loss_dev + j0 : (float*)nullptr, pb, c->ptag, c->perr_dev, kPersistTimeoutTicks);
+        HIP_TRY(c, hipGetLastError());
+        c->ptag += (unsigned)n + 2;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->perr_host, c->perr_dev, 4, hipMemcpyDeviceToHost, c->stream));     // looked at by the next call
+    return RCN_HIP_OK;
+}
+
 // one train_batch (rcn.rs:176-223) on device-resident data; idx selects the batch's rows (or NULL)
 int enqueue_train_step(rcn_hip_ctx* c, const void* x, const void* y, const int32_t* idx, size_t B, double eta, void* loss_dev) {
     const double scale = eta / (double)B;                       // rcn.rs:214: eta / batch.len() as f64
@@ -741,6 +803,9 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
                           &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
             b->release();
         if (c->pin_host) (void)hipHostFree(c->pin_host);
+        c->pll.release();
+        if (c->perr_dev) (void)hipFree(c->perr_dev);
+        if (c->perr_host) (void)hipHostFree(c->perr_host);
         if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -767,8 +832,8 @@ int rcn_hip_set_feature_kernel(rcn_hip_ctx* c, int mode) {
 
 int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
     RCN_TRY(check_ctx(c));
-    if (mode < 0 || mode > 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile) or 2 (feature-sliced)");
-    if (mode == 2 && !pipe_supported(c->nd)) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "feature-sliced path needs >= 2 dense layers whose tail fits LDS");
+    if (mode < 0 || mode > 3) return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile), 2 (feature-sliced) or 3 (resident epoch kernel)");
+    if (mode >= 2 && !pipe_supported(c->nd)) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "feature-sliced path needs >= 2 dense layers whose tail fits LDS");
     DevGuard g(c->device);
     drop_graphs(c);
     c->dense_path = mode;
@@ -1143,6 +1208,11 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
     DevGuard g(c->device);
     RCN_TRY(ensure_dense_ws(c, B));
     if (use_pipe(c, B)) { RCN_TRY(ensure_pipe_ws(c, B)); RCN_TRY(ensure_pack_ws(c, B, nb)); }
+    if (use_persist(c, B)) {
+        // no graph: one resident kernel per segment of the epoch image runs all of its steps
+        if (!launch) return RCN_HIP_OK;
+        return enqueue_persist_epoch(c, X, Y, perm, B, nb, eta, loss_dev);
+    }
     // LDS attributes are per kernel variant and cached (set_dyn_lds); hipFuncSetAttribute is not a stream operation,
     // so the first capture of a variant may set it while capturing.
 

@@ -563,6 +563,51 @@ def test_peer_allreduce_bootstrap_over_rccl_world1(amd, oracle, monkeypatch):
     d.rcn.close()
 
 
+def test_resident_epoch_kernel_matches_sequential_oracle(amd, oracle):
+    """dense path 3 (dense_p2_persist.hpp): one kernel runs all steps of an epoch segment, its workgroups exchanging slab
+    partials, deltas and tail parameters through tagged words.  Must be the reference's sequential train_batch loop
+    (rcn.rs:147-149, 176-223) like the two-kernel pipeline: same tolerances, per-step costs included; a second call continues
+    from the first (tags carry over), and a call longer than one segment of the epoch image is split into several launches."""
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 256, 5, 1536
+    ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=81, wscale=0.1)
+    d = DeviceRCN(dtype=0)
+    d.set_dense_path(3)
+    d.set_params(ws, bs)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    perm = np.random.default_rng(3).permutation(N).astype(np.int32)
+    permd = d.to_device(perm)
+    loss = d.empty(nb)
+    d.train_epoch(Xd, Yd, permd, B, nb, 3.0, loss)
+    gw, gb = d.get_params()
+    losses = loss.cpu().numpy()
+    rw, rb, costs = ws, bs, []
+    for j in range(nb):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, X[sel], Y[sel], 3.0)
+        costs.append(c)
+    for a, b in zip(gw + gb, rw + rb):
+        assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)
+    np.testing.assert_allclose(losses, costs, rtol=1e-3)
+    # second call (identity order, 2 steps) continues from these parameters
+    d.train_epoch(Xd, Yd, None, B, 2, 3.0, None)
+    gw, gb = d.get_params()
+    for j in range(2):
+        rw, rb, _ = oracle.train_batch(rw, rb, X[j * B:(j + 1) * B], Y[j * B:(j + 1) * B], 3.0)
+    for a, b in zip(gw + gb, rw + rb):
+        assert np.all(np.abs(a - b) <= 3e-4 * np.abs(b) + 3e-5)
+    # and it agrees with the two-kernel pipeline on the same inputs to f32 rounding of a different summation grouping
+    d2 = DeviceRCN(dtype=0)
+    d2.set_dense_path(2)
+    d2.set_params(ws, bs)
+    d2.train_epoch(Xd.clone(), Yd.clone(), permd.clone(), B, nb, 3.0, None)
+    d2.train_epoch(Xd, Yd, None, B, 2, 3.0, None)
+    pw, pb = d2.get_params()
+    for a, b in zip(gw + gb, pw + pb):
+        assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5)
+    d.rcn.close(); d2.rcn.close()
+
+
 def test_data_parallel_halves_equal_full_batch(amd, oracle):
     """Shard gradients + sum + one update == train_batch on the concatenated batch, single GPU."""
     from mercer_research_amd.device import DeviceRCN
