@@ -2,10 +2,13 @@
 //
 // k_p2_b / k_p2_a are bound by what surrounds their arithmetic: two dependent launches per step (1.6 us each inside a
 // hipGraph) and W_0 leaving and re-entering the chip every step.  Here the same three kinds of workgroup stay resident for
-// the whole segment and hand their results to each other through global memory in self-validating words -- every value
-// travels with the number of the step that produced it in one 8-byte word, written by one agent-scope atomic store and
-// polled by its consumer until the tag matches (dense_p2_dp.hpp uses the same idea across GPUs).  No launch, no flag, no
-// fence and no grid barrier between steps; a slice of W_0 never leaves its workgroup's registers/LDS until the segment ends.
+// the whole segment and hand their results to each other through global memory, with the two in-launch hand-off forms of
+// cdna_hip_programming.md (Guideline 16): big payloads (slab partials, deltas, activations) are stored write-through as
+// plain 16-byte runs (buffer stores, sc1) and announced by ONE flag word per producer after its waves drained their stores,
+// the consumer polls that word and then reads with sc1 loads; the small tail parameters travel as self-validating 8-byte
+// words {value, step} that are their own flag.  (A first version sent everything as tagged words: correct, but 401 K
+// uncoalesced 8-byte write-through stores per step queued up for 3-10 us before becoming visible.)  No launch, no fence
+// and no grid barrier between steps; a slice of W_0 never leaves its workgroup's registers/LDS until the segment ends.
 //
 //   feature workgroup g (G of them)   owns W_0[:, 16g..16g+15].  Per step: poll delta_1 of the whole batch -> dW_0 slice
 //                                     (MFMA, K-split over 8 waves) -> update in place -> partial z_1 of the NEXT batch
@@ -99,21 +102,56 @@ __device__ inline bool pw_poll_at(const pw_t* base, const int (&off)[N], unsigne
 }
 
 struct PersistBufs {
-    pw_t* slab;      // [2][B/8][G][8][32]
-    pw_t* d1;        // [2][B][32]
-    pw_t* a1;        // [2][B][32]
-    pw_t* d2;        // [2][B][16]
-    pw_t* tail;      // [2][tail parameters, padded to 512]   ([b_0 | W_1 | b_1] at their offsets from the end of W_0)
-    pw_t* loss;      // [2][B/8]
+    float* slab;       // [2][B/8][G][8][32]   partial z_1, written by the feature groups
+    float* d1;         // [2][B][32]           written by the sample groups (as are a1, d2, loss)
+    float* a1;         // [2][B][32]
+    float* d2;         // [2][B][16]
+    float* loss;       // [2][B/8]
+    unsigned* sflag;   // [G]     step tag of the newest complete slab of feature group g
+    unsigned* oflag;   // [B/8]   step tag of the newest complete outputs of sample group t
+    pw_t* tail;        // [2][512] tail parameters [b_0 | W_1 | b_1] as tagged words
 };
 
 constexpr int kPersistThreads = 512, kPersistTailPad = 512;
-inline size_t persist_words(size_t B, size_t G) {
-    return 2 * ((B / kP2Ts) * G * kP2Ts * kP2H + B * kP2H + B * kP2H + B * kP2C + kPersistTailPad + B / kP2Ts);
+// bytes: plain arrays, then the flags (padded), then the tagged words
+inline size_t persist_bytes(size_t B, size_t G) {
+    const size_t NS = B / kP2Ts;
+    return 2 * (NS * G * kP2Ts * kP2H + B * kP2H + B * kP2H + B * kP2C + NS) * sizeof(float) + (64 + NS + 64) * sizeof(unsigned) +
+           2 * kPersistTailPad * sizeof(pw_t) + 256;
 }
 inline int persist_grid(const NetDesc& nd, size_t B) { return pipe_slices(nd) + (int)(B / kP2Ts) + pipe_extra_wgs(nd); }
 inline bool persist_supported(const NetDesc& nd, size_t B) {
     return p2_supported(nd, B) && nd.P - (nd.w_off[0] + nd.dims[0] * nd.dims[1]) <= kPersistTailPad && persist_grid(nd, B) <= 224;
+}
+
+using pu4 = __attribute__((ext_vector_type(4))) unsigned;
+// write-through / cache-bypassing accesses to the exchange arrays (aux 16 = sc1): byte offsets from the array's base
+#define PW_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((ptr), 0, (int)(bytes), 0x00020000)
+__device__ inline void px_store4(__amdgpu_buffer_rsrc_t r, int byte_off, float a, float b, float c, float d) {
+    const float f[4] = {a, b, c, d};
+    pu4 v;
+    __builtin_memcpy(&v, f, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);
+}
+__device__ inline void px_store1(__amdgpu_buffer_rsrc_t r, int byte_off, float a) {
+    unsigned v; __builtin_memcpy(&v, &a, 4);
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, byte_off, 0, 16);
+}
+__device__ inline float px_load1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16);
+    float f; __builtin_memcpy(&f, &v, 4); return f;
+}
+// every storing wave drains its write-through stores before the flag that announces them is written
+__device__ inline void px_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// one wave waits until the flag words its lanes look at (lanes >= nflags look at nothing) all carry `tag`
+__device__ inline bool px_wait_flags(const unsigned* flags, int idx, bool active, unsigned tag, long long timeout, const unsigned* err) {
+    long long t0 = 0;
+    for (unsigned it = 0;; ++it) {
+        const unsigned f = active ? __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+        if (__all((int)(f - tag) >= 0)) return true;
+        if ((it & 1023u) == 1023u && pw_give_up(t0, timeout, err)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
 
 __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
@@ -128,7 +166,10 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
     const int F = nd.dims[0], H = nd.dims[1], C = nd.dims[2];
     const int NS = B / kP2Ts;
     const int tail_begin = nd.w_off[0] + F * H;
-    const size_t slab_half = (size_t)NS * G * kP2Ts * kP2H, dh_half = (size_t)B * kP2H, d2_half = (size_t)B * kP2C;
+    const int slab_half = NS * G * kP2Ts * kP2H, dh_half = B * kP2H, d2_half = B * kP2C;      // values per parity half
+    const auto r_slab = PW_RSRC(bufs.slab, (size_t)2 * slab_half * 4);
+    const auto r_d1 = PW_RSRC(bufs.d1, (size_t)2 * dh_half * 4), r_a1 = PW_RSRC(bufs.a1, (size_t)2 * dh_half * 4);
+    const auto r_d2 = PW_RSRC(bufs.d2, (size_t)2 * d2_half * 4), r_loss = PW_RSRC(bufs.loss, (size_t)2 * NS * 4);
     bool bad = false;
     // A failed wait raises the sticky error word (which makes every other workgroup's next long wait give up too) and this
     // workgroup's LDS flag; a workgroup looks at its flag right after a barrier it has anyway, and leaves.
@@ -155,7 +196,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
         // partial z_1 of batch jn from the slice in LDS -> slab words tagged `tag`
         auto forward = [&](int jn, unsigned tag) {
             const float* __restrict__ cn = xpack + ((size_t)jn * G + g) * B * 16;
-            pw_t* sl = bufs.slab + (size_t)(tag & 1u) * slab_half;
+            const int sl = (int)(tag & 1u) * slab_half;
             float wf[4][kMtp];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -175,13 +216,15 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(wf[i][t], xn[u][i], acc[t]);
-                    pw_t* dst = sl + (((size_t)(s >> 3) * G + g) * kP2Ts + (s & 7)) * kP2H + 4 * g4;    // rows 4 g4 + i of each 16-row tile
+                    // rows 4 g4 .. 4 g4 + 3 of each 16-row tile: 16 contiguous bytes per lane, 64 per sample and tile
+                    const int dst = sl + ((((s >> 3) * G + g) * kP2Ts + (s & 7)) * kP2H + 4 * g4);
 #pragma unroll
-                    for (int t = 0; t < kMtp; ++t)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) pw_store(dst + t * 16 + i, acc[t][i], tag);
+                    for (int t = 0; t < kMtp; ++t) px_store4(r_slab, (dst + t * 16) * 4, acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
                 }
             }
+            px_drain();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(bufs.sflag + g, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         forward(0, base + 1);
         for (int j = 0; j < nb; ++j) {
@@ -189,7 +232,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
             PSTAMP(0);
             const unsigned tag = base + (unsigned)j + 1;
             const float* __restrict__ cp = xpack + ((size_t)j * G + g) * B * 16;
-            const pw_t* dl = bufs.d1 + (size_t)(tag & 1u) * dh_half;
+            const int dl = (int)(tag & 1u) * dh_half;
             // ---- U: dW_0[:, slice] = sum_s delta_1[s] (x) x_s[slice]                                   rcn.rs:310
             acc_t acc[kMtp];
 #pragma unroll
@@ -199,12 +242,16 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
                 float bv[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) bv[q] = xb[q * 64];
-                float av[16];                                           // delta_1 rows n (0..7) and 16 + n (8..15) of samples kc + g4 + 4 q
-                int at[16];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { at[q] = (kc + g4 + 4 * q) * kP2H + n; at[8 + q] = at[q] + 16; }
-                if (!pw_poll_at<16>(dl, at, tag, av, timeout, err)) fail();
+                // samples kc .. kc + 31 belong to sample groups kc/8 .. kc/8 + 3: wait for their flags, then read delta_1
+                if (!px_wait_flags(bufs.oflag, kc / kP2Ts + (lane & 3), lane < 4, tag, timeout, err)) fail();
                 PSTAMP(1);
+                float av[16];                                           // delta_1 rows n (0..7) and 16 + n (8..15) of samples kc + g4 + 4 q
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int at = dl + (kc + g4 + 4 * q) * kP2H + n;
+                    av[q] = px_load1(r_d1, at * 4);
+                    av[8 + q] = px_load1(r_d1, (at + 16) * 4);
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     acc[0] = Mfma16<T>::mfma(av[q], bv[q], acc[0]);
@@ -299,17 +346,24 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
             }
             if (wave == 7) PSTAMP_W(1);
             // ---- slab partials: slices wave, wave + 8, ...; lane <- elements 4 lane .. 4 lane + 3 of the [8][32] tile
-            const pw_t* sp = bufs.slab + (size_t)(tag & 1u) * slab_half + (size_t)t * G * (kP2Ts * kP2H) + 4 * lane;
+            // this wave's slices are wave, wave + 8, ...: wait for their producers' flags (lane q looks at slice wave + 8 q), then
+            // every lane reads its 16 bytes of each [8][32] tile
+            if (!px_wait_flags(bufs.sflag, wave + kP2BWaves * (lane & 7), lane < kPer && wave + kP2BWaves * lane < G, tag, timeout, err)) fail();
+            const int sp = ((int)(tag & 1u) * slab_half + t * G * (kP2Ts * kP2H) + 4 * lane) * 4;
             vec4 z = vec4{0, 0, 0, 0};
+            pu4 raw[kPer];
 #pragma unroll
             for (int q = 0; q < kPer; ++q) {
                 const int gq = wave + kP2BWaves * q;
-                if (gq < G) {                                         // wave-uniform
-                    float v[4];
-                    if (!pw_poll<4>(sp + (size_t)gq * (kP2Ts * kP2H), 1, tag, v, timeout, err)) fail();
-                    z += vec4{v[0], v[1], v[2], v[3]};
-                }
+                raw[q] = __builtin_amdgcn_raw_buffer_load_b128(r_slab, sp + (gq < G ? gq : wave) * (kP2Ts * kP2H * 4), 0, 16);
             }
+#pragma unroll
+            for (int q = 0; q < kPer; ++q)
+                if (wave + kP2BWaves * q < G) {
+                    vec4 v;
+                    __builtin_memcpy(&v, &raw[q], 16);
+                    z += v;
+                }
             zred[wave * 64 + lane] = z;
             if (wave == 0) PSTAMP(2);
             __syncthreads();
@@ -319,13 +373,13 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
                     ((zred[256 + lane] + zred[320 + lane]) + (zred[384 + lane] + zred[448 + lane]));
                 {   // a_1 = sigmoid(z_1 + b_0); lane <- sample lane>>3, hidden 4*(lane&7)+i                rcn.rs:287-289
                     const int s = lane >> 3, h0 = 4 * (lane & 7);
-                    pw_t* ad = bufs.a1 + (size_t)(tag & 1u) * dh_half + (size_t)(s0 + s) * kP2H + h0;
+                    float a[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float a = (h0 + i < H) ? sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]) : 0.f;
-                        a1s[(h0 + i) * kLd + s] = a;
-                        pw_store(ad + i, a, tag);
+                        a[i] = (h0 + i < H) ? sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]) : 0.f;
+                        a1s[(h0 + i) * kLd + s] = a[i];
                     }
+                    px_store4(r_a1, ((int)(tag & 1u) * dh_half + (s0 + s) * kP2H + h0) * 4, a[0], a[1], a[2], a[3]);
                 }
                 acc_t acc = acc_t{0, 0, 0, 0};                        // z_2 = W_1 a_1 + b_1
 #pragma unroll
@@ -345,28 +399,25 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
                     lsum += ok ? diff * diff : 0.f;
                     d2s[c * kLd + n] = dv[i];
                 }
-                if (n < kP2Ts) {
-                    pw_t* dd = bufs.d2 + (size_t)(tag & 1u) * d2_half + (size_t)(s0 + n) * kP2C + 4 * g4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pw_store(dd + i, dv[i], tag);
-                }
+                if (n < kP2Ts) px_store4(r_d2, ((int)(tag & 1u) * d2_half + (s0 + n) * kP2C + 4 * g4) * 4, dv[0], dv[1], dv[2], dv[3]);
 #pragma unroll
                 for (int mt = 0; mt < kMtp; ++mt) {                   // delta_1 = (W_1^T delta_2) (*) a_1 (1 - a_1)   rcn.rs:305-309
                     acc_t ad = acc_t{0, 0, 0, 0};
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) ad = Mfma16<T>::mfma(frag[(8 + mt * 4 + ks) * 64 + lane], d2s[(4 * ks + g4) * kLd + n], ad);
-                    if (n < kP2Ts) {
-                        pw_t* dd = bufs.d1 + (size_t)(tag & 1u) * dh_half + (size_t)(s0 + n) * kP2H + mt * 16 + 4 * g4;
+                    float o4[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float a = a1s[(mt * 16 + Mfma16<T>::row(lane, i)) * kLd + (n & 7)];
-                            pw_store(dd + i, ad[i] * (a * (1.f - a)), tag);
-                        }
+                    for (int i = 0; i < 4; ++i) {
+                        const float a = a1s[(mt * 16 + Mfma16<T>::row(lane, i)) * kLd + (n & 7)];
+                        o4[i] = ad[i] * (a * (1.f - a));                  // padded hidden rows hold a = 0 -> delta 0
                     }
+                    if (n < kP2Ts) px_store4(r_d1, ((int)(tag & 1u) * dh_half + (s0 + n) * kP2H + mt * 16 + 4 * g4) * 4, o4[0], o4[1], o4[2], o4[3]);
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
-                if (lane == 0) pw_store(bufs.loss + (size_t)(tag & 1u) * NS + t, lsum, tag);
+                if (lane == 0) px_store1(r_loss, ((int)(tag & 1u) * NS + t) * 4, lsum);
+                px_drain();                                           // only this wave stored: drain, then announce
+                if (lane == 0) __hip_atomic_store(bufs.oflag + t, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 PSTAMP(4);
             }
             __syncthreads();                                          // wave 0 is done with frag / zred before they are refilled
@@ -391,27 +442,24 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
             if (!step_begin()) return;
             PSTAMP(0);
             const unsigned tag = base + (unsigned)j + 1;
-            // word offsets from the start of the exchange buffer (bufs.slab is its first member and base)
-            const int d_off = (int)((e == 0 ? bufs.d1 + (size_t)(tag & 1u) * dh_half : bufs.d2 + (size_t)(tag & 1u) * d2_half) - bufs.slab);
-            const int a_off = (int)(bufs.a1 + (size_t)(tag & 1u) * dh_half - bufs.slab);
+            const int d_off = (int)(tag & 1u) * (e == 0 ? dh_half : d2_half), a_off = (int)(tag & 1u) * dh_half;
             const int ldD = e == 0 ? kP2H : kP2C;
             acc_t acc[kMtp];
 #pragma unroll
             for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
             for (int kc = wave * kw; kc < (wave + 1) * kw; kc += 32) {
-                // delta rows n and 16 + n, and (tiles of W_1) column c of a_1, of samples kc + g4 + 4 q: one round of loads
+                if (!px_wait_flags(bufs.oflag, kc / kP2Ts + (lane & 3), lane < 4, tag, timeout, err)) fail();
+                PSTAMP(1);
+                // delta rows n and 16 + n, and (tiles of W_1) column c of a_1, of samples kc + g4 + 4 q
                 const int r0 = n < M ? n : M - 1, r1 = 16 + n < M ? 16 + n : M - 1, ca = c < Kin ? c : Kin - 1;
                 float v[24];
-                int at[24];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int smp = kc + g4 + 4 * q;
-                    at[q] = d_off + smp * ldD + r0;
-                    at[8 + q] = d_off + smp * ldD + r1;
-                    at[16 + q] = e != 0 ? a_off + smp * kP2H + ca : at[q];      // e == 0 has no activation operand: repeat a delta word
+                    v[q] = px_load1(e == 0 ? r_d1 : r_d2, (d_off + smp * ldD + r0) * 4);
+                    v[8 + q] = px_load1(e == 0 ? r_d1 : r_d2, (d_off + smp * ldD + r1) * 4);
+                    v[16 + q] = e != 0 ? px_load1(r_a1, (a_off + smp * kP2H + ca) * 4) : 0.f;
                 }
-                if (!pw_poll_at<24>(bufs.slab, at, tag, v, timeout, err)) fail();
-                PSTAMP(1);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     // bias column: the activation is the constant 1, so db = sum_s delta              rcn.rs:302,309
@@ -430,10 +478,10 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
             if (e == 0 && wave == 7 && loss_dev) {                     // cost of this batch: lane t fetches sample group t's part, lane 0 adds in order
                 float tot = 0.f;
                 for (int t0 = 0; t0 < NS; t0 += 64) {
-                    float part[1] = {0.f};
                     const int t = t0 + lane;
-                    if (!pw_poll<1>(bufs.loss + (size_t)(tag & 1u) * NS + (t < NS ? t : NS - 1), 0, tag, part, timeout, err)) fail();
-                    for (int u = 0; u < 64 && t0 + u < NS; ++u) tot += __shfl(part[0], u, 64);
+                    if (!px_wait_flags(bufs.oflag, t < NS ? t : NS - 1, t < NS, tag, timeout, err)) fail();
+                    const float part = px_load1(r_loss, ((int)(tag & 1u) * NS + (t < NS ? t : NS - 1)) * 4);
+                    for (int u = 0; u < 64 && t0 + u < NS; ++u) tot += __shfl(part, u, 64);
                 }
                 if (lane == 0) loss_dev[j] = tot * loss_scale;
             }

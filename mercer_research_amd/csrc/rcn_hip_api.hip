@@ -453,21 +453,24 @@ int enqueue_persist_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const in
     if (*c->perr_host != 0)
         return fail(c, RCN_HIP_ERR_HIP, "train_epoch: a resident epoch kernel timed out in an earlier call (its workgroups were not all on the GPU at "
                                         "once -- is the device shared?); the parameters are no longer consistent.  rcn_hip_set_dense_path(ctx, 2) avoids this kernel");
-    const size_t words = persist_words(B, G);
-    if (c->pll_B != B || c->pll.cap < words * sizeof(pw_t)) {
-        HIP_TRY(c, c->pll.ensure(words * sizeof(pw_t)));
-        HIP_TRY(c, hipMemsetAsync(c->pll.p, 0, c->pll.cap, c->stream));      // tag 0 never matches (tags start at 1)
+    const size_t bytes = persist_bytes(B, G);
+    if (c->pll_B != B || c->pll.cap < bytes) {
+        HIP_TRY(c, c->pll.ensure(bytes));
+        HIP_TRY(c, hipMemsetAsync(c->pll.p, 0, c->pll.cap, c->stream));      // flag / tag 0 never matches (tags start at 1)
         c->pll_B = B;
     }
     const size_t NS = B / kP2Ts;
     PersistBufs pb;
-    pw_t* w = (pw_t*)c->pll.p;
-    pb.slab = w; w += 2 * NS * G * kP2Ts * kP2H;
-    pb.d1 = w;   w += 2 * B * kP2H;
-    pb.a1 = w;   w += 2 * B * kP2H;
-    pb.d2 = w;   w += 2 * B * kP2C;
-    pb.tail = w; w += 2 * kPersistTailPad;
-    pb.loss = w;
+    float* f = (float*)c->pll.p;
+    pb.slab = f; f += 2 * NS * G * kP2Ts * kP2H;
+    pb.d1 = f;   f += 2 * B * kP2H;
+    pb.a1 = f;   f += 2 * B * kP2H;
+    pb.d2 = f;   f += 2 * B * kP2C;
+    pb.loss = f; f += 2 * NS;
+    unsigned* u = (unsigned*)f;
+    pb.sflag = u; u += 64;
+    pb.oflag = u; u += NS;
+    pb.tail = (pw_t*)(((uintptr_t)u + 63) & ~(uintptr_t)63);
     const size_t seg = nb <= pack_segment(c, B) ? nb : pack_segment(c, B);
     const float scale = (float)(eta / (double)B), loss_scale = (float)(1.0 / (2.0 * (double)B));
     const int grid = persist_grid(nd, B);
