@@ -283,3 +283,105 @@ __global__ __launch_bounds__(64 * NKB) void k_conv_wgrad_bf16(const float* __res
 }
 
 }  // namespace rcnx
+
+namespace rcnx {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv3x3_halo_bf16 -- 3x3 convolution, LDS-tiled (channel blocks of 32 or 64).
+//
+// The implicit-GEMM kernel above re-reads every input pixel once per filter tap (nine shifted A tiles out of L2); for
+// thin layers that traffic, not the MFMA, is the limit (5-7 % MFMA-busy by PMC at Cin = 32).  Here a workgroup owns an
+// 8 x 16 block of output pixels of one image and stages the 10 x 18 input HALO of one channel block, as bf16, in LDS; all nine
+// taps then read their A fragments out of that one image (a lane's eight consecutive channels of pixel (y + kh, x + kw):
+// one ds_read_b128, no im2col anywhere), so global A traffic drops from 9 x 128 to 180 pixel rows per tile.  The bf16
+// weights of one filter row (3 taps x BN x Cin) sit beside it and are restaged per filter row.  Wave w computes output
+// rows 2w, 2w+1 of the block (32 pixels) x BN channels.  Same operands, rounding and epilogues as k_conv_fwd_bf16, so
+// the two are interchangeable; used for forward and (on dZ with the flipped weights) for the input gradient.
+constexpr int kHaloTH = 8, kHaloTW = 16;
+
+template <int CB, int BN, int EPI>
+__global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __restrict__ X, const __bf16* __restrict__ WB,
+                                                                const float* __restrict__ bias, float* __restrict__ Y, ConvShape s, int tiles_w,
+                                                                int tiles_h) {
+    static_assert(CB % 16 == 0 && BN % 32 == 0, "channel blocks of the 32x32x16 MFMA");
+    constexpr int NT = BN / 32, LDC = CB + 8;                        // halves per pixel / per weight row in LDS (16-byte aligned, bank-skewed)
+    constexpr int HH = kHaloTH + 2, HW = kHaloTW + 2;
+    constexpr int HCH = HH * HW * (CB / 4);                           // f32x4 chunks of one channel block of the halo
+    constexpr int BCH = 3 * BN * (CB / 8);                            // 16-byte chunks of one filter row's weights for that block
+    __shared__ __attribute__((aligned(16))) __bf16 Hs[HH * HW * LDC];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[3 * BN * LDC];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int tile = blockIdx.x;
+    const int tw = tile % tiles_w; tile /= tiles_w;
+    const int th = tile % tiles_h;
+    const int img = tile / tiles_h;
+    const int oh0 = th * kHaloTH, ow0 = tw * kHaloTW, n0 = blockIdx.y * BN;
+    const int Cin = s.Cin, K = 9 * Cin;                               // Cin: a multiple of CB; K = row length of WB
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int r = lane & 31, h = lane >> 5;
+    const int py = 2 * wave + (r >> 4), px = r & 15;                  // this lane's A row = output pixel (py, px) of the block
+#pragma unroll 1
+    for (int cb = 0; cb < Cin; cb += CB) {
+        if (cb) __syncthreads();                                      // the previous channel block's halo has been consumed
+        // ---- halo: pixel (oh0 - 1 + hy, ow0 - 1 + hx), channels cb .. cb + CB - 1, zero outside the image; unconditional
+        // loads from clamped addresses
+        for (int e = tid; e < HCH; e += kThreads) {
+            const int pix = e / (CB / 4), c4 = (e - pix * (CB / 4)) * 4;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+            const bool ok = (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
+            *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(ok ? v : f32x4{0, 0, 0, 0});
+        }
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            if (kh) __syncthreads();                                  // everyone is done with the previous filter row's weights
+            for (int e = tid; e < BCH; e += kThreads) {
+                const int row = e / (CB / 8), c8 = (e - row * (CB / 8)) * 8;    // row = kw * BN + co
+                const int kw = row / BN, co = row - kw * BN;
+                *reinterpret_cast<bf16x8*>(&Bs[row * LDC + c8]) =
+                    *reinterpret_cast<const bf16x8*>(WB + (long long)(n0 + co) * K + (kh * 3 + kw) * Cin + cb + c8);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const __bf16* a = &Hs[((py + kh) * HW + px + kw) * LDC + 8 * h];
+                const __bf16* b = &Bs[(kw * BN + r) * LDC + 8 * h];
+#pragma unroll
+                for (int ks = 0; ks < CB / 16; ++ks) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a + 16 * ks);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(b + 32 * t * LDC + 16 * ks);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue: accumulator row i of lane = block pixel mfma32_row(lane, i) of this wave's 32
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = n0 + 32 * t + (lane & 31);
+        const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int pr = mfma32_row(lane, i);
+            const int oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + (pr & 15);
+            if (oh < s.H && ow < s.W) {
+                const long long m = ((long long)img * s.H + oh) * s.W + ow;
+                float v = acc[t][i] + bb;
+                if (EPI == 2) v = v > 0.f ? v : 0.f;
+                if (EPI == 3) v = bias[m * s.Cout + co] > 0.f ? v : 0.f;
+                Y[m * s.Cout + co] = v;
+            }
+        }
+    }
+}
+
+}  // namespace rcnx

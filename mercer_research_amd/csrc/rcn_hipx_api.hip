@@ -99,6 +99,21 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
         XTRY(n, n->wb.ensure((size_t)s.Cout * Kp * sizeof(__bf16)));
         hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
         const __bf16* WB = (const __bf16*)n->wb.p;
+        // thin 3x3 layers: the LDS-tiled kernel (one halo per 8x16 output block serves all nine taps)
+        static const int halo_on = [] { const char* e = std::getenv("RCN_HIPX_HALO"); return e ? std::atoi(e) : 1; }();
+        if (halo_on && ks == 3 && !smallc && Z == 1 && (s.Cin == 32 || s.Cin % 64 == 0)) {
+            const int hbn = (s.Cout % 64 == 0) ? 64 : 32;
+            const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
+            const dim3 hgrid((unsigned)(tw * th * s.N), (unsigned)(s.Cout / hbn));
+#define HALO_CASE(CI_, BN_, EPI_) hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th)
+#define HALO_EPI(CI_, BN_) do { if (kepi == 0) HALO_CASE(CI_, BN_, 0); else if (kepi == 1) HALO_CASE(CI_, BN_, 1); else if (kepi == 2) HALO_CASE(CI_, BN_, 2); else HALO_CASE(CI_, BN_, 3); } while (0)
+            if (s.Cin == 32) { if (hbn == 64) HALO_EPI(32, 64); else HALO_EPI(32, 32); }
+            else { if (hbn == 64) HALO_EPI(64, 64); else HALO_EPI(64, 32); }
+#undef HALO_EPI
+#undef HALO_CASE
+            XTRY(n, hipGetLastError());
+            return 0;
+        }
 #define CONVB_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd_bf16<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s)
 #define CONVB_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONVB_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONVB_CASE(KS_, SM_, BN_, 1); else if (kepi == 2) CONVB_CASE(KS_, SM_, BN_, 2); else CONVB_CASE(KS_, SM_, BN_, 3); } while (0)
 #define CONVB_BN(KS_, SM_) do { if (bn == 128) CONVB_EPI(KS_, SM_, 128); else if (bn == 64) CONVB_EPI(KS_, SM_, 64); else CONVB_EPI(KS_, SM_, 32); } while (0)
