@@ -385,3 +385,106 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __r
 }
 
 }  // namespace rcnx
+
+namespace rcnx {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_wgrad3x3_halo_bf16 -- weight gradient of a 3x3 layer, LDS-tiled: the companion of k_conv3x3_halo_bf16.
+//
+// k_conv_wgrad_bf16 gives every 32-row k-block (= one filter tap of 32 channels) its own staged X tile, i.e. reads the
+// input nine times and dZ once per k-group.  Here a workgroup stages, per 8 x 16 block of output pixels, the 10 x 18 input
+// halo of one channel block and the block's dZ ONCE, and its NINE waves each contract one filter tap over the block:
+// wave (kh, kw) reads its A fragments -- 16 consecutive pixels of halo row py + kh starting at column kw, 32 channels -- and
+// the shared dZ fragments with the hardware transposed LDS read (the contraction index, the pixel, is the row of both LDS
+// images), accumulating dW[tap][ci][co] in registers across all the blocks of its chunk.  Global traffic per block: 180
+// input pixels + 128 dZ pixels instead of 9 x 128 + 128 per k-group.  Output: the same slab[chunk][K + 1][Cout] as
+// k_conv_wgrad (row K = bias partial, fp32 sums of the unrounded dZ), so k_reduce_update[_wide] finishes either.
+constexpr int kWgHaloThreads = 9 * 64;
+
+template <int CB, int BN>
+__global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const float* __restrict__ X, const float* __restrict__ dZ,
+                                                                       float* __restrict__ slab, ConvShape s, int tiles_w, int tiles_h,
+                                                                       int blocks_per_chunk, int n_chunks) {
+    constexpr int NA = CB / 32, NT = BN / 32, LDC = CB + 8, LDD = BN + 8;
+    constexpr int HH = kHaloTH + 2, HW = kHaloTW + 2, NPX = kHaloTH * kHaloTW;
+    constexpr int HCH = HH * HW * (CB / 4), DCH = NPX * (BN / 4);
+    __shared__ __attribute__((aligned(16))) __bf16 Hs[HH * HW * LDC];
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[NPX * LDD];
+    __shared__ __attribute__((aligned(16))) float red[kWgHaloThreads * 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kh = wave / 3, kw = wave - 3 * kh;                      // this wave's filter tap
+    const int cb = blockIdx.x * CB, n0 = blockIdx.y * BN, chunk = blockIdx.z;
+    const int Cin = s.Cin, K = 9 * Cin;
+    const int total_blocks = tiles_w * tiles_h * s.N;
+    const int b0 = chunk * blocks_per_chunk, b1 = b0 + blocks_per_chunk < total_blocks ? b0 + blocks_per_chunk : total_blocks;
+
+    f32x16 acc[NA][NT];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+
+    for (int blk = b0; blk < b1; ++blk) {
+        int q = blk;
+        const int tw = q % tiles_w; q /= tiles_w;
+        const int th = q % tiles_h;
+        const int img = q / tiles_h;
+        const int oh0 = th * kHaloTH, ow0 = tw * kHaloTW;
+        if (blk != b0) __syncthreads();                               // the previous block's images have been consumed
+        for (int e = tid; e < HCH; e += kWgHaloThreads) {             // input halo, channels cb .. cb + CB - 1
+            const int pix = e / (CB / 4), c4 = (e - pix * (CB / 4)) * 4;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+            const bool ok = (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
+            *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(ok ? v : f32x4{0, 0, 0, 0});
+        }
+        for (int e = tid; e < DCH; e += kWgHaloThreads) {             // dZ of the block's pixels, channels n0 .. n0 + BN - 1
+            const int pix = e / (BN / 4), c4 = (e - pix * (BN / 4)) * 4;
+            const int oh = oh0 + pix / kHaloTW, ow = ow0 + pix % kHaloTW;
+            const bool ok = oh < s.H && ow < s.W;
+            f32x4 v = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+            v = ok ? v : f32x4{0, 0, 0, 0};
+            *reinterpret_cast<bf16x4*>(&Ds[pix * LDD + c4]) = to_bf16x4(v);
+            colsum += v;                                              // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int py = 0; py < kHaloTH; ++py) {                        // one 16-pixel contraction step per block row
+            bf16x8 af[NA], bf[NT];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) af[a] = tr_fragment(Hs + ((py + kh) * HW + kw) * LDC, LDC, 0, 32 * a, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bf[t] = tr_fragment(Ds + py * kHaloTW * LDD, LDD, 0, 32 * t, lane);
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[t], acc[a][t], 0, 0, 0);
+        }
+    }
+    float* out = slab + (long long)chunk * (K + 1) * s.Cout;
+    const int krow0 = (kh * 3 + kw) * Cin + cb;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(long long)(krow0 + 32 * a + mfma32_row(lane, r)) * s.Cout + n0 + 32 * t + (lane & 31)] = acc[a][t][r];
+    if (blockIdx.x == 0) {                                            // bias row: thread's four columns are 4 (tid % (BN/4)); fixed-order sum
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&red[tid * 4]) = colsum;
+        __syncthreads();
+        if (tid < BN) {
+            const int grp = tid >> 2, comp = tid & 3;
+            float t = 0.f;
+            for (int u = grp; u < kWgHaloThreads; u += BN / 4) t += red[u * 4 + comp];
+            out[(long long)K * s.Cout + n0 + tid] = t;
+        }
+    }
+}
+
+}  // namespace rcnx

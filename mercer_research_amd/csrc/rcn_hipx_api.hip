@@ -160,6 +160,25 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     if (M > 0x7fff0000LL) return fail(n, -3, "too many output pixels in one layer (N*H*W must stay below 2^31)");
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
     XTRY(n, n->slab.ensure((size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
+    static const int wg_halo_on = [] { const char* e = std::getenv("RCN_HIPX_HALO_WGRAD"); return e ? std::atoi(e) : 1; }();
+    if (n->precision == RCN_HIPX_BF16 && wg_halo_on && ks == 3 && !smallc && (s.Cin == 32 || s.Cin % 64 == 0) && (s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2)) {
+        // LDS-tiled: input halo + dZ block staged once per 8x16 pixel block, nine waves = nine filter taps (convnet_bf16.hpp)
+        const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
+        const long long blocks = (long long)tw * th * s.N;
+        int bpc = (int)((blocks + 2047) / 2048);
+        if (bpc < 8) bpc = blocks < 8 ? (int)blocks : 8;
+        const int hchunks = (int)((blocks + bpc - 1) / bpc);
+        XTRY(n, n->slab.ensure((size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
+        const int hb = s.Cin == 32 ? 32 : 64, hbn = (s.Cout % 64 == 0) ? 64 : 32;
+        const dim3 hgrid((unsigned)(s.Cin / hb), (unsigned)(s.Cout / hbn), (unsigned)hchunks);
+#define WGH_CASE(CB_, BN_) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tw, th, bpc, hchunks)
+        if (hb == 32) { if (hbn == 64) WGH_CASE(32, 64); else WGH_CASE(32, 32); }
+        else { if (hbn == 64) WGH_CASE(64, 64); else WGH_CASE(64, 32); }
+#undef WGH_CASE
+        XTRY(n, hipGetLastError());
+        *chunks_out = hchunks;
+        return 0;
+    }
     if (n->precision == RCN_HIPX_BF16 && !smallc) {
         // bf16 operands, transposed LDS reads (convnet_bf16.hpp); NKB waves per workgroup, one 32-row k-block each
         const int nkb = K / 32;
