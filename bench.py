@@ -335,7 +335,7 @@ def main():
                               "step_gflops_per_s": round(flops_step / (elapsed / args.steps) / 1e9, 1),
                               "note": "one train_batch at B=256 is ~1 MB and ~25 MFLOP: bound by launch + dependent-latency floors "
                                       "(1.6 us per dependent launch, >=1 us per global round trip), far from either roof"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU path is timed beside the N = 1 run only
             result["cpu_baseline"] = cpu_baseline()
             result["config"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(result), flush=True)
