@@ -38,13 +38,12 @@ __device__ inline void store4(T* dst, int lane, const typename Mfma16<T>::acc_t&
 }
 
 template <typename T>
-__global__ __launch_bounds__(kDenseThreads) void k_p2_a(
-    NetDesc nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B,
+__device__ __forceinline__ void p2_a_body(
+    const NetDesc& nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B,
     const T* __restrict__ a1, const T* __restrict__ d1, const T* __restrict__ d2, T scale, T* __restrict__ slab, int G,
-    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd) {
+    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd, unsigned char* smem_raw) {
     using acc_t = typename Mfma16<T>::acc_t;
     using vec4 = typename Vec4<T>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* red = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
     const int F = nd.dims[0], H = nd.dims[1];
@@ -154,15 +153,17 @@ __global__ __launch_bounds__(kDenseThreads) void k_p2_a(
 // One workgroup per 8 samples, 8 waves.  All waves sum slabs (slices w, w+8, ...).  Waves 1-7 additionally fetch and
 // mask the tail's operands into LDS as ready-made MFMA fragments (a few loads each), so that wave 0 -- the critical
 // path, ~5.6 cycles per instruction when a wave runs alone on its SIMD -- only reads fragments, issues 16 MFMAs and stores.
+constexpr int kP2BFrag = 28;                                      // fragment words per lane: wz 8, wd 8, b1 4, y 4, b0 4
+inline size_t p2_b_lds_elems() { return (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + kP2C * kLd + kP2BFrag * 64; }
+
 template <typename T>
-__global__ __launch_bounds__(kP2BThreads) void k_p2_b(
-    NetDesc nd, const T* __restrict__ params, const T* __restrict__ slab, int G, const T* __restrict__ Ys, int B,
-    T* __restrict__ a1g, T* __restrict__ d1g, T* __restrict__ d2g, T* __restrict__ loss_part) {
+__device__ __forceinline__ void p2_b_body(
+    const NetDesc& nd, const T* __restrict__ params, const T* __restrict__ slab, int G, const T* __restrict__ Ys, int B,
+    T* __restrict__ a1g, T* __restrict__ d1g, T* __restrict__ d2g, T* __restrict__ loss_part, unsigned char* smem_raw) {
     using acc_t = typename Mfma16<T>::acc_t;
     using vec4 = typename Vec4<T>::type;
-    constexpr int kFrag = 28;                                     // fragment words per lane: wz 8, wd 8, b1 4, y 4, b0 4
+    constexpr int kFrag = kP2BFrag;
     constexpr int kPer = kP2MaxSlices / kP2BWaves;                // slab slices per wave (8)
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(kP2BWaves * 64 * 4 + kP2H * kLd + kP2C * kLd + kFrag * 64) * sizeof(T)];
     T* smem = reinterpret_cast<T*>(smem_raw);
     vec4* zred = reinterpret_cast<vec4*>(smem);                   // [8 waves][64 lanes]
     T* a1s = smem + kP2BWaves * 64 * 4;                           // a_1 tile  [hidden 32][kLd]  (MFMA B operand image)
@@ -283,6 +284,41 @@ __global__ __launch_bounds__(kP2BThreads) void k_p2_b(
     for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
     if (lane == 0 && loss_part) loss_part[blockIdx.x] = lsum;
     RCN_STAMP(1, 6);
+}
+
+// ---- the two kernels of a step, and both in ONE kernel object -------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kDenseThreads) void k_p2_a(
+    NetDesc nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B,
+    const T* __restrict__ a1, const T* __restrict__ d1, const T* __restrict__ d2, T scale, T* __restrict__ slab, int G,
+    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    p2_a_body<T>(nd, params, Xp, Xn, B, a1, d1, d2, scale, slab, G, loss_part, n_loss, loss_scale, loss_out, do_update, do_fwd, smem_dyn);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kP2BThreads) void k_p2_b(
+    NetDesc nd, const T* __restrict__ params, const T* __restrict__ slab, int G, const T* __restrict__ Ys, int B,
+    T* __restrict__ a1g, T* __restrict__ d1g, T* __restrict__ d2g, T* __restrict__ loss_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    p2_b_body<T>(nd, params, slab, G, Ys, B, a1g, d1g, d2g, loss_part, smem_dyn);
+}
+
+// The epoch loop alternates the two strictly, and the pair costs ~0.9 us more than the two back to back with themselves
+// (9.2 us vs 3.85 + 4.45).  Hypothesis tested here: the switch of kernel object (code, descriptor, LDS / register allocation)
+// between launches.  As two ROLES of one kernel object the step is 2 % SLOWER (9.75 vs 9.55 us), so that is not it; kept
+// behind RCN_HIP_P2_ONE_OBJECT=1 as the record of the experiment.
+static_assert(kDenseThreads == kP2BThreads, "one launch shape for both roles");
+inline size_t p2_ab_lds_elems() { return p2_a_lds_elems() > p2_b_lds_elems() ? p2_a_lds_elems() : p2_b_lds_elems(); }
+
+template <typename T>
+__global__ __launch_bounds__(kDenseThreads) void k_p2_ab(
+    int role, NetDesc nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, const T* __restrict__ Ys, int B,
+    T* __restrict__ a1, T* __restrict__ d1, T* __restrict__ d2, T scale, T* __restrict__ slab, int G, T* __restrict__ loss_part, int n_loss,
+    T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    if (role == 0) p2_b_body<T>(nd, params, slab, G, Ys, B, a1, d1, d2, loss_part, smem_dyn);
+    else p2_a_body<T>(nd, params, Xp, Xn, B, a1, d1, d2, scale, slab, G, loss_part, n_loss, loss_scale, loss_out, do_update, do_fwd, smem_dyn);
 }
 
 }  // namespace rcn

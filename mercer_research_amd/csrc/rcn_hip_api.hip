@@ -331,6 +331,10 @@ int ensure_pipe_ws(rcn_hip_ctx* c, size_t B) {
     return RCN_HIP_OK;
 }
 
+// RCN_HIP_P2_ONE_OBJECT=1: both kernels of a pipelined step as roles of one kernel object (dense_p2.hpp: k_p2_ab).  Measured 2 % slower
+// than two kernels (9.75 vs 9.55 us/step), so off by default: the cost of alternating is not the switch of kernel object.
+static bool p2_one_object() { static const int v = [] { const char* e = std::getenv("RCN_HIP_P2_ONE_OBJECT"); return e ? std::atoi(e) : 0; }(); return v != 0; }
+
 template <typename T>
 int launch_pipe_a(rcn_hip_ctx* c, const void* xp, const void* xn, size_t B, double scale, void* loss_out, double loss_scale, bool do_update, bool do_fwd) {
     const NetDesc& nd = c->nd;
@@ -339,9 +343,14 @@ int launch_pipe_a(rcn_hip_ctx* c, const void* xp, const void* xn, size_t B, doub
     const int n_loss = (int)((B + kPipeTs - 1) / kPipeTs);
     if (p2_supported(nd, B)) {       // lean specialisation: one hidden layer <= 32, classes <= 16, B % 256 == 0
         T* a1 = (T*)c->p2buf.p; T* d1 = a1 + B * kP2H; T* d2 = d1 + B * kP2H;
-        hipLaunchKernelGGL((k_p2_a<T>), dim3(grid), dim3(kDenseThreads), p2_a_lds_elems() * sizeof(T), c->stream, nd, (T*)c->params.p, (const T*)xp,
-                           (const T*)xn, (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, G, (const T*)c->loss_part.p, n_loss,
-                           (T)loss_scale, (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0);
+        if (p2_one_object())
+            hipLaunchKernelGGL((k_p2_ab<T>), dim3(grid), dim3(kDenseThreads), p2_ab_lds_elems() * sizeof(T), c->stream, 1, nd, (T*)c->params.p, (const T*)xp,
+                               (const T*)xn, (const T*)nullptr, (int)B, a1, d1, d2, (T)scale, (T*)c->slab.p, G, (T*)c->loss_part.p, n_loss, (T)loss_scale,
+                               (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0);
+        else
+            hipLaunchKernelGGL((k_p2_a<T>), dim3(grid), dim3(kDenseThreads), p2_a_lds_elems() * sizeof(T), c->stream, nd, (T*)c->params.p, (const T*)xp,
+                               (const T*)xn, (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, G, (const T*)c->loss_part.p, n_loss,
+                               (T)loss_scale, (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0);
         HIP_TRY(c, hipGetLastError());
         return RCN_HIP_OK;
     }
@@ -358,8 +367,13 @@ int launch_pipe_b(rcn_hip_ctx* c, const void* ys, size_t B) {
     const NetDesc& nd = c->nd;
     if (p2_supported(nd, B)) {
         T* a1 = (T*)c->p2buf.p; T* d1 = a1 + B * kP2H; T* d2 = d1 + B * kP2H;
-        hipLaunchKernelGGL((k_p2_b<T>), dim3((unsigned)(B / kP2Ts)), dim3(kP2BThreads), 0, c->stream, nd, (const T*)c->params.p, (const T*)c->slab.p,
-                           pipe_slices(nd), (const T*)ys, (int)B, a1, d1, d2, (T*)c->loss_part.p);
+        if (p2_one_object())
+            hipLaunchKernelGGL((k_p2_ab<T>), dim3((unsigned)(B / kP2Ts)), dim3(kDenseThreads), p2_ab_lds_elems() * sizeof(T), c->stream, 0, nd, (T*)c->params.p,
+                               (const T*)nullptr, (const T*)nullptr, (const T*)ys, (int)B, a1, d1, d2, (T)0, (T*)c->slab.p, pipe_slices(nd), (T*)c->loss_part.p, 0,
+                               (T)0, (T*)nullptr, 0, 0);
+        else
+            hipLaunchKernelGGL((k_p2_b<T>), dim3((unsigned)(B / kP2Ts)), dim3(kP2BThreads), p2_b_lds_elems() * sizeof(T), c->stream, nd, (const T*)c->params.p,
+                               (const T*)c->slab.p, pipe_slices(nd), (const T*)ys, (int)B, a1, d1, d2, (T*)c->loss_part.p);
         HIP_TRY(c, hipGetLastError());
         return RCN_HIP_OK;
     }
