@@ -302,7 +302,7 @@ constexpr int kHaloTH = 8, kHaloTW = 16;
 template <int CB, int BN, int EPI>
 __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __restrict__ X, const __bf16* __restrict__ WB,
                                                                 const float* __restrict__ bias, float* __restrict__ Y, ConvShape s, int tiles_w,
-                                                                int tiles_h) {
+                                                                int tiles_h, uint8_t* __restrict__ pool_idx) {
     static_assert(CB % 16 == 0 && BN % 32 == 0, "channel blocks of the 32x32x16 MFMA");
     constexpr int NT = BN / 32, LDC = CB + 8;                        // halves per pixel / per weight row in LDS (16-byte aligned, bank-skewed)
     constexpr int HH = kHaloTH + 2, HW = kHaloTW + 2;
@@ -365,6 +365,40 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __r
         }
     }
     // ---- epilogue: accumulator row i of lane = block pixel mfma32_row(lane, i) of this wave's 32
+    if (EPI == 4) {
+        // bias + ReLU + the 2x2 max-pool that follows, fused: a lane's sixteen rows are columns 4h..4h+3 and 8+4h..8+4h+3 of BOTH
+        // pixel rows of its wave, i.e. four complete pooling windows -- the pool is a max over the lane's own registers.  Writes the
+        // pooled map and the arg-max image exactly as k_pool_fwd does (first maximum in the order 00, 01, 10, 11), so k_pool_bwd is
+        // unchanged; the un-pooled activation is never written.
+        const int OH = s.H / 2, OW = s.W / 2;
+        const int poh = oh0 / 2 + wave;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co = n0 + 32 * t + (lane & 31);
+            const float bb = bias[co];
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int i0 = 4 * gq + 2 * pp;
+                    float v[4] = {acc[t][i0] + bb, acc[t][i0 + 1] + bb, acc[t][8 + i0] + bb, acc[t][8 + i0 + 1] + bb};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                    float best = v[0];
+                    int bk = 0;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+                        if (v[k] > best) { best = v[k]; bk = k; }
+                    const int pow_ = ow0 / 2 + 2 * h + 4 * gq + pp;
+                    if (poh < OH && pow_ < OW) {
+                        const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
+                        Y[o] = best;
+                        pool_idx[o] = (uint8_t)bk;
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int co = n0 + 32 * t + (lane & 31);

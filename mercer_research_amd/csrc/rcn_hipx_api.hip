@@ -75,7 +75,14 @@ int grid1d(long long total, int block) { long long g = (total + block - 1) / blo
 // Y = act(conv(X) + b) as implicit GEMM; `ks` = 1 or 3; epi 0 raw / 1 bias / 2 bias + relu.
 // Few output tiles and a long contraction (the dense layers: M = batch) -> split-K over gridDim.z into raw partial tiles
 // (slab `skbuf`) that k_splitk_epilogue sums in order.
-int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi) {
+// epi 4 (bias + ReLU + the following 2x2 max-pool, written to Y = pooled map and pool_idx) exists only in the LDS-tiled bf16 kernel:
+// callers ask conv_pool_fusable() first
+static bool halo_enabled() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO"); return e ? std::atoi(e) : 1; }(); return v != 0; }
+bool conv_pool_fusable(const rcn_hipx_net* n, const ConvShape& s) {
+    return n->precision == RCN_HIPX_BF16 && halo_enabled() && (s.Cin == 32 || s.Cin % 64 == 0) && s.H % 2 == 0 && s.W % 2 == 0;
+}
+
+int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi, uint8_t* pool_idx = nullptr) {
     const long long M = (long long)s.N * s.H * s.W;
     const bool smallc = ks * ks * s.Cin <= 32;
     if (!smallc && s.Cin % 32) return fail(n, -3, "input channels must be a multiple of 32 (or the whole 3x3xCin patch <= 32)");
@@ -85,7 +92,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     const long long tiles = ((M + kBM - 1) / kBM) * (s.Cout / bn);
     const int nkt = smallc ? 1 : ks * ks * s.Cin / 32;
     int Z = 1;
-    if (tiles < 256 && nkt >= 8) { Z = (int)(512 / tiles); if (Z > nkt / 4) Z = nkt / 4; if (Z < 1) Z = 1; }
+    if (tiles < 256 && nkt >= 8 && epi != 4) { Z = (int)(512 / tiles); if (Z > nkt / 4) Z = nkt / 4; if (Z < 1) Z = 1; }
     float* out = Y;
     int kepi = epi;
     if (Z > 1) {
@@ -100,13 +107,13 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
         hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
         const __bf16* WB = (const __bf16*)n->wb.p;
         // thin 3x3 layers: the LDS-tiled kernel (one halo per 8x16 output block serves all nine taps)
-        static const int halo_on = [] { const char* e = std::getenv("RCN_HIPX_HALO"); return e ? std::atoi(e) : 1; }();
-        if (halo_on && ks == 3 && !smallc && Z == 1 && (s.Cin == 32 || s.Cin % 64 == 0)) {
+        if (epi == 4 && !(ks == 3 && conv_pool_fusable(n, s))) return fail(n, -3, "internal: fused conv+pool epilogue requested for a layer the LDS-tiled kernel does not cover");
+        if (halo_enabled() && ks == 3 && !smallc && Z == 1 && (s.Cin == 32 || s.Cin % 64 == 0)) {
             const int hbn = (s.Cout % 64 == 0) ? 64 : 32;
             const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
             const dim3 hgrid((unsigned)(tw * th * s.N), (unsigned)(s.Cout / hbn));
-#define HALO_CASE(CI_, BN_, EPI_) hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th)
-#define HALO_EPI(CI_, BN_) do { if (kepi == 0) HALO_CASE(CI_, BN_, 0); else if (kepi == 1) HALO_CASE(CI_, BN_, 1); else if (kepi == 2) HALO_CASE(CI_, BN_, 2); else HALO_CASE(CI_, BN_, 3); } while (0)
+#define HALO_CASE(CI_, BN_, EPI_) hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx)
+#define HALO_EPI(CI_, BN_) do { if (kepi == 0) HALO_CASE(CI_, BN_, 0); else if (kepi == 1) HALO_CASE(CI_, BN_, 1); else if (kepi == 2) HALO_CASE(CI_, BN_, 2); else if (kepi == 3) HALO_CASE(CI_, BN_, 3); else HALO_CASE(CI_, BN_, 4); } while (0)
             if (s.Cin == 32) { if (hbn == 64) HALO_EPI(32, 64); else HALO_EPI(32, 32); }
             else { if (hbn == 64) HALO_EPI(64, 64); else HALO_EPI(64, 32); }
 #undef HALO_EPI
@@ -226,7 +233,16 @@ int forward(rcn_hipx_net* n, const float* x, int B) {
             hipLaunchKernelGGL(k_pool_fwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, cur, (float*)l.out.p, (uint8_t*)l.idx.p, B, l.H, l.W, l.Cin);
             XTRY(n, hipGetLastError());
         } else if (l.kind == RCN_HIPX_CONV3X3_RELU) {
-            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, ConvShape{B, l.H, l.W, l.Cin, l.CoutP}, 3, 2));
+            const ConvShape cs{B, l.H, l.W, l.Cin, l.CoutP};
+            if (l.pool_follows && conv_pool_fusable(n, cs)) {
+                // the pool that follows runs in this kernel's epilogue: only the pooled map (and its arg-max image) is written
+                Layer& pl = n->L[i + 1];
+                RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)pl.out.p, cs, 3, 4, (uint8_t*)pl.idx.p));
+                cur = (const float*)pl.out.p;
+                ++i;
+                continue;
+            }
+            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, cs, 3, 2));
         } else {
             RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, ConvShape{B, 1, 1, l.K, l.CoutP}, 1, l.kind == RCN_HIPX_DENSE_RELU ? 2 : 1));
         }
