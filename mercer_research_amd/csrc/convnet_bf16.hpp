@@ -39,6 +39,27 @@ __device__ inline bf16x4 to_bf16x4(const f32x4& v) {
     return h;
 }
 
+// A gradient tensor that exists only at pooled resolution.  dZ of a conv layer followed by a 2x2 max-pool is
+//     dZ[n, y, x, c] = (arg-max of its window == (y & 1, x & 1) && pooled value > 0) ? dP[n, y/2, x/2, c] : 0
+// (k_pool_bwd); the LDS-tiled kernels can rebuild it while staging instead of reading a full-resolution copy that another
+// kernel wrote: three reads at quarter resolution (4 + 4 + 1 bytes per channel) replace one write and one read of 4 x 4.
+struct PooledGrad {
+    const float* dP;          // [N][H/2][W/2][C] gradient wrt the pooled map; nullptr: the tensor is materialised, read it directly
+    const float* P;           // pooled activations (the ReLU gate)
+    const uint8_t* idx;       // arg-max position 0..3 = dy * 2 + dx
+};
+
+__device__ inline f32x4 pooled_grad4(const PooledGrad& g, int img, int y, int x, int c, int H, int W, int C) {
+    const long long o = ((((long long)img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C) + c;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(g.dP + o), pv = *reinterpret_cast<const f32x4*>(g.P + o);
+    const unsigned ii = *reinterpret_cast<const unsigned*>(g.idx + o);
+    const unsigned pos = (unsigned)(((y & 1) << 1) | (x & 1));
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (((ii >> (8 * i)) & 3u) == pos && pv[i] > 0.f) ? d[i] : 0.f;
+    return v;
+}
+
 // Same tiling, split-K and epilogues as k_conv_fwd; WB = weights as bf16 [Cout][Kp], Kp = K rounded up to 32
 template <int KS, bool SMALLC, int BN, int EPI>
 __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restrict__ X, const __bf16* __restrict__ WB,
@@ -299,10 +320,10 @@ namespace rcnx {
 // the two are interchangeable; used for forward and (on dZ with the flipped weights) for the input gradient.
 constexpr int kHaloTH = 8, kHaloTW = 16;
 
-template <int CB, int BN, int EPI>
+template <int CB, int BN, int EPI, bool PIN = false>
 __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __restrict__ X, const __bf16* __restrict__ WB,
                                                                 const float* __restrict__ bias, float* __restrict__ Y, ConvShape s, int tiles_w,
-                                                                int tiles_h, uint8_t* __restrict__ pool_idx) {
+                                                                int tiles_h, uint8_t* __restrict__ pool_idx, PooledGrad pin) {
     static_assert(CB % 16 == 0 && BN % 32 == 0, "channel blocks of the 32x32x16 MFMA");
     constexpr int NT = BN / 32, LDC = CB + 8;                        // halves per pixel / per weight row in LDS (16-byte aligned, bank-skewed)
     constexpr int HH = kHaloTH + 2, HW = kHaloTW + 2;
@@ -335,7 +356,8 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __r
             const int hy = pix / HW, hx = pix - hy * HW;
             const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
             const bool ok = (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
+            const f32x4 v = PIN ? pooled_grad4(pin, img, ok ? ih : 0, ok ? iw : 0, cb + c4, s.H, s.W, Cin)    // the input is a pooled-resolution gradient
+                                : *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
             *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(ok ? v : f32x4{0, 0, 0, 0});
         }
 #pragma unroll 1
@@ -435,10 +457,10 @@ namespace rcnx {
 // k_conv_wgrad (row K = bias partial, fp32 sums of the unrounded dZ), so k_reduce_update[_wide] finishes either.
 constexpr int kWgHaloThreads = 9 * 64;
 
-template <int CB, int BN>
+template <int CB, int BN, bool PDZ = false>
 __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const float* __restrict__ X, const float* __restrict__ dZ,
                                                                        float* __restrict__ slab, ConvShape s, int tiles_w, int tiles_h,
-                                                                       int blocks_per_chunk, int n_chunks) {
+                                                                       int blocks_per_chunk, int n_chunks, PooledGrad pdz) {
     constexpr int NA = CB / 32, NT = BN / 32, LDC = CB + 8, LDD = BN + 8;
     constexpr int HH = kHaloTH + 2, HW = kHaloTW + 2, NPX = kHaloTH * kHaloTW;
     constexpr int HCH = HH * HW * (CB / 4), DCH = NPX * (BN / 4);
@@ -480,7 +502,8 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
             const int pix = e / (BN / 4), c4 = (e - pix * (BN / 4)) * 4;
             const int oh = oh0 + pix / kHaloTW, ow = ow0 + pix % kHaloTW;
             const bool ok = oh < s.H && ow < s.W;
-            f32x4 v = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+            f32x4 v = PDZ ? pooled_grad4(pdz, img, ok ? oh : 0, ok ? ow : 0, n0 + c4, s.H, s.W, s.Cout)
+                          : *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
             v = ok ? v : f32x4{0, 0, 0, 0};
             *reinterpret_cast<bf16x4*>(&Ds[pix * LDD + c4]) = to_bf16x4(v);
             colsum += v;                                              // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)

@@ -82,7 +82,18 @@ bool conv_pool_fusable(const rcn_hipx_net* n, const ConvShape& s) {
     return n->precision == RCN_HIPX_BF16 && halo_enabled() && (s.Cin == 32 || s.Cin % 64 == 0) && s.H % 2 == 0 && s.W % 2 == 0;
 }
 
-int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi, uint8_t* pool_idx = nullptr) {
+// can the LDS-tiled kernel run this 3x3 convolution (as launch_conv would decide)?  Mirrors launch_conv's split-K rule.
+bool conv_halo_runs(const rcn_hipx_net* n, const ConvShape& s) {
+    if (n->precision != RCN_HIPX_BF16 || !halo_enabled() || !(s.Cin == 32 || s.Cin % 64 == 0) || s.Cout % 32) return false;
+    const long long M = (long long)s.N * s.H * s.W;
+    const int bn = s.Cout % 128 == 0 ? 128 : s.Cout % 64 == 0 ? 64 : 32;
+    const long long tiles = ((M + kBM - 1) / kBM) * (s.Cout / bn);
+    const int nkt = 9 * s.Cin / 32;
+    return !(tiles < 256 && nkt >= 8 && 512 / tiles > 1 && nkt / 4 > 1);
+}
+
+int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi, uint8_t* pool_idx = nullptr,
+                const PooledGrad* pin = nullptr) {
     const long long M = (long long)s.N * s.H * s.W;
     const bool smallc = ks * ks * s.Cin <= 32;
     if (!smallc && s.Cin % 32) return fail(n, -3, "input channels must be a multiple of 32 (or the whole 3x3xCin patch <= 32)");
@@ -112,7 +123,9 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
             const int hbn = (s.Cout % 64 == 0) ? 64 : 32;
             const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
             const dim3 hgrid((unsigned)(tw * th * s.N), (unsigned)(s.Cout / hbn));
-#define HALO_CASE(CI_, BN_, EPI_) hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx)
+            const PooledGrad pg = pin ? *pin : PooledGrad{nullptr, nullptr, nullptr};
+#define HALO_CASE(CI_, BN_, EPI_) do { if (pin) hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_, true>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx, pg); \
+                                       else hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_, false>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx, pg); } while (0)
 #define HALO_EPI(CI_, BN_) do { if (kepi == 0) HALO_CASE(CI_, BN_, 0); else if (kepi == 1) HALO_CASE(CI_, BN_, 1); else if (kepi == 2) HALO_CASE(CI_, BN_, 2); else if (kepi == 3) HALO_CASE(CI_, BN_, 3); else HALO_CASE(CI_, BN_, 4); } while (0)
             if (s.Cin == 32) { if (hbn == 64) HALO_EPI(32, 64); else HALO_EPI(32, 32); }
             else { if (hbn == 64) HALO_EPI(64, 64); else HALO_EPI(64, 32); }
@@ -121,6 +134,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
             XTRY(n, hipGetLastError());
             return 0;
         }
+        if (pin) return fail(n, -3, "internal: pooled-resolution input requested for a layer the LDS-tiled kernel does not cover");
 #define CONVB_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd_bf16<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s)
 #define CONVB_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONVB_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONVB_CASE(KS_, SM_, BN_, 1); else if (kepi == 2) CONVB_CASE(KS_, SM_, BN_, 2); else CONVB_CASE(KS_, SM_, BN_, 3); } while (0)
 #define CONVB_BN(KS_, SM_) do { if (bn == 128) CONVB_EPI(KS_, SM_, 128); else if (bn == 64) CONVB_EPI(KS_, SM_, 64); else CONVB_EPI(KS_, SM_, 32); } while (0)
@@ -159,7 +173,12 @@ static int pix_per_chunk(long long M) {
 }
 #define kPixPerChunk (pix_per_chunk(M))
 
-int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, int ks, int* chunks_out) {
+static bool wgrad_halo_on() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO_WGRAD"); return e ? std::atoi(e) : 1; }(); return v != 0; }
+bool wgrad_halo_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) {
+    return n->precision == RCN_HIPX_BF16 && wgrad_halo_on() && ks == 3 && ks * ks * s.Cin > 32 && (s.Cin == 32 || s.Cin % 64 == 0) && s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2;
+}
+
+int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, int ks, int* chunks_out, const PooledGrad* pdz = nullptr) {
     const long long M = (long long)s.N * s.H * s.W;
     const int K = ks * ks * s.Cin;
     const bool smallc = K <= 32;
@@ -167,8 +186,8 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     if (M > 0x7fff0000LL) return fail(n, -3, "too many output pixels in one layer (N*H*W must stay below 2^31)");
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
     XTRY(n, n->slab.ensure((size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
-    static const int wg_halo_on = [] { const char* e = std::getenv("RCN_HIPX_HALO_WGRAD"); return e ? std::atoi(e) : 1; }();
-    if (n->precision == RCN_HIPX_BF16 && wg_halo_on && ks == 3 && !smallc && (s.Cin == 32 || s.Cin % 64 == 0) && (s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2)) {
+    if (pdz && !wgrad_halo_runs(n, s, ks)) return fail(n, -3, "internal: pooled-resolution dZ requested for a layer the LDS-tiled weight-gradient kernel does not cover");
+    if (wgrad_halo_runs(n, s, ks)) {
         // LDS-tiled: input halo + dZ block staged once per 8x16 pixel block, nine waves = nine filter taps (convnet_bf16.hpp)
         const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
         const long long blocks = (long long)tw * th * s.N;
@@ -178,7 +197,9 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         XTRY(n, n->slab.ensure((size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
         const int hb = s.Cin == 32 ? 32 : 64, hbn = (s.Cout % 64 == 0) ? 64 : 32;
         const dim3 hgrid((unsigned)(s.Cin / hb), (unsigned)(s.Cout / hbn), (unsigned)hchunks);
-#define WGH_CASE(CB_, BN_) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tw, th, bpc, hchunks)
+        const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
+#define WGH_CASE(CB_, BN_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, true>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tw, th, bpc, hchunks, pg); \
+                                else hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, false>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tw, th, bpc, hchunks, pg); } while (0)
         if (hb == 32) { if (hbn == 64) WGH_CASE(32, 64); else WGH_CASE(32, 32); }
         else { if (hbn == 64) WGH_CASE(64, 64); else WGH_CASE(64, 32); }
 #undef WGH_CASE
@@ -254,11 +275,21 @@ int forward(rcn_hipx_net* n, const float* x, int B) {
 // backward from dlogits (already in L.back().dout); apply: update parameters with lr, else write gradients to grad (padded layout)
 int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply) {
     std::vector<char> gated(n->L.size(), 0);       // layer's dout already holds dZ (ReLU gate applied by the producer)
+    std::vector<PooledGrad> pooled(n->L.size(), PooledGrad{nullptr, nullptr, nullptr});   // layer's dZ exists only at pooled resolution
     for (int i = (int)n->L.size() - 1; i >= 0; --i) {
         Layer& l = n->L[i];
         const float* in = i == 0 ? x : (const float*)n->L[i - 1].out.p;
         float* din = i == 0 ? nullptr : (float*)n->L[i - 1].dout.p;
         if (l.kind == RCN_HIPX_MAXPOOL2) {
+            // When the LDS-tiled kernels run both consumers of the convolution's dZ (its weight gradient, and its input gradient if
+            // it has one), they rebuild dZ from (dP, P, arg-max) at pooled resolution while staging: no k_pool_bwd, no full-size dZ.
+            static const int fuse_on = [] { const char* e = std::getenv("RCN_HIPX_FUSE_POOL_BWD"); return e ? std::atoi(e) : 1; }();
+            const Layer& cl = n->L[i - 1];
+            const ConvShape cs{B, cl.H, cl.W, cl.Cin, cl.CoutP};
+            if (fuse_on && wgrad_halo_runs(n, cs, 3) && (i - 1 == 0 || conv_halo_runs(n, ConvShape{B, cl.H, cl.W, cl.CoutP, cl.Cin}))) {
+                pooled[i - 1] = PooledGrad{(const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p};
+                continue;
+            }
             // gradient wrt the pool INPUT, with the preceding conv's ReLU mask folded in (pooled value > 0)
             const long long tot = (long long)B * l.oH * l.oW * (l.Cin / 4);
             hipLaunchKernelGGL(k_pool_bwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p,
@@ -288,11 +319,12 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
             // this kernel's epilogue, so that layer finds its dZ ready instead of running a k_relu_bwd pass over the tensor
             const Layer& below = n->L[i - 1];
             const bool gate = below.kind == RCN_HIPX_CONV3X3_RELU || below.kind == RCN_HIPX_DENSE_RELU;
-            RTRY(launch_conv(n, dZ, (const float*)n->wt.p, gate ? (const float*)below.out.p : nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, gate ? 3 : 0));
+            RTRY(launch_conv(n, dZ, (const float*)n->wt.p, gate ? (const float*)below.out.p : nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, gate ? 3 : 0,
+                             nullptr, pooled[i].dP ? &pooled[i] : nullptr));
             gated[i - 1] = gate;
         }
         int chunks = 0;
-        RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks));
+        RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks, pooled[i].dP ? &pooled[i] : nullptr));
         // [W | b] is contiguous (b_off == w_off + K * CoutP): one pass reduces the slab (incl. its bias row) and updates both
         const long long wcount = ((long long)s.Cin * ks * ks + 1) * s.Cout;
         if (chunks >= 8)
