@@ -248,14 +248,14 @@ def main():
     # every pass are recomputed from the resident u8 images inside the timed region.
     e2e = None
     if not use_dp and not args.no_e2e:
-        Xe = d.empty(N_IMAGES, DIMS[0])
         perm1 = perm[:N_IMAGES]
-        d.prepare_epoch(Xe, Y, perm1, B, nb_epoch, ETA, None)
+        d.train_epoch_images(imgs_d, Y, perm1, B, nb_epoch, ETA, None, prepare_only=True)
 
         def e2e_pass(i):
+            # one kernel per segment of the pass: flatten_feature_set + standardise + gather into the training layout, straight
+            # from the u8 pictures (rcn_hip_train_epoch_images_dev); no feature matrix is written
             d.shuffle(perm1, N_IMAGES, 1, seed=0xE2E + i)
-            d.features(imgs_d, True, Xe)
-            d.train_epoch(Xe, Y, perm1, B, nb_epoch, ETA, None)
+            d.train_epoch_images(imgs_d, Y, perm1, B, nb_epoch, ETA, None)
         for i in range(4):
             e2e_pass(i)
         d.synchronize()

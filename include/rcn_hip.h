@@ -166,6 +166,15 @@ int  rcn_hip_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_
  * pass into perm_dev (each pass is rcn.rs:146-149 once). */
 int  rcn_hip_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
                                size_t B, size_t n_batches, double eta, void* loss_dev);
+/* End to end: the same epoch straight from the resident u8 pictures (imgs_dev [N][H][W], perm_dev indexes pictures).  Per
+ * segment of the epoch ONE kernel does flatten_feature_set (rcn.rs:317-356), the standardisation with the current scale_set
+ * (rcn.rs:407-412) and the gather into the training kernels' layout -- no [N][F] feature matrix is ever written; results
+ * are bit-identical to rcn_hip_features_dev(standardize = 1) followed by rcn_hip_train_epoch_dev.  Default conv/pool stack on
+ * 28x28 input and the feature-sliced pipeline only (RCN_HIP_ERR_UNSUPPORTED otherwise). */
+int  rcn_hip_train_epoch_images_dev(rcn_hip_ctx* ctx, const uint8_t* imgs_dev, const void* Y_dev, const int32_t* perm_dev,
+                                    size_t B, size_t n_batches, double eta, void* loss_dev);
+int  rcn_hip_prepare_epoch_images_dev(rcn_hip_ctx* ctx, const uint8_t* imgs_dev, const void* Y_dev, const int32_t* perm_dev,
+                                      size_t B, size_t n_batches, double eta, void* loss_dev);
 /* training_set.shuffle (rcn.rs:146) on the device: writes `passes` independent pseudo-random permutations of 0..n-1
  * (pass p at perm_dev[p*n ..]) keyed by `seed` -- ready to be passed to rcn_hip_train_epoch_dev.  Enqueued on the
  * context's stream (one small kernel); the reference draws from the unseeded thread_rng. */

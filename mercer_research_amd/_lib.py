@@ -71,6 +71,8 @@ SIGNATURES = {
     "rcn_hip_train_batch_dev": (_i, [_vp, _vp, _vp, _sz, _d, _vp]),
     "rcn_hip_train_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
     "rcn_hip_prepare_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
+    "rcn_hip_train_epoch_images_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
+    "rcn_hip_prepare_epoch_images_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
     "rcn_hip_shuffle_dev": (_i, [_vp, _vp, _sz, _sz, C.c_uint64]),
     "rcn_hip_batch_gradient_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "rcn_hip_batch_gradient_perm_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -263,6 +263,35 @@ __global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict_
     }
 }
 
+// flatten_feature_set + standardise of a whole epoch segment, written STRAIGHT into the slice-major image the pipelined
+// training kernels read (dense_pipe.hpp: Xs[batch][slice][sample][16 features], Ys[batch][sample][classes]) -- the
+// end-to-end form: u8 images in, no [N][F] feature matrix in HBM, no separate gather pass.  One wave per (batch, sample);
+// the sample's image is perm[batch * B + sample] (or that index itself).  Same arithmetic as k_features_cpcp with the
+// fused standardisation, so the packed values are bit-identical to features -> standardise -> k_pack_epoch.
+template <int H, int W, typename TO>
+__global__ __launch_bounds__(64) void k_features_cpcp_packed(const uint8_t* __restrict__ imgs, const TO* __restrict__ Y, const int* __restrict__ perm,
+                                                             int B, int n_batches, int G, int C, TO mean, TO sd, TO* __restrict__ xs,
+                                                             TO* __restrict__ ys) {
+    using K = Cpcp<H, W>;
+    __shared__ __attribute__((aligned(16))) float P0[K::N0];
+    __shared__ __attribute__((aligned(16))) float P1[4 * K::N1];
+    const int lane = threadIdx.x;
+    K::template init<64>(P0, P1, lane);
+    __syncthreads();
+    const int total = n_batches * B;
+    for (int L = blockIdx.x; L < total; L += gridDim.x) {
+        const int jb = L / B, smp = L - jb * B;
+        const long long img = perm ? perm[L] : L;
+        TO* xb = xs + ((size_t)jb * G * B + smp) * 16;                 // + slice * B * 16 + feature % 16
+        K::template image<64>(P0, P1, imgs + (size_t)img * (H * W), lane, [&](int e, float fv) {
+            const TO dd = ((TO)fv - mean) / sd;                           // rcn.rs:407-412
+            xb[(size_t)(e >> 4) * B * 16 + (e & 15)] = dd >= (TO)0 ? dd : (TO)0;
+        });
+        if (lane < C) ys[(size_t)L * C + lane] = Y[(size_t)img * C + lane];
+        __syncthreads();
+    }
+}
+
 // ---- gen_scales (rcn.rs:230-251): two-pass population mean / sd, f64 accumulation, per-block partials that
 // the host sums in block order (deterministic).
 template <typename T, bool SQDEV>

@@ -80,7 +80,7 @@ struct rcn_hip_ctx {
     void* pin_dev = nullptr;
     size_t pack_seg_bytes = (size_t)64 << 20;   // size of one half of the epoch image (env RCN_HIP_PACK_SEGMENT_BYTES, for tests)
     DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
-    std::map<EpochKey, hipGraphExec_t> graphs, dp_graphs;
+    std::map<EpochKey, hipGraphExec_t> graphs, dp_graphs, img_graphs;
     ncclComm_t comm = nullptr;              // data-parallel group (rcn_hip_dp_init); one rank per context
     int dp_rank = 0, dp_world = 1;
     struct P2P {                            // peer-read all-reduce over xGMI (dp_p2p.hpp)
@@ -413,6 +413,24 @@ int launch_pack(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* per
     return RCN_HIP_OK;
 }
 
+// the same image straight from u8 pictures: features + standardise + slice-major packing in one kernel (features.hpp)
+template <typename T>
+int launch_feat_pack(rcn_hip_ctx* c, const uint8_t* imgs, const void* Y, const int32_t* perm, size_t B, size_t j0, size_t n, int half, size_t seg) {
+    const NetDesc& nd = c->nd;
+    const int G = pipe_slices(nd), Cc = nd.dims[nd.L], HW = c->fd.H * c->fd.W;
+    const uint8_t* ib = perm ? imgs : imgs + j0 * B * (size_t)HW;
+    const T* Yb = perm ? (const T*)Y : (const T*)Y + j0 * B * (size_t)Cc;
+    const int32_t* pb = perm ? perm + j0 * B : nullptr;
+    T* xs = (T*)c->xpack.p + (size_t)half * seg * G * B * 16;
+    T* ys = (T*)c->ypack.p + (size_t)half * seg * B * Cc;
+    const size_t total = n * B;
+    const int grid = (int)(total < 8192 ? total : 8192);
+    hipLaunchKernelGGL((k_features_cpcp_packed<28, 28, T>), dim3(grid), dim3(64), 0, c->stream, ib, Yb, pb, (int)B, (int)n, G, Cc, (T)c->mean, (T)c->sd, xs, ys);
+    HIP_TRY(c, hipGetLastError());
+    if (half == 0) { c->packed_B = B; c->packed_nb = n; }
+    return RCN_HIP_OK;
+}
+
 int ensure_pack_ws(rcn_hip_ctx* c, size_t B, size_t nb) {
     const size_t seg = pack_segment(c, B), cap = nb <= seg ? nb : 2 * seg;
     HIP_TRY(c, c->xpack.ensure(cap * (size_t)pipe_slices(c->nd) * B * 16 * c->esz()));
@@ -424,14 +442,20 @@ int ensure_pack_ws(rcn_hip_ctx* c, size_t B, size_t nb) {
 // re-packing the next segment (into the other half of the image) just before the step that first needs it.
 // perm (nullable) holds nb*B sample indices; without it batch j is rows [jB, (j+1)B) of X / Y.
 template <typename T>
-int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev,
+                       bool from_images = false) {
     const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L], es = c->esz();
     const double scale = eta / (double)B, loss_scale = 1.0 / (2.0 * (double)B);
     const size_t seg = nb <= pack_segment(c, B) ? nb : pack_segment(c, B);
     auto slot = [&](size_t j) { return ((j / seg) % 2) * seg + j % seg; };
     auto xb = [&](size_t j) { return (const void*)((const char*)c->xpack.p + slot(j) * G * B * 16 * es); };
     auto yb = [&](size_t j) { return (const void*)((const char*)c->ypack.p + slot(j) * B * Cc * es); };
-    auto pack = [&](size_t j0) { return launch_pack<T>(c, X, Y, perm, B, j0, (nb - j0 < seg ? nb - j0 : seg), (int)((j0 / seg) % 2), seg); };
+    // from_images: X is the resident u8 picture set; features, standardisation and packing are one kernel per segment
+    auto pack = [&](size_t j0) {
+        const size_t n = nb - j0 < seg ? nb - j0 : seg;
+        return from_images ? launch_feat_pack<T>(c, (const uint8_t*)X, Y, perm, B, j0, n, (int)((j0 / seg) % 2), seg)
+                           : launch_pack<T>(c, X, Y, perm, B, j0, n, (int)((j0 / seg) % 2), seg);
+    };
     RCN_TRY(pack(0));
     RCN_TRY(launch_pipe_a<T>(c, xb(0), xb(0), B, scale, nullptr, loss_scale, false, true));
     for (size_t j = 0; j < nb; ++j) {
@@ -734,6 +758,8 @@ void drop_graphs(rcn_hip_ctx* c) {
     c->graphs.clear();
     for (auto& kv : c->dp_graphs) (void)hipGraphExecDestroy(kv.second);
     c->dp_graphs.clear();
+    for (auto& kv : c->img_graphs) (void)hipGraphExecDestroy(kv.second);
+    c->img_graphs.clear();
 }
 
 }  // namespace
@@ -1216,7 +1242,8 @@ int rcn_hip_train_batch(rcn_hip_ctx* c, const double* x, const double* y, size_t
     return RCN_HIP_OK;
 }
 
-static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool launch) {
+static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool launch,
+                      bool from_images = false) {
     RCN_TRY(check_ctx(c));
     if (!X || !Y) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_epoch: NULL pointer");
     if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_epoch: batch size must be in 1..2^30");
@@ -1225,7 +1252,10 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
     DevGuard g(c->device);
     RCN_TRY(ensure_dense_ws(c, B));
     if (use_pipe(c, B)) { RCN_TRY(ensure_pipe_ws(c, B)); RCN_TRY(ensure_pack_ws(c, B, nb)); }
-    if (use_persist(c, B)) {
+    if (from_images && !(use_pipe(c, B) && feat_is_cpcp28(c)))
+        return fail(c, RCN_HIP_ERR_UNSUPPORTED, "train_epoch_images: needs the default conv/pool stack on 28x28 input and a layer stack / batch size the "
+                                                  "feature-sliced pipeline covers; use rcn_hip_features_dev + rcn_hip_train_epoch_dev otherwise");
+    if (use_persist(c, B) && !from_images) {
         // no graph: one resident kernel per segment of the epoch image runs all of its steps
         if (!launch) return RCN_HIP_OK;
         return enqueue_persist_epoch(c, X, Y, perm, B, nb, eta, loss_dev);
@@ -1233,16 +1263,17 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
     // LDS attributes are per kernel variant and cached (set_dyn_lds); hipFuncSetAttribute is not a stream operation,
     // so the first capture of a variant may set it while capturing.
 
+    auto& cache = from_images ? c->img_graphs : c->graphs;
     const EpochKey key{X, Y, perm, B, nb, eta, loss_dev};
-    auto it = c->graphs.find(key);
-    if (it == c->graphs.end()) {
+    auto it = cache.find(key);
+    if (it == cache.end()) {
         const size_t F = c->nd.dims[0], Cc = c->nd.dims[c->nd.L], es = c->esz();
         hipGraph_t graph = nullptr;
         HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int st = RCN_HIP_OK;
         if (use_pipe(c, B)) {
-            st = c->dtype == RCN_HIP_F64 ? enqueue_pipe_steps<double>(c, X, Y, perm, B, nb, eta, loss_dev)
-                                         : enqueue_pipe_steps<float>(c, X, Y, perm, B, nb, eta, loss_dev);
+            st = c->dtype == RCN_HIP_F64 ? enqueue_pipe_steps<double>(c, X, Y, perm, B, nb, eta, loss_dev, from_images)
+                                         : enqueue_pipe_steps<float>(c, X, Y, perm, B, nb, eta, loss_dev, from_images);
         } else
         for (size_t j = 0; j < nb && st == RCN_HIP_OK; ++j) {
             const void* xb = perm ? X : (const char*)X + j * B * F * es;
@@ -1258,11 +1289,19 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         HIP_TRY(c, e);
-        if (c->graphs.size() >= 16) drop_graphs(c);
-        it = c->graphs.emplace(key, exec).first;
+        if (cache.size() >= 16) drop_graphs(c);
+        it = cache.emplace(key, exec).first;
     }
     if (launch) HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
     return RCN_HIP_OK;
+}
+
+int rcn_hip_train_epoch_images_dev(rcn_hip_ctx* c, const uint8_t* imgs, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+    return epoch_impl(c, imgs, Y, perm, B, nb, eta, loss_dev, true, true);
+}
+
+int rcn_hip_prepare_epoch_images_dev(rcn_hip_ctx* c, const uint8_t* imgs, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
+    return epoch_impl(c, imgs, Y, perm, B, nb, eta, loss_dev, false, true);
 }
 
 int rcn_hip_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {

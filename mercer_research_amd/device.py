@@ -128,6 +128,14 @@ class DeviceRCN:
             assert X.shape[0] >= B * n_batches
         self._ck(self.lib.rcn_hip_train_epoch_dev(self.ctx, _p(X), _p(Y), _p(perm), B, n_batches, float(eta), _p(loss)))
 
+    def train_epoch_images(self, imgs_u8: torch.Tensor, Y: torch.Tensor, perm: Optional[torch.Tensor], B: int, n_batches: int, eta: float,
+                           loss: Optional[torch.Tensor] = None, prepare_only: bool = False):
+        """The epoch straight from the resident u8 pictures: features + standardise (current scale_set) + packing are one kernel
+        per segment, then the same training steps (include/rcn_hip.h: rcn_hip_train_epoch_images_dev)."""
+        assert imgs_u8.dtype == torch.uint8 and imgs_u8.is_contiguous()
+        fn = self.lib.rcn_hip_prepare_epoch_images_dev if prepare_only else self.lib.rcn_hip_train_epoch_images_dev
+        self._ck(fn(self.ctx, _p(imgs_u8), _p(Y), _p(perm), B, n_batches, float(eta), _p(loss)))
+
     def shuffle(self, perm: torch.Tensor, n: int, passes: int, seed: int):
         """training_set.shuffle (rcn.rs:146) on the device: `passes` pseudo-random permutations of 0..n-1 into perm."""
         assert perm.dtype == torch.int32 and perm.numel() >= n * passes

@@ -90,6 +90,10 @@ extern "C" {
     pub fn rcn_hip_batch_gradient_perm_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b: usize, grad: *mut c_void,
                                            loss_sum: *mut c_void) -> c_int;
     pub fn rcn_hip_apply_gradient_dev(ctx: *mut rcn_hip_ctx, grad: *const c_void, scale: c_double) -> c_int;
+    pub fn rcn_hip_train_epoch_images_dev(ctx: *mut rcn_hip_ctx, imgs: *const u8, y: *const c_void, perm: *const i32, b: usize, n_batches: usize, eta: c_double,
+                                          loss: *mut c_void) -> c_int;
+    pub fn rcn_hip_prepare_epoch_images_dev(ctx: *mut rcn_hip_ctx, imgs: *const u8, y: *const c_void, perm: *const i32, b: usize, n_batches: usize, eta: c_double,
+                                            loss: *mut c_void) -> c_int;
     pub fn rcn_hip_dp_unique_id(id_out: *mut c_void) -> c_int;
     pub fn rcn_hip_dp_init(ctx: *mut rcn_hip_ctx, id: *const c_void, rank: c_int, world: c_int) -> c_int;
     pub fn rcn_hip_dp_finalize(ctx: *mut rcn_hip_ctx) -> c_int;

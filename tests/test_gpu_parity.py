@@ -608,6 +608,59 @@ def test_resident_epoch_kernel_matches_sequential_oracle(amd, oracle):
     d.rcn.close(); d2.rcn.close()
 
 
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "f64"])
+def test_train_epoch_from_images_equals_features_then_train(amd, oracle, dtype, monkeypatch):
+    """rcn_hip_train_epoch_images_dev (u8 pictures -> features -> standardise -> packed epoch image in one kernel per segment,
+    then the training steps) must leave exactly the parameters of rcn_hip_features_dev(standardize) + rcn_hip_train_epoch_dev,
+    shuffled and in stored order, across a segment boundary of the epoch image, and both equal the oracle's loop."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(3 * 49 * 256 * 16 * (8 if dtype == 1 else 4)))     # 3 batches per segment
+    B, nb, N = 256, 5, 1536
+    imgs, labels = synthetic_images(N, seed=23)
+    ws, bs = synthetic_params([784, 30, 10], seed=9)
+    ws = [w * 0.1 for w in ws]
+    res = []
+    for images_path in (True, False):
+        d = DeviceRCN(dtype=dtype)
+        d.set_dense_path(2)
+        d.set_params(ws, bs)
+        dev = d.to_device(imgs)
+        raw = d.features(dev)
+        mean, sd = d.gen_scales(raw)                                  # also sets scale_set
+        Y = d.to_device(one_hot(labels), d.tdtype)
+        perm = d.to_device(np.random.default_rng(4).permutation(N).astype(np.int32))
+        loss = d.empty(nb)
+        if images_path:
+            d.train_epoch_images(dev, Y, perm, B, nb, 3.0, loss)
+            d.train_epoch_images(dev, Y, None, B, 2, 3.0, None)
+        else:
+            X = d.features(dev, standardize=True)
+            d.train_epoch(X, Y, perm, B, nb, 3.0, loss)
+            d.train_epoch(X, Y, None, B, 2, 3.0, None)
+        gw, gb = d.get_params()
+        res.append((gw + gb, loss.cpu().numpy().copy(), (mean, sd)))
+        d.rcn.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][1], res[1][1])
+    # and the oracle's loop on the oracle's features
+    f = oracle.features(imgs, DEFAULT_LAYERS)
+    mo, so = oracle.gen_scales(f)
+    X = oracle.standardize(f, mo, so)
+    Yh = one_hot(labels)
+    p = np.random.default_rng(4).permutation(N)
+    rw, rb = ws, bs
+    for j in range(nb):
+        sel = p[j * B:(j + 1) * B]
+        rw, rb, _ = oracle.train_batch(rw, rb, X[sel], Yh[sel], 3.0)
+    for j in range(2):
+        rw, rb, _ = oracle.train_batch(rw, rb, X[j * B:(j + 1) * B], Yh[j * B:(j + 1) * B], 3.0)
+    tol = (1e-9, 1e-10) if dtype == 1 else (3e-4, 3e-5)
+    for a, b in zip(res[0][0], rw + rb):
+        assert np.all(np.abs(a - b) <= tol[0] * np.abs(b) + tol[1])
+
+
 def test_data_parallel_halves_equal_full_batch(amd, oracle):
     """Shard gradients + sum + one update == train_batch on the concatenated batch, single GPU."""
     from mercer_research_amd.device import DeviceRCN
