@@ -476,10 +476,12 @@ def test_native_rccl_epoch_world1_matches_oracle(amd, oracle, dtype):
     d.rcn.close()
 
 
-@pytest.mark.parametrize("dtype,Bs,nb,fused", [(1, 16, 4, 1), (0, 16, 4, 1), (1, 256, 3, 0), (0, 256, 3, 0), (1, 256, 3, 1), (0, 256, 3, 1)],
+@pytest.mark.parametrize("dtype,Bs,nb,fused,world", [(1, 16, 4, 1, 2), (0, 16, 4, 1, 2), (1, 256, 3, 0, 2), (0, 256, 3, 0, 2), (1, 256, 3, 1, 2),
+                                                      (0, 256, 3, 1, 2), (1, 256, 2, 1, 4), (0, 16, 3, 1, 4), (1, 256, 2, 0, 4)],
                          ids=["f64-sample-tile", "f32-sample-tile", "f64-pipeline-3-kernels", "f32-pipeline-3-kernels",
-                              "f64-pipeline-exchange-in-kernel", "f32-pipeline-exchange-in-kernel"])
-def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused, tmp_path):
+                              "f64-pipeline-exchange-in-kernel", "f32-pipeline-exchange-in-kernel", "f64-4-ranks-exchange-in-kernel",
+                              "f32-4-ranks-sample-tile", "f64-4-ranks-3-kernels"])
+def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused, world, tmp_path):
     """The xGMI peer-read all-reduce (csrc/dp_p2p.hpp) between two PROCESSES (hipIpc handles carried by gloo), both on this
     box's one GPU: the known-answer self-test is exact, both replicas end bit-identical, and two epochs of the sharded
     loop equal the oracle's sequential train_batch on the concatenated global batches."""
@@ -488,11 +490,12 @@ def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused,
     import sys
     # shard batch 16: sample-tile gradient kernels + k_p2p_allreduce; shard batch 256: the feature-sliced pipeline with the
     # exchange either in a third kernel (k_p2_dp_grad / k_p2_dp_apply) or inside the gradient kernel (k_p2_dp_fused)
-    dims, world = [784, 30, 10], 2
+    # (2 or 4 rank processes: with the test runner that stays within the box's limit of 6 processes on the GPU)
+    dims = [784, 30, 10]
     rng = np.random.default_rng(31)
     Xs = [np.maximum(rng.standard_normal((Bs * nb, dims[0])), 0.0) for _ in range(world)]
     Ys = [one_hot(rng.integers(0, dims[-1], Bs * nb), dims[-1]) for _ in range(world)]
-    np.savez(tmp_path / "case.npz", dims=dims, Bs=Bs, nb=nb, seed=17, X0=Xs[0], X1=Xs[1], Y0=Ys[0], Y1=Ys[1])
+    np.savez(tmp_path / "case.npz", dims=dims, Bs=Bs, nb=nb, seed=17, **{f"X{r}": Xs[r] for r in range(world)}, **{f"Y{r}": Ys[r] for r in range(world)})
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -512,8 +515,9 @@ def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused,
     outs = [np.load(tmp_path / f"out{r}.npz") for r in range(world)]
     for o in outs:
         assert int(o["bad"]) == 0 and int(o["timed_out"]) == 0 and int(o["active"]) == (2 if fused else 1)
-    for k in ("w0", "w1", "b0", "b1", "loss"):
-        assert np.array_equal(outs[0][k], outs[1][k]), k            # rank-order sums: replicas are bit-identical
+    for r in range(1, world):
+        for k in ("w0", "w1", "b0", "b1", "loss"):
+            assert np.array_equal(outs[0][k], outs[r][k]), (r, k)     # rank-order sums: replicas are bit-identical
     ws, bs = synthetic_params(dims, seed=17)
     rw, rb = [w * 0.1 for w in ws], bs
     costs = []
