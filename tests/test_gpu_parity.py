@@ -477,10 +477,10 @@ def test_native_rccl_epoch_world1_matches_oracle(amd, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype,Bs,nb,fused,world", [(1, 16, 4, 1, 2), (0, 16, 4, 1, 2), (1, 256, 3, 0, 2), (0, 256, 3, 0, 2), (1, 256, 3, 1, 2),
-                                                      (0, 256, 3, 1, 2), (1, 256, 2, 1, 4), (0, 16, 3, 1, 4), (1, 256, 2, 0, 4)],
+                                                      (0, 256, 3, 1, 2), (1, 256, 2, 1, 4), (0, 16, 3, 1, 4), (1, 256, 2, 0, 4), (1, 256, 2, 1, -2), (1, 256, 2, 0, -2)],
                          ids=["f64-sample-tile", "f32-sample-tile", "f64-pipeline-3-kernels", "f32-pipeline-3-kernels",
                               "f64-pipeline-exchange-in-kernel", "f32-pipeline-exchange-in-kernel", "f64-4-ranks-exchange-in-kernel",
-                              "f32-4-ranks-sample-tile", "f64-4-ranks-3-kernels"])
+                              "f32-4-ranks-sample-tile", "f64-4-ranks-3-kernels", "f64-784-12-7-exchange-in-kernel", "f64-784-12-7-3-kernels"])
 def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused, world, tmp_path):
     """The xGMI peer-read all-reduce (csrc/dp_p2p.hpp) between two PROCESSES (hipIpc handles carried by gloo), both on this
     box's one GPU: the known-answer self-test is exact, both replicas end bit-identical, and two epochs of the sharded
@@ -492,6 +492,8 @@ def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused,
     # exchange either in a third kernel (k_p2_dp_grad / k_p2_dp_apply) or inside the gradient kernel (k_p2_dp_fused)
     # (2 or 4 rank processes: with the test runner that stays within the box's limit of 6 processes on the GPU)
     dims = [784, 30, 10]
+    if world < 0:                                                    # a second shape class member: one tail tile, odd sizes
+        dims, world = [784, 12, 7], -world
     rng = np.random.default_rng(31)
     Xs = [np.maximum(rng.standard_normal((Bs * nb, dims[0])), 0.0) for _ in range(world)]
     Ys = [one_hot(rng.integers(0, dims[-1], Bs * nb), dims[-1]) for _ in range(world)]
