@@ -170,7 +170,10 @@ def format_check(tmp_path_factory):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path_factory.mktemp("fc") / "format_check")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(root, "tests", "cpp", "format_check.cpp"), "-lz", "-o", exe], check=True)
+    # AddressSanitizer + UBSan on the CPU build (the GPU pool has no sanitizer runs): every codec test below -- including the
+    # truncated / malformed inputs -- runs the C++ decoder under them; any report makes the helper exit non-zero
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    os.path.join(root, "tests", "cpp", "format_check.cpp"), "-lz", "-o", exe], check=True)
     return exe
 
 

@@ -303,3 +303,44 @@ def test_golden_dense(oracle, golden_dir):
     assert np.array_equal(nb[0], g["mnist_nb0"]) and np.array_equal(nb[1], g["mnist_nb1"])
     assert np.array_equal(nw[1], g["mnist_nW1"])
     assert np.array_equal(nw[0].ravel(order="F")[::37], g["mnist_nW0_strided"])
+
+
+def test_c_oracle_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The C restatement, compiled with -fsanitize=address,undefined, runs the whole path (features, scales, standardise, two
+    train_batch steps, forward, the operator entry points) without a report.  Sanitizers run on the CPU build only: the GPU
+    pool has none.  A subprocess, because the sanitizer runtime has to be loaded before the interpreter."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
+        pytest.skip("no libasan in this toolchain")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = tmp_path / "librcn_oracle_asan.so"
+    subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-ffp-contract=off",
+                    "-fPIC", "-shared", "-pthread", "-o", str(lib), os.path.join(root, "oracle", "rcn_oracle.c"), "-lm"], check=True)
+    script = tmp_path / "run.py"
+    script.write_text(f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from oracle.rcn_oracle import COracle, DEFAULT_LAYERS, one_hot, synthetic_images, synthetic_params
+o = COracle({str(lib)!r})
+imgs, labels = synthetic_images(64, seed=2)
+f = o.features(imgs, DEFAULT_LAYERS)
+m, s = o.gen_scales(f)
+x = o.standardize(f, m, s)
+ws, bs = synthetic_params([784, 30, 10], seed=1)
+ws = [w * 0.1 for w in ws]
+y = one_hot(labels)
+for j in range(2):
+    ws, bs, c = o.train_batch(ws, bs, x[j * 32:(j + 1) * 32], y[j * 32:(j + 1) * 32], 3.0)
+o.classify_test(ws, bs, x[:4])
+mat = imgs[0].astype(np.float64)
+o.convolve_2d(mat, o.sobel_full(0), 1); o.convolve_2d_separated(mat, 2, 0); o.pool_2d(mat[:27, :27], 1, 1)
+print("ok", c)
+""")
+    env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-500:] + r.stderr[-2000:]
