@@ -97,7 +97,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dp = world > 1 or args.dp
+    real_stdout = None
     if use_dp:
+        # RCCL prints a version banner on STDOUT when a communicator is created; rank 0's stdout must carry exactly one JSON
+        # line, so everything written to fd 1 during the run goes to stderr and the line is written to the saved descriptor
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -338,7 +344,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the CPU path is timed beside the N = 1 run only
             result["cpu_baseline"] = cpu_baseline()
             result["config"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
-        print(json.dumps(result), flush=True)
+        line = json.dumps(result) + "\n"
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.write(real_stdout, line.encode())
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
     if use_dp:
         dist.barrier()                     # nobody unmaps its buffers while a peer may still read them
         if args.dp_impl == "native":
