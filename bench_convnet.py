@@ -43,7 +43,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    real_stdout = None
     if world > 1:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)                # RCCL's version banner goes to stdout: keep rank 0's stdout to the one JSON line
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -93,10 +97,14 @@ def main():
     flops = net.step_flops(B)
     tf = flops * args.steps / el / 1e12                    # per GPU
     if rank == 0:
-        print(json.dumps({"metric": "training images/sec (Track X, trainable conv net; not the BASELINE metric)", "config": args.config, "batch_per_gpu": B, "n_gpus": world,
+        out_line = json.dumps({"metric": "training images/sec (Track X, trainable conv net; not the BASELINE metric)", "config": args.config, "batch_per_gpu": B, "n_gpus": world,
                           "scaling": "weak", "value": round(world * B * args.steps / el, 1), "unit": "images/s", "ms_per_step": round(el / args.steps * 1e3, 4),
                           "step_gflop_per_gpu": round(flops / 1e9, 3), "achieved_tflops_per_gpu": round(tf, 2), "mfma_fp32_peak_tflops": F32_MFMA_PEAK_TFLOPS,
-                          "frac_of_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands (fwd, dgrad), f32 accumulate/storage/update", "data": "synthetic", "final_loss": round(loss.item(), 4)}))
+                          "frac_of_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands (fwd, dgrad), f32 accumulate/storage/update", "data": "synthetic", "final_loss": round(loss.item(), 4)}) + "\n"
+        if real_stdout is not None:
+            os.write(real_stdout, out_line.encode())
+        else:
+            sys.stdout.write(out_line)
     if world > 1:
         dist.destroy_process_group()
 
