@@ -255,13 +255,23 @@ def main():
     e2e = None
     if not use_dp and not args.no_e2e:
         perm1 = perm[:N_IMAGES]
-        d.train_epoch_images(imgs_d, Y, perm1, B, nb_epoch, ETA, None, prepare_only=True)
+        try:
+            d.train_epoch_images(imgs_d, Y, perm1, B, nb_epoch, ETA, None, prepare_only=True)
+            fused_e2e = True
+        except amd.RcnPanic:                  # --path 1 (sample-tile kernels): no packed epoch image to fuse into
+            fused_e2e = False
+            Xe = d.empty(N_IMAGES, DIMS[0])
+            d.prepare_epoch(Xe, Y, perm1, B, nb_epoch, ETA, None)
 
         def e2e_pass(i):
-            # one kernel per segment of the pass: flatten_feature_set + standardise + gather into the training layout, straight
-            # from the u8 pictures (rcn_hip_train_epoch_images_dev); no feature matrix is written
             d.shuffle(perm1, N_IMAGES, 1, seed=0xE2E + i)
-            d.train_epoch_images(imgs_d, Y, perm1, B, nb_epoch, ETA, None)
+            if fused_e2e:
+                # one kernel per segment of the pass: flatten_feature_set + standardise + gather into the training layout, straight
+                # from the u8 pictures (rcn_hip_train_epoch_images_dev); no feature matrix is written
+                d.train_epoch_images(imgs_d, Y, perm1, B, nb_epoch, ETA, None)
+            else:
+                d.features(imgs_d, True, Xe)
+                d.train_epoch(Xe, Y, perm1, B, nb_epoch, ETA, None)
         for i in range(4):
             e2e_pass(i)
         d.synchronize()
