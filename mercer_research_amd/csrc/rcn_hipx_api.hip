@@ -162,16 +162,20 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 }
 
 static int xcd_remap() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_XCD_REMAP"); return e ? std::atoi(e) : 0; }(); return v; }
-// Pixels per weight-gradient chunk: 1024 (measured best on the CIFAR/MNIST nets: parallelism matters there), grown for very
-// large layers so that the slab of partial tiles -- written once, read once by k_reduce_update_wide -- stays near 2048 chunks.
-static int pix_per_chunk(long long M) {
+// Pixels per weight-gradient chunk.  Every chunk costs one (K+1) x Cout partial tile written to the slab and read back by
+// k_reduce_update[_wide], and a chunk is worked on by `tiles` workgroups (k-blocks x n-tiles), so the chunk size aims at a
+// total number of workgroups -- wide layers need few chunks -- with 1024 pixels as the floor (measured best on the small
+// CIFAR / MNIST nets, where parallelism is what matters).
+static int pix_per_chunk(long long M, long long tiles) {
     static const int v = [] { const char* e = std::getenv("RCN_HIPX_PIX_PER_CHUNK"); const int x = e ? std::atoi(e) : 0; return x >= 128 ? x / 128 * 128 : 0; }();
     if (v) return v;
-    long long pix = 1024;
-    if (M / pix > 2048) { pix = (M / 2048 + 127) / 128 * 128; if (pix > 16384) pix = 16384; }
+    static const long long target = [] { const char* e = std::getenv("RCN_HIPX_WG_TARGET"); const long long x = e ? std::atoll(e) : 0; return x > 0 ? x : 4096; }();
+    long long pix = (M * tiles / target + 127) / 128 * 128;
+    if (pix < 1024) pix = 1024;
+    if (pix > 32768) pix = 32768;
     return (int)pix;
 }
-#define kPixPerChunk (pix_per_chunk(M))
+#define kPixPerChunk (pix_per_chunk(M, (long long)(smallc ? 1 : K / 32) * (s.Cout / bn)))
 
 static bool wgrad_halo_on() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO_WGRAD"); return e ? std::atoi(e) : 1; }(); return v != 0; }
 bool wgrad_halo_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) {
@@ -191,11 +195,16 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         // LDS-tiled: input halo + dZ block staged once per 8x16 pixel block, nine waves = nine filter taps (convnet_bf16.hpp)
         const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
         const long long blocks = (long long)tw * th * s.N;
-        int bpc = (int)((blocks + 2047) / 2048);
+        const int hb = s.Cin == 32 ? 32 : 64, hbn = (s.Cout % 64 == 0) ? 64 : 32;
+        // Pixel blocks per chunk: every chunk costs one (K+1) x Cout partial tile written and read back by the reduce, so aim at
+        // `target` workgroups in total (tiles per chunk x chunks) rather than at a fixed chunk count -- wide layers have many
+        // tiles per chunk and need few chunks.
+        static const int target = [] { const char* e = std::getenv("RCN_HIPX_WGH_TARGET"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 512; }();
+        const long long tiles = (long long)(s.Cin / hb) * (s.Cout / hbn);
+        int bpc = (int)((blocks * tiles + target - 1) / target);
         if (bpc < 8) bpc = blocks < 8 ? (int)blocks : 8;
         const int hchunks = (int)((blocks + bpc - 1) / bpc);
         XTRY(n, n->slab.ensure((size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
-        const int hb = s.Cin == 32 ? 32 : 64, hbn = (s.Cout % 64 == 0) ? 64 : 32;
         const dim3 hgrid((unsigned)(s.Cin / hb), (unsigned)(s.Cout / hbn), (unsigned)hchunks);
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
 #define WGH_CASE(CB_, BN_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, true>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tw, th, bpc, hchunks, pg); \
