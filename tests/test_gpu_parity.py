@@ -61,6 +61,37 @@ def test_operators_bit_exact(amd, oracle, shape):
         assert np.array_equal(amd.convolve_2d(reals, k5, amd.Padding.NONE), oracle.convolve_2d(reals, k5, PAD_NONE))
 
 
+def test_operators_random_shapes_agree_with_oracle_including_panics(amd, oracle):
+    """150 random (matrix shape, kernel shape, padding) draws: wherever the oracle's restatement of the reference panics
+    (utils/kernel.rs:123-135, 154-158, 199-201, 246-251) the library returns the shape error, and everywhere else the result is
+    bit-identical -- ragged, tiny and non-square shapes included."""
+    from oracle.rcn_oracle import OracleError
+    rng = np.random.default_rng(2024)
+    n_ok = n_panic = 0
+    for _ in range(150):
+        R, Cc = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        m = np.round(rng.standard_normal((R, Cc)) * 50)
+        kr, kc = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        k = np.round(rng.standard_normal((kr, kc)) * 3)
+        pad = int(rng.integers(0, 2))
+        cases = [(lambda: amd.convolve_2d(m, k, amd.Padding(pad)), lambda: oracle.convolve_2d(m, k, pad)),
+                 (lambda: amd.convolve_2d_separated(m, amd.SeparableOperator(int(rng.integers(0, 4))), amd.Padding(pad)), None),
+                 (lambda: amd.pool_2d(m, amd.Padding(pad), amd.Pooling.MAX), lambda: oracle.pool_2d(m, pad, POOL_MAX))]
+        op = int(rng.integers(0, 4))
+        cases[1] = (lambda: amd.convolve_2d_separated(m, amd.SeparableOperator(op), amd.Padding(pad)), lambda: oracle.convolve_2d_separated(m, op, pad))
+        for g, c in cases:
+            try:
+                want = c()
+            except OracleError:
+                with pytest.raises(amd.RcnPanic):
+                    g()
+                n_panic += 1
+                continue
+            assert np.array_equal(g(), want)
+            n_ok += 1
+    assert n_ok > 200 and n_panic > 40, (n_ok, n_panic)
+
+
 def test_operator_reference_kats(amd):
     """utils/kernel.rs:436-441 (identity Same conv on 0..900) through the HIP path."""
     m = np.arange(900, dtype=np.float64).reshape(30, 30)
