@@ -25,11 +25,14 @@ __device__ inline int conv_out_slot(int cnt_in, int i, int o) {
 }
 
 // TC: compute type (float exact up to 5 conv layers, else double); TO: output type (ctx dtype)
+// `spill` (nullable): when the maps of one image do not fit LDS (large inputs, several un-pooled conv layers) the two ping-pong
+// buffers live in global memory instead, 2 * max_elems values per workgroup -- same code, same results, the reads go through
+// L1/L2 (a workgroup's own stores are visible to it after the barrier); the reference has no such size limit.
 template <typename TC, typename TO>
 __global__ __launch_bounds__(kFeatThreads) void k_features(
-    FeatDesc fd, const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, int standardize, TO mean, TO sd) {
+    FeatDesc fd, const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, int standardize, TO mean, TO sd, TC* __restrict__ spill) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    TC* bufA = reinterpret_cast<TC*>(smem_raw);
+    TC* bufA = spill ? spill + (size_t)blockIdx.x * 2 * fd.max_elems : reinterpret_cast<TC*>(smem_raw);
     TC* bufB = bufA + fd.max_elems;
     const int tid = threadIdx.x;
     const int HW = fd.H * fd.W;

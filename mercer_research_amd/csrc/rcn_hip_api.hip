@@ -828,10 +828,7 @@ int rcn_hip_create(const rcn_hip_cfg* cfg, rcn_hip_ctx** out) {
     // LDS feasibility of the dense kernels for these layer sizes
     if (dense_fwd_lds_elems(c->nd) * c->esz() > 160 * 1024)
         return fail(c, RCN_HIP_ERR_UNSUPPORTED, "hidden layer sizes need more than 160 KiB of LDS per workgroup");
-    const size_t feat_lds = 2 * (size_t)c->fd.max_elems * (c->n_conv <= 5 ? 4 : 8);
-    if (feat_lds > 160 * 1024)
-        return fail(c, RCN_HIP_ERR_UNSUPPORTED, "image/feature maps need more than 160 KiB of LDS per workgroup (fused feature kernel)");
-    return RCN_HIP_OK;
+    return RCN_HIP_OK;            // (feature maps that do not fit LDS are staged in global memory: k_features' `spill`)
 }
 
 void rcn_hip_destroy(rcn_hip_ctx* c) {
@@ -1097,13 +1094,21 @@ int rcn_hip_features_dev(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, void* ou
         return RCN_HIP_OK;
     }
     const bool wide = c->n_conv > 5;             // |v| <= 255*8^n stays below 2^24 only up to 5 conv layers
-    const size_t lds = 2 * (size_t)c->fd.max_elems * (wide ? 8 : 4);
-    const int grid = (int)(n < 4096 ? n : 4096);
+    size_t lds = 2 * (size_t)c->fd.max_elems * (wide ? 8 : 4);
+    int grid = (int)(n < 4096 ? n : 4096);
+    void* spill = nullptr;
+    if (lds > 160 * 1024) {
+        // the maps of one image do not fit LDS: ping-pong buffers in global memory, one pair per workgroup
+        if (grid > 512) grid = 512;
+        HIP_TRY(c, c->scratch1.ensure((size_t)grid * lds));
+        spill = c->scratch1.p;
+        lds = 0;
+    }
 #define LAUNCH_FEAT(TC, TO)                                                                                                   \
     do {                                                                                                                      \
         RCN_TRY(set_dyn_lds(c, k_features<TC, TO>, lds));                                                                     \
         hipLaunchKernelGGL((k_features<TC, TO>), dim3(grid), dim3(kFeatThreads), lds, c->stream, c->fd, imgs, (int)n, (TO*)out, \
-                           standardize, (TO)c->mean, (TO)c->sd);                                                              \
+                           standardize, (TO)c->mean, (TO)c->sd, (TC*)spill);                                                  \
     } while (0)
     if (c->dtype == RCN_HIP_F64) { if (wide) LAUNCH_FEAT(double, double); else LAUNCH_FEAT(float, double); }
     else { if (wide) LAUNCH_FEAT(double, float); else LAUNCH_FEAT(float, float); }

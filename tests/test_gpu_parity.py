@@ -203,6 +203,52 @@ def test_features_other_stacks_bit_exact(amd, oracle, spec, shape):
     assert np.array_equal(r.flatten_feature_set(imgs), oracle.features(imgs, spec))
 
 
+def test_features_random_stacks_agree_with_oracle_including_panics(amd, oracle):
+    """40 random conv/pool stacks (up to 5 layers, Padding::None / Same mixed, pools anywhere) on random non-square inputs:
+    where the oracle's flatten_feature_set panics the context cannot be created, elsewhere the features are bit-identical
+    and the feature length matches."""
+    from oracle.rcn_oracle import OracleError
+    rng = np.random.default_rng(77)
+    n_ok = n_panic = 0
+    for _ in range(40):
+        H, W = int(rng.integers(2, 34)), int(rng.integers(2, 34))
+        spec = []
+        for _l in range(int(rng.integers(1, 6))):
+            if rng.random() < 0.6 and sum(1 for k, _a in spec if k == LAYER_CONV) < 3:
+                spec.append((LAYER_CONV, int(rng.integers(0, 2))))
+            else:
+                spec.append((LAYER_POOL, POOL_MAX))
+        spec = tuple(spec)
+        imgs = rng.integers(0, 256, (3, H, W)).astype(np.uint8)
+        try:
+            want = oracle.features(imgs, spec)
+        except OracleError:
+            with pytest.raises(amd.RcnPanic):
+                amd.RCN(10, _layers(amd, spec), [4], input_shape=(H, W), dtype=1)
+            n_panic += 1
+            continue
+        r = amd.RCN(10, _layers(amd, spec), [4], input_shape=(H, W), dtype=1)
+        assert r.feature_len == want.shape[1]
+        assert np.array_equal(r.flatten_feature_set(imgs), want), (spec, H, W)
+        r.close()
+        n_ok += 1
+    assert n_ok >= 20 and n_panic >= 3, (n_ok, n_panic)
+
+
+def test_features_maps_larger_than_lds_spill_to_global_memory(amd, oracle):
+    """Three un-pooled Same convolutions on a 48x40 input: 64 maps of 1920 values = 480 KB per image and buffer, three times
+    what a CU's LDS holds.  The reference has no such limit (rcn.rs:317-356); the generic feature kernel then keeps its two
+    ping-pong buffers in global memory -- same code, bit-identical result."""
+    spec = ((LAYER_CONV, PAD_SAME), (LAYER_CONV, PAD_SAME), (LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX))
+    imgs = np.random.default_rng(8).integers(0, 256, (5, 48, 40)).astype(np.uint8)
+    want = oracle.features(imgs, spec)
+    for dtype in (1, 0):
+        r = amd.RCN(10, _layers(amd, spec), [4], input_shape=(48, 40), dtype=dtype)
+        assert r.feature_len == want.shape[1] == 64 * 24 * 20
+        assert np.array_equal(r.flatten_feature_set(imgs), want)
+        r.close()
+
+
 def test_feature_stack_errors(amd):
     P, L = amd.Padding, amd.RCNLayer
     # fan-in formula 4^c/2^p*l != feature length (rcn.rs:443): RCN::new and the feature path work, train panics in gemv
