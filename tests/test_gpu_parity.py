@@ -368,6 +368,38 @@ def test_train_batch_matches_oracle(amd, oracle, dims, B, dtype, path):
     _check_params(gw + gb, nw + nb, dtype)
 
 
+def test_train_batch_random_layer_stacks_match_oracle(amd, oracle):
+    """25 random dense stacks -- 1 to 3 hidden layers of 1..70 units, 2..16 classes, F in {16, 24, 48, 100, 784}, batch 1..300 --
+    through whichever kernels the library picks (path 0) and through each forced path that applies, in the f64 context: forward
+    outputs, cost and every updated parameter against the oracle's sequential train_batch (rcn.rs:176-314)."""
+    rng = np.random.default_rng(909)
+    ran = 0
+    for case in range(25):
+        F = int(rng.choice([16, 24, 48, 100, 784]))
+        hidden = [int(rng.integers(1, 71)) for _ in range(int(rng.integers(1, 4)))]
+        dims = [F] + hidden + [int(rng.integers(2, 17))]
+        B = int(rng.choice([1, 2, 7, 32, 33, 100, 256, 300]))
+        ws, bs, X, Y = _dense_case(dims, B, seed=1000 + case, wscale=0.1)
+        ref_out = oracle.classify_test(ws, bs, X)
+        nw, nb, cost = oracle.train_batch(ws, bs, X, Y, 3.0)
+        for path in (0, 1, 2):
+            r = _dense_rcn(amd, dims, 1, 0)
+            try:
+                r.set_dense_path(path)
+            except amd.RcnPanic:                 # the feature-sliced pipeline needs >= 2 dense layers whose tail fits LDS
+                r.close()
+                continue
+            r.set_params(ws, bs)
+            assert np.abs(r.classify_test(X) - ref_out).max() <= 1e-13, (dims, B, path)
+            loss = r.train_batch(X, Y, 3.0, want_loss=True)
+            assert abs(loss - cost) <= 1e-12 * max(cost, 1e-3), (dims, B, path)
+            gw, gb = r.get_params()
+            _check_params(gw + gb, nw + nb, 1)
+            r.close()
+            ran += 1
+    assert ran >= 60
+
+
 def _dense_rcn(amd, dims, dtype, path=0):
     """An RCN whose conv/pool stack yields exactly dims[0] features: conv(Same) + pool(Max) on a 2a x 2b image gives
     4*a*b features and satisfies the reference's fan-in formula (one conv, one pool; rcn.rs:443)."""
