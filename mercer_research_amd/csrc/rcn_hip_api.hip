@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include "dense.hpp"
 #include "dense_pipe.hpp"
+#include "dense_wide.hpp"
 #include "dense_p2.hpp"
 #include "features.hpp"
 #include "ops.hpp"
@@ -285,8 +286,35 @@ int launch_fwd_v(rcn_hip_ctx* c, const void* x, const void* y, const int32_t* id
     return RCN_HIP_OK;
 }
 
+// layer stacks too wide for k_dense_fwd's LDS image: layer by layer on global activations (dense_wide.hpp)
+template <typename T>
+int launch_fwd_wide(rcn_hip_ctx* c, bool train, const void* x, const void* y, const int32_t* idx, size_t B, void* out) {
+    const NetDesc& nd = c->nd;
+    T* acts = (T*)c->acts.p;
+    T* deltas = (T*)c->deltas.p;
+    auto layer = [&](int j) { return acts + B * (size_t)nd.act_off[j]; };          // activations of layer j >= 1: [B][d_j]
+    auto grid = [](long long total) { long long g = (total + 255) / 256; return (unsigned)(g < 1 ? 1 : g > 8192 ? 8192 : g); };
+    for (int j = 0; j < nd.L; ++j) {
+        const T* ain = j == 0 ? (const T*)x : layer(j);
+        T* aout = (!train && j + 1 == nd.L && out) ? (T*)out : layer(j + 1);
+        hipLaunchKernelGGL((k_wide_forward<T>), dim3(grid((long long)B * nd.dims[j + 1])), dim3(256), 0, c->stream, nd, (const T*)c->params.p, j, ain,
+                           (long long)nd.dims[j], j == 0 ? idx : (const int32_t*)nullptr, (int)B, aout);
+    }
+    if (train) {
+        const int tiles = (int)((B + kTileS - 1) / kTileS);
+        hipLaunchKernelGGL((k_wide_output_delta<T>), dim3(tiles), dim3(64), 0, c->stream, nd, (const T*)layer(nd.L), (const T*)y, idx, (int)B,
+                           deltas + B * (size_t)nd.act_off[nd.L], (T*)c->loss_part.p);
+        for (int j = nd.L - 1; j >= 1; --j)
+            hipLaunchKernelGGL((k_wide_delta<T>), dim3(grid((long long)B * nd.dims[j])), dim3(256), 0, c->stream, nd, (const T*)c->params.p, j,
+                               (const T*)(deltas + B * (size_t)nd.act_off[j + 1]), (const T*)layer(j), (int)B, deltas + B * (size_t)nd.act_off[j]);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
 template <typename T>
 int launch_fwd(rcn_hip_ctx* c, bool train, const void* x, const void* y, const int32_t* idx, size_t B, void* out) {
+    if (dense_is_wide(c->nd, sizeof(T))) return launch_fwd_wide<T>(c, train, x, y, idx, B, out);
     const bool vec = dense_vec_rows(c->nd, sizeof(T)) && ((uintptr_t)x % 16 == 0);
     const bool st = dense_tail_staged(c->nd);
 #define RCN_FWD(TR, V, S) return launch_fwd_v<T, TR, V, S>(c, x, y, idx, B, out)
@@ -825,9 +853,7 @@ int rcn_hip_create(const rcn_hip_cfg* cfg, rcn_hip_ctx** out) {
     else { HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIP_TRY(c, c->params.ensure((size_t)c->nd.P * c->esz()));
     HIP_TRY(c, hipMemsetAsync(c->params.p, 0, (size_t)c->nd.P * c->esz(), c->stream));
-    // LDS feasibility of the dense kernels for these layer sizes
-    if (dense_fwd_lds_elems(c->nd) * c->esz() > 160 * 1024)
-        return fail(c, RCN_HIP_ERR_UNSUPPORTED, "hidden layer sizes need more than 160 KiB of LDS per workgroup");
+    // (layer stacks whose tile image exceeds LDS run layer by layer on global activations: dense_wide.hpp)
     return RCN_HIP_OK;            // (feature maps that do not fit LDS are staged in global memory: k_features' `spill`)
 }
 
@@ -1662,6 +1688,7 @@ int rcn_hip_forward_dev(rcn_hip_ctx* c, const void* x, size_t n, void* out) {
     if (n > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "forward: too many samples in one call");
     RCN_TRY(need_params(c));
     DevGuard g(c->device);
+    if (dense_is_wide(c->nd, c->esz())) RCN_TRY(ensure_dense_ws(c, n));       // the layer-by-layer path keeps hidden activations in global memory
     if (c->dtype == RCN_HIP_F64) return launch_fwd<double>(c, false, x, nullptr, nullptr, n, out);
     return launch_fwd<float>(c, false, x, nullptr, nullptr, n, out);
 }

@@ -400,6 +400,31 @@ def test_train_batch_random_layer_stacks_match_oracle(amd, oracle):
     assert ran >= 60
 
 
+@pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
+def test_wide_hidden_layers_run_layer_by_layer(amd, oracle, dtype):
+    """Hidden layers too wide for the LDS-resident forward kernel (about 512 units in f32, 128 in f64): the reference has no
+    width limit (RCN::new never fails), so the step then runs layer by layer on global activations (dense_wide.hpp).  Forward,
+    cost, one train_batch and the batched evaluation against the oracle."""
+    dims = [784, 700, 260, 10]
+    B = 37
+    ws, bs, X, Y = _dense_case(dims, B, seed=5150, wscale=0.02)
+    r = _dense_rcn(amd, dims, dtype, 0)
+    r.set_params(ws, bs)
+    out = r.classify_test(X)
+    ref_out = oracle.classify_test(ws, bs, X)
+    assert np.abs(out - ref_out).max() <= (1e-12 if dtype == 1 else 5e-6)
+    loss = r.train_batch(X, Y, 3.0, want_loss=True)
+    nw, nb, cost = oracle.train_batch(ws, bs, X, Y, 3.0)
+    assert abs(loss - cost) <= (1e-11 if dtype == 1 else 1e-4) * max(cost, 1e-3)
+    gw, gb = r.get_params()
+    if dtype == 1:
+        _check_params(gw + gb, nw + nb, 1)
+    else:
+        for a, b in zip(gw + gb, nw + nb):
+            assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5)
+    r.close()
+
+
 def _dense_rcn(amd, dims, dtype, path=0):
     """An RCN whose conv/pool stack yields exactly dims[0] features: conv(Same) + pool(Max) on a 2a x 2b image gives
     4*a*b features and satisfies the reference's fan-in formula (one conv, one pool; rcn.rs:443)."""
