@@ -265,11 +265,23 @@ int set_dyn_lds(rcn_hip_ctx* c, K kernel, size_t bytes) {
 }
 
 // ---- dense launches ---------------------------------------------------------------------------------------------
+void drop_graphs(rcn_hip_ctx* c);
+
+// Workspaces that captured hipGraphs point into: growing one moves it (DevBuf::ensure frees and reallocates), so every cached
+// graph -- whichever call shape it was captured for -- would replay on freed memory.  A moved workspace drops them all; they are
+// re-captured on demand.  (Found by running the benchmark with a warm-up shorter than the timed run.)
+hipError_t ws_ensure(rcn_hip_ctx* c, DevBuf& b, size_t bytes) {
+    const void* before = b.p;
+    const hipError_t e = b.ensure(bytes);
+    if (e == hipSuccess && before && b.p != before) drop_graphs(c);
+    return e;
+}
+
 int ensure_dense_ws(rcn_hip_ctx* c, size_t B) {
     const size_t sd = (size_t)sum_hidden_dims(c->nd);
-    HIP_TRY(c, c->acts.ensure(B * sd * c->esz()));
-    HIP_TRY(c, c->deltas.ensure(B * sd * c->esz()));
-    HIP_TRY(c, c->loss_part.ensure(((B + kTileS - 1) / kTileS) * c->esz()));
+    HIP_TRY(c, ws_ensure(c, c->acts, B * sd * c->esz()));
+    HIP_TRY(c, ws_ensure(c, c->deltas, B * sd * c->esz()));
+    HIP_TRY(c, ws_ensure(c, c->loss_part, ((B + kTileS - 1) / kTileS) * c->esz()));
     return RCN_HIP_OK;
 }
 
@@ -353,9 +365,9 @@ bool use_pipe(const rcn_hip_ctx* c, size_t B) {
 int ensure_pipe_ws(rcn_hip_ctx* c, size_t B) {
     const size_t Bp = (B + 15) / 16 * 16;
     const size_t mp = p2_supported(c->nd, B) ? (size_t)kP2H : (size_t)pipe_mp(c->nd);     // slab row: the specialised kernels pad to 32
-    HIP_TRY(c, c->slab.ensure((size_t)pipe_slices(c->nd) * Bp * mp * c->esz()));
-    HIP_TRY(c, c->loss_part.ensure(((B + kPipeTs - 1) / kPipeTs) * c->esz()));
-    if (p2_supported(c->nd, B)) HIP_TRY(c, c->p2buf.ensure(B * (size_t)(2 * kP2H + kP2C) * c->esz()));
+    HIP_TRY(c, ws_ensure(c, c->slab, (size_t)pipe_slices(c->nd) * Bp * mp * c->esz()));
+    HIP_TRY(c, ws_ensure(c, c->loss_part, ((B + kPipeTs - 1) / kPipeTs) * c->esz()));
+    if (p2_supported(c->nd, B)) HIP_TRY(c, ws_ensure(c, c->p2buf, B * (size_t)(2 * kP2H + kP2C) * c->esz()));
     return RCN_HIP_OK;
 }
 
@@ -461,8 +473,8 @@ int launch_feat_pack(rcn_hip_ctx* c, const uint8_t* imgs, const void* Y, const i
 
 int ensure_pack_ws(rcn_hip_ctx* c, size_t B, size_t nb) {
     const size_t seg = pack_segment(c, B), cap = nb <= seg ? nb : 2 * seg;
-    HIP_TRY(c, c->xpack.ensure(cap * (size_t)pipe_slices(c->nd) * B * 16 * c->esz()));
-    HIP_TRY(c, c->ypack.ensure(cap * B * (size_t)c->nd.dims[c->nd.L] * c->esz()));
+    HIP_TRY(c, ws_ensure(c, c->xpack, cap * (size_t)pipe_slices(c->nd) * B * 16 * c->esz()));
+    HIP_TRY(c, ws_ensure(c, c->ypack, cap * B * (size_t)c->nd.dims[c->nd.L] * c->esz()));
     return RCN_HIP_OK;
 }
 
@@ -1579,7 +1591,7 @@ static int dp_epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int
     DevGuard g(c->device);
     RCN_TRY(ensure_dense_ws(c, B));
     const size_t es = c->esz(), P = (size_t)c->nd.P, F = c->nd.dims[0], Cc = c->nd.dims[c->nd.L];
-    HIP_TRY(c, c->grad.ensure((P + 1) * es));                 // [gradient | loss]: one all-reduce carries both
+    HIP_TRY(c, ws_ensure(c, c->grad, (P + 1) * es));          // [gradient | loss]: one all-reduce carries both
     rcn::Rccl& r = rcn::Rccl::get();
     const double Bg = (double)B * (double)c->dp_world;          // the global batch.len() of rcn.rs:214
     const double scale = eta / Bg, loss_scale = 1.0 / (2.0 * Bg);

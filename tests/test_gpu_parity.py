@@ -801,6 +801,30 @@ def test_train_epoch_from_images_equals_features_then_train(amd, oracle, dtype, 
         assert np.all(np.abs(a - b) <= tol[0] * np.abs(b) + tol[1])
 
 
+def test_cached_epoch_graphs_survive_workspace_growth(amd, oracle):
+    """A short epoch call, then a longer one (its packed image needs a larger workspace, which moves), then the short shape
+    again: the graph cached for the first shape pointed into the old workspace and must not be replayed as is.  Parameters after
+    the three calls equal the oracle's sequential loop.  (A use-after-free found by benchmarking with warm-up < timed steps.)"""
+    from mercer_research_amd.device import DeviceRCN
+    B, N = 256, 5120
+    ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=321, wscale=0.1)
+    d = DeviceRCN(dtype=1)
+    d.set_params(ws, bs)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    perm = np.random.default_rng(12).permutation(N).astype(np.int32)
+    permd = d.to_device(perm)
+    calls = [(0, 2), (2, 17), (0, 2), (5, 9)]                      # (first batch, number of batches)
+    rw, rb = ws, bs
+    for j0, nb in calls:
+        d.train_epoch(Xd, Yd, permd[j0 * B:], B, nb, 3.0, None)
+        for j in range(j0, j0 + nb):
+            sel = perm[j * B:(j + 1) * B]
+            rw, rb, _ = oracle.train_batch(rw, rb, X[sel], Y[sel], 3.0)
+    gw, gb = d.get_params()
+    _check_params(gw + gb, rw + rb, 1)
+    d.rcn.close()
+
+
 def test_data_parallel_halves_equal_full_batch(amd, oracle):
     """Shard gradients + sum + one update == train_batch on the concatenated batch, single GPU."""
     from mercer_research_amd.device import DeviceRCN
