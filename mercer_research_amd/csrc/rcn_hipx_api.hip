@@ -68,6 +68,16 @@ int fail(rcn_hipx_net* n, int code, const std::string& m) { if (n) n->err = m; r
 #define XTRY(net, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(net, e_ == hipErrorOutOfMemory ? -7 : -4, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 #define RTRY(expr) do { int s_ = (expr); if (s_ != 0) return s_; } while (0)
 
+void drop_graphs(rcn_hipx_net* n);
+// scratch buffers that captured graphs point into: one that grows moves, and every cached graph would replay on freed memory --
+// drop them, they are re-captured on demand (sizes are settled by the eager step that precedes every capture)
+hipError_t scratch_ensure(rcn_hipx_net* n, Buf& b, size_t bytes) {
+    const void* before = b.p;
+    const hipError_t e = b.ensure(bytes);
+    if (e == hipSuccess && before && b.p != before) drop_graphs(n);
+    return e;
+}
+
 struct Dev { int prev = -1; explicit Dev(int d) { (void)hipGetDevice(&prev); if (prev != d) (void)hipSetDevice(d); else prev = -1; } ~Dev() { if (prev >= 0) (void)hipSetDevice(prev); } };
 
 int grid1d(long long total, int block) { long long g = (total + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
@@ -107,14 +117,14 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     float* out = Y;
     int kepi = epi;
     if (Z > 1) {
-        XTRY(n, n->skbuf.ensure((size_t)Z * M * s.Cout * sizeof(float)));
+        XTRY(n, scratch_ensure(n, n->skbuf, (size_t)Z * M * s.Cout * sizeof(float)));
         out = (float*)n->skbuf.p; kepi = 0;
     }
     const dim3 grid((unsigned)((M + kBM - 1) / kBM), (unsigned)(s.Cout / bn), (unsigned)Z);
     if (bf16) {
         // operands rounded to bf16: the weights once here, transposed to [Cout][Kp]; the activations inside the kernel
         const int K = ks * ks * s.Cin, Kp = (K + 31) / 32 * 32;
-        XTRY(n, n->wb.ensure((size_t)s.Cout * Kp * sizeof(__bf16)));
+        XTRY(n, scratch_ensure(n, n->wb, (size_t)s.Cout * Kp * sizeof(__bf16)));
         hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
         const __bf16* WB = (const __bf16*)n->wb.p;
         // thin 3x3 layers: the LDS-tiled kernel (one halo per 8x16 output block serves all nine taps)
@@ -189,7 +199,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const int bn = (s.Cout % 64 == 0) ? 64 : 32;
     if (M > 0x7fff0000LL) return fail(n, -3, "too many output pixels in one layer (N*H*W must stay below 2^31)");
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
-    XTRY(n, n->slab.ensure((size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
+    XTRY(n, scratch_ensure(n, n->slab, (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
     if (pdz && !wgrad_halo_runs(n, s, ks)) return fail(n, -3, "internal: pooled-resolution dZ requested for a layer the LDS-tiled weight-gradient kernel does not cover");
     if (wgrad_halo_runs(n, s, ks)) {
         // LDS-tiled: input halo + dZ block staged once per 8x16 pixel block, nine waves = nine filter taps (convnet_bf16.hpp)
@@ -204,7 +214,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         int bpc = (int)((blocks * tiles + target - 1) / target);
         if (bpc < 8) bpc = blocks < 8 ? (int)blocks : 8;
         const int hchunks = (int)((blocks + bpc - 1) / bpc);
-        XTRY(n, n->slab.ensure((size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
+        XTRY(n, scratch_ensure(n, n->slab, (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
         const dim3 hgrid((unsigned)(s.Cin / hb), (unsigned)(s.Cout / hbn), (unsigned)hchunks);
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
 #define WGH_CASE(CB_, BN_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, true>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tw, th, bpc, hchunks, pg); \
@@ -313,7 +323,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         // dZ: gradient wrt the pre-activation
         const float* dZ = (const float*)l.dout.p;
         if (l.kind != RCN_HIPX_DENSE && !l.pool_follows && !gated[i]) {
-            XTRY(n, n->dz.ensure((size_t)M * l.CoutP * sizeof(float)));
+            XTRY(n, scratch_ensure(n, n->dz, (size_t)M * l.CoutP * sizeof(float)));
             hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d(M * l.CoutP, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (float*)n->dz.p, M * l.CoutP);
             XTRY(n, hipGetLastError());
             dZ = (const float*)n->dz.p;
@@ -321,7 +331,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         // dgrad first (needs the weights BEFORE this step's update): dX = conv(dZ, flip(W)^T)
         if (din) {
             const long long wn = (long long)ks * ks * s.Cin * s.Cout;
-            XTRY(n, n->wt.ensure((size_t)wn * sizeof(float)));
+            XTRY(n, scratch_ensure(n, n->wt, (size_t)wn * sizeof(float)));
             hipLaunchKernelGGL(k_flip_weights, dim3(grid1d(wn, 256)), dim3(256), 0, n->stream, (const float*)P(n, l.w_off), (float*)n->wt.p, ks, s.Cin, s.Cout);
             XTRY(n, hipGetLastError());
             // the layer below is a ReLU layer feeding this one directly (no pool in between): gate the gradient with its output in
@@ -350,7 +360,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
 int loss_and_dlogits(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, bool want_grad) {
     Layer& l = n->L.back();
     const int blocks = (B + 255) / 256;
-    XTRY(n, n->loss_part.ensure(blocks * sizeof(float)));
+    XTRY(n, scratch_ensure(n, n->loss_part, blocks * sizeof(float)));
     hipLaunchKernelGGL(k_softmax_ce, dim3(blocks), dim3(256), 0, n->stream, (const float*)l.out.p, labels, B, n->classes, l.CoutP, want_grad ? (float*)l.dout.p : (float*)nullptr,
                        (float*)n->loss_part.p, 1.0f / (float)B);
     if (loss_dev) hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, n->stream, (const float*)n->loss_part.p, blocks, 1.0f / (float)B, loss_dev);

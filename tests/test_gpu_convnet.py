@@ -135,6 +135,35 @@ def test_bf16_mfma_path_matches_bf16_operand_oracle(in_shape, layers, B):
     _close(net.get_params(), co.flatten(nw, nb), rtol=2e-2)
 
 
+def test_cached_step_graphs_survive_scratch_growth():
+    """Steps at batch 4 (graph cached), then at batch 48 (larger scratch buffers: they move), then batch 4 again: the graph
+    cached for the first shape pointed into the old scratch and must not be replayed as is.  Five steps against the oracle."""
+    import torch
+    in_shape = (8, 8, 3)
+    layers = (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 32), ("dense", 10))
+    rng = np.random.default_rng(44)
+    net = _net(in_shape, layers, 48)
+    shapes = co.param_shapes(in_shape, layers)
+    ws = [rng.standard_normal(k) * np.sqrt(2.0 / k[0]) for k, _ in shapes]
+    bs = [rng.standard_normal(n) * 0.1 for _, n in shapes]
+    net.set_params(co.flatten(ws, bs))
+    w = [a.astype(np.float32).astype(np.float64) for a in ws]
+    b = [a.astype(np.float32).astype(np.float64) for a in bs]
+    batches = {}
+    for B in (4, 48):
+        x = rng.standard_normal((B,) + in_shape).astype(np.float32)
+        y = rng.integers(0, 10, B).astype(np.int32)
+        batches[B] = (x, y, net.to_device(x), net.to_device(y))
+    loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+    for B in (4, 4, 48, 4, 48):
+        x, y, xd, yd = batches[B]
+        with torch.cuda.stream(net.stream):
+            net.train_step(xd, yd, 0.05, loss)
+        w, b, _ = co.sgd_step(x.astype(np.float64), y, w, b, layers, 0.05)
+    net.synchronize()
+    _close(net.get_params(), co.flatten(w, b), rtol=1e-3)
+
+
 def test_training_reduces_loss_on_cifar_shape():
     """CIFAR-10 shape net of SURVEY.md §8(d): 32x32x3, conv 3->32, pool, 32->64, pool, 64->128, pool -> 2048 -> 256 -> 10."""
     import torch
