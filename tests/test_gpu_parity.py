@@ -825,6 +825,61 @@ def test_cached_epoch_graphs_survive_workspace_growth(amd, oracle):
     d.rcn.close()
 
 
+def test_random_call_sequences_track_the_oracle(amd, oracle):
+    """40 randomly chosen calls on ONE f64 context -- train_batch and train_epoch at changing batch sizes / lengths / index
+    arguments, evaluation and forward calls in between, the dense path switched now and then -- with the oracle stepping the
+    same parameters.  Shakes out state that outlives a call (cached graphs, workspaces, packed images)."""
+    from mercer_research_amd.device import DeviceRCN
+    rng = np.random.default_rng(4242)
+    N = 2048
+    ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=99, wscale=0.1)
+    d = DeviceRCN(dtype=1)
+    d.set_params(ws, bs)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    rw, rb = ws, bs
+    for step in range(40):
+        op = rng.choice(["batch", "epoch", "epoch_perm", "eval", "forward", "path"], p=[0.25, 0.2, 0.3, 0.1, 0.1, 0.05])
+        if op == "batch":
+            B = int(rng.choice([1, 7, 32, 256, 512]))
+            j = int(rng.integers(0, N - B))
+            d.train_batch(Xd[j:j + B].contiguous(), Yd[j:j + B].contiguous(), 3.0)
+            rw, rb, _ = oracle.train_batch(rw, rb, X[j:j + B], Y[j:j + B], 3.0)
+        elif op == "epoch":
+            B = int(rng.choice([32, 256]))
+            nb = int(rng.integers(1, N // B + 1))
+            d.train_epoch(Xd, Yd, None, B, nb, 3.0, None)
+            for j in range(nb):
+                rw, rb, _ = oracle.train_batch(rw, rb, X[j * B:(j + 1) * B], Y[j * B:(j + 1) * B], 3.0)
+        elif op == "epoch_perm":
+            B = int(rng.choice([16, 256]))
+            nb = int(rng.integers(1, N // B + 1))
+            perm = rng.permutation(N).astype(np.int32)
+            d.train_epoch(Xd, Yd, d.to_device(perm), B, nb, 3.0, None)
+            for j in range(nb):
+                sel = perm[j * B:(j + 1) * B]
+                rw, rb, _ = oracle.train_batch(rw, rb, X[sel], Y[sel], 3.0)
+        elif op == "eval":
+            n = int(rng.integers(1, N))
+            want = int(sum(oracle.eval_accept(o, y) for o, y in zip(oracle.classify_test(rw, rb, X[:n]), Y[:n])))    # rcn.rs:152-157
+            got = d.evaluate(Xd[:n].contiguous(), Yd[:n].contiguous())
+            assert got == want
+        elif op == "forward":
+            n = int(rng.integers(1, 300))
+            out = d.forward(Xd[:n].contiguous())
+            d.synchronize()
+            assert np.abs(out.cpu().numpy() - oracle.classify_test(rw, rb, X[:n])).max() <= 1e-9
+        else:
+            d.set_dense_path(int(rng.choice([0, 1, 2])))
+        if op in ("batch", "epoch", "epoch_perm") and step % 5 == 4:
+            gw, gb = d.get_params()
+            for a, b in zip(gw + gb, rw + rb):
+                assert np.all(np.abs(a - b) <= 1e-8 * np.abs(b) + 1e-9), (step, op)
+    gw, gb = d.get_params()
+    for a, b in zip(gw + gb, rw + rb):
+        assert np.all(np.abs(a - b) <= 1e-8 * np.abs(b) + 1e-9)
+    d.rcn.close()
+
+
 def test_data_parallel_halves_equal_full_batch(amd, oracle):
     """Shard gradients + sum + one update == train_batch on the concatenated batch, single GPU."""
     from mercer_research_amd.device import DeviceRCN
