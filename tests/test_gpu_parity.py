@@ -880,6 +880,42 @@ def test_random_call_sequences_track_the_oracle(amd, oracle):
     d.rcn.close()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["exchange-in-kernel", "3-kernels"])
+def test_random_data_parallel_call_sequences_world1(amd, oracle, monkeypatch, fused):
+    """The data-parallel loop with the peer exchange forced on at world size 1 (so every kernel, graph and sequence number of the
+    multi-GPU path runs): 25 calls of random length and position, some of them the plain single-GPU epoch in between (they share
+    the packed-image workspace), tracked by the oracle in f64."""
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_DP_P2P", "2")
+    monkeypatch.setenv("RCN_HIP_DP_FUSED", fused)
+    rng = np.random.default_rng(777)
+    N, B = 8192, 256
+    ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=98, wscale=0.1)
+    d = DeviceRCN(dtype=1)
+    d.set_params(ws, bs)
+    d.dp_init()
+    assert d.dp_p2p_mode() == (2 if fused == "1" else 1)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    perm = rng.permutation(N).astype(np.int32)
+    permd = d.to_device(perm)
+    rw, rb = ws, bs
+    for call in range(25):
+        nb = int(rng.integers(1, 25))
+        j0 = int(rng.integers(0, N // B - nb + 1))
+        use_perm = rng.random() < 0.7
+        plain = rng.random() < 0.25
+        fn = d.train_epoch if plain else d.dp_train_epoch
+        fn(Xd if use_perm else Xd[j0 * B:], Yd if use_perm else Yd[j0 * B:], permd[j0 * B:] if use_perm else None, B, nb, 3.0, None)
+        for j in range(j0, j0 + nb):
+            sel = perm[j * B:(j + 1) * B] if use_perm else np.arange(j * B, (j + 1) * B)
+            rw, rb, _ = oracle.train_batch(rw, rb, X[sel], Y[sel], 3.0)
+    gw, gb = d.get_params()
+    for a, b in zip(gw + gb, rw + rb):
+        assert np.all(np.abs(a - b) <= 1e-8 * np.abs(b) + 1e-9)
+    d.dp_finalize()
+    d.rcn.close()
+
+
 def test_data_parallel_halves_equal_full_batch(amd, oracle):
     """Shard gradients + sum + one update == train_batch on the concatenated batch, single GPU."""
     from mercer_research_amd.device import DeviceRCN
