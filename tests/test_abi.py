@@ -116,3 +116,17 @@ def test_cpp_host_mirror_compiles_and_links(lib, tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "host_demo.cpp"),
                     "-L" + os.path.dirname(_lib.LIB_PATH), "-lrcn_hip", "-lz", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-o", str(exe)], check=True)
     assert exe.exists()
+
+
+def test_rust_shim_declares_exactly_the_header_functions():
+    """rust/rcn-hip-sys cannot be compiled here (no cargo), so at least its extern block is held in lock-step with the header:
+    the same set of rcn_hip_* functions as include/rcn_hip.h (which test_library_exports_every_declared_symbol ties to the
+    library and to the ctypes table)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "rcn_hip.h")).read()
+    rust = open(os.path.join(root, "rust", "rcn-hip-sys", "src", "lib.rs")).read()
+    in_header = set(re.findall(r"\b(rcn_hip_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S)))
+    in_rust = set(re.findall(r"pub fn (rcn_hip_[a-z0-9_]+)\s*\(", rust))
+    assert in_header - in_rust == set(), f"missing in the Rust shim: {sorted(in_header - in_rust)}"
+    assert in_rust - in_header == set(), f"not in the header: {sorted(in_rust - in_header)}"
