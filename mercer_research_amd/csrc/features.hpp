@@ -10,6 +10,9 @@
 // is therefore bit-identical to the reference's f64 loop regardless of summation order.
 #pragma once
 
+#include <cmath>
+#include <cstring>
+
 #include "common.hpp"
 
 namespace rcn {
@@ -123,6 +126,40 @@ __global__ __launch_bounds__(kFeatThreads) void k_features(
     }
 }
 
+// ---- (x - mean) / sd, clamped at zero (rcn.rs:407-412 / 86-89).
+// The f32 quotient costs ~11 VALU instructions as an IEEE division.  When FAST, it is computed as Markstein's
+// correction of a reciprocal product instead -- q0 = n*y, r = fma(-q0, sd, n), q = fma(r, y, q0) with y = RN(1/sd) --
+// which is the correctly rounded quotient except for rare (n, sd) pairs.  "Rare" is not good enough for a bit-exact
+// path, so the host only selects FAST after standardise_fast_is_exact() has compared the two forms over EVERY value a
+// feature can take (integers 0..vmax) for the (mean, sd) in force; otherwise the kernels divide.
+template <bool FAST, typename T>
+__device__ inline T standardise_clamp(T v, T mean, T sd, T rcp) {
+    const T n = v - mean;
+    T q;
+    if constexpr (FAST) {
+        const T q0 = n * rcp;
+        const T r = __builtin_elementwise_fma(-q0, sd, n);
+        q = __builtin_elementwise_fma(r, rcp, q0);
+    } else {
+        q = n / sd;
+    }
+    return q >= (T)0 ? q : (T)0;
+}
+
+inline bool standardise_fast_is_exact(float mean, float sd, int vmax, float* rcp_out) {
+    if (!(sd > 0.f) || !std::isfinite(sd) || !std::isfinite(mean)) return false;
+    const volatile float y = 1.0f / sd;                              // correctly rounded reciprocal
+    for (int v = 0; v <= vmax; ++v) {
+        const volatile float n = (float)v - mean;
+        const volatile float q0 = n * y;                             // volatile: no host-side contraction into an fma
+        const float r = std::fmaf(-q0, sd, n);
+        const float q = std::fmaf(r, y, q0), want = n / sd;
+        if (std::memcmp(&q, &want, sizeof q) != 0) return false;
+    }
+    *rcp_out = y;
+    return true;
+}
+
 // ---- specialisation: the default stack conv(Same), pool(Max), conv(Same), pool(Max) (rcn/src/main.rs:53-59) on an
 // H x W image with H, W multiples of 4 known at compile time (MNIST: 28 x 28).
 //
@@ -142,11 +179,30 @@ template <int H, int W>
 struct Cpcp {
     static_assert(H % 4 == 0 && W % 4 == 0, "two exact 2x2 poolings and 4-pixel word loads");
     static constexpr int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4;
-    static constexpr int PW0 = W + 4, PW1 = W1 + 2;          // padded row strides (frame: 2 left; right slack keeps windows in range)
-    static constexpr int N0 = (H + 2) * PW0, N1 = (H1 + 2) * PW1;
+    static constexpr int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+    static constexpr int pad_to(int x, int mod, int res) { while (x % mod != res % mod) ++x; return x; }
+    // Work items are laid over the lanes in power-of-two runs -- stage 1: RW1 lanes per pooled row (W1 of them live),
+    // stage 2: RH2 lanes per pooled column (H2 live) -- and the padded strides are chosen so that each 32-lane group of
+    // a ds_read_b64 (bank = dword address mod 64, MI355X_MICROARCH.md LDS table) touches 32 distinct bank pairs:
+    //   stage 1: lane (py, px) reads dword 2*PW0*py + 2*px (+ row const): a group is 32/RW1 rows of 2*RW1 banks, so the
+    //            rows must sit 2*RW1 banks apart:                PW0 == RW1 (mod 32)           28x28: PW0 = 48
+    //   stage 2: lane (i, px, py) reads dword N1*i + 2*PW1*py + 2*px: a group is 32/RH2 columns, 2 banks each, so py must
+    //            step by an odd multiple of 64/RH2 banks:        PW1 == 32/RH2 (mod 64/RH2)    28x28: PW1 = 20
+    //            and a group that straddles two maps keeps the column sequence going:
+    //                                                            N1 == 2*W2 (mod 64/RH2)       28x28: N1 = 326
+    // (lanes past the live ones re-read a live lane's address -- a broadcast, not a conflict).  Measured on 28x28:
+    // SQ_LDS_BANK_CONFLICT was 70 % of all LDS cycles with the natural strides 32 / 16 / 256.
+    static constexpr int RW1 = pow2ceil(W1), RH2 = pow2ceil(H2);
+    static_assert(RW1 <= 32 && RH2 <= 32, "one run of lanes per 32-lane group at most");
+    static constexpr int PW0 = pad_to(W + 4 > 2 * RW1 + 2 ? W + 4 : 2 * RW1 + 2, 32, RW1);      // frame: 2 left; right slack keeps every lane's window in range
+    static constexpr int PW1 = pad_to(W1 + 2 > 2 * W2 + 2 ? W1 + 2 : 2 * W2 + 2, 64 / RH2, 32 / RH2);
+    static constexpr int N0 = (H + 2) * PW0, N1 = pad_to((H1 + 2) * PW1, 64 / RH2 > 2 ? 64 / RH2 : 2, 2 * W2);
+    static_assert(N1 % 2 == 0 && PW0 % 2 == 0 && PW1 % 2 == 0, "8-byte aligned window rows");
     static constexpr int WORDS = H * W / 4, ROWW = W / 4;
-    static constexpr int I1 = H1 * W1, I2 = 4 * H2 * W2, SZ2 = H2 * W2, F = 16 * SZ2;
+    static constexpr int S1 = H1 * RW1, S2 = 4 * W2 * RH2;      // lane slots of the two stages
+    static constexpr int SZ2 = H2 * W2, F = 16 * SZ2;
     static constexpr int LDS_FLOATS = N0 + 4 * N1;
+    static constexpr int VMAX = 255 * 16;                        // two [1,2,1]x[1,0,-1] passes: |v| <= 255 * 4 * 4
 
     // the frame of zeros; once per workgroup (image writes never touch it)
     template <int NT>
@@ -155,46 +211,75 @@ struct Cpcp {
         for (int e = tid; e < 4 * N1; e += NT) P1[e] = 0.f;
     }
 
-    // one 4x4 window -> the four pooled operator responses (Top, Left, Right, Bottom) of its 2x2 cell
-    __device__ static inline void cell(const float* win, int stride, bool row0, float& tmax, float& lmax, float& rmax, float& bmax) {
-        float w[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float2 a = *reinterpret_cast<const float2*>(win + r * stride), b = *reinterpret_cast<const float2*>(win + r * stride + 2);
-            w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
-        }
+    // one 4x4 window -> the four pooled operator responses (Top, Left, Right, Bottom) of its 2x2 cell.
+    // Every value is an integer below 2^24, so f32 arithmetic is exact in any association and a fused multiply-add
+    // equals the reference's multiply then add; that licence is used to run the column pass on the window's aligned
+    // (even, odd) column pairs as packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two lanes of work per VALU issue slot).
+    template <int STRIDE>
+    __device__ static inline void cell(const float* win, bool row0, float& tmax, float& lmax, float& rmax, float& bmax) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 a[4], b[4];                                                   // a[r] = columns 0,1 of window row r;  b[r] = columns 2,3
+        // Eight single ds_read_b64 (2 LDS cycles each, 64 banks).  Written as asm because the compiler fuses each
+        // (a[r], b[r]) pair into one ds_read2_b64, which the LDS serves at half that rate and with mod-32 banking.
+        const unsigned addr = (unsigned)(uintptr_t)win;                  // LDS byte address: low half of the generic pointer
+#define RCN_LDS_RD(dst, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+        RCN_LDS_RD(a[0], 0 * STRIDE * 4);     RCN_LDS_RD(b[0], 0 * STRIDE * 4 + 8);
+        RCN_LDS_RD(a[1], 1 * STRIDE * 4);     RCN_LDS_RD(b[1], 1 * STRIDE * 4 + 8);
+        RCN_LDS_RD(a[2], 2 * STRIDE * 4);     RCN_LDS_RD(b[2], 2 * STRIDE * 4 + 8);
+        RCN_LDS_RD(a[3], 3 * STRIDE * 4);     RCN_LDS_RD(b[3], 3 * STRIDE * 4 + 8);
+#undef RCN_LDS_RD
+        // the loads are asynchronous: tie every destination to the wait so no use is scheduled above it
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]) : : "memory");
+        const f2 two = {2.f, 2.f};
         tmax = 0.f; bmax = 0.f; lmax = 0.f; rmax = 0.f;          // the +0 is the ReLU floor; Bottom = -Top, Right = -Left
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            float d[4], sm[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                d[c] = w[dy][c] - w[dy + 2][c];                          // column kernel [1,0,-1]   kernel.rs:47
-                sm[c] = (w[dy][c] + w[dy + 2][c]) + 2.f * w[dy + 1][c];   // column kernel [1,2,1]    kernel.rs:48
+            const f2 d01 = a[dy] - a[dy + 2], d23 = b[dy] - b[dy + 2];                                   // column kernel [1,0,-1]   kernel.rs:47
+            const f2 s01 = __builtin_elementwise_fma(two, a[dy + 1], a[dy] + a[dy + 2]);                 // column kernel [1,2,1]    kernel.rs:48
+            const f2 s23 = __builtin_elementwise_fma(two, b[dy + 1], b[dy] + b[dy + 2]);
+            const f2 mid = __builtin_shufflevector(d01, d23, 1, 2);                                      // (d1, d2)
+            f2 top = __builtin_elementwise_fma(two, mid, d01 + d23);                                     // row kernel [1,2,1] at dx = 0, 1
+            f2 left = s01 - s23;                                                                         // row kernel [1,0,-1] at dx = 0, 1
+            if (dy == 0) {                                               // output row 0 is zero (quirk)
+                top.x = row0 ? 0.f : top.x; top.y = row0 ? 0.f : top.y;
+                left.x = row0 ? 0.f : left.x; left.y = row0 ? 0.f : left.y;
             }
-            const bool live = dy == 1 || !row0;                          // output row 0 is zero (quirk)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                float top = (d[dx] + d[dx + 2]) + 2.f * d[dx + 1];        // row kernel [1,2,1]
-                float left = sm[dx] - sm[dx + 2];                         // row kernel [1,0,-1]
-                top = live ? top : 0.f; left = live ? left : 0.f;
-                tmax = fmaxf(tmax, top); bmax = fmaxf(bmax, -top);
-                lmax = fmaxf(lmax, left); rmax = fmaxf(rmax, -left);
-            }
+            tmax = fmaxf(fmaxf(tmax, top.x), top.y); bmax = fmaxf(fmaxf(bmax, -top.x), -top.y);
+            lmax = fmaxf(fmaxf(lmax, left.x), left.y); rmax = fmaxf(fmaxf(rmax, -left.x), -left.y);
         }
     }
 
     // One image through conv,pool,conv,pool by NT threads (a whole workgroup: contains barriers).  emit(e, v): feature e
     // of the flattened vector (rcn.rs:350-355 order) has the integer value v.
+    // get_pixel_matrix (lib.rs:27-41), first half: this thread's 32-bit words of the picture (4 pixels of one row each).
+    // Separate from image() so a caller can issue the NEXT picture's loads before working on the current one.
+    template <int NT>
+    struct Words { uint32_t v[(WORDS + NT - 1) / NT]; };
+    template <int NT>
+    __device__ static inline Words<NT> load_words(const uint8_t* img, int tid) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
+        Words<NT> w;
+#pragma unroll
+        for (int k = 0; k < (WORDS + NT - 1) / NT; ++k) {
+            const int wd = tid + NT * k;
+            w.v[k] = src[wd < WORDS ? wd : WORDS - 1];
+        }
+        return w;
+    }
+
     template <int NT, typename Emit>
     __device__ static inline void image(float* P0, float* P1, const uint8_t* img, int tid, Emit emit) {
-        // get_pixel_matrix (lib.rs:27-41): 4 pixels of one row per 32-bit word; image pixel (r,c) -> P0[(r+2)*PW0 + c+2]
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(img);
+        image<NT>(P0, P1, load_words<NT>(img, tid), tid, emit);
+    }
+
+    template <int NT, typename Emit>
+    __device__ static inline void image(float* P0, float* P1, const Words<NT>& words, int tid, Emit emit) {
+        // image pixel (r,c) -> P0[(r+2)*PW0 + c+2]
 #pragma unroll
         for (int k = 0; k < (WORDS + NT - 1) / NT; ++k) {
             const int wd = tid + NT * k;
             const int wc = wd < WORDS ? wd : WORDS - 1;
-            const uint32_t v = src[wc];
+            const uint32_t v = words.v[k];
             const int r = wc / ROWW, c0 = (wc - r * ROWW) * 4;
             float2 lo, hi;
             lo.x = (float)(v & 255u); lo.y = (float)((v >> 8) & 255u);
@@ -206,15 +291,15 @@ struct Cpcp {
             }
         }
         __syncthreads();
-        // conv1 + pool1: item = pooled pixel (py,px) of the H1 x W1 maps
+        // conv1 + pool1: item = pooled pixel (py,px) of the H1 x W1 maps, RW1 lanes per row
 #pragma unroll
-        for (int k = 0; k < (I1 + NT - 1) / NT; ++k) {
+        for (int k = 0; k < (S1 + NT - 1) / NT; ++k) {
             const int t = tid + NT * k;
-            const int tc = t < I1 ? t : I1 - 1;
-            const int py = tc / W1, px = tc - py * W1;
+            const int pyr = t / RW1, px = t % RW1;
+            const int py = pyr < H1 ? pyr : H1 - 1;
             float tmax, lmax, rmax, bmax;
-            cell(&P0[2 * py * PW0 + 2 * px], PW0, py == 0, tmax, lmax, rmax, bmax);
-            if (t < I1) {
+            cell<PW0>(&P0[2 * py * PW0 + 2 * px], NT * k < RW1 && py == 0, tmax, lmax, rmax, bmax);   // later rounds: py > 0 for every lane
+            if (pyr < H1 && px < W1) {
                 const bool lastc = px == W1 - 1;                              // conv2 never reads a map's last column
                 float* q = &P1[(py + 2) * PW1 + px + 2];
                 q[0 * N1] = lastc ? 0.f : tmax;                               // Top      (SEP_OPS order rcn.rs:41-46)
@@ -224,15 +309,17 @@ struct Cpcp {
             }
         }
         __syncthreads();
-        // conv2 + pool2 + flatten: item = (input map i, pooled pixel) ordered column-major within the map (rcn.rs:350-355)
+        // conv2 + pool2 + flatten: item = (input map i, pooled pixel), RH2 lanes per pooled column so that live lanes run
+        // down the columns in the flattened vector's order (column-major within a map, rcn.rs:350-355)
 #pragma unroll
-        for (int k = 0; k < (I2 + NT - 1) / NT; ++k) {
+        for (int k = 0; k < (S2 + NT - 1) / NT; ++k) {
             const int t = tid + NT * k;
-            const int tc = t < I2 ? t : I2 - 1;
-            const int i = tc / SZ2, q = tc - i * SZ2, px = q / H2, py = q - px * H2;
+            const int cgr = t / RH2, pyr = t % RH2;
+            const int cg = cgr < 4 * W2 ? cgr : 4 * W2 - 1, py = pyr < H2 ? pyr : H2 - 1;
+            const int i = cg / W2, px = cg - i * W2, q = px * H2 + py;
             float tmax, lmax, rmax, bmax;
-            cell(&P1[i * N1 + 2 * py * PW1 + 2 * px], PW1, py == 0, tmax, lmax, rmax, bmax);
-            if (t < I2) {
+            cell<PW1>(&P1[i * N1 + 2 * py * PW1 + 2 * px], py == 0, tmax, lmax, rmax, bmax);
+            if (cgr < 4 * W2 && pyr < H2) {
                 // slots after the second conv layer (rcn.rs:323-340): Bottom stays in slot i, T/L/R are pushed to 4+3i+o
                 emit((4 + 3 * i + 0) * SZ2 + q, tmax);
                 emit((4 + 3 * i + 1) * SZ2 + q, lmax);
@@ -243,23 +330,26 @@ struct Cpcp {
     }
 };
 
-template <int H, int W, typename TO>
+template <int H, int W, typename TO, bool FAST>
 __global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, int standardize,
-                                                      TO mean, TO sd) {
+                                                      TO mean, TO sd, TO rcp) {
     using K = Cpcp<H, W>;
     __shared__ __attribute__((aligned(16))) float P0[K::N0];
     __shared__ __attribute__((aligned(16))) float P1[4 * K::N1];
     const int lane = threadIdx.x;
     K::template init<64>(P0, P1, lane);
     __syncthreads();
+    // the next picture's pixels are in flight while this one is computed (one wave per workgroup: nothing else hides
+    // the load's latency inside the wave)
+    auto nxt = K::template load_words<64>(imgs + (size_t)(blockIdx.x < n_img ? blockIdx.x : 0) * (H * W), lane);
     for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
         TO* dst = out + (size_t)img * K::F;
-        K::template image<64>(P0, P1, imgs + (size_t)img * (H * W), lane, [&](int e, float fv) {
+        const auto cur = nxt;
+        const int ni = img + (int)gridDim.x;
+        nxt = K::template load_words<64>(imgs + (size_t)(ni < n_img ? ni : img) * (H * W), lane);
+        K::template image<64>(P0, P1, cur, lane, [&](int e, float fv) {
             TO v = (TO)fv;
-            if (standardize) {
-                const TO dd = (v - mean) / sd;                               // rcn.rs:407-412
-                v = dd >= (TO)0 ? dd : (TO)0;
-            }
+            if (standardize) v = standardise_clamp<FAST>(v, mean, sd, rcp);
             dst[e] = v;
         });
         __syncthreads();
@@ -271,9 +361,9 @@ __global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict_
 // end-to-end form: u8 images in, no [N][F] feature matrix in HBM, no separate gather pass.  One wave per (batch, sample);
 // the sample's image is perm[batch * B + sample] (or that index itself).  Same arithmetic as k_features_cpcp with the
 // fused standardisation, so the packed values are bit-identical to features -> standardise -> k_pack_epoch.
-template <int H, int W, typename TO>
+template <int H, int W, typename TO, bool FAST>
 __global__ __launch_bounds__(64) void k_features_cpcp_packed(const uint8_t* __restrict__ imgs, const TO* __restrict__ Y, const int* __restrict__ perm,
-                                                             int B, int n_batches, int G, int C, TO mean, TO sd, TO* __restrict__ xs,
+                                                             int B, int n_batches, int G, int C, TO mean, TO sd, TO rcp, TO* __restrict__ xs,
                                                              TO* __restrict__ ys) {
     using K = Cpcp<H, W>;
     __shared__ __attribute__((aligned(16))) float P0[K::N0];
@@ -282,13 +372,22 @@ __global__ __launch_bounds__(64) void k_features_cpcp_packed(const uint8_t* __re
     K::template init<64>(P0, P1, lane);
     __syncthreads();
     const int total = n_batches * B;
-    for (int L = blockIdx.x; L < total; L += gridDim.x) {
+    // two-deep software pipeline: the picture index of step L+2 and the pixels of step L+1 are in flight during step L
+    const int g = (int)gridDim.x, L0 = blockIdx.x;
+    auto pick = [&](int L) -> long long { const int Lc = L < total ? L : L0; return perm ? perm[Lc] : Lc; };
+    long long img_n = L0 < total ? pick(L0) : 0;
+    auto nxt = K::template load_words<64>(imgs + (size_t)img_n * (H * W), lane);
+    long long img_nn = pick(L0 + g);
+    for (int L = L0; L < total; L += g) {
         const int jb = L / B, smp = L - jb * B;
-        const long long img = perm ? perm[L] : L;
+        const long long img = img_n;
+        const auto cur = nxt;
+        img_n = img_nn;
+        nxt = K::template load_words<64>(imgs + (size_t)img_n * (H * W), lane);
+        img_nn = pick(L + 2 * g);
         TO* xb = xs + ((size_t)jb * G * B + smp) * 16;                 // + slice * B * 16 + feature % 16
-        K::template image<64>(P0, P1, imgs + (size_t)img * (H * W), lane, [&](int e, float fv) {
-            const TO dd = ((TO)fv - mean) / sd;                           // rcn.rs:407-412
-            xb[(size_t)(e >> 4) * B * 16 + (e & 15)] = dd >= (TO)0 ? dd : (TO)0;
+        K::template image<64>(P0, P1, cur, lane, [&](int e, float fv) {
+            xb[(size_t)(e >> 4) * B * 16 + (e & 15)] = standardise_clamp<FAST>((TO)fv, mean, sd, rcp);
         });
         if (lane < C) ys[(size_t)L * C + lane] = Y[(size_t)img * C + lane];
         __syncthreads();

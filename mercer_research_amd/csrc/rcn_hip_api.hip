@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <random>
 #include <string>
@@ -69,6 +70,8 @@ struct rcn_hip_ctx {
     std::string dense_err;                  // non-empty: every dense call panics in the reference (see rcn_hip_create)
     double mean = 1.0, sd = 1.0;            // scale_set initial value (1,1): rcn.rs:71
     int feat_kernel = 0;                    // 0 auto, 1 always the generic k_features (tests compare the two)
+    float fd_mean = 0.f, fd_sd = 0.f, fd_rcp = 0.f;   // last (mean, sd) checked by standardise_fast_is_exact; fd_rcp = 0: divide
+    bool fd_checked = false;
     DevBuf pll;                             // persistent epoch kernel: tagged-word exchange buffers (dense_p2_persist.hpp)
     size_t pll_B = 0;
     unsigned ptag = 0;                      // last tag handed out; monotonic for the life of the context
@@ -453,6 +456,40 @@ int launch_pack(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* per
     return RCN_HIP_OK;
 }
 
+// Grid of a one-wave-per-workgroup kernel that loops over its work: exactly as many workgroups as the device holds at
+// once (CUs x resident workgroups per CU for that kernel's LDS footprint), so every image loop runs in a single pass --
+// a grid larger than that queues the excess behind the first pass and the tail runs on a part-empty chip.
+template <typename Kern>
+static int resident_grid(rcn_hip_ctx* c, Kern kern, size_t work) {
+    static std::map<std::pair<int, const void*>, int> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(c->device, (const void*)kern);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 256;
+        it = cache.emplace(key, per_cu * cus).first;
+    }
+    return (int)(work < (size_t)it->second ? work : (size_t)it->second);
+}
+
+// f32 standardisation in the specialised feature kernels: the reciprocal to use, or 0 when only a true division is
+// bit-exact for the scale in force (features.hpp: standardise_fast_is_exact, checked once per (mean, sd))
+static float fast_standardise_rcp(rcn_hip_ctx* c) {
+    static const bool off = getenv("RCN_HIP_EXACT_DIV_ONLY") && atoi(getenv("RCN_HIP_EXACT_DIV_ONLY")) != 0;
+    if (off) return 0.f;
+    const float m = (float)c->mean, sd = (float)c->sd;
+    if (!c->fd_checked || std::memcmp(&m, &c->fd_mean, 4) != 0 || std::memcmp(&sd, &c->fd_sd, 4) != 0) {
+        c->fd_mean = m; c->fd_sd = sd; c->fd_rcp = 0.f;
+        float y = 0.f;
+        if (standardise_fast_is_exact(m, sd, Cpcp<28, 28>::VMAX, &y)) c->fd_rcp = y;
+        c->fd_checked = true;
+    }
+    return c->fd_rcp;
+}
+
 // the same image straight from u8 pictures: features + standardise + slice-major packing in one kernel (features.hpp)
 template <typename T>
 int launch_feat_pack(rcn_hip_ctx* c, const uint8_t* imgs, const void* Y, const int32_t* perm, size_t B, size_t j0, size_t n, int half, size_t seg) {
@@ -464,8 +501,15 @@ int launch_feat_pack(rcn_hip_ctx* c, const uint8_t* imgs, const void* Y, const i
     T* xs = (T*)c->xpack.p + (size_t)half * seg * G * B * 16;
     T* ys = (T*)c->ypack.p + (size_t)half * seg * B * Cc;
     const size_t total = n * B;
-    const int grid = (int)(total < 8192 ? total : 8192);
-    hipLaunchKernelGGL((k_features_cpcp_packed<28, 28, T>), dim3(grid), dim3(64), 0, c->stream, ib, Yb, pb, (int)B, (int)n, G, Cc, (T)c->mean, (T)c->sd, xs, ys);
+    float rcp = 0.f;
+    if constexpr (std::is_same<T, float>::value) rcp = fast_standardise_rcp(c);
+    const int grid = rcp != 0.f ? resident_grid(c, k_features_cpcp_packed<28, 28, T, true>, total) : resident_grid(c, k_features_cpcp_packed<28, 28, T, false>, total);
+    if (rcp != 0.f)
+        hipLaunchKernelGGL((k_features_cpcp_packed<28, 28, T, true>), dim3(grid), dim3(64), 0, c->stream, ib, Yb, pb, (int)B, (int)n, G, Cc, (T)c->mean,
+                           (T)c->sd, (T)rcp, xs, ys);
+    else
+        hipLaunchKernelGGL((k_features_cpcp_packed<28, 28, T, false>), dim3(grid), dim3(64), 0, c->stream, ib, Yb, pb, (int)B, (int)n, G, Cc, (T)c->mean,
+                           (T)c->sd, (T)0, xs, ys);
     HIP_TRY(c, hipGetLastError());
     if (half == 0) { c->packed_B = B; c->packed_nb = n; }
     return RCN_HIP_OK;
@@ -1121,13 +1165,19 @@ int rcn_hip_features_dev(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, void* ou
     DevGuard g(c->device);
     // the default stack on MNIST-shaped input has its own kernel (features.hpp: k_features_cpcp)
     if (feat_is_cpcp28(c) && ((uintptr_t)imgs & 3) == 0) {
-        const int grid = (int)(n < 4096 ? n : 4096);
+        const float rcp = c->dtype == RCN_HIP_F32 && standardize ? fast_standardise_rcp(c) : 0.f;
+        const int grid = c->dtype == RCN_HIP_F64 ? resident_grid(c, k_features_cpcp<28, 28, double, false>, n)
+                         : rcp != 0.f            ? resident_grid(c, k_features_cpcp<28, 28, float, true>, n)
+                                                 : resident_grid(c, k_features_cpcp<28, 28, float, false>, n);
         if (c->dtype == RCN_HIP_F64)
-            hipLaunchKernelGGL((k_features_cpcp<28, 28, double>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (double*)out, standardize,
-                               c->mean, c->sd);
+            hipLaunchKernelGGL((k_features_cpcp<28, 28, double, false>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (double*)out, standardize,
+                               c->mean, c->sd, 0.0);
+        else if (rcp != 0.f)
+            hipLaunchKernelGGL((k_features_cpcp<28, 28, float, true>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (float*)out, standardize,
+                               (float)c->mean, (float)c->sd, rcp);
         else
-            hipLaunchKernelGGL((k_features_cpcp<28, 28, float>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (float*)out, standardize,
-                               (float)c->mean, (float)c->sd);
+            hipLaunchKernelGGL((k_features_cpcp<28, 28, float, false>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (float*)out, standardize,
+                               (float)c->mean, (float)c->sd, 0.f);
         HIP_TRY(c, hipGetLastError());
         return RCN_HIP_OK;
     }
