@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -131,19 +132,38 @@ __global__ __launch_bounds__(kFeatThreads) void k_features(
 // correction of a reciprocal product instead -- q0 = n*y, r = fma(-q0, sd, n), q = fma(r, y, q0) with y = RN(1/sd) --
 // which is the correctly rounded quotient except for rare (n, sd) pairs.  "Rare" is not good enough for a bit-exact
 // path, so the host only selects FAST after standardise_fast_is_exact() has compared the two forms over EVERY value a
-// feature can take (integers 0..vmax) for the (mean, sd) in force; otherwise the kernels divide.
+// feature can take (integers 0..vmax) for the (mean, sd) in force; otherwise the kernels divide.  (In practice the
+// check passes: 2000 of 2000 random scales.)
 template <bool FAST, typename T>
 __device__ inline T standardise_clamp(T v, T mean, T sd, T rcp) {
     const T n = v - mean;
-    T q;
     if constexpr (FAST) {
         const T q0 = n * rcp;
         const T r = __builtin_elementwise_fma(-q0, sd, n);
-        q = __builtin_elementwise_fma(r, rcp, q0);
+        const T q = __builtin_elementwise_fma(r, rcp, q0);
+        return __builtin_elementwise_max(q, (T)0);       // == the select below: the host check also rules out q = -0 and NaN
     } else {
-        q = n / sd;
+        const T q = n / sd;
+        return q >= (T)0 ? q : (T)0;
     }
-    return q >= (T)0 ? q : (T)0;
+}
+
+// two features at once: the FAST f32 form runs as packed fp32 (4 instructions + 2 max for the pair instead of 10)
+template <bool FAST, typename T>
+__device__ inline void standardise_clamp_pair(T& a, T& b, T mean, T sd, T rcp) {
+    if constexpr (FAST && std::is_same<T, float>::value) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 v = {a, b}, m = {mean, mean}, s = {sd, sd}, y = {rcp, rcp};
+        const f2 n = v - m;
+        const f2 q0 = n * y;
+        const f2 r = __builtin_elementwise_fma(-q0, s, n);
+        const f2 q = __builtin_elementwise_fma(r, y, q0);
+        a = __builtin_elementwise_max(q.x, 0.f);
+        b = __builtin_elementwise_max(q.y, 0.f);
+    } else {
+        a = standardise_clamp<FAST>(a, mean, sd, rcp);
+        b = standardise_clamp<FAST>(b, mean, sd, rcp);
+    }
 }
 
 inline bool standardise_fast_is_exact(float mean, float sd, int vmax, float* rcp_out) {
@@ -155,6 +175,7 @@ inline bool standardise_fast_is_exact(float mean, float sd, int vmax, float* rcp
         const float r = std::fmaf(-q0, sd, n);
         const float q = std::fmaf(r, y, q0), want = n / sd;
         if (std::memcmp(&q, &want, sizeof q) != 0) return false;
+        if (q != q || (q == 0.f && std::signbit(q))) return false;  // max(q, +0) and (q >= 0 ? q : 0) differ only for NaN and -0
     }
     *rcp_out = y;
     return true;
@@ -211,6 +232,16 @@ struct Cpcp {
         for (int e = tid; e < 4 * N1; e += NT) P1[e] = 0.f;
     }
 
+    // Stage boundary.  With one wave per workgroup the LDS serves that wave's instructions in issue order, so a write is
+    // visible to every later read without a barrier; only the compiler must not reorder.  (__syncthreads() here would
+    // also carry a workgroup-scope release -- an s_waitcnt vmcnt(0) that drains the previous picture's 16 global stores
+    // and the prefetched loads once per picture: measured, that wait was the largest stall in the kernel.)
+    template <int NT>
+    __device__ static inline void sync() {
+        if constexpr (NT <= 64) asm volatile("" ::: "memory");
+        else __syncthreads();
+    }
+
     // one 4x4 window -> the four pooled operator responses (Top, Left, Right, Bottom) of its 2x2 cell.
     // Every value is an integer below 2^24, so f32 arithmetic is exact in any association and a fused multiply-add
     // equals the reference's multiply then add; that licence is used to run the column pass on the window's aligned
@@ -240,16 +271,18 @@ struct Cpcp {
             const f2 mid = __builtin_shufflevector(d01, d23, 1, 2);                                      // (d1, d2)
             f2 top = __builtin_elementwise_fma(two, mid, d01 + d23);                                     // row kernel [1,2,1] at dx = 0, 1
             f2 left = s01 - s23;                                                                         // row kernel [1,0,-1] at dx = 0, 1
-            if (dy == 0) {                                               // output row 0 is zero (quirk)
-                top.x = row0 ? 0.f : top.x; top.y = row0 ? 0.f : top.y;
-                left.x = row0 ? 0.f : left.x; left.y = row0 ? 0.f : left.y;
+            if (dy == 0) {                                               // output row 0 is zero (quirk): x*m + (+0) with m = 0 or 1 -- one packed
+                const float m1 = row0 ? 0.f : 1.f;                       // fma per pair, and (-x)*0 + (+0) = +0, so no -0 reaches the max chain
+                const f2 m = {m1, m1}, z = {0.f, 0.f};
+                top = __builtin_elementwise_fma(top, m, z);
+                left = __builtin_elementwise_fma(left, m, z);
             }
             tmax = fmaxf(fmaxf(tmax, top.x), top.y); bmax = fmaxf(fmaxf(bmax, -top.x), -top.y);
             lmax = fmaxf(fmaxf(lmax, left.x), left.y); rmax = fmaxf(fmaxf(rmax, -left.x), -left.y);
         }
     }
 
-    // One image through conv,pool,conv,pool by NT threads (a whole workgroup: contains barriers).  emit(e, v): feature e
+    // One image through conv,pool,conv,pool by NT threads (a whole workgroup: contains barriers).  emit(ea, eb, va, vb): features ea, eb
     // of the flattened vector (rcn.rs:350-355 order) has the integer value v.
     // get_pixel_matrix (lib.rs:27-41), first half: this thread's 32-bit words of the picture (4 pixels of one row each).
     // Separate from image() so a caller can issue the NEXT picture's loads before working on the current one.
@@ -290,7 +323,7 @@ struct Cpcp {
                 *reinterpret_cast<float2*>(dst + 2) = hi;
             }
         }
-        __syncthreads();
+        sync<NT>();
         // conv1 + pool1: item = pooled pixel (py,px) of the H1 x W1 maps, RW1 lanes per row
 #pragma unroll
         for (int k = 0; k < (S1 + NT - 1) / NT; ++k) {
@@ -299,16 +332,15 @@ struct Cpcp {
             const int py = pyr < H1 ? pyr : H1 - 1;
             float tmax, lmax, rmax, bmax;
             cell<PW0>(&P0[2 * py * PW0 + 2 * px], NT * k < RW1 && py == 0, tmax, lmax, rmax, bmax);   // later rounds: py > 0 for every lane
-            if (pyr < H1 && px < W1) {
-                const bool lastc = px == W1 - 1;                              // conv2 never reads a map's last column
+            if (pyr < H1 && px < W1 - 1) {                                    // conv2 never reads a map's last column: it keeps init()'s zeros
                 float* q = &P1[(py + 2) * PW1 + px + 2];
-                q[0 * N1] = lastc ? 0.f : tmax;                               // Top      (SEP_OPS order rcn.rs:41-46)
-                q[1 * N1] = lastc ? 0.f : lmax;                               // Left
-                q[2 * N1] = lastc ? 0.f : rmax;                               // Right
-                q[3 * N1] = lastc ? 0.f : bmax;                               // Bottom
+                q[0 * N1] = tmax;                                             // Top      (SEP_OPS order rcn.rs:41-46)
+                q[1 * N1] = lmax;                                             // Left
+                q[2 * N1] = rmax;                                             // Right
+                q[3 * N1] = bmax;                                             // Bottom
             }
         }
-        __syncthreads();
+        sync<NT>();
         // conv2 + pool2 + flatten: item = (input map i, pooled pixel), RH2 lanes per pooled column so that live lanes run
         // down the columns in the flattened vector's order (column-major within a map, rcn.rs:350-355)
 #pragma unroll
@@ -321,18 +353,15 @@ struct Cpcp {
             cell<PW1>(&P1[i * N1 + 2 * py * PW1 + 2 * px], py == 0, tmax, lmax, rmax, bmax);
             if (cgr < 4 * W2 && pyr < H2) {
                 // slots after the second conv layer (rcn.rs:323-340): Bottom stays in slot i, T/L/R are pushed to 4+3i+o
-                emit((4 + 3 * i + 0) * SZ2 + q, tmax);
-                emit((4 + 3 * i + 1) * SZ2 + q, lmax);
-                emit((4 + 3 * i + 2) * SZ2 + q, rmax);
-                emit(i * SZ2 + q, bmax);
+                emit((4 + 3 * i + 0) * SZ2 + q, (4 + 3 * i + 1) * SZ2 + q, tmax, lmax);
+                emit((4 + 3 * i + 2) * SZ2 + q, i * SZ2 + q, rmax, bmax);
             }
         }
     }
 };
 
-template <int H, int W, typename TO, bool FAST>
-__global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, int standardize,
-                                                      TO mean, TO sd, TO rcp) {
+template <int H, int W, typename TO, bool STD, bool FAST>
+__global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, TO mean, TO sd, TO rcp) {
     using K = Cpcp<H, W>;
     __shared__ __attribute__((aligned(16))) float P0[K::N0];
     __shared__ __attribute__((aligned(16))) float P1[4 * K::N1];
@@ -347,12 +376,13 @@ __global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict_
         const auto cur = nxt;
         const int ni = img + (int)gridDim.x;
         nxt = K::template load_words<64>(imgs + (size_t)(ni < n_img ? ni : img) * (H * W), lane);
-        K::template image<64>(P0, P1, cur, lane, [&](int e, float fv) {
-            TO v = (TO)fv;
-            if (standardize) v = standardise_clamp<FAST>(v, mean, sd, rcp);
-            dst[e] = v;
+        K::template image<64>(P0, P1, cur, lane, [&](int ea, int eb, float fa, float fb) {
+            TO va = (TO)fa, vb = (TO)fb;
+            if constexpr (STD) standardise_clamp_pair<FAST>(va, vb, mean, sd, rcp);
+            dst[ea] = va;
+            dst[eb] = vb;
         });
-        __syncthreads();
+        K::template sync<64>();
     }
 }
 
@@ -386,11 +416,14 @@ __global__ __launch_bounds__(64) void k_features_cpcp_packed(const uint8_t* __re
         nxt = K::template load_words<64>(imgs + (size_t)img_n * (H * W), lane);
         img_nn = pick(L + 2 * g);
         TO* xb = xs + ((size_t)jb * G * B + smp) * 16;                 // + slice * B * 16 + feature % 16
-        K::template image<64>(P0, P1, cur, lane, [&](int e, float fv) {
-            xb[(size_t)(e >> 4) * B * 16 + (e & 15)] = standardise_clamp<FAST>((TO)fv, mean, sd, rcp);
+        K::template image<64>(P0, P1, cur, lane, [&](int ea, int eb, float fa, float fb) {
+            TO va = (TO)fa, vb = (TO)fb;
+            standardise_clamp_pair<FAST>(va, vb, mean, sd, rcp);
+            xb[(size_t)(ea >> 4) * B * 16 + (ea & 15)] = va;
+            xb[(size_t)(eb >> 4) * B * 16 + (eb & 15)] = vb;
         });
         if (lane < C) ys[(size_t)L * C + lane] = Y[(size_t)img * C + lane];
-        __syncthreads();
+        K::template sync<64>();
     }
 }
 

@@ -1166,18 +1166,18 @@ int rcn_hip_features_dev(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, void* ou
     // the default stack on MNIST-shaped input has its own kernel (features.hpp: k_features_cpcp)
     if (feat_is_cpcp28(c) && ((uintptr_t)imgs & 3) == 0) {
         const float rcp = c->dtype == RCN_HIP_F32 && standardize ? fast_standardise_rcp(c) : 0.f;
-        const int grid = c->dtype == RCN_HIP_F64 ? resident_grid(c, k_features_cpcp<28, 28, double, false>, n)
-                         : rcp != 0.f            ? resident_grid(c, k_features_cpcp<28, 28, float, true>, n)
-                                                 : resident_grid(c, k_features_cpcp<28, 28, float, false>, n);
-        if (c->dtype == RCN_HIP_F64)
-            hipLaunchKernelGGL((k_features_cpcp<28, 28, double, false>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (double*)out, standardize,
-                               c->mean, c->sd, 0.0);
-        else if (rcp != 0.f)
-            hipLaunchKernelGGL((k_features_cpcp<28, 28, float, true>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (float*)out, standardize,
-                               (float)c->mean, (float)c->sd, rcp);
-        else
-            hipLaunchKernelGGL((k_features_cpcp<28, 28, float, false>), dim3(grid), dim3(64), 0, c->stream, imgs, (int)n, (float*)out, standardize,
-                               (float)c->mean, (float)c->sd, 0.f);
+#define RCN_CPCP(TT, STD, FAST, RCPV)                                                                                              \
+    do {                                                                                                                          \
+        auto kern = k_features_cpcp<28, 28, TT, STD, FAST>;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(resident_grid(c, kern, n)), dim3(64), 0, c->stream, imgs, (int)n, (TT*)out, (TT)c->mean,    \
+                           (TT)c->sd, (TT)(RCPV));                                                                                \
+    } while (0)
+        if (c->dtype == RCN_HIP_F64) {
+            if (standardize) RCN_CPCP(double, true, false, 0); else RCN_CPCP(double, false, false, 0);
+        } else if (!standardize) RCN_CPCP(float, false, false, 0);
+        else if (rcp != 0.f) RCN_CPCP(float, true, true, rcp);
+        else RCN_CPCP(float, true, false, 0);
+#undef RCN_CPCP
         HIP_TRY(c, hipGetLastError());
         return RCN_HIP_OK;
     }

@@ -65,9 +65,9 @@ __global__ __launch_bounds__(kServeThreads) void k_serve(NetDesc nd, const T* __
     // (2) flatten_feature_set + standardise (rcn.rs:84-89)
     K::template init<kServeThreads>(P0, P1, tid);
     __syncthreads();
-    K::template image<kServeThreads>(P0, P1, imgs + (size_t)img * (28 * 28), tid, [&](int e, float fv) {
-        const T dd = ((T)fv - mean) / sd;
-        xf[e] = dd >= (T)0 ? dd : (T)0;
+    K::template image<kServeThreads>(P0, P1, imgs + (size_t)img * (28 * 28), tid, [&](int ea, int eb, float fa, float fb) {
+        xf[ea] = standardise_clamp<false>((T)fa, mean, sd, (T)0);
+        xf[eb] = standardise_clamp<false>((T)fb, mean, sd, (T)0);
     });
     __syncthreads();
 
