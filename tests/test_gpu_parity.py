@@ -186,6 +186,37 @@ def test_features_specialised_and_generic_kernels_agree(amd, oracle, dtype):
     d.rcn.close()
 
 
+def test_fused_standardisation_is_the_division_bit_for_bit_under_random_scales(amd):
+    """The specialised f32 feature kernel standardises with a corrected reciprocal product that the host admits only after
+    checking it against the division (rcn.rs:407-412) for every value a feature can take; the generic kernel always
+    divides.  Under random scales -- including ones the check must refuse (sd <= 0) and extreme ones -- the two kernels'
+    outputs carry the same bits, signs of zero included, and every attainable feature value is exercised."""
+    from mercer_research_amd.device import DeviceRCN
+    rng = np.random.default_rng(2024)
+    imgs = rng.integers(0, 256, (600, 28, 28)).astype(np.uint8)
+    imgs[:200] = (rng.random((200, 28, 28)) < 0.5) * 255             # saturated edges: the largest responses (up to 4080)
+    d = DeviceRCN(dtype=0)
+    dev = d.to_device(imgs)
+
+    def bits(kernel):
+        d.set_feature_kernel(kernel)
+        t = d.features(dev, standardize=True)
+        d.synchronize()
+        return t.cpu().numpy().view(np.uint32)
+
+    d.set_feature_kernel(0)
+    raw = d.features(dev); d.synchronize()
+    assert raw.max().item() > 3000
+    scales = [(1.0, 1.0), (0.0, 1.0), (33.3184, 78.5675), (-5.0, 3.0), (12.5, -7.0), (100.0, 1e-30), (1e30, 3.0), (7.0, 1e30),
+              (0.1, 0.3), (4080.0, 1.0 / 3.0)]
+    scales += [(float(rng.uniform(0, 400)), float(rng.uniform(1e-3, 900))) for _ in range(30)]
+    for mean, sd in scales:
+        d.rcn.scale_set = (mean, sd)
+        fast, slow = bits(0), bits(1)
+        assert np.array_equal(fast, slow), (mean, sd)
+    d.rcn.close()
+
+
 @pytest.mark.parametrize("spec,shape", [
     (((LAYER_CONV, PAD_NONE), (LAYER_POOL, POOL_MAX)), (9, 11)),
     (((LAYER_CONV, PAD_SAME), (LAYER_POOL, POOL_MAX)), (9, 11)),
