@@ -125,6 +125,7 @@ inline bool persist_supported(const NetDesc& nd, size_t B) {
 }
 
 using pu4 = __attribute__((ext_vector_type(4))) unsigned;
+using pu2 = __attribute__((ext_vector_type(2))) unsigned;
 // write-through / cache-bypassing accesses to the exchange arrays (aux 16 = sc1): byte offsets from the array's base
 #define PW_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((ptr), 0, (int)(bytes), 0x00020000)
 __device__ inline void px_store4(__amdgpu_buffer_rsrc_t r, int byte_off, float a, float b, float c, float d) {

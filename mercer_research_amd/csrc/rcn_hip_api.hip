@@ -29,6 +29,7 @@
 #include "dp_p2p.hpp"
 #include "dense_p2_dp.hpp"
 #include "dense_p2_persist.hpp"
+#include "dense_p2_step.hpp"
 #include <chrono>
 
 using namespace rcn;
@@ -79,6 +80,8 @@ struct rcn_hip_ctx {
     unsigned* perr_host = nullptr;
     int dense_path = 0;                     // 0 auto, 1 sample-tile kernels (dense.hpp), 2 feature-sliced pipeline (dense_pipe.hpp)
     DevBuf slab, xpack, ypack, p2buf;
+    DevBuf stepx;                           // one-launch step (dense_p2_step.hpp): flags of the sample groups, then the tag word
+    size_t stepx_B = 0;
     size_t packed_B = 0, packed_nb = 0;     // what the epoch image currently holds (k_pack_epoch)
     void* pin_host = nullptr;               // small pinned, device-mapped staging block for the serving path (classify)
     void* pin_dev = nullptr;
@@ -552,6 +555,79 @@ int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32
     return RCN_HIP_OK;
 }
 
+constexpr long long kPersistTimeoutTicks = 5000000LL;        // 50 ms of the 100 MHz wall clock per wait
+
+// ---- one launch per step (dense_p2_step.hpp): A(F0) S0 S1 ... S_{nb-1}, S_j = sample groups of batch j + feature slices
+// (update from batch j, partials of batch j+1) + tail tiles in ONE kernel; the last node advances the tag word so the
+// captured graph can be replayed.
+bool use_step(const rcn_hip_ctx* c, size_t B) {
+    if (c->dtype != RCN_HIP_F32 || !step_supported(c->nd, B)) return false;
+    if (c->dense_path == 4) return true;
+    if (c->dense_path != 0) return false;
+    static const int auto_on = [] { const char* e = std::getenv("RCN_HIP_STEP_KERNEL"); return e ? std::atoi(e) : 0; }();
+    return auto_on != 0;
+}
+
+int ensure_step_ws(rcn_hip_ctx* c, size_t B) {
+    const size_t NS = B / kP2Ts, bytes = (NS * kStepFlagStride + 64) * sizeof(unsigned) + B * kP2H * sizeof(pw_t);
+    if (!c->perr_dev) {
+        HIP_TRY(c, hipMalloc((void**)&c->perr_dev, 256));
+        HIP_TRY(c, hipHostMalloc((void**)&c->perr_host, 64, hipHostMallocDefault));
+        *c->perr_host = 0;
+        HIP_TRY(c, hipMemsetAsync(c->perr_dev, 0, 256, c->stream));
+    }
+    if (*c->perr_host != 0)
+        return fail(c, RCN_HIP_ERR_HIP, "train_epoch: a wait inside the one-launch step timed out in an earlier call; the parameters are no longer "
+                                        "consistent.  rcn_hip_set_dense_path(ctx, 2) avoids this kernel");
+    if (c->stepx_B != B || c->stepx.cap < bytes) {
+        HIP_TRY(c, ws_ensure(c, c->stepx, bytes));
+        HIP_TRY(c, hipMemsetAsync(c->stepx.p, 0, c->stepx.cap, c->stream));       // flags 0, tag word 0: the first tag is 1
+        drop_graphs(c);                                                            // cached graphs count on the tag word's history
+        c->stepx_B = B;
+    }
+    return RCN_HIP_OK;
+}
+
+int enqueue_step_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool from_images) {
+    using T = float;
+    const NetDesc& nd = c->nd;
+    const size_t G = pipe_slices(nd), Cc = nd.dims[nd.L], es = sizeof(T), NS = B / kP2Ts;
+    const double scale = eta / (double)B, loss_scale = 1.0 / (2.0 * (double)B);
+    const size_t seg = nb <= pack_segment(c, B) ? nb : pack_segment(c, B);
+    auto slot = [&](size_t j) { return ((j / seg) % 2) * seg + j % seg; };
+    auto xb = [&](size_t j) { return (const T*)((const char*)c->xpack.p + slot(j) * G * B * 16 * es); };
+    auto yb = [&](size_t j) { return (const T*)((const char*)c->ypack.p + slot(j) * B * Cc * es); };
+    auto pack = [&](size_t j0) {
+        const size_t n = nb - j0 < seg ? nb - j0 : seg;
+        return from_images ? launch_feat_pack<T>(c, (const uint8_t*)X, Y, perm, B, j0, n, (int)((j0 / seg) % 2), seg)
+                           : launch_pack<T>(c, X, Y, perm, B, j0, n, (int)((j0 / seg) % 2), seg);
+    };
+    StepBufs sb;
+    sb.slab = (T*)c->slab.p;
+    sb.a1 = (T*)c->p2buf.p; sb.d1 = sb.a1 + B * kP2H; sb.d2 = sb.d1 + B * kP2H;
+    sb.loss = (T*)c->loss_part.p;
+    sb.oflag = (unsigned*)c->stepx.p;
+    unsigned* tagw = sb.oflag + NS * kStepFlagStride + 32;
+    sb.tag = tagw;
+    sb.d1w = (pw_t*)(sb.oflag + NS * kStepFlagStride + 64);
+    static const int first_look = [] { const char* e = std::getenv("RCN_HIP_STEP_FIRST_LOOK"); return e ? std::atoi(e) : 320; }();   // 100 MHz ticks
+    const int grid = step_grid(nd, B);
+    RCN_TRY(pack(0));
+    RCN_TRY(launch_pipe_a<T>(c, xb(0), xb(0), B, scale, nullptr, loss_scale, false, true));
+    for (size_t j = 0; j < nb; ++j) {
+        const bool more = j + 1 < nb;
+        if (more && (j + 1) % seg == 0) RCN_TRY(pack(j + 1));
+        T* lj = loss_dev ? (T*)loss_dev + j : nullptr;
+        hipLaunchKernelGGL(k_p2_step, dim3(grid), dim3(kPersistThreads), 0, c->stream, nd, (T*)c->params.p, xb(j), more ? xb(j + 1) : xb(j), yb(j), (int)B,
+                           (int)G, (T)scale, (T)loss_scale, lj, sb, (unsigned)(j + 1), more ? 1 : 0, c->perr_dev, kPersistTimeoutTicks, first_look);
+        HIP_TRY(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_add_u32, dim3(1), dim3(1), 0, c->stream, tagw, (unsigned)(nb + 1));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->perr_host, c->perr_dev, 4, hipMemcpyDeviceToHost, c->stream));     // looked at by the next call
+    return RCN_HIP_OK;
+}
+
 // ---- one resident kernel per epoch segment (dense_p2_persist.hpp) ------------------------------------------------
 bool use_persist(const rcn_hip_ctx* c, size_t B) {
     if (c->dtype != RCN_HIP_F32 || !persist_supported(c->nd, B)) return false;
@@ -561,7 +637,6 @@ bool use_persist(const rcn_hip_ctx* c, size_t B) {
     return auto_on != 0;
 }
 
-constexpr long long kPersistTimeoutTicks = 5000000LL;        // 50 ms of the 100 MHz wall clock per wait
 
 int enqueue_persist_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev) {
     const NetDesc& nd = c->nd;
@@ -954,7 +1029,8 @@ int rcn_hip_set_feature_kernel(rcn_hip_ctx* c, int mode) {
 
 int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
     RCN_TRY(check_ctx(c));
-    if (mode < 0 || mode > 3) return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile), 2 (feature-sliced) or 3 (resident epoch kernel)");
+    if (mode < 0 || mode > 4)
+        return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile), 2 (feature-sliced), 3 (resident epoch kernel) or 4 (one launch per step)");
     if (mode >= 2 && !pipe_supported(c->nd)) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "feature-sliced path needs >= 2 dense layers whose tail fits LDS");
     DevGuard g(c->device);
     drop_graphs(c);
@@ -1345,6 +1421,8 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
     DevGuard g(c->device);
     RCN_TRY(ensure_dense_ws(c, B));
     if (use_pipe(c, B)) { RCN_TRY(ensure_pipe_ws(c, B)); RCN_TRY(ensure_pack_ws(c, B, nb)); }
+    const bool step = use_pipe(c, B) && use_step(c, B);
+    if (step) RCN_TRY(ensure_step_ws(c, B));
     if (from_images && !(use_pipe(c, B) && feat_is_cpcp28(c)))
         return fail(c, RCN_HIP_ERR_UNSUPPORTED, "train_epoch_images: needs the default conv/pool stack on 28x28 input and a layer stack / batch size the "
                                                   "feature-sliced pipeline covers; use rcn_hip_features_dev + rcn_hip_train_epoch_dev otherwise");
@@ -1364,7 +1442,9 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
         hipGraph_t graph = nullptr;
         HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int st = RCN_HIP_OK;
-        if (use_pipe(c, B)) {
+        if (step) {
+            st = enqueue_step_epoch(c, X, Y, perm, B, nb, eta, loss_dev, from_images);
+        } else if (use_pipe(c, B)) {
             st = c->dtype == RCN_HIP_F64 ? enqueue_pipe_steps<double>(c, X, Y, perm, B, nb, eta, loss_dev, from_images)
                                          : enqueue_pipe_steps<float>(c, X, Y, perm, B, nb, eta, loss_dev, from_images);
         } else

@@ -135,7 +135,7 @@ class RCN:
         self._ck(self._lib.rcn_hip_synchronize(self._ctx))
 
     def set_dense_path(self, mode: int):
-        """0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline (include/rcn_hip.h)."""
+        """0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline, 3 resident epoch kernel, 4 one launch per step (include/rcn_hip.h)."""
         self._ck(self._lib.rcn_hip_set_dense_path(self._ctx, int(mode)))
 
     def set_feature_kernel(self, mode: int):

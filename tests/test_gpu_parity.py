@@ -779,6 +779,50 @@ def test_resident_epoch_kernel_matches_sequential_oracle(amd, oracle):
     d.rcn.close(); d2.rcn.close()
 
 
+@pytest.mark.parametrize("B", [256, 512])
+def test_one_launch_step_is_the_two_kernel_pipeline_bit_for_bit(amd, B, monkeypatch):
+    """dense path 4 (dense_p2_step.hpp): sample groups, feature slices and tail tiles of a step in ONE launch, the deltas handed
+    over inside the launch as tagged words.  Same arithmetic and summation orders as the two-kernel pipeline (path 2), so the
+    parameters and the per-step costs carry the same bits -- shuffled and in stored order, across segment boundaries of the
+    epoch image, over repeated graph replays (the tag word advances) and from u8 pictures."""
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(3 * 49 * B * 16 * 4))      # 3 batches per segment
+    nb, N = 7, 8 * B
+    imgs, labels = synthetic_images(N, seed=31)
+    ws, bs = synthetic_params([784, 30, 10], seed=13)
+    ws = [w * 0.1 for w in ws]
+    perm = np.random.default_rng(8).permutation(N).astype(np.int32)
+    got = {}
+    for path in (2, 4):
+        d = DeviceRCN(dtype=0)
+        d.set_dense_path(path)
+        d.set_params(ws, bs)
+        dev = d.to_device(imgs)
+        Yd = d.to_device(one_hot(labels, 10), d.tdtype)
+        X = d.features(dev)
+        mean, sd = d.gen_scales(X)
+        d.rcn.scale_set = (mean, sd)
+        Xs = d.features(dev, standardize=True)
+        permd = d.to_device(perm)
+        loss = d.empty(nb)
+        costs = []
+        for _ in range(3):                                           # three replays of the same captured graph
+            d.train_epoch(Xs, Yd, permd, B, nb, 3.0, loss)
+            d.synchronize()
+            costs.append(loss.cpu().numpy().copy())
+        d.train_epoch(Xs, Yd, None, B, 2, 3.0, None)                 # stored order, another graph
+        d.train_epoch_images(dev, Yd, permd, B, nb, 3.0, loss)       # straight from the pictures
+        d.synchronize()
+        costs.append(loss.cpu().numpy().copy())
+        got[path] = (sum(d.get_params(), []), costs)
+        d.rcn.close()
+    for a, b in zip(got[2][0], got[4][0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(got[2][1], got[4][1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.isfinite(got[4][1][-1]).all() and got[4][1][-1][-1] < got[4][1][0][0]
+
+
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "f64"])
 def test_train_epoch_from_images_equals_features_then_train(amd, oracle, dtype, monkeypatch):
     """rcn_hip_train_epoch_images_dev (u8 pictures -> features -> standardise -> packed epoch image in one kernel per segment,
