@@ -57,7 +57,9 @@ __device__ inline float  sigmoid_ref(float x)  { return 1.0f / (1.0f + expf(-x))
 __device__ inline double sigmoid_ref(double x) { return 1.0 / (1.0 + exp(-x)); }
 // f32 only: hardware exp2 / rcp (v_exp_f32, v_rcp_f32; ~1 ulp each, i.e. ~1e-7 relative on the result, inside the
 // 2e-6 activation tolerance of the f32 path) -- 4 instructions instead of ~35 on a path that is issue-bound.
-__device__ inline float  sigmoid_fast(float x)  { return __frcp_rn(1.0f + __expf(-x)); }
+// (__builtin_amdgcn_rcpf IS v_rcp_f32; HIP's __frcp_rn is the correctly rounded reciprocal, i.e. a ten-instruction
+// IEEE division, which is what this used to compile to.)
+__device__ inline float  sigmoid_fast(float x)  { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ inline double sigmoid_fast(double x) { return sigmoid_ref(x); }
 
 // ---- diagnostic build only (-DRCN_STAMPS, never shipped): per-workgroup phase timestamps (100 MHz s_memrealtime)
