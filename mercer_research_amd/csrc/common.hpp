@@ -62,6 +62,29 @@ __device__ inline double sigmoid_ref(double x) { return 1.0 / (1.0 + exp(-x)); }
 __device__ inline float  sigmoid_fast(float x)  { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ inline double sigmoid_fast(double x) { return sigmoid_ref(x); }
 
+// Sum over the wave, result in lane 0, in exactly the order of the shuffle-down tree
+//     for (off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64)
+// so the bits do not depend on which form runs.  f32: two lane swaps (v_permlane32_swap / v_permlane16_swap, new in
+// gfx950) and four DPP row shifts -- six VALU instructions instead of six ds_bpermute round trips (~100 clocks each) at
+// the very end of a kernel whose last wave is the critical path.
+__device__ inline float wave_sum_lane0(float v) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);     // lane i: v[i], v[i + 32]
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);         // lane i < 16: v[i], v[i + 16]
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, true));    // row_shl:8  lane i += lane i + 8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, true));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, true));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, true));
+    return v;
+}
+__device__ inline double wave_sum_lane0(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
 // ---- diagnostic build only (-DRCN_STAMPS, never shipped): per-workgroup phase timestamps (100 MHz s_memrealtime)
 #ifdef RCN_STAMPS
 __device__ unsigned long long g_rcn_stamps[2][512][16];

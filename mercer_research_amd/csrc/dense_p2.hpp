@@ -239,7 +239,8 @@ __device__ __forceinline__ void p2_b_body(
         vec4 a;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[i] = (h0 + i < H) ? sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]) : (T)0;
+            const auto sg = sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]);   // unconditionally: as `c ? f(x) : 0` this is four branches
+            a[i] = (h0 + i < H) ? sg : (T)0;
             a1s[(h0 + i) * kLd + s] = a[i];
         }
         *reinterpret_cast<vec4*>(a1g + (size_t)(s0 + s) * kP2H + h0) = a;
@@ -280,8 +281,7 @@ __device__ __forceinline__ void p2_b_body(
         }
         if (n < kP2Ts) store4<T>(d1g + (size_t)(s0 + n) * kP2H + mt * 16, lane, o);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+    lsum = wave_sum_lane0(lsum);
     if (lane == 0 && loss_part) loss_part[blockIdx.x] = lsum;
     RCN_STAMP(1, 6);
 }

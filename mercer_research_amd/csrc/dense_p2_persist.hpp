@@ -377,7 +377,8 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
                     float a[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        a[i] = (h0 + i < H) ? sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]) : 0.f;
+                        const auto sg = sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]);   // unconditionally: as `c ? f(x) : 0` this is four branches
+                        a[i] = (h0 + i < H) ? sg : 0.f;
                         a1s[(h0 + i) * kLd + s] = a[i];
                     }
                     px_store4(r_a1, ((int)(tag & 1u) * dh_half + (s0 + s) * kP2H + h0) * 4, a[0], a[1], a[2], a[3]);
@@ -414,8 +415,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_epoch(
                     }
                     if (n < kP2Ts) px_store4(r_d1, ((int)(tag & 1u) * dh_half + (s0 + n) * kP2H + mt * 16 + 4 * g4) * 4, o4[0], o4[1], o4[2], o4[3]);
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
+                lsum = wave_sum_lane0(lsum);
                 if (lane == 0) px_store1(r_loss, ((int)(tag & 1u) * NS + t) * 4, lsum);
                 px_drain();                                           // only this wave stored: drain, then announce
                 if (lane == 0) __hip_atomic_store(bufs.oflag + t, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_step(
             float a[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = (h0 + i < H) ? sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]) : 0.f;
+                const auto sg = sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]);   // unconditionally: as `c ? f(x) : 0` this is four branches
+                a[i] = (h0 + i < H) ? sg : 0.f;
                 a1s[(h0 + i) * kLd + s] = a[i];
             }
             px_store4(r_a1, ((s0 + s) * kP2H + h0) * 4, a[0], a[1], a[2], a[3]);
@@ -193,8 +194,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_p2_step(
                 px_store4(r_d1w, wo + 16, o4[2], __uint_as_float(tag), o4[3], __uint_as_float(tag));
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
+        lsum = wave_sum_lane0(lsum);
         if (lane == 0) px_store1(r_loss, t * 4, lsum);
         SSTAMP(3);
         px_drain();                                                   // only this wave stored: drain, then announce
