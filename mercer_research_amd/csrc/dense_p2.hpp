@@ -233,13 +233,19 @@ __device__ __forceinline__ void p2_b_body(
     z = ((zred[lane] + zred[64 + lane]) + (zred[128 + lane] + zred[192 + lane])) +
         ((zred[256 + lane] + zred[320 + lane]) + (zred[384 + lane] + zred[448 + lane]));   // ... and a fixed order across waves
 
+    // every fragment word this wave will use, in ONE round of LDS reads right behind the barrier (read where they are used,
+    // each group costs the chain another LDS round trip: the compiler may not hoist them over the a_1 / delta_2 tile writes)
+    T fr[kFrag];
+#pragma unroll
+    for (int q = 0; q < kFrag; ++q) fr[q] = frag[q * 64 + lane];
+
     // ---- a_1 = sigmoid(z_1 + b_0); lane <- sample lane>>3, hidden 4*(lane&7)+i                       rcn.rs:287-289
     {
         const int s = lane >> 3, h0 = 4 * (lane & 7);
         vec4 a;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const auto sg = sigmoid_fast(z[i] + frag[(24 + i) * 64 + lane]);   // unconditionally: as `c ? f(x) : 0` this is four branches
+            const auto sg = sigmoid_fast(z[i] + fr[24 + i]);   // unconditionally: as `c ? f(x) : 0` this is four branches
             a[i] = (h0 + i < H) ? sg : (T)0;
             a1s[(h0 + i) * kLd + s] = a[i];
         }
@@ -251,15 +257,15 @@ __device__ __forceinline__ void p2_b_body(
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
         const T bv = a1s[(4 * ks + g4) * kLd + (n & 7)];
-        acc = Mfma16<T>::mfma(frag[ks * 64 + lane], n < kP2Ts ? bv : (T)0, acc);
+        acc = Mfma16<T>::mfma(fr[ks], n < kP2Ts ? bv : (T)0, acc);
     }
     T lsum = 0;
     acc_t dv;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = Mfma16<T>::row(lane, i);
-        const T a2 = sigmoid_fast(acc[i] + frag[(16 + i) * 64 + lane]);
-        const T diff = a2 - frag[(20 + i) * 64 + lane];
+        const T a2 = sigmoid_fast(acc[i] + fr[16 + i]);
+        const T diff = a2 - fr[20 + i];
         const bool ok = c < C && n < kP2Ts;
         dv[i] = ok ? diff * (a2 * ((T)1 - a2)) : (T)0;
         lsum += ok ? diff * diff : (T)0;
@@ -272,7 +278,7 @@ __device__ __forceinline__ void p2_b_body(
     for (int mt = 0; mt < kMtp; ++mt) {
         acc_t ad = acc_t{0, 0, 0, 0};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ad = Mfma16<T>::mfma(frag[(8 + mt * 4 + ks) * 64 + lane], d2s[(4 * ks + g4) * kLd + n], ad);
+        for (int ks = 0; ks < 4; ++ks) ad = Mfma16<T>::mfma(fr[8 + mt * 4 + ks], d2s[(4 * ks + g4) * kLd + n], ad);
         acc_t o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
