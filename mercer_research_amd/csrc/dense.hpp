@@ -303,12 +303,34 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_fwd(
     }
 }
 
+// The tail parameters of the one-hidden-layer shape class as k_p2_b's finishing wave wants them (dense_p2.hpp): an image
+// [28 words][64 lanes] of ready-made MFMA operand fragments -- words 0..7 W_1 as A[m = c][k = h], 8..15 W_1^T as
+// A[m = h][k = c], 16..19 b_1 and 24..27 b_0 per accumulator / slab element (20..23, the targets, are per batch and not
+// part of the image).  One updated parameter lands in every place it occupies; pads stay the zeros the image starts with.
+// f32 accumulator map (row = 4 (lane >> 4) + i) only.
+__device__ inline void p2_frag_scatter(int jl, int cc, int m, int H, float v, float* __restrict__ img) {
+    if (jl == 1 && cc < H) {
+        const int h = cc, c = m;
+        img[(h >> 2) * 64 + (h & 3) * 16 + c] = v;
+        img[(8 + (h >> 4) * 4 + (c >> 2)) * 64 + (c & 3) * 16 + (h & 15)] = v;
+    } else if (jl == 1) {
+        const int c = m;                                                          // b_1[c]
+#pragma unroll
+        for (int nn = 0; nn < 16; ++nn) img[(16 + (c & 3)) * 64 + (c >> 2) * 16 + nn] = v;
+    } else {
+        const int h = m;                                                          // b_0[h] (bias column of W_0)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) img[(24 + (h & 3)) * 64 + (h >> 2) + 8 * s] = v;
+    }
+}
+__device__ inline void p2_frag_scatter(int, int, int, int, double, double*) {}    // the f64 context builds its fragments in the kernel
+
 // One 16-column tile (columns n0..n0+15) of [W_j | b_j]: dW = Delta_{j+1} . [A_j | 1]^T summed over the whole batch
 // (the MFMA contraction index is the sample), then either the SGD update or the raw gradient.
 template <typename T, bool APPLY>
 __device__ inline void wgrad_tile_ld(const NetDesc& nd, int j, int n0, T* __restrict__ params, T* __restrict__ grad_out,
                                      const T* __restrict__ Aprev, long long ldAin, const int* __restrict__ idx,
-                                     const T* __restrict__ D, int ldD, int B, T scale, T* red) {
+                                     const T* __restrict__ D, int ldD, int B, T scale, T* red, T* __restrict__ fragimg = nullptr) {
     using acc_t = typename Mfma16<T>::acc_t;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int Kin = nd.dims[j], M = nd.dims[j + 1];
@@ -364,8 +386,11 @@ __device__ inline void wgrad_tile_ld(const NetDesc& nd, int j, int n0, T* __rest
             if (m < M && cc <= Kin) {
                 const T gsum = sum_partials<T>(red, mt, cl, ml);
                 const size_t p = (size_t)nd.w_off[j] + (size_t)cc * M + m;
-                if (APPLY) params[p] = params[p] - scale * gsum;                // rcn.rs:214,221
-                else grad_out[p] = gsum;
+                if (APPLY) {
+                    const T nv = params[p] - scale * gsum;                      // rcn.rs:214,221
+                    params[p] = nv;
+                    if (fragimg) p2_frag_scatter(j, cc, m, nd.dims[1], nv, fragimg);
+                } else grad_out[p] = gsum;
             }
         }
         __syncthreads();

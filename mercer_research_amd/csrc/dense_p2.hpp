@@ -41,7 +41,8 @@ template <typename T>
 __device__ __forceinline__ void p2_a_body(
     const NetDesc& nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B,
     const T* __restrict__ a1, const T* __restrict__ d1, const T* __restrict__ d2, T scale, T* __restrict__ slab, int G,
-    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd, unsigned char* smem_raw) {
+    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd, unsigned char* smem_raw,
+    T* __restrict__ fragimg = nullptr) {
     using acc_t = typename Mfma16<T>::acc_t;
     using vec4 = typename Vec4<T>::type;
     T* red = reinterpret_cast<T*>(smem_raw);
@@ -54,8 +55,8 @@ __device__ __forceinline__ void p2_a_body(
         if (!do_update) return;
         const int e = (int)blockIdx.x - G;
         if (e == 0 && tid == 0 && loss_out) finish_loss<T>(loss_part, n_loss, loss_scale, loss_out);
-        if (e == 0) wgrad_tile_ld<T, true>(nd, 0, F, params, (T*)nullptr, (const T*)nullptr, 0, (const int*)nullptr, d1, kP2H, B, scale, red);
-        else        wgrad_tile_ld<T, true>(nd, 1, (e - 1) * 16, params, (T*)nullptr, a1, kP2H, (const int*)nullptr, d2, kP2C, B, scale, red);
+        if (e == 0) wgrad_tile_ld<T, true>(nd, 0, F, params, (T*)nullptr, (const T*)nullptr, 0, (const int*)nullptr, d1, kP2H, B, scale, red, fragimg);
+        else        wgrad_tile_ld<T, true>(nd, 1, (e - 1) * 16, params, (T*)nullptr, a1, kP2H, (const int*)nullptr, d2, kP2C, B, scale, red, fragimg);
         return;
     }
 
@@ -159,7 +160,8 @@ inline size_t p2_b_lds_elems() { return (size_t)kP2BWaves * 64 * 4 + kP2H * kLd 
 template <typename T>
 __device__ __forceinline__ void p2_b_body(
     const NetDesc& nd, const T* __restrict__ params, const T* __restrict__ slab, int G, const T* __restrict__ Ys, int B,
-    T* __restrict__ a1g, T* __restrict__ d1g, T* __restrict__ d2g, T* __restrict__ loss_part, unsigned char* smem_raw) {
+    T* __restrict__ a1g, T* __restrict__ d1g, T* __restrict__ d2g, T* __restrict__ loss_part, unsigned char* smem_raw,
+    const T* __restrict__ fragimg = nullptr) {
     using acc_t = typename Mfma16<T>::acc_t;
     using vec4 = typename Vec4<T>::type;
     constexpr int kFrag = kP2BFrag;
@@ -182,8 +184,19 @@ __device__ __forceinline__ void p2_b_body(
         const int g = wave + kP2BWaves * q;
         t[q] = sp[(size_t)(g < G ? g : wave) * 64];
     }
+    // With a fragment image (kept current by k_p2_a's tail tiles, dense.hpp: p2_frag_scatter) the finishing wave fetches its
+    // 24 parameter words itself, 256 contiguous bytes per load; only the targets still go through LDS.  Without one, waves
+    // 1-5 and 7 gather them from the parameter vector: ~24 loads of 64 scattered addresses per workgroup, which the CU's
+    // address unit works through for ~0.35 us behind the slab stream -- measured, that is when those waves reach the barrier.
+    T fr[kFrag];
+    if (fragimg && wave == 0) {
+#pragma unroll
+        for (int q = 0; q < kFrag; ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : fragimg[q * 64 + lane];
+    }
+    const bool gather = fragimg == nullptr;
     const T* W1 = params + nd.w_off[1];                           // C x H column-major: (c, h) at h*C + c
-    if (wave == 1 || wave == 2) {                                 // z_2 = W_1 a_1:   A[m = c][k = h]; 4 k-steps each
+    if (!gather && wave != 6) {
+    } else if (wave == 1 || wave == 2) {                                 // z_2 = W_1 a_1:   A[m = c][k = h]; 4 k-steps each
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ks = 4 * (wave - 1) + q, h = 4 * ks + g4;
@@ -235,9 +248,13 @@ __device__ __forceinline__ void p2_b_body(
 
     // every fragment word this wave will use, in ONE round of LDS reads right behind the barrier (read where they are used,
     // each group costs the chain another LDS round trip: the compiler may not hoist them over the a_1 / delta_2 tile writes)
-    T fr[kFrag];
+    if (gather) {
 #pragma unroll
-    for (int q = 0; q < kFrag; ++q) fr[q] = frag[q * 64 + lane];
+        for (int q = 0; q < kFrag; ++q) fr[q] = frag[q * 64 + lane];
+    } else {
+#pragma unroll
+        for (int q = 20; q < 24; ++q) fr[q] = frag[q * 64 + lane];
+    }
 
     // ---- a_1 = sigmoid(z_1 + b_0); lane <- sample lane>>3, hidden 4*(lane&7)+i                       rcn.rs:287-289
     {
@@ -292,22 +309,31 @@ __device__ __forceinline__ void p2_b_body(
     RCN_STAMP(1, 6);
 }
 
+// the whole fragment image from the parameter vector (once per train_epoch / train_batch call; afterwards k_p2_a keeps it current)
+__global__ __launch_bounds__(512) void k_p2_fragimg(NetDesc nd, const float* __restrict__ params, float* __restrict__ img) {
+    const int F = nd.dims[0], H = nd.dims[1], C = nd.dims[2];
+    for (int e = threadIdx.x; e < kP2BFrag * 64; e += 512) img[e] = 0.f;
+    __syncthreads();
+    for (int e = threadIdx.x; e < (H + 1) * C; e += 512) p2_frag_scatter(1, e / C, e % C, H, params[nd.w_off[1] + e], img);
+    for (int e = threadIdx.x; e < H; e += 512) p2_frag_scatter(0, F, e, H, params[nd.w_off[0] + H * F + e], img);
+}
+
 // ---- the two kernels of a step, and both in ONE kernel object -------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kDenseThreads) void k_p2_a(
     NetDesc nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B,
     const T* __restrict__ a1, const T* __restrict__ d1, const T* __restrict__ d2, T scale, T* __restrict__ slab, int G,
-    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd) {
+    const T* __restrict__ loss_part, int n_loss, T loss_scale, T* __restrict__ loss_out, int do_update, int do_fwd, T* __restrict__ fragimg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    p2_a_body<T>(nd, params, Xp, Xn, B, a1, d1, d2, scale, slab, G, loss_part, n_loss, loss_scale, loss_out, do_update, do_fwd, smem_dyn);
+    p2_a_body<T>(nd, params, Xp, Xn, B, a1, d1, d2, scale, slab, G, loss_part, n_loss, loss_scale, loss_out, do_update, do_fwd, smem_dyn, fragimg);
 }
 
 template <typename T>
 __global__ __launch_bounds__(kP2BThreads) void k_p2_b(
     NetDesc nd, const T* __restrict__ params, const T* __restrict__ slab, int G, const T* __restrict__ Ys, int B,
-    T* __restrict__ a1g, T* __restrict__ d1g, T* __restrict__ d2g, T* __restrict__ loss_part) {
+    T* __restrict__ a1g, T* __restrict__ d1g, T* __restrict__ d2g, T* __restrict__ loss_part, const T* __restrict__ fragimg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    p2_b_body<T>(nd, params, slab, G, Ys, B, a1g, d1g, d2g, loss_part, smem_dyn);
+    p2_b_body<T>(nd, params, slab, G, Ys, B, a1g, d1g, d2g, loss_part, smem_dyn, fragimg);
 }
 
 // The epoch loop alternates the two strictly, and the pair costs ~0.9 us more than the two back to back with themselves

@@ -80,6 +80,8 @@ struct rcn_hip_ctx {
     unsigned* perr_host = nullptr;
     int dense_path = 0;                     // 0 auto, 1 sample-tile kernels (dense.hpp), 2 feature-sliced pipeline (dense_pipe.hpp)
     DevBuf slab, xpack, ypack, p2buf;
+    DevBuf fragimg;                         // tail parameters as k_p2_b's operand fragments (dense.hpp: p2_frag_scatter), f32 pipeline only
+    bool frag_on = false;                   // set while enqueue_pipe_steps<float> runs: its k_p2_a / k_p2_b launches use the image
     DevBuf stepx;                           // one-launch step (dense_p2_step.hpp): flags of the sample groups, then the tag word
     size_t stepx_B = 0;
     size_t packed_B = 0, packed_nb = 0;     // what the epoch image currently holds (k_pack_epoch)
@@ -374,6 +376,7 @@ int ensure_pipe_ws(rcn_hip_ctx* c, size_t B) {
     HIP_TRY(c, ws_ensure(c, c->slab, (size_t)pipe_slices(c->nd) * Bp * mp * c->esz()));
     HIP_TRY(c, ws_ensure(c, c->loss_part, ((B + kPipeTs - 1) / kPipeTs) * c->esz()));
     if (p2_supported(c->nd, B)) HIP_TRY(c, ws_ensure(c, c->p2buf, B * (size_t)(2 * kP2H + kP2C) * c->esz()));
+    if (p2_supported(c->nd, B)) HIP_TRY(c, ws_ensure(c, c->fragimg, (size_t)kP2BFrag * 64 * c->esz()));
     return RCN_HIP_OK;
 }
 
@@ -396,7 +399,7 @@ int launch_pipe_a(rcn_hip_ctx* c, const void* xp, const void* xn, size_t B, doub
         else
             hipLaunchKernelGGL((k_p2_a<T>), dim3(grid), dim3(kDenseThreads), p2_a_lds_elems() * sizeof(T), c->stream, nd, (T*)c->params.p, (const T*)xp,
                                (const T*)xn, (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, G, (const T*)c->loss_part.p, n_loss,
-                               (T)loss_scale, (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0);
+                               (T)loss_scale, (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0, c->frag_on ? (T*)c->fragimg.p : (T*)nullptr);
         HIP_TRY(c, hipGetLastError());
         return RCN_HIP_OK;
     }
@@ -419,7 +422,8 @@ int launch_pipe_b(rcn_hip_ctx* c, const void* ys, size_t B) {
                                (T)0, (T*)nullptr, 0, 0);
         else
             hipLaunchKernelGGL((k_p2_b<T>), dim3((unsigned)(B / kP2Ts)), dim3(kP2BThreads), p2_b_lds_elems() * sizeof(T), c->stream, nd, (const T*)c->params.p,
-                               (const T*)c->slab.p, pipe_slices(nd), (const T*)ys, (int)B, a1, d1, d2, (T*)c->loss_part.p);
+                               (const T*)c->slab.p, pipe_slices(nd), (const T*)ys, (int)B, a1, d1, d2, (T*)c->loss_part.p,
+                               c->frag_on ? (const T*)c->fragimg.p : (const T*)nullptr);
         HIP_TRY(c, hipGetLastError());
         return RCN_HIP_OK;
     }
@@ -543,6 +547,17 @@ int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32
         return from_images ? launch_feat_pack<T>(c, (const uint8_t*)X, Y, perm, B, j0, n, (int)((j0 / seg) % 2), seg)
                            : launch_pack<T>(c, X, Y, perm, B, j0, n, (int)((j0 / seg) % 2), seg);
     };
+    // f32, default shape class: the tail parameters also live as an image of k_p2_b's operand fragments, built here from the
+    // parameter vector and kept current by k_p2_a's tail tiles for the rest of this call
+    struct FragGuard { rcn_hip_ctx* c; ~FragGuard() { c->frag_on = false; } } frag_guard{c};
+    if constexpr (std::is_same<T, float>::value) {
+        static const bool frag_off = getenv("RCN_HIP_NO_FRAGIMG") && atoi(getenv("RCN_HIP_NO_FRAGIMG")) != 0;
+        if (p2_supported(c->nd, B) && !p2_one_object() && !frag_off && c->fragimg.p) {
+            hipLaunchKernelGGL(k_p2_fragimg, dim3(1), dim3(512), 0, c->stream, c->nd, (const float*)c->params.p, (float*)c->fragimg.p);
+            HIP_TRY(c, hipGetLastError());
+            c->frag_on = true;
+        }
+    }
     RCN_TRY(pack(0));
     RCN_TRY(launch_pipe_a<T>(c, xb(0), xb(0), B, scale, nullptr, loss_scale, false, true));
     for (size_t j = 0; j < nb; ++j) {
