@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_p2_dp_fused(
     NetDesc nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B, const T* __restrict__ a1,
     const T* __restrict__ d1, const T* __restrict__ d2, T scale, T* __restrict__ slab, int G, const T* __restrict__ loss_part, int n_loss,
     T loss_scale, T* __restrict__ loss_out, int do_fwd, P2PDesc d, const unsigned* __restrict__ seq_base, unsigned seq_off, size_t stride,
-    unsigned* __restrict__ err, long long timeout_ticks, T* __restrict__ tail_scratch) {
+    unsigned* __restrict__ err, long long timeout_ticks, T* __restrict__ tail_scratch, T* __restrict__ fragimg) {
     using acc_t = typename Mfma16<T>::acc_t;
     using vec4 = typename Vec4<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -310,8 +310,11 @@ __global__ __launch_bounds__(kDenseThreads) void k_p2_dp_fused(
         if (e == 0 && tid == 0) { finish_loss<T>(loss_part, n_loss, loss_scale, &own_loss); ll_store(mine, (size_t)nd.P, own_loss, seq); }
         for (int i = tid; i < cnt; i += kDenseThreads) {
             T g;
-            if (ll_gather_sum<T>(d, stride, (size_t)(p0 + i), seq, tail_scratch[p0 + i], timeout_ticks, g)) params[p0 + i] = params[p0 + i] - scale * g;   // rcn.rs:214,221
-            else ok = false;
+            if (ll_gather_sum<T>(d, stride, (size_t)(p0 + i), seq, tail_scratch[p0 + i], timeout_ticks, g)) {
+                const T nv = params[p0 + i] - scale * g;                                                  // rcn.rs:214,221
+                params[p0 + i] = nv;
+                if (fragimg) p2_frag_scatter(j, n0 + i / M, i % M, H, nv, fragimg);                        // k_p2_b's operand image (dense.hpp)
+            } else ok = false;
         }
         if (e == 0 && tid == 0) {
             T g;

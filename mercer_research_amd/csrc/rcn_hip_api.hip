@@ -843,6 +843,16 @@ int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const in
     const size_t lds = p2_a_lds_elems() * sizeof(T);
     const int n_loss = (int)((B + kPipeTs - 1) / kPipeTs);
     T* a1 = (T*)c->p2buf.p; T* d1 = a1 + B * kP2H; T* d2 = d1 + B * kP2H;
+    // the in-kernel exchange form keeps k_p2_b's operand image current too (its tail tiles apply the summed gradient themselves)
+    struct FragGuard { rcn_hip_ctx* c; ~FragGuard() { c->frag_on = false; } } frag_guard{c};
+    if constexpr (std::is_same<T, float>::value) {
+        static const bool frag_off = getenv("RCN_HIP_NO_FRAGIMG") && atoi(getenv("RCN_HIP_NO_FRAGIMG")) != 0;
+        if (fused && !p2_one_object() && !frag_off && c->fragimg.p) {
+            hipLaunchKernelGGL(k_p2_fragimg, dim3(1), dim3(512), 0, c->stream, c->nd, (const float*)c->params.p, (float*)c->fragimg.p);
+            HIP_TRY(c, hipGetLastError());
+            c->frag_on = true;
+        }
+    }
     RCN_TRY(pack(0));
     RCN_TRY(launch_pipe_a<T>(c, xb(0), xb(0), B, 0.0, nullptr, 0.0, false, true));      // partial z_1 of the first batch, current W_0
     for (size_t j = 0; j < nb; ++j) {
@@ -855,7 +865,7 @@ int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const in
             hipLaunchKernelGGL((k_p2_dp_fused<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)xb(j),
                                (const T*)(more ? xb(j + 1) : xb(j)), (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, (int)G,
                                (const T*)c->loss_part.p, n_loss, (T)loss_scale, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev,
-                               kP2PTimeoutTicks, (T*)c->grad.p);
+                               kP2PTimeoutTicks, (T*)c->grad.p, c->frag_on ? (T*)c->fragimg.p : (T*)nullptr);
             HIP_TRY(c, hipGetLastError());
             continue;
         }
