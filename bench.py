@@ -354,6 +354,30 @@ def main():
                               "step_gflops_per_s": round(flops_step / (elapsed / args.steps) / 1e9, 1),
                               "note": "one train_batch at B=256 is ~1 MB and ~25 MFLOP: bound by launch + dependent-latency floors "
                                       "(1.6 us per dependent launch, >=1 us per global round trip), far from either roof"}
+        if not use_dp and not args.no_e2e and args.dtype == "f32":
+            # second kernel of the path with a roofline worth quoting: flatten_feature_set (conv, pool, conv, pool -> 784 features),
+            # one launch over 8 copies of this rank's pictures, timed like the step kernels (HIP events on the context's stream)
+            try:
+                big = imgs_d.repeat(8, 1, 1).contiguous()
+                nfe = big.shape[0]
+                outf = d.empty(nfe, d.F)
+                for _ in range(3):
+                    d.features(big, True, outf)
+                fa, fb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                fa.record(d.stream)
+                for _ in range(10):
+                    d.features(big, True, outf)
+                fb.record(d.stream)
+                d.synchronize()
+                fus = fa.elapsed_time(fb) * 1e3 / 10
+                fbytes = nfe * (784 + 784 * 4)
+                result["roofline"]["feature_kernel"] = {
+                    "kernel": "k_features_cpcp (fused standardisation)", "bound": "hbm", "images_per_launch": nfe,
+                    "algorithmic_bytes_per_launch": fbytes, "us_per_launch_hip_events": round(fus, 1), "achieved": round(fbytes / fus / 1e3, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fbytes / fus / 1e3 / HBM_PEAK_GBS, 4), "images_per_s": round(nfe / fus * 1e6, 1)}
+                del big, outf
+            except Exception as ex:                      # a secondary figure must never cost the headline line
+                result["roofline"]["feature_kernel"] = {"error": str(ex)[:200]}
         if not args.no_cpu_baseline and world == 1:      # the CPU path is timed beside the N = 1 run only
             result["cpu_baseline"] = cpu_baseline()
             result["config"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
