@@ -765,7 +765,14 @@ int p2p_export(rcn_hip_ctx* c, void* out) {
     q.stride = (((size_t)c->nd.P + 1) + 3) & ~(size_t)3;
     // [2 plain slots | 2 slots of self-validating words, 2 * esz bytes per value]  (dp_p2p.hpp / dense_p2_dp.hpp)
     const size_t bytes = 6 * q.stride * c->esz();
-    HIP_TRY(c, hipMalloc(&q.local_buf, bytes));
+    // Uncached (fine-grained) device memory for everything a peer reads while a kernel of ours is still running: the words of
+    // the in-kernel exchange must leave this GPU's L2 when they are stored, not when the kernel ends -- the allocation type RCCL
+    // uses for its own low-latency buffers.  (Ordinary hipMalloc memory is only guaranteed visible to a peer at kernel
+    // boundaries; two ranks sharing ONE GPU, the only multi-rank case the development box offers, share its L2 and cannot
+    // tell the difference.)  RCN_HIP_DP_CACHED_BUF=1 restores hipMalloc for A/B measurements.
+    static const bool cached_buf = getenv("RCN_HIP_DP_CACHED_BUF") && atoi(getenv("RCN_HIP_DP_CACHED_BUF")) != 0;
+    if (cached_buf) HIP_TRY(c, hipMalloc(&q.local_buf, bytes));
+    else HIP_TRY(c, hipExtMallocWithFlags(&q.local_buf, bytes, hipDeviceMallocUncached));
     HIP_TRY(c, hipExtMallocWithFlags((void**)&q.local_flags, 4096, hipDeviceMallocUncached));
     HIP_TRY(c, hipMalloc((void**)&q.err_dev, 256));
     HIP_TRY(c, hipHostMalloc((void**)&q.err_host, 64, hipHostMallocDefault));
