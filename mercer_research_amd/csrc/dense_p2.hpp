@@ -243,8 +243,19 @@ __device__ __forceinline__ void p2_b_body(
     __syncthreads();
     RCN_STAMP(1, 2);
     if (wave != 0) return;
-    z = ((zred[lane] + zred[64 + lane]) + (zred[128 + lane] + zred[192 + lane])) +
-        ((zred[256 + lane] + zred[320 + lane]) + (zred[384 + lane] + zred[448 + lane]));   // ... and a fixed order across waves
+    {   // ... and a fixed order across waves.  Written on the two halves of each 16-byte word so that it compiles to packed adds on the
+        // register pairs the reads delivered (left to itself the compiler packs ACROSS the eight operands and spends ~40 moves on it)
+        typedef T h2 __attribute__((ext_vector_type(2)));
+        vec4 r[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) r[w] = zred[w * 64 + lane];
+        h2 lo[8], hi[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { lo[w] = h2{r[w][0], r[w][1]}; hi[w] = h2{r[w][2], r[w][3]}; }
+        const h2 zl = ((lo[0] + lo[1]) + (lo[2] + lo[3])) + ((lo[4] + lo[5]) + (lo[6] + lo[7]));
+        const h2 zh = ((hi[0] + hi[1]) + (hi[2] + hi[3])) + ((hi[4] + hi[5]) + (hi[6] + hi[7]));
+        z = vec4{zl[0], zl[1], zh[0], zh[1]};
+    }
 
     // every fragment word this wave will use, in ONE round of LDS reads right behind the barrier (read where they are used,
     // each group costs the chain another LDS round trip: the compiler may not hoist them over the a_1 / delta_2 tile writes)
@@ -271,10 +282,12 @@ __device__ __forceinline__ void p2_b_body(
     RCN_STAMP(1, 3);
     // ---- z_2 = W_1 a_1 + b_1, a_2 = sigmoid, delta_2 = (a_2 - y)(*)a_2(1-a_2)                    rcn.rs:287-289, 299
     acc_t acc = acc_t{0, 0, 0, 0};
+    {
+        T bv[8];                                                  // all eight operands in one round of LDS reads, then the MFMA chain
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const T bv = a1s[(4 * ks + g4) * kLd + (n & 7)];
-        acc = Mfma16<T>::mfma(fr[ks], n < kP2Ts ? bv : (T)0, acc);
+        for (int ks = 0; ks < 8; ++ks) bv[ks] = a1s[(4 * ks + g4) * kLd + (n & 7)];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc = Mfma16<T>::mfma(fr[ks], n < kP2Ts ? bv[ks] : (T)0, acc);
     }
     T lsum = 0;
     acc_t dv;
@@ -291,18 +304,24 @@ __device__ __forceinline__ void p2_b_body(
     if (n < kP2Ts) store4<T>(d2g + (size_t)(s0 + n) * kP2C, lane, dv);
     RCN_STAMP(1, 4);
     // ---- delta_1 = (W_1^T delta_2) (*) a_1 (1 - a_1)                                                rcn.rs:305-309
+    {
+        T dvv[4], av[kMtp][4];                                    // again one round of LDS reads for both M-tiles
 #pragma unroll
-    for (int mt = 0; mt < kMtp; ++mt) {
-        acc_t ad = acc_t{0, 0, 0, 0};
+        for (int ks = 0; ks < 4; ++ks) dvv[ks] = d2s[(4 * ks + g4) * kLd + n];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ad = Mfma16<T>::mfma(fr[8 + mt * 4 + ks], d2s[(4 * ks + g4) * kLd + n], ad);
-        acc_t o;
+        for (int mt = 0; mt < kMtp; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const T a = a1s[(mt * 16 + Mfma16<T>::row(lane, i)) * kLd + (n & 7)];
-            o[i] = ad[i] * (a * ((T)1 - a));                      // padded hidden rows hold a = 0 -> delta 0
+            for (int i = 0; i < 4; ++i) av[mt][i] = a1s[(mt * 16 + Mfma16<T>::row(lane, i)) * kLd + (n & 7)];
+#pragma unroll
+        for (int mt = 0; mt < kMtp; ++mt) {
+            acc_t ad = acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ad = Mfma16<T>::mfma(fr[8 + mt * 4 + ks], dvv[ks], ad);
+            acc_t o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = ad[i] * (av[mt][i] * ((T)1 - av[mt][i]));      // padded hidden rows hold a = 0 -> delta 0
+            if (n < kP2Ts) store4<T>(d1g + (size_t)(s0 + n) * kP2H + mt * 16, lane, o);
         }
-        if (n < kP2Ts) store4<T>(d1g + (size_t)(s0 + n) * kP2H + mt * 16, lane, o);
     }
     lsum = wave_sum_lane0(lsum);
     if (lane == 0 && loss_part) loss_part[blockIdx.x] = lsum;
