@@ -368,6 +368,7 @@ __device__ inline void wgrad_tile_ld(const NetDesc& nd, int j, int n0, T* __rest
                     av[q][mt] = D[(size_t)sc * ldD + (row < M ? row : M - 1)];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);                 // all loads of the chunk in flight before the first MFMA waits on one
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const bool sv = kc + 4 * q + g < ke;

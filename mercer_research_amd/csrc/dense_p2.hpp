@@ -95,6 +95,9 @@ __device__ __forceinline__ void p2_a_body(
 #pragma unroll
                 for (int t = 0; t < kMtp; ++t) av[q][t] = db[q * 4 * kP2H + t * 16];
             }
+            // every load of the chunk is in flight before the first MFMA waits on one: without this fence the scheduler starts
+            // the MFMA chain after 16 of the 24 loads and issues the last 8 behind the first wait -- a second memory round trip
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
 #pragma unroll

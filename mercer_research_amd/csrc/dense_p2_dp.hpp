@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_p2_dp_grad(
 #pragma unroll
             for (int t = 0; t < kMtp; ++t) av[q][t] = db[q * 4 * kP2H + t * 16];
         }
+        __builtin_amdgcn_sched_barrier(0);           // every load in flight before the first MFMA waits on one (dense_p2.hpp)
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_p2_dp_fused(
 #pragma unroll
                 for (int t = 0; t < kMtp; ++t) av[q][t] = db[q * 4 * kP2H + t * 16];
             }
+            __builtin_amdgcn_sched_barrier(0);           // every load in flight before the first MFMA waits on one (dense_p2.hpp)
 #pragma unroll
             for (int q = 0; q < 8; ++q)
 #pragma unroll
