@@ -57,6 +57,7 @@ __device__ __forceinline__ void p2_a_body(
         if (e == 0 && tid == 0 && loss_out) finish_loss<T>(loss_part, n_loss, loss_scale, loss_out);
         if (e == 0) wgrad_tile_ld<T, true>(nd, 0, F, params, (T*)nullptr, (const T*)nullptr, 0, (const int*)nullptr, d1, kP2H, B, scale, red, fragimg);
         else        wgrad_tile_ld<T, true>(nd, 1, (e - 1) * 16, params, (T*)nullptr, a1, kP2H, (const int*)nullptr, d2, kP2C, B, scale, red, fragimg);
+        RCN_STAMP(0, 6);
         return;
     }
 

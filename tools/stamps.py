@@ -39,3 +39,6 @@ for kid, name, nwg, npts in ((0, "k_pipe_a (stamps 0-3: last launch, U only; 4-5
     rel = np.where(s > 0, rel, np.nan)
     print("  mean us since first WG start at each stamp:", np.round(np.nanmean(rel, axis=0), 2))
     print("  max  us:", np.round(np.nanmax(rel, axis=0), 2))
+tail = st[0, 49:52, :7].astype(np.int64)
+t0a = st[0, :52, 0].astype(np.int64).min()
+print("k_p2_a tail tiles (db_0, [W_1|b_1] x2): start, end us since the first workgroup's start:", np.round((tail[:, 0] - t0a) / 100.0, 2), np.round((tail[:, 6] - t0a) / 100.0, 2))
