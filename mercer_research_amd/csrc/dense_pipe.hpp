@@ -235,16 +235,20 @@ __global__ void k_shuffle_indices(int* __restrict__ perm, unsigned n, unsigned p
     perm[gid] = (int)x;
 }
 
-// Gathers `nb` shuffled batches into the slice-major image described above.  Grid: (G + 1, nb): blockIdx.x < G packs one
-// 16-feature slice of one batch, blockIdx.x == G packs that batch's targets.  perm == NULL: identity (chunks_exact over
-// the set as stored).
+// Gathers `nb` shuffled batches into the slice-major image described above.  Grid: ((G + 1) / 2 + 1, nb): blockIdx.x < (G + 1) / 2
+// packs TWO neighbouring 16-feature slices of one batch -- 128 contiguous bytes of every (f32) sample row, a whole cache line
+// per gathered row instead of half of one (as one slice per workgroup the other half was fetched again by the neighbouring
+// slice's workgroup, on another XCD) -- the last blockIdx.x packs that batch's targets.  perm == NULL: identity
+// (chunks_exact over the set as stored).
+inline int pack_grid_x(int G) { return (G + 1) / 2 + 1; }
+
 template <typename T, bool VECX>
 __global__ __launch_bounds__(256) void k_pack_epoch(const T* __restrict__ X, const T* __restrict__ Y, const int* __restrict__ perm,
                                                     int B, int F, int C, int G, T* __restrict__ Xs, T* __restrict__ Ys) {
     using vec4 = typename Vec4<T>::type;
-    const int j = blockIdx.y, g = blockIdx.x;
+    const int j = blockIdx.y, gp = blockIdx.x;
     const int* pj = perm ? perm + (size_t)j * B : nullptr;
-    if (g == G) {
+    if (gp == (G + 1) / 2) {
         T* dst = Ys + (size_t)j * B * C;
         for (int e = threadIdx.x; e < B * C; e += blockDim.x) {
             const int s = e / C, m = e - s * C;
@@ -253,10 +257,12 @@ __global__ __launch_bounds__(256) void k_pack_epoch(const T* __restrict__ X, con
         }
         return;
     }
-    T* dst = Xs + ((size_t)j * G + g) * B * 16;
-    const int f0 = 16 * g;
-    for (int e = threadIdx.x; e < B * 4; e += blockDim.x) {            // one 4-feature group per thread-iteration
-        const int s = e >> 2, q = e & 3, f = f0 + 4 * q;
+    T* dst = Xs + ((size_t)j * G + 2 * gp) * B * 16;                   // chunk of slice 2 gp; slice 2 gp + 1 follows B * 16 elements later
+    const int f0 = 32 * gp;
+    const bool two = 2 * gp + 1 < G;
+    for (int e = threadIdx.x; e < B * 8; e += blockDim.x) {            // one 4-feature group per thread-iteration
+        const int s = e >> 3, q = e & 7, f = f0 + 4 * q;
+        if (q >= 4 && !two) continue;
         const long long r = pj ? (long long)pj[s] : (long long)j * B + s;
         vec4 v = vec4{0, 0, 0, 0};
         if (VECX) {
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void k_pack_epoch(const T* __restrict__ X, con
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (f + i < F) ? X[r * (long long)F + f + i] : (T)0;
         }
-        *reinterpret_cast<vec4*>(dst + (size_t)s * 16 + 4 * q) = v;
+        *reinterpret_cast<vec4*>(dst + (size_t)(q >> 2) * B * 16 + (size_t)s * 16 + 4 * (q & 3)) = v;
     }
 }
 

@@ -456,8 +456,8 @@ int launch_pack(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* per
     const int32_t* pb = perm ? perm + j0 * B : nullptr;
     T* xs = (T*)c->xpack.p + (size_t)half * seg * G * B * 16;
     T* ys = (T*)c->ypack.p + (size_t)half * seg * B * Cc;
-    if (vec) hipLaunchKernelGGL((k_pack_epoch<T, true>), dim3(G + 1, (unsigned)n), dim3(256), 0, c->stream, Xb, Yb, pb, (int)B, F, Cc, G, xs, ys);
-    else hipLaunchKernelGGL((k_pack_epoch<T, false>), dim3(G + 1, (unsigned)n), dim3(256), 0, c->stream, Xb, Yb, pb, (int)B, F, Cc, G, xs, ys);
+    if (vec) hipLaunchKernelGGL((k_pack_epoch<T, true>), dim3(pack_grid_x(G), (unsigned)n), dim3(256), 0, c->stream, Xb, Yb, pb, (int)B, F, Cc, G, xs, ys);
+    else hipLaunchKernelGGL((k_pack_epoch<T, false>), dim3(pack_grid_x(G), (unsigned)n), dim3(256), 0, c->stream, Xb, Yb, pb, (int)B, F, Cc, G, xs, ys);
     HIP_TRY(c, hipGetLastError());
     if (half == 0) { c->packed_B = B; c->packed_nb = n; }
     return RCN_HIP_OK;
