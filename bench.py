@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- training images/sec of the rcn hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1: this process only spawns the N ranks (no GPU call in it)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus 2 --dry-launch                    # CPU rehearsal of the launch path: gloo rendezvous, one line, no GPU
 
 Workload (BASELINE.json configs[1]): synthetic MNIST-shape 28x28x1 u8 images (16 384 per rank,
 seeded), the default rcn net conv(Same),pool,conv(Same),pool -> 784 -> 30 -> 10 (sigmoid, quadratic cost), N(0,1)
 parameters, eta = 3.0, batch 256 PER GPU, fp32 arithmetic.  A "step" is one train_batch (rcn.rs:176-223) over one
 256-image batch of the resident, already feature-extracted set -- exactly the reference's epoch-loop semantics
-(features are computed once at load, rcn.rs:399-401); every step is a full forward + backward + SGD update on a
-fresh batch, shuffled per epoch like rcn.rs:146.  N > 1: one process per GPU, weak scaling (global batch 256*N),
-gradients combined by one RCCL all-reduce of the flat 23 860-element buffer per step (mercer_research_amd/dp.py).
+(features are computed once at load, rcn.rs:399-401).  The run is ONE continuous training session: step s is batch
+s mod 64 of epoch s div 64; at every epoch boundary the set is shuffled on the device (rcn.rs:146) and the shuffled order
+is materialised once (rcn_hip_epoch_begin_dev), then the chunks are walked (rcn.rs:147-149, rcn_hip_epoch_steps_dev).
+Warm-up steps are the first W steps of that session, the timed K steps follow them directly; whatever epoch boundaries
+fall inside the timed region are paid inside it.  N > 1: one process per GPU, weak scaling (global batch 256*N), summed
+shard gradients exchanged once per step (include/rcn_hip.h: rcn_hip_dp_*).
 
-Rank 0 prints ONE JSON line.  Extra objects on it: "roofline" (dominant kernel, HIP events) and "cpu_baseline"
-(the oracle's restatement of rcn's rayon loop timed on this host's cores -- a reported baseline, not the target).
+Rank 0 prints ONE JSON line.  Extra objects on it: "roofline" (dominant kernel, HIP events), "cpu_baseline" (the oracle's
+restatement of rcn's rayon loop timed on this host -- a reported baseline, not the target), config.steady_state_* (>= 4096
+device-timed steps in the same process), config.f64_* (the reference's own arithmetic type), config.loss_curve (256 steps
+against the CPU restatement on the same batches) and "trackx" (the north-star's trainable-convolution extension, CIFAR shape).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,11 +40,28 @@ N_IMAGES = 16384
 ETA = 3.0
 DIMS = [784, 30, 10]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+F32_MFMA_PEAK_TFLOPS = 157.3   # same guide: fp32 MFMA = fp32 vector peak
+STEADY_STEPS = 4096
+METRIC = "training images/sec, MNIST-shape 28x28x1 batch=256, at 1/2/4/8 MI355X"
+WORKLOAD = ("MNIST-shape 28x28x1, rcn default net conv(Same)-pool-conv(Same)-pool -> 784-30-10 sigmoid/MSE, "
+            "train_batch B=256 per GPU over 16384 resident pre-extracted feature vectors per GPU, eta=3.0")
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
+def csrc_sha16() -> str:
+    """Fingerprint of the kernel sources: profiles/r2_pmc_summary.json records the one it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mercer_research_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        p = os.path.join(d, f)
+        if os.path.isfile(p):
+            h.update(f.encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(seconds_budget: float = 8.0):
     """rcn's CPU path (oracle/rcn_oracle.c restated from rcn.rs:176-314, threaded like the rayon loop) on this host:
-    B = 32 (BASELINE.json configs[0]), all host cores, bounded sample."""
+    B = 32 (BASELINE.json configs[0]), all host cores and one core, bounded sample."""
     import tempfile
     from oracle.rcn_oracle import COracle, DEFAULT_LAYERS, build_oracle, one_hot, synthetic_images, synthetic_params
     try:
@@ -60,20 +84,52 @@ def cpu_baseline(seconds_budget: float = 12.0):
         o.train_steps_inplace(holder, X, Y, B, 16, ETA, threads=cores)
         steps += 16
         el = time.perf_counter() - t0
-        if el >= seconds_budget or steps >= 20000:
+        if el >= seconds_budget * 0.6 or steps >= 20000:
             break
     multi = steps * B / el
     holder1 = o.net(ws, bs)
     t0 = time.perf_counter()
     s1 = 0
-    while time.perf_counter() - t0 < min(4.0, seconds_budget / 3):
+    while time.perf_counter() - t0 < seconds_budget * 0.4:
         o.train_steps_inplace(holder1, X, Y, B, 8, ETA, threads=0)
         s1 += 8
     single = s1 * B / (time.perf_counter() - t0)
     return {"value": round(max(multi, single), 1), "unit": "images/s", "cores": cores if multi >= single else 1, "kind": "port",
-            "sample": f"{steps} train_batch steps of B={B} (784-30-10, f64) over {n} synthetic feature vectors, "
-                      f"{cores} threads: {multi:.0f} img/s; 1 thread: {single:.0f} img/s",
+            "host_hardware_threads": cores,
+            "sample": f"{steps} train_batch steps of B={B} (784-30-10, f64) over {n} synthetic feature vectors on all {cores} hardware threads "
+                      f"of this host: {multi:.0f} img/s; {s1} steps on 1 thread: {single:.0f} img/s (the mutex-serialised, reallocating sum of "
+                      f"rcn.rs:192-204 does not scale, so `value` is the faster of the two and `cores` says which)",
             "threads_all_cores_images_per_s": round(multi, 1), "single_thread_images_per_s": round(single, 1)}
+
+
+def dry_launch(args) -> int:
+    """The launch path without a GPU: every rank joins a gloo group over 127.0.0.1, one all-reduce proves the rendezvous,
+    rank 0 prints the one line.  What tests/test_bench_launch.py runs on the CPU."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    sys.stdout.flush()
+    real_stdout = os.dup(1)                 # gloo (like RCCL) prints a connection banner on stdout: keep fd 1 to the one JSON line
+    os.dup2(2, 1)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        ranks_sum = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks_sum = 1.0
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps({"metric": METRIC, "value": None, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                          "data": "synthetic", "dry_launch": True, "rendezvous_check": ranks_sum == world * (world + 1) / 2,
+                          "config": {"workload": WORKLOAD, "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}"}}) + "\n").encode())
+    return 0
 
 
 def main():
@@ -84,11 +140,21 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the secondary end-to-end (u8 image -> features -> step) measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the f64 / loss-curve / Track X legs (headline, roofline and steady state only)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline")
     ap.add_argument("--dp-impl", choices=["native", "torch"], default="native",
-                    help="data-parallel loop: native = RCCL calls inside librcn_hip (rcn_hip_dp_*), torch = torch.distributed all_reduce per step")
+                    help="data-parallel loop: native = exchange inside librcn_hip (rcn_hip_dp_*), torch = torch.distributed all_reduce per step")
     ap.add_argument("--dp", action="store_true", help="use the data-parallel step (gradient -> all-reduce -> apply) even at world size 1")
+    ap.add_argument("--dry-launch", action="store_true", help="rendezvous the ranks over gloo on the CPU and print the line; no GPU work")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the spawning parent waits for its ranks")
     args = ap.parse_args()
+
+    from mercer_research_amd.launch import spawn_ranks, under_launcher
+    if args.gpus > 1 and not under_launcher():
+        # `python bench.py --gpus N`: this parent makes no GPU call at all; it starts N fresh ranks and relays rank 0's line
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout_s=args.launch_timeout))
+    if args.dry_launch:
+        sys.exit(dry_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -109,9 +175,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    n_gpus = max(args.gpus, world) if world > 1 else args.gpus
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    n_gpus = world
 
     import mercer_research_amd as amd
     from mercer_research_amd.device import DeviceRCN
@@ -123,8 +187,6 @@ def main():
     imgs, labels = synthetic_images(N_IMAGES, seed=1234 + rank)          # every rank owns a different shard of data
     ws, bs = synthetic_params(DIMS, seed=42)                             # identical replicas (rcn.rs:500-523 shapes)
     d.set_params(ws, bs)
-    # data-parallel: with the peer-read exchange the step runs on the feature-sliced pipeline (k_p2_b, k_p2_dp_grad,
-    # k_p2_dp_apply); on the RCCL fallback the gradient-out form runs on the sample-tile kernels (--path 1 forces those)
     d.set_dense_path(args.path)
     with torch.cuda.stream(d.stream):
         imgs_d = torch.from_numpy(imgs).to(d.device)
@@ -133,90 +195,165 @@ def main():
     nb_epoch = N_IMAGES // B_PER_GPU
     B = B_PER_GPU
     step_no = [0]
-    # training_set.shuffle (rcn.rs:146): one fresh permutation per pass over the set, drawn ON the device by
-    # rcn_hip_shuffle_dev in-stream (one small kernel per chunk of passes -- a side-stream torch.randperm serialises
-    # against graph replays on this stack and cost 1.8 us/step), inside the timed region.  One hipGraph replay covers
-    # EPG passes; every step sees a fresh batch of a fresh shuffle.
-    EPG = 8                                                          # passes (epochs) per graph replay
-    chunk_steps = EPG * nb_epoch
-    perm = torch.empty(EPG * N_IMAGES, dtype=torch.int32, device=d.device)
-    chunk_no = [0]
+    epoch_no = [0]
+    perm = torch.empty(N_IMAGES, dtype=torch.int32, device=d.device)
+    fallbacks = []
 
+    def epoch_seed():
+        return 0x5DEECE66D + rank * 7919 + epoch_no[0]
+
+    def segments(k: int):
+        """(position in the epoch, number of steps) pieces that the next k steps of the session fall into"""
+        pos, done, out = step_no[0] % nb_epoch, 0, []
+        while done < k:
+            take = min(nb_epoch - pos, k - done)
+            out.append((pos, take))
+            done += take
+            pos = (pos + take) % nb_epoch
+        return out
+
+    allreduce_kind = None
     if not use_dp:
-        def plan(k: int):
-            """chunk sizes (in steps) that run(k) will issue"""
-            return [min(chunk_steps, k - i) for i in range(0, k, chunk_steps)]
+        # begun["ok"]: the epoch image form (rcn_hip_epoch_begin_dev / _steps_dev) is available -- it is for the feature-sliced
+        # pipeline; with --path 1 (sample-tile kernels) each piece gathers its rows by index instead.  live: the image holds the
+        # session's current epoch.
+        begun = {"ok": True, "live": False}
+        with torch.cuda.stream(d.stream):
+            perm.copy_(torch.arange(N_IMAGES, dtype=torch.int32, device=d.device))
+
+        def lay_out():
+            if begun["ok"]:
+                try:
+                    d.epoch_begin(X, Y, perm, B, nb_epoch)              # the shuffled order materialised once per epoch
+                    begun["live"] = True
+                except amd.RcnHipError:
+                    begun["ok"] = False
 
         def prime(k: int):
-            """instantiate the graphs run(k) will replay (set-up, untimed): one per chunk length"""
-            for take in set(plan(k)):
-                d.prepare_epoch(X, Y, perm, B, take, ETA, None)
+            """instantiate the graphs the next k steps will replay (set-up, untimed)"""
+            if begun["ok"] and not begun["live"]:
+                lay_out()                                               # any image will do for capturing; run() lays out the real one
+            for pos, take in set(segments(k)):
+                if begun["ok"]:
+                    d.epoch_steps(pos, take, ETA, None, prepare_only=True)
+                else:
+                    d.prepare_epoch(X, Y, perm[pos * B:], B, take, ETA, None)
 
         def run(k: int):
-            """k consecutive train_batch steps in chunks of up to EPG passes; a new permutation every pass."""
-            for take in plan(k):
-                d.shuffle(perm, N_IMAGES, EPG, seed=0x5DEECE66D + rank * 7919 + chunk_no[0])
-                d.train_epoch(X, Y, perm, B, take, ETA, None)
+            for pos, take in segments(k):
+                if pos == 0:
+                    d.shuffle(perm, N_IMAGES, 1, seed=epoch_seed())     # training_set.shuffle, rcn.rs:146 -- on the device, in-stream
+                    epoch_no[0] += 1
+                    lay_out()
+                if begun["ok"]:
+                    d.epoch_steps(pos, take, ETA, None)
+                else:
+                    d.train_epoch(X, Y, perm[pos * B:], B, take, ETA, None)
                 step_no[0] += take
-                chunk_no[0] += 1
     else:
         # one process per GPU: every rank shuffles its own resident shard of the data, takes 256 rows per step, and the
-        # summed shard gradients meet in ONE all-reduce of the flat parameter-shaped buffer (RCCL over xGMI)
-        native = args.dp_impl == "native"
-        if native:
+        # summed shard gradients meet once per step (xGMI peer exchange inside the kernels, or ONE ncclAllReduce of the flat
+        # parameter-shaped buffer)
+        def dp_native_setup() -> bool:
             try:
                 d.dp_init()                   # RCCL communicator owned by the library; torch only carried its 128-byte id
                 ok = 1
             except Exception as e:            # e.g. librccl not loadable: every rank falls back together
-                print(f"[bench] native RCCL loop unavailable on rank {rank}: {e}", file=sys.stderr, flush=True)
+                print(f"[bench] native data-parallel loop unavailable on rank {rank}: {e}", file=sys.stderr, flush=True)
                 ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            native = bool(flag.item())
-            args.dp_impl = "native" if native else "torch"
-        if native:
-            d.dp_broadcast_params(0)
-            allreduce_kind = {0: "ncclAllReduce (RCCL)", 1: "xgmi peer reads between kernels, fused with the update (csrc/dense_p2_dp.hpp, 3 kernels/step)",
-                              2: "xgmi peer reads inside the gradient kernel (csrc/dense_p2_dp.hpp, 2 kernels/step)"}[d.dp_p2p_mode()]
+            return bool(flag.item())
 
-            def prime(k: int):
-                """instantiate the graphs run(k) will replay from the current position (set-up, untimed, not collective)"""
-                pos, done, seen = step_no[0] % nb_epoch, 0, set()
-                while done < k:
-                    take = min(nb_epoch - pos, k - done)
-                    if (pos, take) not in seen:
-                        seen.add((pos, take))
-                        d.dp_prepare_epoch(X, Y, perm[pos * B:], B, take, ETA, None)
-                    done += take
-                    pos = (pos + take) % nb_epoch
+        def dp_kind():
+            return {0: "ncclAllReduce (RCCL)", 1: "xgmi peer reads between kernels, fused with the update (csrc/dense_p2_dp.hpp, 3 kernels/step)",
+                    2: "xgmi peer reads inside the gradient kernel (csrc/dense_p2_dp.hpp, 2 kernels/step)"}[d.dp_p2p_mode()]
 
-            def run(k: int):
-                # the whole loop is native: per step gradient kernels -> ncclAllReduce -> update, enqueued by
-                # rcn_hip_dp_train_epoch_dev; Python only starts each pass (one in-stream shuffle + one call per 64 steps)
-                done = 0
-                while done < k:
-                    pos = step_no[0] % nb_epoch
+        native = args.dp_impl == "native" and dp_native_setup()
+        args.dp_impl = "native" if native else "torch"
+        dp = None
+
+        def prime(k: int):
+            if args.dp_impl != "native":
+                return
+            for pos, take in set(segments(k)):
+                d.dp_prepare_epoch(X, Y, perm[pos * B:], B, take, ETA, None)
+
+        def run(k: int):
+            if args.dp_impl == "native":
+                # the whole loop is native: per step gradient kernels -> exchange -> update, enqueued by
+                # rcn_hip_dp_train_epoch_dev; Python only starts each piece (one in-stream shuffle per epoch)
+                for pos, take in segments(k):
                     if pos == 0:
-                        d.shuffle(perm, N_IMAGES, 1, seed=0x5DEECE66D + rank * 7919 + chunk_no[0])
-                        chunk_no[0] += 1
-                    take = min(nb_epoch - pos, k - done)
+                        d.shuffle(perm, N_IMAGES, 1, seed=epoch_seed())
+                        epoch_no[0] += 1
                     d.dp_train_epoch(X, Y, perm[pos * B:], B, take, ETA, None)
                     step_no[0] += take
-                    done += take
-        else:
-            allreduce_kind = "torch.distributed all_reduce (RCCL)"
-            dp = DataParallelStep(d)
-            dp.broadcast_params(0)
-
-            def run(k: int):
+            else:
                 with torch.cuda.stream(d.stream):
                     for _ in range(k):
                         pos = step_no[0] % nb_epoch
                         if pos == 0:
-                            d.shuffle(perm, N_IMAGES, 1, seed=0x5DEECE66D + rank * 7919 + chunk_no[0])
-                            chunk_no[0] += 1
+                            d.shuffle(perm, N_IMAGES, 1, seed=epoch_seed())
+                            epoch_no[0] += 1
                         dp.train_batch(X, Y, ETA, B * world, perm=perm[pos * B:(pos + 1) * B])
                         step_no[0] += 1
+
+        def replicas_check():
+            with torch.cuda.stream(d.stream):
+                pf = d.params_flat().to(torch.float64)
+                chk = torch.stack([pf.sum(), (pf * pf).sum(), pf.abs().max()])
+            d.stream.synchronize()
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            return bool(torch.equal(lo, hi)) and bool(torch.isfinite(chk).all())
+
+        def healthy(k: int) -> bool:
+            """k steps of the loop as configured, then: no sticky timeout on any rank and bit-identical replicas"""
+            ok = 1
+            try:
+                prime(k)
+                run(k)
+                d.synchronize()
+            except Exception as e:
+                print(f"[bench] rank {rank}: data-parallel loop failed its rehearsal: {e}", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            same = replicas_check() if flag.item() else False
+            return bool(flag.item()) and same
+
+        # Rehearse before anything is timed, and step down together if the rehearsal fails: in-kernel xGMI exchange ->
+        # ncclAllReduce inside the library -> torch.distributed all_reduce.  Every rank takes the same branch (votes above).
+        rehearsal = max(8, min(args.warmup, 64))
+        while True:
+            if args.dp_impl == "native":
+                d.dp_broadcast_params(0)
+                allreduce_kind = dp_kind()
+            else:
+                allreduce_kind = "torch.distributed all_reduce (RCCL)"
+                dp = DataParallelStep(d)
+                dp.broadcast_params(0)
+            if healthy(rehearsal):
+                break
+            fallbacks.append(allreduce_kind)
+            if args.dp_impl != "native":
+                raise SystemExit("[bench] the torch.distributed data-parallel loop failed its rehearsal too")
+            was_p2p = d.dp_p2p_mode() != 0
+            try:
+                d.dp_finalize()
+            except Exception as e:
+                print(f"[bench] rank {rank}: dp_finalize after a failed rehearsal: {e}", file=sys.stderr, flush=True)
+            d.set_params(ws, bs)
+            step_no[0] = 0
+            epoch_no[0] = 0
+            if was_p2p:
+                os.environ["RCN_HIP_DP_P2P"] = "0"          # same library loop on ncclAllReduce
+                if not dp_native_setup():
+                    args.dp_impl = "torch"
+            else:
+                args.dp_impl = "torch"
 
     def sync():
         d.synchronize()
@@ -225,39 +362,49 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    can_prime = (not use_dp) or (use_dp and args.dp_impl == "native")
-    if can_prime:
-        prime(args.warmup)
+    def timed(k: int):
+        """k steps bracketed by barrier + synchronise on both sides: (wall seconds [max over ranks], device ms on this rank)"""
+        prime(k)
+        prime(k)            # twice: a call shape that needs a larger workspace moves it, which drops the graphs captured before it
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(d.stream)
+        run(k)
+        ev1.record(d.stream)
+        sync()
+        el = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        if use_dp:
+            t = torch.tensor([el], dtype=torch.float64, device=d.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, dev_ms
+
+    prime(args.warmup)
     run(args.warmup)
-    if can_prime:
-        # twice: a call shape that needs a larger workspace moves it, which drops the graphs captured before it (they point into
-        # the old one); the second pass re-instantiates those, so that nothing is captured inside the timed region
-        prime(args.steps)
-        prime(args.steps)
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(d.stream)
-    run(args.steps)
-    ev1.record(d.stream)
-    sync()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if use_dp:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=d.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, dev_ms = timed(args.steps)
     loss_t = d.empty(1)
     d.train_batch(X[:B], Y[:B], 0.0, loss_t)                             # eta = 0: reads the current cost, changes nothing
     d.synchronize()
     final_loss = float(loss_t.item())
+    if not use_dp:
+        step_no[0] = (step_no[0] + nb_epoch - 1) // nb_epoch * nb_epoch     # train_batch re-packed the image: the session resumes at the next epoch
+        begun["live"] = False
+
+    # ---- steady state: the same session carried on for >= 4096 more steps, in this process, device-timed ----
+    if args.steps >= STEADY_STEPS:
+        steady_el, steady_dev_ms, steady_k = elapsed, dev_ms, args.steps
+    else:
+        steady_k = STEADY_STEPS
+        steady_el, steady_dev_ms = timed(steady_k)
 
     # SURVEY.md §8(d) asks for two numbers: train-only (the headline `value`: features resident, the reference's epoch-loop
     # semantics) and END-TO-END: u8 image -> feature kernel (+ standardise, fused) -> train_batch, i.e. the features of
     # every pass are recomputed from the resident u8 images inside the timed region.
     e2e = None
     if not use_dp and not args.no_e2e:
-        perm1 = perm[:N_IMAGES]
+        perm1 = perm
         try:
             d.train_epoch_images(imgs_d, Y, perm1, B, nb_epoch, ETA, None, prepare_only=True)
             fused_e2e = True
@@ -289,29 +436,26 @@ def main():
 
     # data-parallel runs: every rank must hold bit-identical parameters (identical update from rank-ordered sums); a stale or
     # torn read in the exchange would show up here as diverged replicas
-    replicas_identical = None
-    if use_dp:
-        with torch.cuda.stream(d.stream):
-            pf = d.params_flat().to(torch.float64)
-            chk = torch.stack([pf.sum(), (pf * pf).sum(), pf.abs().max()])
-        d.synchronize()
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        replicas_identical = bool(torch.equal(lo, hi)) and bool(torch.isfinite(chk).all())
+    replicas_identical = replicas_check() if use_dp else None
 
     images = args.steps * B * world
     result = {
-        "metric": "training images/sec, MNIST-shape 28x28x1 batch=256, at 1/2/4/8 MI355X",
+        "metric": METRIC,
         "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "MNIST-shape 28x28x1, rcn default net conv(Same)-pool-conv(Same)-pool -> 784-30-10 sigmoid/MSE, "
-                               "train_batch B=256 per GPU over 16384 resident pre-extracted feature vectors per GPU, eta=3.0",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "step_form": f"gradient -> all-reduce -> apply ({args.dp_impl} loop)" if use_dp else "fused update", "images_per_rank": N_IMAGES,
+        "config": {"workload": WORKLOAD,
+                   "global_batch": B * world, "parallelism": f"dp{world}", "step_form": f"gradient -> exchange -> apply ({args.dp_impl} loop)" if use_dp else "fused update", "images_per_rank": N_IMAGES,
+                   "session": f"steps {args.warmup}..{args.warmup + args.steps} of one continuous training session (64 steps per epoch; device shuffle + one "
+                              f"gather of the shuffled order at every epoch boundary, inside the timed region whenever it is crossed)",
                    "device_ms_per_step_rank0": round(dev_ms / args.steps, 6), "final_cost_rank0": final_loss,
+                   "steady_state_steps": steady_k,
+                   "steady_state_images_per_s": round(steady_k * B * world / steady_el, 1),
+                   "steady_state_us_per_step": round(steady_el * 1e6 / steady_k, 4),
+                   "steady_state_device_us_per_step_rank0": round(steady_dev_ms * 1e3 / steady_k, 4),
                    "end_to_end_images_per_s": round(e2e, 1) if e2e else None,
-                   "allreduce": allreduce_kind if use_dp else None, "replicas_identical": replicas_identical},
+                   "allreduce": allreduce_kind if use_dp else None, "replicas_identical": replicas_identical,
+                   "dp_fallbacks_taken": fallbacks if use_dp else None},
     }
 
     if rank == 0:
@@ -319,6 +463,9 @@ def main():
         # HIP events on the kernels' own stream: each kernel back to back with itself, and the alternating pair as the epoch
         # loop issues it (walking the last epoch's packed batches).  A kernel's duration inside the real loop is the pair
         # time split in the ratio of the two stand-alone times; that is what a profiler's per-dispatch average shows.
+        if not use_dp and begun["ok"]:
+            d.shuffle(perm, N_IMAGES, 1, seed=0x7001)
+            lay_out()                                                    # time_kernels walks the batches of the image it finds
         us_first, us_second, us_pair = d.time_kernels(X[:B], Y[:B], reps=504)
         es = 8 if args.dtype == "f64" else 4
         P, F, H, C = d.P, DIMS[0], DIMS[1], DIMS[2]
@@ -338,20 +485,24 @@ def main():
             k = 1                                   # k_p2_a owns the features and W_0; k_p2_b is the small tail kernel
         us = us_pair * (us_first, us_second)[k] / (us_first + us_second)
         flops_step = 2 * B * ((F * H + H * C) * 2 + H * C)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+        traffic, traffic_src, traffic_stale = None, None, None
+        pmc = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(names[k], {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get(names[k], {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/r2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/prof_bench.sh)"
+                traffic_stale = pj.get("csrc_sha16") != csrc_sha16()     # True: kernels changed since the counters were collected
             except Exception:
                 traffic = None
         result["roofline"] = {"bound": "hbm", "kernel": names[k], "achieved": round(by[k] / us / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(by[k] / us / 1e3 / HBM_PEAK_GBS, 5), "traffic": traffic,
-                              "traffic_source": "profiles/r1_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+                              "traffic_source": traffic_src, "traffic_measured_on_other_kernel_sources": traffic_stale,
+                              "traffic_over_algorithmic": round(traffic / by[k], 2) if traffic else None,
                               "algorithmic_bytes_per_launch": round(by[k]), "us_per_launch_hip_events": round(us, 3),
                               "us_alternating_pair": round(us_pair, 3),
                               "us_standalone_" + names[0]: round(us_first, 3), "us_standalone_" + names[1]: round(us_second, 3),
-                              "step_gflops_per_s": round(flops_step / (elapsed / args.steps) / 1e9, 1),
+                              "step_gflops_per_s": round(flops_step / (steady_el / steady_k) / 1e9, 1),
                               "note": "one train_batch at B=256 is ~1 MB and ~25 MFLOP: bound by launch + dependent-latency floors "
                                       "(1.6 us per dependent launch, >=1 us per global round trip), far from either roof"}
         if not use_dp and not args.no_e2e and args.dtype == "f32":
@@ -378,6 +529,21 @@ def main():
                 del big, outf
             except Exception as ex:                      # a secondary figure must never cost the headline line
                 result["roofline"]["feature_kernel"] = {"error": str(ex)[:200]}
+        extras = not use_dp and not args.no_extras
+        if extras and args.dtype == "f32":
+            try:
+                result["config"].update(f64_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, local_rank))
+            except Exception as ex:
+                result["config"]["f64_error"] = str(ex)[:200]
+        if extras:
+            try:
+                result["config"]["loss_curve"] = loss_curve_leg(torch, amd, DeviceRCN, imgs, labels, imgs_d, labels_d, ws, bs, local_rank, dtype)
+            except Exception as ex:
+                result["config"]["loss_curve"] = {"error": str(ex)[:300]}
+            try:
+                result["trackx"] = trackx_leg(torch, local_rank)
+            except Exception as ex:
+                result["trackx"] = {"error": str(ex)[:300]}
         if not args.no_cpu_baseline and world == 1:      # the CPU path is timed beside the N = 1 run only
             result["cpu_baseline"] = cpu_baseline()
             result["config"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
@@ -391,8 +557,124 @@ def main():
     if use_dp:
         dist.barrier()                     # nobody unmaps its buffers while a peer may still read them
         if args.dp_impl == "native":
-            d.dp_finalize()
+            try:
+                d.dp_finalize()
+            except Exception as e:
+                print(f"[bench] rank {rank}: dp_finalize: {e}", file=sys.stderr, flush=True)
         dist.destroy_process_group()
+
+
+def f64_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, dev):
+    """The reference's own arithmetic type (f64 throughout, rcn.rs:28,31,49) on the same pipeline and workload: 1024 device-timed
+    steps of the same session shape."""
+    d = DeviceRCN(classes=10, feedforward_cfg=[30], input_shape=(28, 28), dtype=amd.F64, device=dev)
+    d.set_params(ws, bs)
+    X, Y = d.load_data(imgs_d, labels_d)
+    nb, B = N_IMAGES // B_PER_GPU, B_PER_GPU
+    perm = torch.empty(N_IMAGES, dtype=torch.int32, device=d.device)
+
+    def epochs(n, seed0):
+        for e in range(n):
+            d.shuffle(perm, N_IMAGES, 1, seed=seed0 + e)
+            d.epoch_begin(X, Y, perm, B, nb)
+            d.epoch_steps(0, nb, ETA, None)
+    epochs(2, 11)
+    d.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 16
+    a.record(d.stream)
+    epochs(n, 100)
+    b.record(d.stream)
+    d.synchronize()
+    us = a.elapsed_time(b) * 1e3 / (n * nb)
+    d.rcn.close()
+    return {"f64_images_per_s": round(B / us * 1e6, 1), "f64_us_per_step": round(us, 4), "f64_steps": n * nb}
+
+
+def loss_curve_leg(torch, amd, DeviceRCN, imgs, labels, imgs_d, labels_d, ws, bs, dev, dtype, steps: int = 256):
+    """Matched loss curve: `steps` consecutive train_batch steps of the bench workload (B = 256, eta = 3, N(0,1) parameters of seed
+    42, four shuffled epochs) on the GPU with the per-step cost recorded, against the CPU restatement (oracle/rcn_oracle.c, f64)
+    fed the identical batches in the identical order."""
+    from oracle.rcn_oracle import COracle, DEFAULT_LAYERS, one_hot
+    d = DeviceRCN(classes=10, feedforward_cfg=[30], input_shape=(28, 28), dtype=dtype, device=dev)
+    d.set_params(ws, bs)
+    X, Y = d.load_data(imgs_d, labels_d)
+    nb, B = N_IMAGES // B_PER_GPU, B_PER_GPU
+    perm = torch.empty(N_IMAGES, dtype=torch.int32, device=d.device)
+    loss = d.empty(steps)
+    perms = []
+    for e in range(steps // nb):
+        d.shuffle(perm, N_IMAGES, 1, seed=0xC0FFEE + e)
+        d.synchronize()
+        perms.append(perm.cpu().numpy().astype(np.int64))
+        d.epoch_begin(X, Y, perm, B, nb)
+        d.epoch_steps(0, nb, ETA, loss[e * nb:])
+    d.synchronize()
+    gpu = loss.double().cpu().numpy()
+    d.rcn.close()
+    o = COracle()
+    t0 = time.perf_counter()
+    feats = o.features(imgs, DEFAULT_LAYERS)
+    m, s = o.gen_scales(feats)
+    Xo, Yo = o.standardize(feats, m, s), one_hot(labels)
+    h = o.net(ws, bs)
+    cpu = np.zeros(steps)
+    import ctypes as C
+    for e, p in enumerate(perms):
+        for j in range(nb):
+            idx = p[j * B:(j + 1) * B]
+            xb, yb = np.ascontiguousarray(Xo[idx]), np.ascontiguousarray(Yo[idx])
+            cpu[e * nb + j] = o.lib.rcn_o_train_batch(C.byref(h.net), xb.ctypes.data_as(C.POINTER(C.c_double)), yb.ctypes.data_as(C.POINTER(C.c_double)), B, ETA)
+    rel = np.abs(gpu - cpu) / np.maximum(np.abs(cpu), 1e-300)
+    return {"steps": steps, "final_cost_gpu": float(gpu[-1]), "final_cost_cpu_restatement_f64": float(cpu[-1]),
+            "max_rel_dev_over_curve": float(rel.max()), "max_rel_dev_first_32_steps": float(rel[:32].max()),
+            "mean_cost_gpu": float(gpu.mean()), "mean_cost_cpu": float(cpu.mean()),
+            "cpu_seconds": round(time.perf_counter() - t0, 2),
+            "note": "per-step quadratic cost before each update, identical batches in identical order; eta = 3 on un-scaled N(0,1) parameters "
+                    "saturates the sigmoids, so f32 rounding differences grow along the trajectory (tests/test_gpu_parity.py states the envelope)"}
+
+
+def trackx_leg(torch, dev):
+    """North-star extension (no reference counterpart): the trainable-convolution net of BASELINE.json configs[2] -- CIFAR-10 shape
+    32x32x3, 3 conv + 2 dense, B = 512, fp32 MFMA -- whole training step, hipGraph-replayed; plus the bf16-operand form."""
+    from bench_convnet import BF16_MFMA_PEAK_TFLOPS, CONFIGS
+    from mercer_research_amd.convnet import ConvNet
+    in_shape, layers, B = CONFIGS["cifar"]
+    out = {"config": "CIFAR-10 shape 32x32x3, conv3x3 3->32, pool, 32->64, pool, 64->128, pool -> 2048 -> 256 -> 10, batch 512, softmax + cross-entropy, SGD"}
+    rng = np.random.default_rng(0)
+    for prec in ("fp32", "bf16"):
+        net = ConvNet(in_shape, layers, B, device=dev)
+        net.init_params(1)
+        net.set_precision(prec)
+        xs = [net.to_device(rng.standard_normal((B,) + in_shape).astype(np.float32)) for _ in range(4)]
+        ys = [net.to_device(rng.integers(0, 10, B).astype(np.int32)) for _ in range(4)]
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        for i in range(16):
+            net.train_step(xs[i % 4], ys[i % 4], 0.01, loss)
+        net.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 100
+        a.record(net.stream)
+        for i in range(n):
+            net.train_step(xs[i % 4], ys[i % 4], 0.01, loss)
+        b.record(net.stream)
+        net.synchronize()
+        ms = a.elapsed_time(b) / n
+        flops = net.step_flops(B)
+        tf = flops / (ms * 1e-3) / 1e12
+        peak = F32_MFMA_PEAK_TFLOPS if prec == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        out[prec] = {"ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1), "step_gflop": round(flops / 1e9, 2), "tflops": round(tf, 2),
+                     "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 4)}
+        net.close()
+    pm = os.path.join(ROOT, "profiles", "r2_trackx_mfma_pmc.json")
+    if os.path.exists(pm):
+        try:
+            pj = json.load(open(pm))
+            out["conv_fwd_mfma_busy"] = pj.get("conv_fwd_mfma_busy")
+            out["conv_fwd_mfma_busy_source"] = "profiles/r2_trackx_mfma_pmc.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES; tools/prof_trackx.sh)"
+        except Exception:
+            pass
+    return out
 
 
 if __name__ == "__main__":

@@ -22,7 +22,9 @@ CONFIGS = {
     "synth224": ((224, 224, 3), (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("conv", 64), ("pool",), ("conv", 128), ("conv", 128), ("pool",),
                                  ("conv", 256), ("conv", 256), ("pool",), ("dense", 10)), 128),
 }
-F32_MFMA_PEAK_TFLOPS = 157.3
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+BF16_MFMA_PEAK_TFLOPS = 2516.8    # same guide: dense bf16 MFMA = 16x the fp32 MFMA rate (~2.5 PFLOP/s; never the 2:1-sparsity figure)
+HBM_PEAK_GBS = 8000.0
 
 
 def main():
@@ -35,20 +37,24 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="GEMM operand precision of forward / dgrad: fp32 MFMA, or bf16 MFMA with fp32 accumulate / storage / update")
     args = ap.parse_args()
+    from mercer_research_amd.launch import spawn_ranks, under_launcher
+    if args.gpus > 1 and not under_launcher():
+        # `python bench_convnet.py --gpus N`: the parent makes no GPU call; it starts N fresh ranks and relays rank 0's line
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout_s=1500.0))
     import torch
     import torch.distributed as dist
     from mercer_research_amd.convnet import ConvNet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     real_stdout = None
     if world > 1:
         sys.stdout.flush()
         real_stdout = os.dup(1)                # RCCL's version banner goes to stdout: keep rank 0's stdout to the one JSON line
         os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     in_shape, layers, B = CONFIGS[args.config]
@@ -97,10 +103,20 @@ def main():
     flops = net.step_flops(B)
     tf = flops * args.steps / el / 1e12                    # per GPU
     if rank == 0:
+        # the peak a fraction is quoted against is the peak of the MFMA the GEMMs actually issue: fp32 MFMA (157.3 TF) in fp32
+        # mode, dense bf16 MFMA (~2.5 PF) in bf16 mode -- and for the bf16 path, which is HBM-bound, the step's HBM floor
+        # (every activation and activation gradient written once and read once per pass, as stored) is the more telling roof
+        bf16 = args.precision == "bf16"
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS
+        floor_bytes = net.step_hbm_floor_bytes(B) if hasattr(net, "step_hbm_floor_bytes") else None
+        floor_ms = floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 if floor_bytes else None
         out_line = json.dumps({"metric": "training images/sec (Track X, trainable conv net; not the BASELINE metric)", "config": args.config, "batch_per_gpu": B, "n_gpus": world,
                           "scaling": "weak", "value": round(world * B * args.steps / el, 1), "unit": "images/s", "ms_per_step": round(el / args.steps * 1e3, 4),
-                          "step_gflop_per_gpu": round(flops / 1e9, 3), "achieved_tflops_per_gpu": round(tf, 2), "mfma_fp32_peak_tflops": F32_MFMA_PEAK_TFLOPS,
-                          "frac_of_fp32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands (fwd, dgrad), f32 accumulate/storage/update", "data": "synthetic", "final_loss": round(loss.item(), 4)}) + "\n"
+                          "step_gflop_per_gpu": round(flops / 1e9, 3), "achieved_tflops_per_gpu": round(tf, 2),
+                          "mfma_peak_tflops": peak, "mfma_peak_kind": "bf16 dense MFMA" if bf16 else "fp32 MFMA",
+                          "frac_of_mfma_peak": round(tf / peak, 4),
+                          "hbm_floor_ms": round(floor_ms, 4) if floor_ms else None, "frac_of_hbm_floor": round(floor_ms / (el / args.steps * 1e3), 4) if floor_ms else None,
+                          "dtype": "f32" if not bf16 else "bf16 MFMA operands (fwd, dgrad, wgrad), f32 accumulate/update", "data": "synthetic", "final_loss": round(loss.item(), 4)}) + "\n"
         if real_stdout is not None:
             os.write(real_stdout, out_line.encode())
         else:

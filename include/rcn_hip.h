@@ -175,6 +175,20 @@ int  rcn_hip_train_epoch_images_dev(rcn_hip_ctx* ctx, const uint8_t* imgs_dev, c
                                     size_t B, size_t n_batches, double eta, void* loss_dev);
 int  rcn_hip_prepare_epoch_images_dev(rcn_hip_ctx* ctx, const uint8_t* imgs_dev, const void* Y_dev, const int32_t* perm_dev,
                                       size_t B, size_t n_batches, double eta, void* loss_dev);
+/* One epoch of RCN::train the way the reference structures it (rcn.rs:144-149): `training_set.shuffle` happens ONCE, then
+ * `chunks_exact(batch_size)` walks it.  rcn_hip_epoch_begin_dev materialises the shuffled order once -- batches 0..n_batches of
+ * (X_dev, Y_dev, perm_dev), same meaning as in rcn_hip_train_epoch_dev -- as the training kernels' slice-major epoch image
+ * (one gather pass); rcn_hip_epoch_steps_dev then runs train_batch (rcn.rs:176-223) over batches first_batch ..
+ * first_batch + n_batches of the begun epoch, in any number of calls, without packing again (one hipGraph per
+ * (first_batch, n_batches, eta, loss_dev), captured at first use; rcn_hip_prepare_epoch_steps_dev only instantiates it).
+ * The image holds up to two segments (~128 MB) of batches: RCN_HIP_ERR_UNSUPPORTED beyond that, or when the layer stack /
+ * batch size does not run on the feature-sliced pipeline -- rcn_hip_train_epoch_dev covers those.  Any other training call
+ * that re-packs the image ends the begun epoch (RCN_HIP_ERR_STATE from the next steps call).  Results are bit-identical to
+ * rcn_hip_train_epoch_dev over the same batches.  The _images form is rcn_hip_train_epoch_images_dev's begin. */
+int  rcn_hip_epoch_begin_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev, size_t B, size_t n_batches);
+int  rcn_hip_epoch_begin_images_dev(rcn_hip_ctx* ctx, const uint8_t* imgs_dev, const void* Y_dev, const int32_t* perm_dev, size_t B, size_t n_batches);
+int  rcn_hip_epoch_steps_dev(rcn_hip_ctx* ctx, size_t first_batch, size_t n_batches, double eta, void* loss_dev /* nullable, n_batches scalars */);
+int  rcn_hip_prepare_epoch_steps_dev(rcn_hip_ctx* ctx, size_t first_batch, size_t n_batches, double eta, void* loss_dev);
 /* training_set.shuffle (rcn.rs:146) on the device: writes `passes` independent pseudo-random permutations of 0..n-1
  * (pass p at perm_dev[p*n ..]) keyed by `seed` -- ready to be passed to rcn_hip_train_epoch_dev.  Enqueued on the
  * context's stream (one small kernel); the reference draws from the unseeded thread_rng. */
@@ -223,6 +237,16 @@ int  rcn_hip_dp_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const voi
 int  rcn_hip_dp_p2p_export(rcn_hip_ctx* ctx, void* handles_out /* RCN_HIP_DP_P2P_HANDLE_BYTES */);
 int  rcn_hip_dp_p2p_attach(rcn_hip_ctx* ctx, const void* all_handles /* world x RCN_HIP_DP_P2P_HANDLE_BYTES */, int rank, int world);
 int  rcn_hip_dp_p2p_selftest(rcn_hip_ctx* ctx, int iters, unsigned* mismatches, unsigned* timed_out);
+/* The whole admission procedure of rcn_hip_dp_init -- export, gather, attach, known-answer exchange, tagged-word self-test, one
+ * min-vote over the ranks after every stage so that all ranks land on the same form -- over a transport the caller supplies
+ * instead of RCCL: `allgather` receives this rank's `bytes` bytes and must fill `all` with every rank's, in rank order;
+ * `vote_min` must replace *v by the minimum of *v over the ranks; both return 0 on success and are called the same number of
+ * times on every rank.  Afterwards rcn_hip_dp_p2p_active tells which form was admitted (identical on every rank); with 0 the
+ * context has no exchange of its own and the caller combines rcn_hip_batch_gradient_dev / rcn_hip_apply_gradient_dev itself.
+ * RCN_HIP_DP_FAULT="<stage>:<rank>,..." (stages export, attach, kat, ll, llskip) makes a rank fail a stage on purpose (tests). */
+typedef int (*rcn_hip_allgather_fn)(void* user, const void* mine, void* all, size_t bytes);
+typedef int (*rcn_hip_vote_min_fn)(void* user, int* v);
+int  rcn_hip_dp_p2p_admit(rcn_hip_ctx* ctx, int rank, int world, rcn_hip_allgather_fn allgather, rcn_hip_vote_min_fn vote_min, void* user);
 int  rcn_hip_dp_p2p_active(const rcn_hip_ctx* ctx);   /* 0 ncclAllReduce, 1 peer exchange at kernel boundaries, 2 also inside the gradient kernel */
 /* classify_test (rcn.rs:105-116) for n samples: a <- sigmoid(W a + b) through every layer. out: n x classes */
 int  rcn_hip_forward(rcn_hip_ctx* ctx, const double* x, size_t n, double* out);

@@ -73,6 +73,10 @@ SIGNATURES = {
     "rcn_hip_prepare_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
     "rcn_hip_train_epoch_images_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
     "rcn_hip_prepare_epoch_images_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
+    "rcn_hip_epoch_begin_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz]),
+    "rcn_hip_epoch_begin_images_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz]),
+    "rcn_hip_epoch_steps_dev": (_i, [_vp, _sz, _sz, _d, _vp]),
+    "rcn_hip_prepare_epoch_steps_dev": (_i, [_vp, _sz, _sz, _d, _vp]),
     "rcn_hip_shuffle_dev": (_i, [_vp, _vp, _sz, _sz, C.c_uint64]),
     "rcn_hip_batch_gradient_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "rcn_hip_batch_gradient_perm_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),
@@ -86,6 +90,7 @@ SIGNATURES = {
     "rcn_hip_dp_p2p_export": (_i, [_vp, _vp]),
     "rcn_hip_dp_p2p_attach": (_i, [_vp, _vp, _i, _i]),
     "rcn_hip_dp_p2p_selftest": (_i, [_vp, _i, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "rcn_hip_dp_p2p_admit": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "rcn_hip_dp_p2p_active": (_i, [_vp]),
     "rcn_hip_dp_prepare_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
     "rcn_hip_dp_train_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),

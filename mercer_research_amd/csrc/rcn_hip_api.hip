@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <new>
@@ -51,9 +52,9 @@ struct DevBuf {
 };
 
 struct EpochKey {
-    const void* X; const void* Y; const void* perm; size_t B; size_t nb; double eta; const void* loss;
+    const void* X; const void* Y; const void* perm; size_t B; size_t nb; double eta; const void* loss; size_t j0 = 0;
     bool operator<(const EpochKey& o) const {
-        return std::tie(X, Y, perm, B, nb, eta, loss) < std::tie(o.X, o.Y, o.perm, o.B, o.nb, o.eta, o.loss);
+        return std::tie(X, Y, perm, B, nb, eta, loss, j0) < std::tie(o.X, o.Y, o.perm, o.B, o.nb, o.eta, o.loss, o.j0);
     }
 };
 
@@ -85,11 +86,13 @@ struct rcn_hip_ctx {
     DevBuf stepx;                           // one-launch step (dense_p2_step.hpp): flags of the sample groups, then the tag word
     size_t stepx_B = 0;
     size_t packed_B = 0, packed_nb = 0;     // what the epoch image currently holds (k_pack_epoch)
+    size_t epoch_B = 0, epoch_nb = 0, epoch_seg = 0;   // rcn_hip_epoch_begin*_dev: the image holds batches 0..epoch_nb of a begun epoch
+                                                       // (epoch_nb = 0: none; any other call that re-packs the image ends it)
     void* pin_host = nullptr;               // small pinned, device-mapped staging block for the serving path (classify)
     void* pin_dev = nullptr;
     size_t pack_seg_bytes = (size_t)64 << 20;   // size of one half of the epoch image (env RCN_HIP_PACK_SEGMENT_BYTES, for tests)
     DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
-    std::map<EpochKey, hipGraphExec_t> graphs, dp_graphs, img_graphs;
+    std::map<EpochKey, hipGraphExec_t> graphs, dp_graphs, img_graphs, step_graphs;
     ncclComm_t comm = nullptr;              // data-parallel group (rcn_hip_dp_init); one rank per context
     int dp_rank = 0, dp_world = 1;
     struct P2P {                            // peer-read all-reduce over xGMI (dp_p2p.hpp)
@@ -274,15 +277,19 @@ int set_dyn_lds(rcn_hip_ctx* c, K kernel, size_t bytes) {
 
 // ---- dense launches ---------------------------------------------------------------------------------------------
 void drop_graphs(rcn_hip_ctx* c);
+void drop_img_graphs(rcn_hip_ctx* c);
 
 // Workspaces that captured hipGraphs point into: growing one moves it (DevBuf::ensure frees and reallocates), so every cached
 // graph -- whichever call shape it was captured for -- would replay on freed memory.  A moved workspace drops them all; they are
 // re-captured on demand.  (Found by running the benchmark with a warm-up shorter than the timed run.)
 hipError_t ws_ensure(rcn_hip_ctx* c, DevBuf& b, size_t bytes) {
-    const void* before = b.p;
-    const hipError_t e = b.ensure(bytes);
-    if (e == hipSuccess && before && b.p != before) drop_graphs(c);
-    return e;
+    // DevBuf::ensure frees the old block BEFORE it allocates the new one: the cached graphs must go first (they may still be
+    // in flight on the stream -- drop_graphs drains it), and they must go on the out-of-memory path too, where b.p ends up null
+    if (b.p && bytes > b.cap) {
+        drop_graphs(c);
+        if (&b == &c->xpack || &b == &c->ypack) c->epoch_nb = 0;      // a begun epoch's image goes with its buffer
+    }
+    return b.ensure(bytes);
 }
 
 int ensure_dense_ws(rcn_hip_ctx* c, size_t B) {
@@ -460,6 +467,7 @@ int launch_pack(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* per
     else hipLaunchKernelGGL((k_pack_epoch<T, false>), dim3(pack_grid_x(G), (unsigned)n), dim3(256), 0, c->stream, Xb, Yb, pb, (int)B, F, Cc, G, xs, ys);
     HIP_TRY(c, hipGetLastError());
     if (half == 0) { c->packed_B = B; c->packed_nb = n; }
+    c->epoch_nb = 0;                        // whatever epoch rcn_hip_epoch_begin_dev had laid out is overwritten
     return RCN_HIP_OK;
 }
 
@@ -519,6 +527,7 @@ int launch_feat_pack(rcn_hip_ctx* c, const uint8_t* imgs, const void* Y, const i
                            (T)c->sd, (T)0, xs, ys);
     HIP_TRY(c, hipGetLastError());
     if (half == 0) { c->packed_B = B; c->packed_nb = n; }
+    c->epoch_nb = 0;
     return RCN_HIP_OK;
 }
 
@@ -532,13 +541,15 @@ int ensure_pack_ws(rcn_hip_ctx* c, size_t B, size_t nb) {
 // nb consecutive train_batch steps through the feature-sliced pipeline: pack, A(F0) B0 A(U0,F1) B1 ... A(U_{nb-1}),
 // re-packing the next segment (into the other half of the image) just before the step that first needs it.
 // perm (nullable) holds nb*B sample indices; without it batch j is rows [jB, (j+1)B) of X / Y.
+// prepacked (rcn_hip_epoch_steps_dev): the image already holds the begun epoch (laid out with segment length pre_seg); the call
+// runs its batches j0 .. j0+nb and packs nothing.
 template <typename T>
 int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev,
-                       bool from_images = false) {
+                       bool from_images = false, bool prepacked = false, size_t j0 = 0, size_t pre_seg = 0) {
     const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L], es = c->esz();
     const double scale = eta / (double)B, loss_scale = 1.0 / (2.0 * (double)B);
-    const size_t seg = nb <= pack_segment(c, B) ? nb : pack_segment(c, B);
-    auto slot = [&](size_t j) { return ((j / seg) % 2) * seg + j % seg; };
+    const size_t seg = prepacked ? pre_seg : (nb <= pack_segment(c, B) ? nb : pack_segment(c, B));
+    auto slot = [&](size_t j) { j += j0; return ((j / seg) % 2) * seg + j % seg; };
     auto xb = [&](size_t j) { return (const void*)((const char*)c->xpack.p + slot(j) * G * B * 16 * es); };
     auto yb = [&](size_t j) { return (const void*)((const char*)c->ypack.p + slot(j) * B * Cc * es); };
     // from_images: X is the resident u8 picture set; features, standardisation and packing are one kernel per segment
@@ -558,12 +569,12 @@ int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32
             c->frag_on = true;
         }
     }
-    RCN_TRY(pack(0));
+    if (!prepacked) RCN_TRY(pack(0));
     RCN_TRY(launch_pipe_a<T>(c, xb(0), xb(0), B, scale, nullptr, loss_scale, false, true));
     for (size_t j = 0; j < nb; ++j) {
         RCN_TRY(launch_pipe_b<T>(c, yb(j), B));
         const bool more = j + 1 < nb;
-        if (more && (j + 1) % seg == 0) RCN_TRY(pack(j + 1));
+        if (!prepacked && more && (j + 1) % seg == 0) RCN_TRY(pack(j + 1));
         void* lj = loss_dev ? (char*)loss_dev + j * es : nullptr;
         RCN_TRY(launch_pipe_a<T>(c, xb(j), more ? xb(j + 1) : xb(j), B, scale, lj, loss_scale, true, more));
     }
@@ -723,6 +734,21 @@ int enqueue_train_step(rcn_hip_ctx* c, const void* x, const void* y, const int32
 
 int check_ctx(const rcn_hip_ctx* c) { return c ? RCN_HIP_OK : RCN_HIP_ERR_INVALID_ARG; }
 
+// The in-kernel waits (peer exchange, resident / one-launch step kernels) are bounded: a wait that expires sets a sticky
+// device word, every later kernel of that family drains, and the updates of the call are only partly applied.  The word is
+// copied back asynchronously at the end of each epoch call; after a stream synchronise it is current.  Every entry point
+// that tells the caller "the work is complete / here are the parameters" calls this behind its synchronise.
+int sticky_errors(rcn_hip_ctx* c) {
+    if (c->p2p.err_host && c->p2p.err_dev) {
+        if (*c->p2p.err_host != 0)
+            return fail(c, RCN_HIP_ERR_HIP, "data-parallel exchange: rank " + std::to_string(c->dp_rank) + " timed out waiting for peer data (sticky word " +
+                                                std::to_string(*c->p2p.err_host) + "); the last call's updates are incomplete and the replicas are no longer in step");
+    }
+    if (c->perr_host && *c->perr_host != 0)
+        return fail(c, RCN_HIP_ERR_HIP, "a bounded wait inside the resident / one-launch step kernel expired; the last call's updates are incomplete");
+    return RCN_HIP_OK;
+}
+
 int need_dense(rcn_hip_ctx* c) {
     if (!c->dense_err.empty()) return fail(c, RCN_HIP_ERR_SHAPE, c->dense_err);
     return RCN_HIP_OK;
@@ -737,6 +763,7 @@ int need_params(rcn_hip_ctx* c) {
 // ---- peer-read all-reduce plumbing (dp_p2p.hpp) ------------------------------------------------------------------
 void p2p_release(rcn_hip_ctx* c) {
     auto& q = c->p2p;
+    if (!c->dp_graphs.empty() && c->stream) (void)hipStreamSynchronize(c->stream);     // a replay may still be in flight
     for (auto& kv : c->dp_graphs) (void)hipGraphExecDestroy(kv.second);      // they hold pointers into the buffers freed below
     c->dp_graphs.clear();
     for (int r = 0; r < kP2PMaxWorld; ++r) {
@@ -814,7 +841,12 @@ P2PDesc p2p_desc(const rcn_hip_ctx* c) {
     return d;
 }
 
-constexpr long long kP2PTimeoutTicks = 100000000LL;        // 1 s of the 100 MHz wall clock
+// 1 s of the 100 MHz wall clock; RCN_HIP_DP_TIMEOUT_TICKS overrides it (the tests force a tiny one to see the sticky error surface)
+static long long p2p_timeout_ticks() {
+    const char* e = std::getenv("RCN_HIP_DP_TIMEOUT_TICKS");
+    const long long t = e ? std::atoll(e) : 0;
+    return t > 0 ? t : 100000000LL;
+}
 
 // one all-reduce step on the context's stream; mode 0 applies the update, mode 1 writes the raw sums to p2p.raw
 template <typename T>
@@ -872,7 +904,7 @@ int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const in
             hipLaunchKernelGGL((k_p2_dp_fused<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)xb(j),
                                (const T*)(more ? xb(j + 1) : xb(j)), (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, (int)G,
                                (const T*)c->loss_part.p, n_loss, (T)loss_scale, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev,
-                               kP2PTimeoutTicks, (T*)c->grad.p, c->frag_on ? (T*)c->fragimg.p : (T*)nullptr);
+                               p2p_timeout_ticks(), (T*)c->grad.p, c->frag_on ? (T*)c->fragimg.p : (T*)nullptr);
             HIP_TRY(c, hipGetLastError());
             continue;
         }
@@ -880,7 +912,7 @@ int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const in
                            (const T*)d2, (T*)q.local_buf, q.stride, seq_base, seq, (int)G, (const T*)c->loss_part.p, n_loss, (T)loss_scale);
         HIP_TRY(c, hipGetLastError());
         hipLaunchKernelGGL((k_p2_dp_apply<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)(more ? xb(j + 1) : xb(j)),
-                           (int)B, (T)scale, (T*)c->slab.p, (int)G, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev, kP2PTimeoutTicks);
+                           (int)B, (T)scale, (T*)c->slab.p, (int)G, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev, p2p_timeout_ticks());
         HIP_TRY(c, hipGetLastError());
     }
     return RCN_HIP_OK;
@@ -897,7 +929,7 @@ int p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* err)
     for (int it = 0; it < iters; ++it) {
         const unsigned seq = q.seq + 1;
         char* slot = (char*)q.local_buf + (size_t)(seq & 1u) * q.stride * es;
-        const long long to = it == 0 ? 10 * kP2PTimeoutTicks : kP2PTimeoutTicks;      // the first exchange absorbs start-up skew
+        const long long to = it == 0 ? 10 * p2p_timeout_ticks() : p2p_timeout_ticks();      // the first exchange absorbs start-up skew
         if (c->dtype == RCN_HIP_F64) {
             hipLaunchKernelGGL((k_p2p_fill<double>), dim3(48), dim3(256), 0, c->stream, (double*)slot, q.stride, c->dp_rank, seq);
             RCN_TRY(p2p_step<double>(c, 1, 0.0, nullptr, to));
@@ -930,9 +962,9 @@ int p2p_selftest_fused(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned
     for (int it = 0; it < iters; ++it) {
         const unsigned seq = ++q.seq;
         if (c->dtype == RCN_HIP_F64)
-            hipLaunchKernelGGL((k_p2p_ll_selftest<double>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, kP2PTimeoutTicks, (unsigned*)q.mism.p);
+            hipLaunchKernelGGL((k_p2p_ll_selftest<double>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, p2p_timeout_ticks(), (unsigned*)q.mism.p);
         else
-            hipLaunchKernelGGL((k_p2p_ll_selftest<float>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, kP2PTimeoutTicks, (unsigned*)q.mism.p);
+            hipLaunchKernelGGL((k_p2p_ll_selftest<float>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, p2p_timeout_ticks(), (unsigned*)q.mism.p);
         HIP_TRY(c, hipGetLastError());
     }
     unsigned host[2] = {0, 0};
@@ -944,7 +976,18 @@ int p2p_selftest_fused(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned
     return RCN_HIP_OK;
 }
 
+void drop_img_graphs(rcn_hip_ctx* c) {
+    if (c->img_graphs.empty()) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->img_graphs) (void)hipGraphExecDestroy(kv.second);
+    c->img_graphs.clear();
+}
+
 void drop_graphs(rcn_hip_ctx* c) {
+    // a replay may still be running on the stream: destroying its executable under it is a use-after-free
+    if (c->stream && !(c->graphs.empty() && c->dp_graphs.empty() && c->img_graphs.empty() && c->step_graphs.empty())) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->step_graphs) (void)hipGraphExecDestroy(kv.second);
+    c->step_graphs.clear();
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     for (auto& kv : c->dp_graphs) (void)hipGraphExecDestroy(kv.second);
@@ -1074,7 +1117,7 @@ int rcn_hip_synchronize(rcn_hip_ctx* c) {
     RCN_TRY(check_ctx(c));
     DevGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return RCN_HIP_OK;
+    return sticky_errors(c);
 }
 
 int rcn_hip_feature_len(const rcn_hip_ctx* c, int64_t* out) {
@@ -1124,6 +1167,7 @@ int rcn_hip_get_params(rcn_hip_ctx* c, int layer, double* W, double* b) {
     const size_t rows = c->nd.dims[layer + 1], cols = c->nd.dims[layer];
     std::vector<double> flat(rows * cols + rows);
     RCN_TRY(download(c, (char*)c->params.p + (size_t)c->nd.w_off[layer] * c->esz(), flat.data(), flat.size()));
+    RCN_TRY(sticky_errors(c));                 // download synchronised the stream: parameters of a timed-out call are not handed out as good
     std::memcpy(W, flat.data(), rows * cols * 8);
     std::memcpy(b, flat.data() + rows * cols, rows * 8);
     return RCN_HIP_OK;
@@ -1149,6 +1193,7 @@ int rcn_hip_params_dev(rcn_hip_ctx* c, void** p, int64_t* count) {
     if (!c || !p || !count) return RCN_HIP_ERR_INVALID_ARG;
     *p = c->params.p; *count = c->nd.P;
     c->params_set = true;      // the caller may fill the buffer directly (e.g. a DP broadcast)
+    if ((c->p2p.err_host && *c->p2p.err_host != 0) || (c->perr_host && *c->perr_host != 0)) return sticky_errors(c);   // no sync here: last known state
     return RCN_HIP_OK;
 }
 
@@ -1350,6 +1395,7 @@ static int gen_scales_impl(rcn_hip_ctx* c, const void* dev, size_t count, double
     const double mu = s / (double)count;                      // rcn.rs:240
     RCN_TRY(run(true, mu, &q));
     const double sdv = std::sqrt(q / (double)count);          // rcn.rs:247
+    if (mu != c->mean || sdv != c->sd) drop_img_graphs(c);    // captured feature launches carry the old scale_set by value
     c->mean = mu; c->sd = sdv;                                // rcn.rs:249-250
     if (mean) *mean = mu;
     if (sd) *sd = sdv;
@@ -1380,6 +1426,12 @@ int rcn_hip_gen_scales(rcn_hip_ctx* c, const double* feats, size_t n, double* me
 
 int rcn_hip_set_scale(rcn_hip_ctx* c, double mean, double sd) {
     RCN_TRY(check_ctx(c));
+    if (mean != c->mean || sd != c->sd) {
+        // the graphs of rcn_hip_train_epoch_images_dev hold (mean, sd, reciprocal, kernel variant) by value: a replay after
+        // this call would standardise with the old scale_set (rcn_hip.h promises the current one)
+        DevGuard g(c->device);
+        drop_img_graphs(c);
+    }
     c->mean = mean; c->sd = sd;
     return RCN_HIP_OK;
 }
@@ -1517,6 +1569,88 @@ int rcn_hip_prepare_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, cons
     return epoch_impl(c, X, Y, perm, B, nb, eta, loss_dev, false);
 }
 
+// ---- one epoch of RCN::train as the reference structures it: shuffle once (rcn.rs:146), then walk the chunks (rcn.rs:147-149) ----
+// begin: the shuffled order is materialised ONCE as the slice-major epoch image (k_pack_epoch, or the fused feature kernel from u8
+// pictures); steps: train_batch over batches j0 .. j0+n of that image, any number of calls, no re-packing.
+static int epoch_begin_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, bool from_images) {
+    RCN_TRY(check_ctx(c));
+    if (!X || !Y) return fail(c, RCN_HIP_ERR_INVALID_ARG, "epoch_begin: NULL pointer");
+    if (B == 0 || B > 0x7fffffffULL / 2) return fail(c, RCN_HIP_ERR_INVALID_ARG, "epoch_begin: batch size must be in 1..2^30");
+    RCN_TRY(need_dense(c));
+    c->epoch_nb = 0;
+    if (nb == 0) return RCN_HIP_OK;
+    if (!use_pipe(c, B) || (from_images && !feat_is_cpcp28(c)))
+        return fail(c, RCN_HIP_ERR_UNSUPPORTED, "epoch_begin: this layer stack / batch size does not run on the feature-sliced pipeline (or, from images, the "
+                                                  "conv/pool stack is not the default one on 28x28); use rcn_hip_train_epoch_dev");
+    const size_t seg = nb <= pack_segment(c, B) ? nb : pack_segment(c, B);
+    if (nb > 2 * seg)
+        return fail(c, RCN_HIP_ERR_UNSUPPORTED, "epoch_begin: the epoch image holds at most " + std::to_string(2 * seg) + " batches of this size; use "
+                                                  "rcn_hip_train_epoch_dev, which re-packs segment by segment");
+    DevGuard g(c->device);
+    RCN_TRY(ensure_dense_ws(c, B));
+    RCN_TRY(ensure_pipe_ws(c, B));
+    RCN_TRY(ensure_pack_ws(c, B, nb));
+    for (size_t j = 0; j < nb; j += seg) {
+        const size_t n = nb - j < seg ? nb - j : seg;
+        const int half = (int)((j / seg) % 2);
+        if (from_images)
+            RCN_TRY(c->dtype == RCN_HIP_F64 ? launch_feat_pack<double>(c, (const uint8_t*)X, Y, perm, B, j, n, half, seg)
+                                            : launch_feat_pack<float>(c, (const uint8_t*)X, Y, perm, B, j, n, half, seg));
+        else
+            RCN_TRY(c->dtype == RCN_HIP_F64 ? launch_pack<double>(c, X, Y, perm, B, j, n, half, seg) : launch_pack<float>(c, X, Y, perm, B, j, n, half, seg));
+    }
+    c->epoch_B = B; c->epoch_nb = nb; c->epoch_seg = seg;
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_epoch_begin_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb) {
+    return epoch_begin_impl(c, X, Y, perm, B, nb, false);
+}
+
+int rcn_hip_epoch_begin_images_dev(rcn_hip_ctx* c, const uint8_t* imgs, const void* Y, const int32_t* perm, size_t B, size_t nb) {
+    return epoch_begin_impl(c, imgs, Y, perm, B, nb, true);
+}
+
+static int epoch_steps_impl(rcn_hip_ctx* c, size_t j0, size_t n, double eta, void* loss_dev, bool launch) {
+    RCN_TRY(check_ctx(c));
+    if (c->epoch_nb == 0) return fail(c, RCN_HIP_ERR_STATE, "epoch_steps: no epoch begun (rcn_hip_epoch_begin_dev), or another training call has re-packed the image since");
+    if (j0 > c->epoch_nb || n > c->epoch_nb - j0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "epoch_steps: batches beyond the begun epoch");
+    if (n == 0) return RCN_HIP_OK;
+    RCN_TRY(need_params(c));
+    const size_t B = c->epoch_B, nb_epoch = c->epoch_nb, seg = c->epoch_seg;
+    DevGuard g(c->device);
+    RCN_TRY(ensure_dense_ws(c, B));
+    RCN_TRY(ensure_pipe_ws(c, B));
+    const EpochKey key{c->xpack.p, c->ypack.p, nullptr, B, n, eta, loss_dev, j0 + 1 + (seg << 32)};
+    auto it = c->step_graphs.find(key);
+    if (it == c->step_graphs.end()) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int st = c->dtype == RCN_HIP_F64 ? enqueue_pipe_steps<double>(c, nullptr, nullptr, nullptr, B, n, eta, loss_dev, false, true, j0, seg)
+                                               : enqueue_pipe_steps<float>(c, nullptr, nullptr, nullptr, B, n, eta, loss_dev, false, true, j0, seg);
+        hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        c->epoch_B = B; c->epoch_nb = nb_epoch; c->epoch_seg = seg;
+        if (st != RCN_HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+        HIP_TRY(c, e);
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(c, e);
+        if (c->step_graphs.size() >= 64) { drop_graphs(c); }
+        it = c->step_graphs.emplace(key, exec).first;
+    }
+    if (launch) HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_epoch_steps_dev(rcn_hip_ctx* c, size_t first_batch, size_t n_batches, double eta, void* loss_dev) {
+    return epoch_steps_impl(c, first_batch, n_batches, eta, loss_dev, true);
+}
+
+int rcn_hip_prepare_epoch_steps_dev(rcn_hip_ctx* c, size_t first_batch, size_t n_batches, double eta, void* loss_dev) {
+    return epoch_steps_impl(c, first_batch, n_batches, eta, loss_dev, false);
+}
+
 int rcn_hip_shuffle_dev(rcn_hip_ctx* c, int32_t* perm, size_t n, size_t passes, uint64_t seed) {
     RCN_TRY(check_ctx(c));
     if (!perm || n == 0 || n > 0x40000000ULL || passes == 0 || n * passes > 0xffffffffULL) return fail(c, RCN_HIP_ERR_INVALID_ARG, "shuffle: bad argument");
@@ -1583,45 +1717,55 @@ int rcn_hip_apply_gradient_dev(rcn_hip_ctx* c, const void* grad, double scale) {
             return fail(ctx, RCN_HIP_ERR_HIP, std::string(#expr) + ": " + rcn::Rccl::get().GetErrorString(r_)); \
     } while (0)
 
-// Sets up the peer-read all-reduce behind an existing RCCL communicator, and keeps it only if EVERY rank could map every
-// peer and a known-answer exchange came back exact on every rank.  Every rank executes the same collectives whatever
-// fails locally (a failure only lowers its vote), so a rank that cannot use xGMI peer reads makes the whole group stay
-// on ncclAllReduce instead of deadlocking it.
-static int p2p_bootstrap_over_rccl(rcn_hip_ctx* c) {
-    rcn::Rccl& r = rcn::Rccl::get();
+// ---- admission of the peer exchange -----------------------------------------------------------------------------------
+// Sets up the peer-read all-reduce for a group of ranks, and keeps it only if EVERY rank could map every peer and a known-answer
+// exchange came back exact on every rank; then asks the same of the in-kernel (tagged-word) form.  Every rank executes the same
+// sequence of collectives whatever fails locally (a failure only lowers its vote), so a rank that cannot use xGMI peer reads makes
+// the whole group stay on the previous form instead of deadlocking it.  The collectives come from a transport: RCCL on the
+// communicator of rcn_hip_dp_init, or two caller-supplied callbacks (rcn_hip_dp_p2p_admit: any out-of-band channel).
+//
+// Outcome (identical on every rank):  0 = no peer exchange (the loop uses ncclAllReduce, or the caller's own all-reduce),
+// 1 = peer exchange at kernel boundaries, 2 = peer exchange inside the gradient kernel.
+//
+// Fault injection for the tests, RCN_HIP_DP_FAULT="<stage>:<rank>[,<stage>:<rank>...]": the named rank behaves as if that stage had
+// failed locally -- export | attach | kat (known-answer mismatch) | ll (tagged-word self-test mismatch) | llskip (the rank never
+// launches its side of the tagged-word self-test, so its peers really time out).
+struct P2PTransport {
+    std::function<int(const void* mine, void* all, size_t bytes_per_rank)> allgather;     // host buffers, rank order
+    std::function<int(int& v)> vote_min;                                                    // v <- min over ranks
+};
+
+static bool p2p_fault(const rcn_hip_ctx* c, const char* stage) {
+    const char* e = std::getenv("RCN_HIP_DP_FAULT");
+    if (!e) return false;
+    const std::string want = std::string(stage) + ":" + std::to_string(c->dp_rank);
+    std::string all(e);
+    size_t pos = 0;
+    while (pos <= all.size()) {
+        const size_t end = all.find(',', pos);
+        if (all.substr(pos, end == std::string::npos ? std::string::npos : end - pos) == want) return true;
+        if (end == std::string::npos) break;
+        pos = end + 1;
+    }
+    return false;
+}
+
+static int p2p_admission(rcn_hip_ctx* c, const P2PTransport& t) {
     const int world = c->dp_world, rank = c->dp_rank;
-    DevBuf xch;
-    HIP_TRY(c, xch.ensure((size_t)(world + 1) * kP2PHandleBytes + 64));
-    char* d_all = (char*)xch.p;
-    char* d_mine = d_all + (size_t)world * kP2PHandleBytes;
-    int* d_vote = (int*)(d_mine + kP2PHandleBytes);
     char mine[kP2PHandleBytes] = {};
-    int ok = p2p_export(c, mine) == RCN_HIP_OK ? 1 : 0;
+    int ok = (p2p_export(c, mine) == RCN_HIP_OK && !p2p_fault(c, "export")) ? 1 : 0;
     std::vector<char> all((size_t)world * kP2PHandleBytes);
-    auto vote = [&](int& v) -> int {          // v <- min over ranks
-        HIP_TRY(c, hipMemcpyAsync(d_vote, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
-        NCCL_TRY(c, r.AllReduce(d_vote, d_vote, 1, ncclInt, ncclMin, c->comm, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&v, d_vote, sizeof v, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        return RCN_HIP_OK;
-    };
     int st = RCN_HIP_OK;
     do {
-        if ((st = [&]() -> int {
-                HIP_TRY(c, hipMemcpyAsync(d_mine, mine, kP2PHandleBytes, hipMemcpyHostToDevice, c->stream));
-                NCCL_TRY(c, r.AllGather(d_mine, d_all, kP2PHandleBytes, ncclChar, c->comm, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                return RCN_HIP_OK;
-            }()) != RCN_HIP_OK) break;
-        if ((st = vote(ok)) != RCN_HIP_OK) break;            // did every rank export?
+        if ((st = t.allgather(mine, all.data(), kP2PHandleBytes)) != RCN_HIP_OK) break;
+        if ((st = t.vote_min(ok)) != RCN_HIP_OK) break;          // did every rank export?
         if (!ok) break;
-        ok = p2p_attach(c, all.data(), rank, world) == RCN_HIP_OK ? 1 : 0;
-        if ((st = vote(ok)) != RCN_HIP_OK) break;            // did every rank map every peer?
+        ok = (p2p_attach(c, all.data(), rank, world) == RCN_HIP_OK && !p2p_fault(c, "attach")) ? 1 : 0;
+        if ((st = t.vote_min(ok)) != RCN_HIP_OK) break;          // did every rank map every peer?
         if (!ok) break;
         unsigned bad = 0, err = 0;
-        ok = (p2p_selftest(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0) ? 1 : 0;
-        if ((st = vote(ok)) != RCN_HIP_OK) break;            // did every rank see exact sums, without a timeout?
+        ok = (p2p_selftest(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "kat")) ? 1 : 0;
+        if ((st = t.vote_min(ok)) != RCN_HIP_OK) break;          // did every rank see exact sums, without a timeout?
         if (!ok) break;
         c->p2p.on = true;
         // second, independent question: may the exchange also run INSIDE the gradient kernel (tagged words, no flags)?  A failed
@@ -1629,16 +1773,48 @@ static int p2p_bootstrap_over_rccl(rcn_hip_ctx* c) {
         // (after every rank has drained: the vote synchronises) when only this stage failed.
         const char* fe = std::getenv("RCN_HIP_DP_FUSED");
         int okf = (fe && fe[0] == '0') ? 0 : 1;
-        if ((st = vote(okf)) != RCN_HIP_OK) break;           // every rank must want it (same environment everywhere, normally)
+        if ((st = t.vote_min(okf)) != RCN_HIP_OK) break;         // every rank must want it (same environment everywhere, normally)
         if (!okf) break;
-        okf = (p2p_selftest_fused(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0) ? 1 : 0;
-        if ((st = vote(okf)) != RCN_HIP_OK) break;
+        if (p2p_fault(c, "llskip")) { c->p2p.seq += 16; okf = 0; }         // this rank stays silent: its peers' waits expire
+        else okf = (p2p_selftest_fused(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "ll")) ? 1 : 0;
+        if ((st = t.vote_min(okf)) != RCN_HIP_OK) break;
         if (okf) c->p2p.fused = true;
-        else if (hipMemsetAsync(c->p2p.err_dev, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) c->p2p.on = false;
+        else {
+            // every rank has drained (the vote synchronised them); clear the sticky word and the pinned mirror of it
+            if (hipMemsetAsync(c->p2p.err_dev, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) c->p2p.on = false;
+            if (c->p2p.err_host) *c->p2p.err_host = 0;
+        }
     } while (0);
-    xch.release();
     if (!c->p2p.on) { const int rk = c->dp_rank, w = c->dp_world; p2p_release(c); c->dp_rank = rk; c->dp_world = w; }
-    c->err.clear();                                          // a failed attempt is not an error: the loop runs on ncclAllReduce
+    c->err.clear();                                              // a failed attempt is not an error: the loop runs on the previous form
+    return st;
+}
+
+static int p2p_bootstrap_over_rccl(rcn_hip_ctx* c) {
+    rcn::Rccl& r = rcn::Rccl::get();
+    const int world = c->dp_world;
+    DevBuf xch;
+    HIP_TRY(c, xch.ensure((size_t)(world + 1) * kP2PHandleBytes + 64));
+    char* d_all = (char*)xch.p;
+    char* d_mine = d_all + (size_t)world * kP2PHandleBytes;
+    int* d_vote = (int*)(d_mine + kP2PHandleBytes);
+    P2PTransport t;
+    t.vote_min = [&](int& v) -> int {
+        HIP_TRY(c, hipMemcpyAsync(d_vote, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+        NCCL_TRY(c, r.AllReduce(d_vote, d_vote, 1, ncclInt, ncclMin, c->comm, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&v, d_vote, sizeof v, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return RCN_HIP_OK;
+    };
+    t.allgather = [&](const void* mine, void* all, size_t bytes) -> int {
+        HIP_TRY(c, hipMemcpyAsync(d_mine, mine, bytes, hipMemcpyHostToDevice, c->stream));
+        NCCL_TRY(c, r.AllGather(d_mine, d_all, bytes, ncclChar, c->comm, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(all, d_all, (size_t)world * bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return RCN_HIP_OK;
+    };
+    const int st = p2p_admission(c, t);
+    xch.release();
     return st;
 }
 
@@ -1676,15 +1852,24 @@ int rcn_hip_dp_finalize(rcn_hip_ctx* c) {
     RCN_TRY(check_ctx(c));
     DevGuard g(c->device);
     if (!c->comm) {
-        if (c->p2p.exported) { HIP_TRY(c, hipStreamSynchronize(c->stream)); p2p_release(c); c->dp_rank = 0; c->dp_world = 1; }
+        if (c->p2p.exported) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const int sticky = sticky_errors(c);
+            const std::string sticky_msg = c->err;
+            p2p_release(c); c->dp_rank = 0; c->dp_world = 1;
+            if (sticky != RCN_HIP_OK) return fail(c, sticky, sticky_msg);
+        }
         return RCN_HIP_OK;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int sticky = sticky_errors(c);        // reported, but the group is torn down all the same
+    const std::string sticky_msg = c->err;
     NCCL_TRY(c, rcn::Rccl::get().CommDestroy(c->comm));
     c->comm = nullptr;
     p2p_release(c);
     c->dp_rank = 0;
     c->dp_world = 1;
+    if (sticky != RCN_HIP_OK) return fail(c, sticky, sticky_msg);
     return RCN_HIP_OK;
 }
 
@@ -1722,6 +1907,26 @@ int rcn_hip_dp_p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, uns
     *mismatches += bad2;
     *timed_out |= to2;
     return RCN_HIP_OK;
+}
+
+int rcn_hip_dp_p2p_admit(rcn_hip_ctx* c, int rank, int world, rcn_hip_allgather_fn allgather, rcn_hip_vote_min_fn vote_min, void* user) {
+    RCN_TRY(check_ctx(c));
+    if (!allgather || !vote_min || world < 1 || world > kP2PMaxWorld || rank < 0 || rank >= world)
+        return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_p2p_admit: bad callbacks / rank / world (1..8 ranks)");
+    RCN_TRY(need_dense(c));
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    p2p_release(c);
+    c->dp_rank = rank;
+    c->dp_world = world;
+    P2PTransport t;
+    t.allgather = [&](const void* mine, void* all, size_t bytes) -> int {
+        return allgather(user, mine, all, bytes) == 0 ? RCN_HIP_OK : fail(c, RCN_HIP_ERR_HIP, "dp_p2p_admit: the caller's allgather failed");
+    };
+    t.vote_min = [&](int& v) -> int {
+        return vote_min(user, &v) == 0 ? RCN_HIP_OK : fail(c, RCN_HIP_ERR_HIP, "dp_p2p_admit: the caller's vote failed");
+    };
+    return p2p_admission(c, t);
 }
 
 int rcn_hip_dp_p2p_active(const rcn_hip_ctx* c) { return c && c->p2p.on ? (c->p2p.fused ? 2 : 1) : 0; }
@@ -1811,11 +2016,11 @@ static int dp_epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int
             if (f64) {
                 RCN_TRY(launch_fwd<double>(c, true, xb, yb, ib, B, nullptr));
                 RCN_TRY(launch_wgrad<double>(c, false, xb, ib, B, 0.0, slot, slot + P * es, loss_scale));
-                RCN_TRY(p2p_step<double>(c, 0, scale, lj, kP2PTimeoutTicks));
+                RCN_TRY(p2p_step<double>(c, 0, scale, lj, p2p_timeout_ticks()));
             } else {
                 RCN_TRY(launch_fwd<float>(c, true, xb, yb, ib, B, nullptr));
                 RCN_TRY(launch_wgrad<float>(c, false, xb, ib, B, 0.0, slot, slot + P * es, loss_scale));
-                RCN_TRY(p2p_step<float>(c, 0, scale, lj, kP2PTimeoutTicks));
+                RCN_TRY(p2p_step<float>(c, 0, scale, lj, p2p_timeout_ticks()));
             }
         }
         HIP_TRY(c, hipMemcpyAsync(c->p2p.err_host, c->p2p.err_dev, 4, hipMemcpyDeviceToHost, c->stream));   // read at the next call

@@ -65,7 +65,8 @@ class DeviceRCN:
             return t.to(dtype) if dtype is not None else t
 
     def synchronize(self):
-        self.stream.synchronize()
+        """Waits for the context's stream and surfaces a sticky in-kernel timeout of the last call (rcn_hip_synchronize)."""
+        self._ck(self.lib.rcn_hip_synchronize(self.ctx))
 
     def set_dense_path(self, mode: int):
         self.rcn.set_dense_path(mode)
@@ -136,6 +137,20 @@ class DeviceRCN:
         fn = self.lib.rcn_hip_prepare_epoch_images_dev if prepare_only else self.lib.rcn_hip_train_epoch_images_dev
         self._ck(fn(self.ctx, _p(imgs_u8), _p(Y), _p(perm), B, n_batches, float(eta), _p(loss)))
 
+    def epoch_begin(self, X: torch.Tensor, Y: torch.Tensor, perm: Optional[torch.Tensor], B: int, n_batches: int):
+        """training_set.shuffle + chunks_exact (rcn.rs:146-147) materialised once: batches 0..n_batches of (X, Y, perm) become the
+        training kernels' epoch image; epoch_steps then walks them without packing again."""
+        if X.dtype == torch.uint8:
+            assert X.is_contiguous()
+            self._ck(self.lib.rcn_hip_epoch_begin_images_dev(self.ctx, _p(X), _p(Y), _p(perm), B, n_batches))
+        else:
+            self._ck(self.lib.rcn_hip_epoch_begin_dev(self.ctx, _p(X), _p(Y), _p(perm), B, n_batches))
+
+    def epoch_steps(self, first_batch: int, n_batches: int, eta: float, loss: Optional[torch.Tensor] = None, prepare_only: bool = False):
+        """train_batch (rcn.rs:176-223) over batches first_batch .. first_batch + n_batches of the begun epoch."""
+        fn = self.lib.rcn_hip_prepare_epoch_steps_dev if prepare_only else self.lib.rcn_hip_epoch_steps_dev
+        self._ck(fn(self.ctx, first_batch, n_batches, float(eta), _p(loss)))
+
     def shuffle(self, perm: torch.Tensor, n: int, passes: int, seed: int):
         """training_set.shuffle (rcn.rs:146) on the device: `passes` pseudo-random permutations of 0..n-1 into perm."""
         assert perm.dtype == torch.int32 and perm.numel() >= n * passes
@@ -201,6 +216,36 @@ class DeviceRCN:
         bad, to = C.c_uint(), C.c_uint()
         self._ck(self.lib.rcn_hip_dp_p2p_selftest(self.ctx, selftest_iters, C.byref(bad), C.byref(to)))
         return int(bad.value), int(to.value)
+
+    def dp_p2p_admit(self, group=None) -> int:
+        """rcn_hip_dp_init's admission procedure (export -> gather -> attach -> known-answer votes) with torch.distributed (any
+        backend, e.g. gloo) as the transport instead of RCCL.  Collective.  Returns the admitted form: 0 none, 1 peer exchange at
+        kernel boundaries, 2 inside the gradient kernel -- the same on every rank."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+        VM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int))
+
+        def allgather(_user, mine, allp, nbytes):
+            try:
+                box = [None] * world
+                dist.all_gather_object(box, C.string_at(mine, nbytes), group=group)
+                C.memmove(allp, b"".join(box), nbytes * world)
+                return 0
+            except Exception:
+                return 1
+
+        def vote_min(_user, v):
+            try:
+                t = torch.tensor([v[0]], dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                v[0] = int(t.item())
+                return 0
+            except Exception:
+                return 1
+        ag, vm = AG(allgather), VM(vote_min)
+        self._ck(self.lib.rcn_hip_dp_p2p_admit(self.ctx, rank, world, C.cast(ag, C.c_void_p), C.cast(vm, C.c_void_p), None))
+        return self.dp_p2p_mode()
 
     def dp_finalize(self):
         self._ck(self.lib.rcn_hip_dp_finalize(self.ctx))

@@ -85,6 +85,11 @@ extern "C" {
                                    eta: c_double, loss_dev: *mut c_void) -> c_int;
     pub fn rcn_hip_prepare_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b: usize, n_batches: usize,
                                      eta: c_double, loss_dev: *mut c_void) -> c_int;
+    // one epoch as the reference structures it: shuffle once (rcn.rs:146), then walk the chunks (rcn.rs:147-149)
+    pub fn rcn_hip_epoch_begin_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b: usize, n_batches: usize) -> c_int;
+    pub fn rcn_hip_epoch_begin_images_dev(ctx: *mut rcn_hip_ctx, imgs: *const u8, y: *const c_void, perm: *const i32, b: usize, n_batches: usize) -> c_int;
+    pub fn rcn_hip_epoch_steps_dev(ctx: *mut rcn_hip_ctx, first_batch: usize, n_batches: usize, eta: c_double, loss_dev: *mut c_void) -> c_int;
+    pub fn rcn_hip_prepare_epoch_steps_dev(ctx: *mut rcn_hip_ctx, first_batch: usize, n_batches: usize, eta: c_double, loss_dev: *mut c_void) -> c_int;
     pub fn rcn_hip_shuffle_dev(ctx: *mut rcn_hip_ctx, perm_dev: *mut i32, n: usize, passes: usize, seed: u64) -> c_int; // rcn.rs:146
     pub fn rcn_hip_batch_gradient_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, b: usize, grad: *mut c_void, loss_sum: *mut c_void) -> c_int;
     pub fn rcn_hip_batch_gradient_perm_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b: usize, grad: *mut c_void,
@@ -103,6 +108,9 @@ extern "C" {
     pub fn rcn_hip_dp_p2p_export(ctx: *mut rcn_hip_ctx, handles_out: *mut c_void) -> c_int;
     pub fn rcn_hip_dp_p2p_attach(ctx: *mut rcn_hip_ctx, all_handles: *const c_void, rank: c_int, world: c_int) -> c_int;
     pub fn rcn_hip_dp_p2p_selftest(ctx: *mut rcn_hip_ctx, iters: c_int, mismatches: *mut u32, timed_out: *mut u32) -> c_int;
+    pub fn rcn_hip_dp_p2p_admit(ctx: *mut rcn_hip_ctx, rank: c_int, world: c_int,
+                                allgather: Option<unsafe extern "C" fn(user: *mut c_void, mine: *const c_void, all: *mut c_void, bytes: usize) -> c_int>,
+                                vote_min: Option<unsafe extern "C" fn(user: *mut c_void, v: *mut c_int) -> c_int>, user: *mut c_void) -> c_int;
     pub fn rcn_hip_dp_p2p_active(ctx: *const rcn_hip_ctx) -> c_int;
     pub fn rcn_hip_set_feature_kernel(ctx: *mut rcn_hip_ctx, mode: c_int) -> c_int;
     pub fn rcn_hip_dp_prepare_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b_shard: usize, n_batches: usize,

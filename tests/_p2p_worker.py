@@ -1,7 +1,18 @@
-"""Worker of test_gpu_parity.test_peer_allreduce_two_processes_one_gpu: one data-parallel rank.  Run as
-python tests/_p2p_worker.py <rank> <world> <port> <dtype> <outdir>; ranks share GPU 0 (the dev box has one), which
-exercises the whole protocol -- hipIpc export/attach, flags, double buffering, rank-order sums -- except the
-cross-device memory path itself (that is what rcn_hip_dp_init's known-answer vote checks on a multi-GPU node)."""
+"""Worker of the multi-process peer-exchange tests (test_gpu_parity.test_peer_allreduce_two_processes_one_gpu and
+test_gpu_round2): one data-parallel rank.  Run as
+    python tests/_p2p_worker.py <rank> <world> <port> <dtype> <outdir> [case]
+ranks share GPU 0 (the dev box has one), which exercises the whole protocol -- hipIpc export/attach, flags, double buffering,
+rank-order sums, the admission votes -- except the cross-device memory path itself (that is what rcn_hip_dp_init's known-answer
+vote checks on a multi-GPU node).
+
+cases:
+  default   explicit handle exchange (rcn_hip_dp_p2p_export / _attach / _selftest), two epochs of the sharded loop
+  admit     the SAME admission procedure rcn_hip_dp_init runs (rcn_hip_dp_p2p_admit, votes after every stage) over gloo; the
+            environment's RCN_HIP_DP_FAULT makes one rank fail a stage; whatever form is admitted, two epochs are trained -- on the
+            library's loop when a peer exchange was admitted, else by all-reducing rcn_hip_batch_gradient_dev's buffer through gloo
+  sticky    rank 1 leaves after one step; rank 0's second step waits for data that never comes (20 ms timeout) and every
+            "the work is done" entry point must say so
+"""
 import os
 import sys
 
@@ -13,8 +24,11 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, dtype, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    case_name = sys.argv[6] if len(sys.argv) > 6 else "default"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
     import torch.distributed as dist
+    import mercer_research_amd as amd
     from mercer_research_amd.device import DeviceRCN
     from oracle.rcn_oracle import synthetic_params     # data generator only
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -24,14 +38,66 @@ def main():
     ws = [w * 0.1 for w in ws]
     d = DeviceRCN(feedforward_cfg=dims[1:-1], classes=dims[-1], dtype=dtype)
     d.set_params(ws, bs)
-    bad, timed_out = d.dp_p2p_setup(selftest_iters=12)
     X, Y = d.to_device(case[f"X{rank}"], d.tdtype), d.to_device(case[f"Y{rank}"], d.tdtype)
     loss = d.empty(nb)
-    d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, loss)
-    d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, None)           # a second call: sequence numbers carry over
+
+    if case_name == "sticky":
+        mode = d.dp_p2p_admit()
+        assert mode != 0, "the peer exchange was not admitted"
+        d.dp_train_epoch(X, Y, None, Bs, 1, 3.0, None)             # one healthy step on both ranks
+        d.synchronize()
+        dist.barrier()
+        said = {}
+        if rank == 0:
+            os.environ["RCN_HIP_DP_TIMEOUT_TICKS"] = "2000000"     # 20 ms of the 100 MHz clock, read when the next call is enqueued
+            d.dp_train_epoch(X, Y, None, Bs, 1, 3.0, None)         # rank 1 never runs this step
+            for name, fn in (("synchronize", d.synchronize), ("get_params", d.get_params), ("finalize", d.dp_finalize)):
+                try:
+                    fn()
+                    said[name] = "ok"
+                except amd.RcnHipError as e:
+                    said[name] = "error"
+                    assert "timed out" in str(e) or "expired" in str(e), str(e)
+            print("STICKY " + " ".join(f"{k}={v}" for k, v in said.items()), flush=True)
+        dist.barrier()                                             # rank 1 keeps its buffers mapped until rank 0 has given up
+        if rank != 0:
+            d.dp_finalize()
+        d.rcn.close()
+        dist.destroy_process_group()
+        return
+
+    if case_name == "admit":
+        bad = timed_out = 0
+        mode = d.dp_p2p_admit()
+        modes = [None] * world
+        dist.all_gather_object(modes, mode)
+        assert len(set(modes)) == 1, f"ranks disagree on the admitted form: {modes}"
+    else:
+        bad, timed_out = d.dp_p2p_setup(selftest_iters=12)
+        mode = d.dp_p2p_mode()
+
+    if mode != 0:
+        d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, loss)
+        d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, None)           # a second call: sequence numbers carry over
+    else:
+        # no exchange admitted: the data-parallel halves of train_batch with the caller's own all-reduce (here: gloo via the host)
+        grad = d.empty(d.P)
+        ls = d.empty(1)
+        for ep in range(2):
+            for j in range(nb):
+                d.batch_gradient(X[j * Bs:(j + 1) * Bs], Y[j * Bs:(j + 1) * Bs], grad, ls)
+                d.synchronize()
+                g, l = grad.cpu(), ls.cpu()
+                dist.all_reduce(g)
+                dist.all_reduce(l)
+                with torch.cuda.stream(d.stream):
+                    grad.copy_(g.to(d.device))
+                    if ep == 0:
+                        loss[j] = float(l.item()) / (2.0 * Bs * world)
+                d.apply_gradient(grad, 3.0 / (Bs * world))
     gw, gb = d.get_params()
     d.synchronize()
-    np.savez(os.path.join(outdir, f"out{rank}.npz"), bad=bad, timed_out=timed_out, active=d.dp_p2p_mode(), loss=loss.cpu().numpy(),
+    np.savez(os.path.join(outdir, f"out{rank}.npz"), bad=bad, timed_out=timed_out, active=mode, loss=loss.cpu().numpy(),
              **{f"w{i}": w for i, w in enumerate(gw)}, **{f"b{i}": b for i, b in enumerate(gb)})
     dist.barrier()                                             # nobody unmaps while a peer may still read
     d.dp_finalize()

@@ -1,0 +1,379 @@
+"""GPU tests added in round 2 (run with -m gpu on an MI355X), all through the C ABI:
+
+* the >= 200-step loss-curve parity check on the BENCH workload (BASELINE.json north_star "at matched loss curve");
+* rcn_hip_epoch_begin_dev / rcn_hip_epoch_steps_dev == rcn_hip_train_epoch_dev bit for bit;
+* regressions for the round-1 advisor findings (stale image-epoch graphs after a scale change, sticky in-kernel timeouts
+  surfacing from synchronize / get_params, graphs dropped when a workspace is released);
+* the statistics of rcn_hip_init_params (rcn.rs:500-523: every W then b of a layer ~ N(0,1), un-scaled).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.rcn_oracle import DEFAULT_LAYERS, one_hot, synthetic_images, synthetic_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BENCH_B, BENCH_N, BENCH_ETA, BENCH_DIMS = 256, 16384, 3.0, [784, 30, 10]
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import mercer_research_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def bench_workload(oracle):
+    """bench.py's workload on the CPU side: 16 384 synthetic pictures (seed 1234) -> oracle features -> standardised; N(0,1)
+    parameters of seed 42 (un-scaled, rcn.rs:500-523)."""
+    imgs, labels = synthetic_images(BENCH_N, seed=1234)
+    feats = oracle.features(imgs, DEFAULT_LAYERS)
+    m, s = oracle.gen_scales(feats)
+    X, Y = oracle.standardize(feats, m, s), one_hot(labels)
+    ws, bs = synthetic_params(BENCH_DIMS, seed=42)
+    return imgs, labels, X, Y, ws, bs
+
+
+def _oracle_curve(oracle, X, Y, ws, bs, perms, nb, B, eta):
+    h = oracle.net(ws, bs)
+    costs = []
+    for p in perms:
+        for j in range(nb):
+            idx = p[j * B:(j + 1) * B]
+            xb, yb = np.ascontiguousarray(X[idx]), np.ascontiguousarray(Y[idx])
+            costs.append(oracle.lib.rcn_o_train_batch(C.byref(h.net), xb.ctypes.data_as(C.POINTER(C.c_double)), yb.ctypes.data_as(C.POINTER(C.c_double)), B, eta))
+    return np.array(costs), h.weights(), h.biases()
+
+
+# f32 envelope of the curve (measured on MI355X, stated here because the tolerance belongs in the test): eta = 3 on un-scaled
+# N(0,1) parameters saturates the sigmoids (|z_1| ~ sqrt(784) |x|), every step is a large move and f32 rounding differences
+# are amplified along the trajectory.  Per-step parity from identical parameters is tight (test_gpu_parity: 1e-5); along 256
+# chained steps the f32 cost stays within F32_CURVE_RTOL of the f64 restatement's at every step and within F32_MEAN_RTOL on
+# the mean over the curve.  SURVEY §8(c)'s 1e-3 is the bar for the first F32_TIGHT_STEPS steps.
+F32_TIGHT_STEPS, F32_TIGHT_RTOL = 32, 1e-3
+F32_CURVE_RTOL, F32_MEAN_RTOL = 5e-2, 5e-3
+
+
+@pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
+def test_loss_curve_256_steps_on_the_bench_workload_matches_the_cpu_restatement(amd, oracle, bench_workload, dtype):
+    """256 consecutive train_batch steps of bench.py's workload (B = 256, eta = 3.0, synthetic_params(seed = 42), 16 384 synthetic
+    pictures, four device-shuffled epochs through rcn_hip_epoch_begin_dev / rcn_hip_epoch_steps_dev -- the loop bench.py times) with
+    the per-step quadratic cost recorded, against oracle/rcn_oracle.c's train_batch (rcn.rs:176-223, f64) on the identical
+    batches in the identical order.  f64 context: <= 1e-9 relative at every step and on the final parameters."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    imgs, labels, X, Y, ws, bs = bench_workload
+    B, nb, steps = BENCH_B, BENCH_N // BENCH_B, 256
+    d = DeviceRCN(dtype=dtype)
+    d.set_params(ws, bs)
+    imgs_d, labels_d = d.to_device(imgs), d.to_device(labels)
+    Xd, Yd = d.load_data(imgs_d, labels_d)                      # HIP features + gen_scales + standardise
+    assert np.allclose(Xd.double().cpu().numpy(), X, rtol=1e-5 if dtype == 0 else 1e-10, atol=1e-6 if dtype == 0 else 1e-12)   # (x - mean) / sd cancels near the mean
+    perm = torch.empty(BENCH_N, dtype=torch.int32, device=d.device)
+    loss = d.empty(steps)
+    perms = []
+    for e in range(steps // nb):
+        d.shuffle(perm, BENCH_N, 1, seed=0xC0FFEE + e)
+        d.synchronize()
+        perms.append(perm.cpu().numpy().astype(np.int64))
+        assert np.array_equal(np.sort(perms[-1]), np.arange(BENCH_N))
+        d.epoch_begin(Xd, Yd, perm, B, nb)
+        d.epoch_steps(0, 40, BENCH_ETA, loss[e * nb:])           # an epoch walked in two pieces, as a session interrupted mid-epoch
+        d.epoch_steps(40, nb - 40, BENCH_ETA, loss[e * nb + 40:])
+    gw, gb = d.get_params()
+    gpu = loss.double().cpu().numpy()
+    d.rcn.close()
+    cpu, rw, rb = _oracle_curve(oracle, X, Y, ws, bs, perms, nb, B, BENCH_ETA)
+    assert np.all(np.isfinite(gpu)) and np.all(np.isfinite(cpu))
+    rel = np.abs(gpu - cpu) / np.abs(cpu)
+    if dtype == 1:
+        assert rel.max() <= 1e-9, (rel.max(), int(rel.argmax()))
+        for a, b in zip(gw + gb, rw + rb):
+            assert np.all(np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-10)
+    else:
+        assert rel[:F32_TIGHT_STEPS].max() <= F32_TIGHT_RTOL, (rel[:F32_TIGHT_STEPS].max(), int(rel[:F32_TIGHT_STEPS].argmax()))
+        assert rel.max() <= F32_CURVE_RTOL, (rel.max(), int(rel.argmax()))
+        assert abs(gpu.mean() - cpu.mean()) <= F32_MEAN_RTOL * cpu.mean()
+    # the curve is a training curve: the cost at the end is below the cost at the start on both sides
+    assert gpu[-16:].mean() < gpu[:16].mean() and cpu[-16:].mean() < cpu[:16].mean()
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "f64"])
+def test_epoch_begin_steps_equals_train_epoch_bit_for_bit(amd, dtype, monkeypatch):
+    """rcn_hip_epoch_begin_dev + any split of rcn_hip_epoch_steps_dev == rcn_hip_train_epoch_dev over the same batches: same
+    kernels on the same image, so the parameters and the recorded costs are identical bit for bit -- including an epoch that
+    spans both segments of the image, and from u8 pictures (rcn_hip_epoch_begin_images_dev)."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(5 * 49 * 256 * 16 * (8 if dtype == 1 else 4)))     # 5 batches per segment
+    B, nb, N = 256, 9, 2560
+    imgs, labels = synthetic_images(N, seed=31)
+    ws, bs = synthetic_params(BENCH_DIMS, seed=3)
+    ws = [w * 0.1 for w in ws]
+    perm_h = np.random.default_rng(8).permutation(N).astype(np.int32)
+    out = {}
+    for form in ("train_epoch", "begin_steps", "begin_steps_images", "train_epoch_images"):
+        d = DeviceRCN(dtype=dtype)
+        d.set_params(ws, bs)
+        dev = d.to_device(imgs)
+        raw = d.features(dev)
+        d.gen_scales(raw)
+        Xd = d.features(dev, standardize=True)
+        Yd = d.to_device(one_hot(labels), d.tdtype)
+        perm = d.to_device(perm_h)
+        loss = d.empty(nb)
+        if form == "train_epoch":
+            d.train_epoch(Xd, Yd, perm, B, nb, 3.0, loss)
+        elif form == "train_epoch_images":
+            d.train_epoch_images(dev, Yd, perm, B, nb, 3.0, loss)
+        else:
+            d.epoch_begin(dev if form.endswith("images") else Xd, Yd, perm, B, nb)
+            for j0, n in ((0, 1), (1, 3), (4, 0), (4, 5)):           # crosses the segment boundary at batch 5 inside the last piece
+                d.epoch_steps(j0, n, 3.0, loss[j0:] if n else None)
+            d.epoch_steps(4, 5, 3.0, None, prepare_only=True)        # instantiating again is a no-op
+        gw, gb = d.get_params()
+        out[form] = (gw + gb, loss.cpu().numpy().copy())
+        if form == "begin_steps":
+            with pytest.raises(amd.RcnHipError):
+                d.epoch_steps(8, 2, 3.0, None)                       # beyond the begun epoch
+            d.train_batch(Xd[:B], Yd[:B], 3.0, None)                 # re-packs the image: the begun epoch is over
+            with pytest.raises(amd.RcnHipError):
+                d.epoch_steps(0, 1, 3.0, None)
+        d.rcn.close()
+    ref = out["train_epoch"]
+    for form in ("begin_steps", "begin_steps_images", "train_epoch_images"):
+        for a, b in zip(out[form][0], ref[0]):
+            assert np.array_equal(a, b), form
+        assert np.array_equal(out[form][1], ref[1]), form
+
+
+def test_epoch_begin_is_refused_where_the_pipeline_does_not_run(amd):
+    from mercer_research_amd.device import DeviceRCN
+    ws, bs = synthetic_params(BENCH_DIMS, seed=3)
+    d = DeviceRCN(dtype=0)
+    d.set_params(ws, bs)
+    d.set_dense_path(1)                                              # sample-tile kernels: no epoch image
+    X = d.empty(512, 784).zero_()
+    Y = d.empty(512, 10).zero_()
+    with pytest.raises(amd.RcnPanic):
+        d.epoch_begin(X, Y, None, 256, 2)
+    with pytest.raises(amd.RcnHipError):
+        d.epoch_steps(0, 1, 3.0, None)
+    d.rcn.close()
+
+
+# ------------------------------------------------------------------------------------------------ advisor regressions
+
+def test_image_epoch_graph_is_not_replayed_with_a_stale_scale_set(amd):
+    """the graphs of rcn_hip_train_epoch_images_dev bake (mean, sd, reciprocal, kernel variant) into the captured
+    feature launch.  prepare/capture -> set_scale(other) -> replay with the same arguments must standardise with the NEW scale_set,
+    i.e. equal features_dev(standardize = 1) under the new scale followed by train_epoch_dev."""
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 256, 3, 768
+    imgs, labels = synthetic_images(N, seed=77)
+    ws, bs = synthetic_params(BENCH_DIMS, seed=5)
+    ws = [w * 0.1 for w in ws]
+    for dtype in (0, 1):
+        res = []
+        for images_path in (True, False):
+            d = DeviceRCN(dtype=dtype)
+            d.set_params(ws, bs)
+            dev = d.to_device(imgs)
+            Y = d.to_device(one_hot(labels), d.tdtype)
+            d.rcn.scale_set = (20.0, 50.0)
+            if images_path:
+                d.train_epoch_images(dev, Y, None, B, nb, 3.0, None)          # captures with (20, 50) and runs once
+                d.set_params(ws, bs)
+                d.rcn.scale_set = (35.5, 81.25)                                  # load_data(test) overwrites scale_set (rcn.rs:136-137, 406)
+                d.train_epoch_images(dev, Y, None, B, nb, 3.0, None)          # same arguments: must NOT replay the old standardisation
+            else:
+                d.rcn.scale_set = (35.5, 81.25)
+                X = d.features(dev, standardize=True)
+                d.train_epoch(X, Y, None, B, nb, 3.0, None)
+            gw, gb = d.get_params()
+            res.append(gw + gb)
+            d.rcn.close()
+        for a, b in zip(*res):
+            assert np.array_equal(a, b)
+
+
+def test_gen_scales_also_invalidates_image_epoch_graphs(amd):
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 256, 2, 512
+    imgs, labels = synthetic_images(N, seed=78)
+    imgs2, _ = synthetic_images(N, seed=79)
+    ws, bs = synthetic_params(BENCH_DIMS, seed=5)
+    ws = [w * 0.1 for w in ws]
+    res = []
+    for images_path in (True, False):
+        d = DeviceRCN(dtype=0)
+        d.set_params(ws, bs)
+        dev, dev2 = d.to_device(imgs), d.to_device((imgs2 // 2).astype(np.uint8))
+        Y = d.to_device(one_hot(labels), d.tdtype)
+        d.gen_scales(d.features(dev))
+        if images_path:
+            d.train_epoch_images(dev, Y, None, B, nb, 3.0, None)
+            d.set_params(ws, bs)
+        d.gen_scales(d.features(dev2))                                        # a different data set's statistics
+        if images_path:
+            d.train_epoch_images(dev, Y, None, B, nb, 3.0, None)
+        else:
+            d.train_epoch(d.features(dev, standardize=True), Y, None, B, nb, 3.0, None)
+        gw, gb = d.get_params()
+        res.append(gw + gb)
+        d.rcn.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+def _spawn_ranks(tmp_path, world, dtype, case_name, env_extra, dims=(784, 30, 10), Bs=256, nb=2, seed=17):
+    rng = np.random.default_rng(31)
+    dims = list(dims)
+    Xs = [np.maximum(rng.standard_normal((Bs * nb, dims[0])), 0.0) for _ in range(world)]
+    Ys = [one_hot(rng.integers(0, dims[-1], Bs * nb), dims[-1]) for _ in range(world)]
+    np.savez(tmp_path / "case.npz", dims=dims, Bs=Bs, nb=nb, seed=seed, **{f"X{r}": Xs[r] for r in range(world)}, **{f"Y{r}": Ys[r] for r in range(world)})
+    port = _free_port()
+    worker = os.path.join(ROOT, "tests", "_p2p_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(dtype), str(tmp_path), case_name], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, _ = pr.communicate()
+        logs.append(out.decode(errors="replace")[-3000:])
+    assert all(pr.returncode == 0 for pr in procs), "\n----\n".join(logs)
+    return Xs, Ys, logs
+
+
+def test_sticky_timeout_of_the_peer_exchange_surfaces_from_synchronize_and_get_params(amd, tmp_path):
+    """a peer wait that times out in the LAST call used to go unnoticed (the word was only looked at by the next
+    epoch call).  Two ranks on this GPU; rank 1 stops after one step, rank 0's second step waits (20 ms bound) for data that never
+    comes: rcn_hip_synchronize, rcn_hip_get_params and rcn_hip_dp_finalize must each report it."""
+    _, _, logs = _spawn_ranks(tmp_path, 2, 0, "sticky", {})
+    assert "STICKY synchronize=error get_params=error finalize=error" in logs[0], logs[0]
+
+
+# (fault, the form every rank must land on).  No fault: the in-kernel exchange.  A rank that cannot export / map its peers / gets a
+# wrong known-answer sum: nobody uses the peer exchange (0).  A rank whose tagged-word self-test fails, or that stays silent in it
+# so that its peer's waits really expire: the kernel-boundary exchange (1) on every rank, with the sticky error word cleared.
+@pytest.mark.parametrize("fault,expect", [("", 2), ("export:1", 0), ("attach:0", 0), ("kat:1", 0), ("ll:1", 1), ("llskip:0", 1), ("kat:0,ll:1", 0)],
+                         ids=["no-fault", "export-fails-on-rank1", "peer-map-fails-on-rank0", "known-answer-mismatch-on-rank1",
+                              "tagged-word-selftest-mismatch-on-rank1", "tagged-word-selftest-timeout", "two-faults"])
+def test_admission_votes_land_every_rank_on_the_same_form_and_the_epoch_equals_the_oracle(amd, oracle, tmp_path, fault, expect):
+    """The admission logic of rcn_hip_dp_init (one procedure, p2p_admission in csrc/rcn_hip_api.hip, run here over gloo by
+    rcn_hip_dp_p2p_admit) under injected faults: every rank executes the same votes, lands on the same form, and two epochs of the
+    sharded loop on that form equal the oracle's train_batch on the concatenated global batches (f64, 1e-11)."""
+    env = {"RCN_HIP_DP_FAULT": fault} if fault else {}
+    if "llskip" in fault:
+        env["RCN_HIP_DP_TIMEOUT_TICKS"] = "5000000"                # 50 ms per expired wait instead of 1 s
+    world, Bs, nb, dims = 2, 256, 2, [784, 30, 10]
+    Xs, Ys, logs = _spawn_ranks(tmp_path, world, 1, "admit", env, dims=dims, Bs=Bs, nb=nb)
+    outs = [np.load(tmp_path / f"out{r}.npz") for r in range(world)]
+    assert [int(o["active"]) for o in outs] == [expect] * world, (fault, [int(o["active"]) for o in outs], logs)
+    for k in ("w0", "w1", "b0", "b1", "loss"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k           # replicas bit-identical on every form
+    ws, bs = synthetic_params(dims, seed=17)
+    rw, rb, costs = [w * 0.1 for w in ws], bs, []
+    for ep in range(2):
+        for j in range(nb):
+            xb = np.concatenate([X[j * Bs:(j + 1) * Bs] for X in Xs])
+            yb = np.concatenate([Y[j * Bs:(j + 1) * Bs] for Y in Ys])
+            rw, rb, c = oracle.train_batch(rw, rb, xb, yb, 3.0)
+            if ep == 0:
+                costs.append(c)
+    for a, b in zip([outs[0]["w0"], outs[0]["w1"], outs[0]["b0"], outs[0]["b1"]], [rw[0], rw[1], rb[0], rb[1]]):
+        assert np.all(np.abs(a - b) <= 1e-11 * np.abs(b) + 1e-12)
+    np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-10)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_workspace_growth_failure_path_leaves_no_dangling_graphs(amd):
+    """DevBuf::ensure frees the old block before it allocates; the cached graphs must be dropped whenever the old
+    block is released.  Exercised through the success path (the failure path shares the code): grow every workspace between
+    replays of different cached shapes and compare with fresh contexts."""
+    from mercer_research_amd.device import DeviceRCN
+    ws, bs = synthetic_params(BENCH_DIMS, seed=6)
+    ws = [w * 0.1 for w in ws]
+    rng = np.random.default_rng(0)
+    X, Y = rng.random((4096, 784)), one_hot(rng.integers(0, 10, 4096))
+    d = DeviceRCN(dtype=1)
+    d.set_params(ws, bs)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    seq = [(256, 2), (512, 3), (256, 2), (1024, 4), (512, 3), (256, 2)]
+    for B, nb in seq:
+        d.train_epoch(Xd, Yd, None, B, nb, 3.0, None)
+    got = d.get_params()
+    d.rcn.close()
+    r = DeviceRCN(dtype=1)
+    r.set_params(ws, bs)
+    Xd, Yd = r.to_device(X, r.tdtype), r.to_device(Y, r.tdtype)
+    for B, nb in seq:
+        for j in range(nb):
+            r.train_batch(Xd[j * B:(j + 1) * B], Yd[j * B:(j + 1) * B], 3.0, None)
+    ref = r.get_params()
+    r.rcn.close()
+    for a, b in zip(got[0] + got[1], ref[0] + ref[1]):
+        assert np.all(np.abs(a - b) <= 1e-11 * np.abs(b) + 1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ init statistics
+
+def test_init_params_draws_unscaled_standard_normals_w_then_b_per_layer(amd):
+    """rcn_hip_init_params = load_weights_and_bias (rcn.rs:425-457) with get_weight_matrix / get_bias_vector (rcn.rs:500-523): every
+    entry ~ N(0,1), NOT scaled by 1/sqrt(fan-in) (the scaling is commented out at rcn.rs:509).  Moments over the 23 520 entries of
+    W_0: |mean| < 4 sigma/sqrt(n), variance within 4 standard errors of 1, skew ~ 0, excess kurtosis ~ 0, a KS test against N(0,1);
+    the same seed gives the same stream, different seeds differ, seed 0 is non-deterministic; and the stream is consumed W_l then
+    b_l, layer by layer (rcn.rs:446-455)."""
+    from scipy import stats
+    r = amd.RCN(10, amd.default_convpool(), [30], input_shape=(28, 28), dtype=amd.F64)
+    r.load_weights_and_bias(12345)
+    w, b = r.get_params()
+    allv = np.concatenate([w[0].ravel(), b[0], w[1].ravel(), b[1]])
+    n = allv.size
+    assert n == 23860
+    assert abs(allv.mean()) < 4 / np.sqrt(n)
+    assert abs(allv.var() - 1.0) < 4 * np.sqrt(2.0 / n)
+    assert abs(stats.skew(allv)) < 4 * np.sqrt(6.0 / n)
+    assert abs(stats.kurtosis(allv)) < 4 * np.sqrt(24.0 / n)
+    assert stats.kstest(allv, "norm").pvalue > 1e-3
+    # un-scaled: a 1/sqrt(784) scaling would give W_0 a standard deviation of 0.036
+    assert 0.97 < w[0].std() < 1.03 and 0.9 < w[1].std() < 1.1
+    # each layer's W and b pass on their own (a generator that re-seeded per tensor, or filled b from W's tail, would not)
+    assert stats.kstest(w[0].ravel(), "norm").pvalue > 1e-3 and stats.kstest(w[1].ravel(), "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(w[0].ravel()[:300], w[1].ravel())[0, 1]) < 0.25
+    # determinism per seed
+    r.load_weights_and_bias(12345)
+    w2, b2 = r.get_params()
+    assert all(np.array_equal(x, y) for x, y in zip(w + b, w2 + b2))
+    r.load_weights_and_bias(12346)
+    w3, _ = r.get_params()
+    assert not np.array_equal(w[0], w3[0])
+    r.load_weights_and_bias(0)
+    wa, _ = r.get_params()
+    r.load_weights_and_bias(0)
+    wb, _ = r.get_params()
+    assert not np.array_equal(wa[0], wb[0])            # seed 0: thread_rng-like, not reproducible
+    # draw order: the stream fills W_0 (column-major), then b_0, then W_1, then b_1 -- the f32 context rounds the same stream
+    r32 = amd.RCN(10, amd.default_convpool(), [30], input_shape=(28, 28), dtype=amd.F32)
+    r32.load_weights_and_bias(12345)
+    w32, b32 = r32.get_params()
+    for x, y in zip(w + b, w32 + b32):
+        assert np.array_equal(x.astype(np.float32).astype(np.float64), y)
+    r.close()
+    r32.close()
