@@ -9,6 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librcn_hip.so")
+LIB_EXP_PATH = os.path.join(HERE, "librcn_hip_exp.so")      # + the parked experiments (tests / tools only; build.py: build_experiments)
 
 F32, F64 = 0, 1
 
@@ -106,6 +107,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_lib_exp = None
 _hip_preloaded = False
 
 
@@ -154,6 +156,14 @@ def load(path: str | None = None) -> C.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+def load_experiments() -> C.CDLL:
+    """The build that also carries the parked experiments (dense paths 3 and 4).  Not used by the product path."""
+    global _lib_exp
+    if _lib_exp is None:
+        _lib_exp = load(LIB_EXP_PATH)
+    return _lib_exp
 
 
 def check(lib, ctx, status: int) -> None:

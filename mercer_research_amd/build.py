@@ -32,6 +32,20 @@ def stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
 
 
+LIB_EXP = os.path.join(HERE, "librcn_hip_exp.so")   # the same library + the parked experiments (dense paths 3, 4, one-object step); tests / tools only
+
+
+def build_experiments(force: bool = False, verbose: bool = False) -> str:
+    deps = [os.path.join(CSRC, f) for f in SOURCES + DEPS]
+    if not force and os.path.exists(LIB_EXP) and all(os.path.getmtime(f) <= os.path.getmtime(LIB_EXP) for f in deps):
+        return LIB_EXP
+    cmd = [hipcc()] + FLAGS + ["-DRCN_HIP_EXPERIMENTS", "-o", LIB_EXP] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB_EXP
+
+
 LIBX = os.path.join(HERE, "librcn_hipx.so")          # Track X (trainable conv net; include/rcn_hipx.h)
 LIBX_SRC = os.path.join(CSRC, "rcn_hipx_api.hip")
 LIBX_DEPS = [LIBX_SRC, os.path.join(CSRC, "convnet.hpp"), os.path.join(CSRC, "convnet_bf16.hpp"), os.path.join(HERE, "..", "include", "rcn_hipx.h")]
@@ -71,6 +85,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.run(cmd, check=True)
     build_cli(force, verbose)
     build_x(force, verbose)
+    build_experiments(force, verbose)
     return LIB
 
 

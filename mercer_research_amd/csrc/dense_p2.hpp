@@ -359,6 +359,7 @@ __global__ __launch_bounds__(kP2BThreads) void k_p2_b(
     p2_b_body<T>(nd, params, slab, G, Ys, B, a1g, d1g, d2g, loss_part, smem_dyn, fragimg);
 }
 
+#ifdef RCN_HIP_EXPERIMENTS
 // The epoch loop alternates the two strictly, and the pair costs ~0.9 us more than the two back to back with themselves
 // (9.2 us vs 3.85 + 4.45).  Hypothesis tested here: the switch of kernel object (code, descriptor, LDS / register allocation)
 // between launches.  As two ROLES of one kernel object the step is 2 % SLOWER (9.75 vs 9.55 us), so that is not it; kept
@@ -375,5 +376,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_p2_ab(
     if (role == 0) p2_b_body<T>(nd, params, slab, G, Ys, B, a1, d1, d2, loss_part, smem_dyn);
     else p2_a_body<T>(nd, params, Xp, Xn, B, a1, d1, d2, scale, slab, G, loss_part, n_loss, loss_scale, loss_out, do_update, do_fwd, smem_dyn);
 }
+
+#endif  // RCN_HIP_EXPERIMENTS
 
 }  // namespace rcn

@@ -29,8 +29,14 @@
 #include "serve.hpp"
 #include "dp_p2p.hpp"
 #include "dense_p2_dp.hpp"
+// Parked experiments (a resident kernel per epoch segment, one launch per step, both step kernels as roles of one kernel object):
+// correct, measured, slower than or equal to the default two-kernel pipeline.  They are compiled only into
+// librcn_hip_exp.so (-DRCN_HIP_EXPERIMENTS; mercer_research_amd/build.py: build_experiments), which their tests and the stamp tools
+// load; the shipping library does not carry them.
+#ifdef RCN_HIP_EXPERIMENTS
 #include "dense_p2_persist.hpp"
 #include "dense_p2_step.hpp"
+#endif
 #include <chrono>
 
 using namespace rcn;
@@ -389,7 +395,11 @@ int ensure_pipe_ws(rcn_hip_ctx* c, size_t B) {
 
 // RCN_HIP_P2_ONE_OBJECT=1: both kernels of a pipelined step as roles of one kernel object (dense_p2.hpp: k_p2_ab).  Measured 2 % slower
 // than two kernels (9.75 vs 9.55 us/step), so off by default: the cost of alternating is not the switch of kernel object.
+#ifdef RCN_HIP_EXPERIMENTS
 static bool p2_one_object() { static const int v = [] { const char* e = std::getenv("RCN_HIP_P2_ONE_OBJECT"); return e ? std::atoi(e) : 0; }(); return v != 0; }
+#else
+static constexpr bool p2_one_object() { return false; }
+#endif
 
 template <typename T>
 int launch_pipe_a(rcn_hip_ctx* c, const void* xp, const void* xn, size_t B, double scale, void* loss_out, double loss_scale, bool do_update, bool do_fwd) {
@@ -399,11 +409,13 @@ int launch_pipe_a(rcn_hip_ctx* c, const void* xp, const void* xn, size_t B, doub
     const int n_loss = (int)((B + kPipeTs - 1) / kPipeTs);
     if (p2_supported(nd, B)) {       // lean specialisation: one hidden layer <= 32, classes <= 16, B % 256 == 0
         T* a1 = (T*)c->p2buf.p; T* d1 = a1 + B * kP2H; T* d2 = d1 + B * kP2H;
+#ifdef RCN_HIP_EXPERIMENTS
         if (p2_one_object())
             hipLaunchKernelGGL((k_p2_ab<T>), dim3(grid), dim3(kDenseThreads), p2_ab_lds_elems() * sizeof(T), c->stream, 1, nd, (T*)c->params.p, (const T*)xp,
                                (const T*)xn, (const T*)nullptr, (int)B, a1, d1, d2, (T)scale, (T*)c->slab.p, G, (T*)c->loss_part.p, n_loss, (T)loss_scale,
                                (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0);
         else
+#endif
             hipLaunchKernelGGL((k_p2_a<T>), dim3(grid), dim3(kDenseThreads), p2_a_lds_elems() * sizeof(T), c->stream, nd, (T*)c->params.p, (const T*)xp,
                                (const T*)xn, (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, G, (const T*)c->loss_part.p, n_loss,
                                (T)loss_scale, (T*)loss_out, do_update ? 1 : 0, do_fwd ? 1 : 0, c->frag_on ? (T*)c->fragimg.p : (T*)nullptr);
@@ -423,11 +435,13 @@ int launch_pipe_b(rcn_hip_ctx* c, const void* ys, size_t B) {
     const NetDesc& nd = c->nd;
     if (p2_supported(nd, B)) {
         T* a1 = (T*)c->p2buf.p; T* d1 = a1 + B * kP2H; T* d2 = d1 + B * kP2H;
+#ifdef RCN_HIP_EXPERIMENTS
         if (p2_one_object())
             hipLaunchKernelGGL((k_p2_ab<T>), dim3((unsigned)(B / kP2Ts)), dim3(kDenseThreads), p2_ab_lds_elems() * sizeof(T), c->stream, 0, nd, (T*)c->params.p,
                                (const T*)nullptr, (const T*)nullptr, (const T*)ys, (int)B, a1, d1, d2, (T)0, (T*)c->slab.p, pipe_slices(nd), (T*)c->loss_part.p, 0,
                                (T)0, (T*)nullptr, 0, 0);
         else
+#endif
             hipLaunchKernelGGL((k_p2_b<T>), dim3((unsigned)(B / kP2Ts)), dim3(kP2BThreads), p2_b_lds_elems() * sizeof(T), c->stream, nd, (const T*)c->params.p,
                                (const T*)c->slab.p, pipe_slices(nd), (const T*)ys, (int)B, a1, d1, d2, (T*)c->loss_part.p,
                                c->frag_on ? (const T*)c->fragimg.p : (const T*)nullptr);
@@ -581,6 +595,7 @@ int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32
     return RCN_HIP_OK;
 }
 
+#ifdef RCN_HIP_EXPERIMENTS
 constexpr long long kPersistTimeoutTicks = 5000000LL;        // 50 ms of the 100 MHz wall clock per wait
 
 // ---- one launch per step (dense_p2_step.hpp): A(F0) S0 S1 ... S_{nb-1}, S_j = sample groups of batch j + feature slices
@@ -711,6 +726,11 @@ int enqueue_persist_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const in
     HIP_TRY(c, hipMemcpyAsync(c->perr_host, c->perr_dev, 4, hipMemcpyDeviceToHost, c->stream));     // looked at by the next call
     return RCN_HIP_OK;
 }
+
+#else
+static bool use_step(const rcn_hip_ctx*, size_t) { return false; }
+static bool use_persist(const rcn_hip_ctx*, size_t) { return false; }
+#endif
 
 // one train_batch (rcn.rs:176-223) on device-resident data; idx selects the batch's rows (or NULL)
 int enqueue_train_step(rcn_hip_ctx* c, const void* x, const void* y, const int32_t* idx, size_t B, double eta, void* loss_dev) {
@@ -1106,6 +1126,9 @@ int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
     RCN_TRY(check_ctx(c));
     if (mode < 0 || mode > 4)
         return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile), 2 (feature-sliced), 3 (resident epoch kernel) or 4 (one launch per step)");
+#ifndef RCN_HIP_EXPERIMENTS
+    if (mode >= 3) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path: modes 3 and 4 are parked experiments, compiled only into librcn_hip_exp.so (RCN_HIP_EXPERIMENTS)");
+#endif
     if (mode >= 2 && !pipe_supported(c->nd)) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "feature-sliced path needs >= 2 dense layers whose tail fits LDS");
     DevGuard g(c->device);
     drop_graphs(c);
@@ -1506,15 +1529,19 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
     RCN_TRY(ensure_dense_ws(c, B));
     if (use_pipe(c, B)) { RCN_TRY(ensure_pipe_ws(c, B)); RCN_TRY(ensure_pack_ws(c, B, nb)); }
     const bool step = use_pipe(c, B) && use_step(c, B);
+#ifdef RCN_HIP_EXPERIMENTS
     if (step) RCN_TRY(ensure_step_ws(c, B));
+#endif
     if (from_images && !(use_pipe(c, B) && feat_is_cpcp28(c)))
         return fail(c, RCN_HIP_ERR_UNSUPPORTED, "train_epoch_images: needs the default conv/pool stack on 28x28 input and a layer stack / batch size the "
                                                   "feature-sliced pipeline covers; use rcn_hip_features_dev + rcn_hip_train_epoch_dev otherwise");
+#ifdef RCN_HIP_EXPERIMENTS
     if (use_persist(c, B) && !from_images) {
         // no graph: one resident kernel per segment of the epoch image runs all of its steps
         if (!launch) return RCN_HIP_OK;
         return enqueue_persist_epoch(c, X, Y, perm, B, nb, eta, loss_dev);
     }
+#endif
     // LDS attributes are per kernel variant and cached (set_dyn_lds); hipFuncSetAttribute is not a stream operation,
     // so the first capture of a variant may set it while capturing.
 
@@ -1526,9 +1553,12 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
         hipGraph_t graph = nullptr;
         HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         int st = RCN_HIP_OK;
+#ifdef RCN_HIP_EXPERIMENTS
         if (step) {
             st = enqueue_step_epoch(c, X, Y, perm, B, nb, eta, loss_dev, from_images);
-        } else if (use_pipe(c, B)) {
+        } else
+#endif
+        if (use_pipe(c, B)) {
             st = c->dtype == RCN_HIP_F64 ? enqueue_pipe_steps<double>(c, X, Y, perm, B, nb, eta, loss_dev, from_images)
                                          : enqueue_pipe_steps<float>(c, X, Y, perm, B, nb, eta, loss_dev, from_images);
         } else

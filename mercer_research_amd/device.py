@@ -23,14 +23,14 @@ class DeviceRCN:
     issued under `with torch.cuda.stream(self.stream)` and our kernels are ordered with each other."""
 
     def __init__(self, classes: int = 10, convpool_cfg: Optional[Sequence[RCNLayer]] = None, feedforward_cfg: Sequence[int] = (30,),
-                 input_shape: Tuple[int, int] = (28, 28), dtype: int = _lib.F32, device: int = 0):
+                 input_shape: Tuple[int, int] = (28, 28), dtype: int = _lib.F32, device: int = 0, experiments: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceRCN needs a GPU; there is no CPU fallback")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.rcn = RCN(classes, convpool_cfg if convpool_cfg is not None else default_convpool(), list(feedforward_cfg),
-                       input_shape=input_shape, dtype=dtype, device=device, stream=self.stream.cuda_stream)
+                       input_shape=input_shape, dtype=dtype, device=device, stream=self.stream.cuda_stream, experiments=experiments)
         self.tdtype = torch.float64 if dtype == _lib.F64 else torch.float32
         self.lib, self.ctx = self.rcn._lib, self.rcn._ctx
         self.F, self.classes = self.rcn.feature_len, classes

@@ -80,8 +80,8 @@ class RCN:
 
     def __init__(self, classes: int, convpool_cfg: Sequence[RCNLayer], feedforward_cfg: Sequence[int],
                  training_path: str = "", testing_path: str = "", *, input_shape: Tuple[int, int] = (28, 28),
-                 dtype: int = F32, device: int = 0, stream: Optional[int] = None):
-        self._lib = _lib.load()
+                 dtype: int = F32, device: int = 0, stream: Optional[int] = None, experiments: bool = False):
+        self._lib = _lib.load_experiments() if experiments else _lib.load()
         self._ctx = C.c_void_p()
         self.classes = int(classes)
         self.convpool_cfg = list(convpool_cfg)

@@ -130,3 +130,21 @@ def test_rust_shim_declares_exactly_the_header_functions():
     in_rust = set(re.findall(r"pub fn (rcn_hip_[a-z0-9_]+)\s*\(", rust))
     assert in_header - in_rust == set(), f"missing in the Rust shim: {sorted(in_header - in_rust)}"
     assert in_rust - in_header == set(), f"not in the header: {sorted(in_rust - in_header)}"
+
+
+def test_parked_experiments_are_not_in_the_shipping_library(lib):
+    """the resident epoch kernel (dense_p2_persist.hpp), the one-launch step (dense_p2_step.hpp) and the
+    one-object step kernel (k_p2_ab) live only in librcn_hip_exp.so, which the product never loads."""
+    from mercer_research_amd import _lib
+    names = (b"k_p2_step", b"k_p2_epoch", b"k_p2_ab")
+    ship = open(_lib.LIB_PATH, "rb").read()
+    exp = open(_lib.LIB_EXP_PATH, "rb").read()
+    for n in names:
+        assert n not in ship, n
+        assert n in exp, n
+    for root, _, files in os.walk(os.path.join(ROOT, "mercer_research_amd")):
+        for f in files:
+            if f.endswith(".py") and f not in ("_lib.py", "build.py", "rcn.py", "device.py"):
+                assert "load_experiments" not in open(os.path.join(root, f)).read(), f
+    for f in ("bench.py", "bench_convnet.py", "__graft_entry__.py"):
+        assert "experiments" not in open(os.path.join(ROOT, f)).read(), f

@@ -742,7 +742,7 @@ def test_resident_epoch_kernel_matches_sequential_oracle(amd, oracle):
     from mercer_research_amd.device import DeviceRCN
     B, nb, N = 256, 5, 1536
     ws, bs, X, Y = _dense_case([784, 30, 10], N, seed=81, wscale=0.1)
-    d = DeviceRCN(dtype=0)
+    d = DeviceRCN(dtype=0, experiments=True)         # librcn_hip_exp.so: the shipping library does not carry this kernel
     d.set_dense_path(3)
     d.set_params(ws, bs)
     Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
@@ -794,7 +794,7 @@ def test_one_launch_step_is_the_two_kernel_pipeline_bit_for_bit(amd, B, monkeypa
     perm = np.random.default_rng(8).permutation(N).astype(np.int32)
     got = {}
     for path in (2, 4):
-        d = DeviceRCN(dtype=0)
+        d = DeviceRCN(dtype=0, experiments=path == 4)    # path 4 lives in librcn_hip_exp.so only; path 2 is the shipping library's
         d.set_dense_path(path)
         d.set_params(ws, bs)
         dev = d.to_device(imgs)

@@ -8,12 +8,12 @@ sys.path.insert(0, ROOT)
 from mercer_research_amd import build as hb, _lib
 out = os.path.join(ROOT, "gpurun_out", "librcn_hip_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.run([hb.hipcc()] + hb.FLAGS + ["-w", "-DRCN_STAMPS", "-o", out, os.path.join(hb.CSRC, "rcn_hip_api.hip")], check=True)
-_lib.LIB_PATH = out
+subprocess.run([hb.hipcc()] + hb.FLAGS + ["-w", "-DRCN_STAMPS", "-DRCN_HIP_EXPERIMENTS", "-o", out, os.path.join(hb.CSRC, "rcn_hip_api.hip")], check=True)
+_lib.LIB_EXP_PATH = out
 import torch
 from mercer_research_amd.device import DeviceRCN
 from mercer_research_amd.synth import synthetic_params
-d = DeviceRCN()
+d = DeviceRCN(experiments=True)          # librcn_hip_exp.so
 lib = d.lib
 lib.rcn_hip_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
 ws, bs = synthetic_params([784, 30, 10], seed=42)
