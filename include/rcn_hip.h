@@ -248,6 +248,20 @@ typedef int (*rcn_hip_allgather_fn)(void* user, const void* mine, void* all, siz
 typedef int (*rcn_hip_vote_min_fn)(void* user, int* v);
 int  rcn_hip_dp_p2p_admit(rcn_hip_ctx* ctx, int rank, int world, rcn_hip_allgather_fn allgather, rcn_hip_vote_min_fn vote_min, void* user);
 int  rcn_hip_dp_p2p_active(const rcn_hip_ctx* ctx);   /* 0 ncclAllReduce, 1 peer exchange at kernel boundaries, 2 also inside the gradient kernel */
+/* ---- RCN::train's data flow with both data sets RESIDENT in HBM (rcn.rs:126-167): what a host-language `RCN::train` calls.
+ * rcn_hip_load_data = the arithmetic of load_data after the image decode (rcn.rs:399-414) for `n` images: imgs n x in_h x in_w u8,
+ * labels n class indices (position in the sorted directory listing, rcn.rs:374-377,401) -> flatten_feature_set, gen_scales (this
+ * OVERWRITES the context's scale_set, as the reference does: after train + test loads it holds the TEST set's statistics,
+ * rcn.rs:134-137), standardise + clamp, one-hot expectations (rcn.rs:466-471); features and expectations stay on the device in
+ * slot 0 (training set) / 1 (testing set).  Blocks.  mean / sd (nullable) receive the set's statistics.
+ * rcn_hip_train_set_epoch = one pass of rcn.rs:146-149 over a loaded slot: `perm` (host, nullable) is the shuffled order -- the
+ * first floor(n / B) * B entries are used, chunks_exact drops the tail -- or NULL to shuffle on the device with `shuffle_seed`
+ * (0 = non-deterministic like thread_rng); loss_out (host, nullable) receives the floor(n / B) per-step costs (then the call blocks).
+ * rcn_hip_evaluate_set = the per-epoch accuracy count of rcn.rs:152-157 over a loaded slot. */
+int  rcn_hip_load_data(rcn_hip_ctx* ctx, int slot, const uint8_t* imgs, const int32_t* labels, size_t n, double* mean, double* sd);
+int  rcn_hip_train_set_epoch(rcn_hip_ctx* ctx, int slot, const int32_t* perm, uint64_t shuffle_seed, size_t B, double eta, double* loss_out);
+int  rcn_hip_evaluate_set(rcn_hip_ctx* ctx, int slot, int64_t* accepted);
+int  rcn_hip_set_size(const rcn_hip_ctx* ctx, int slot, int64_t* n);
 /* classify_test (rcn.rs:105-116) for n samples: a <- sigmoid(W a + b) through every layer. out: n x classes */
 int  rcn_hip_forward(rcn_hip_ctx* ctx, const double* x, size_t n, double* out);
 int  rcn_hip_forward_dev(rcn_hip_ctx* ctx, const void* x_dev, size_t n, void* out_dev);

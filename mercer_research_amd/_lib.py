@@ -95,6 +95,10 @@ SIGNATURES = {
     "rcn_hip_dp_p2p_active": (_i, [_vp]),
     "rcn_hip_dp_prepare_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
     "rcn_hip_dp_train_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
+    "rcn_hip_load_data": (_i, [_vp, _i, _u8p, _i32p, _sz, _dp, _dp]),
+    "rcn_hip_train_set_epoch": (_i, [_vp, _i, _i32p, C.c_uint64, _sz, _d, _dp]),
+    "rcn_hip_evaluate_set": (_i, [_vp, _i, _i64p]),
+    "rcn_hip_set_size": (_i, [_vp, _i, _i64p]),
     "rcn_hip_forward": (_i, [_vp, _dp, _sz, _dp]),
     "rcn_hip_forward_dev": (_i, [_vp, _vp, _sz, _vp]),
     "rcn_hip_classify": (_i, [_vp, _dp, _sz, _i32p]),

@@ -432,6 +432,13 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_wgrad(
 }
 
 // p <- p - scale * g  (the update half of train_batch when gradients were all-reduced first)
+// get_expected_vec (rcn.rs:466-471) for a whole resident set: y[i][c] = (c == labels[i])
+template <typename T>
+__global__ void k_one_hot(const int32_t* __restrict__ labels, size_t n, int C, T* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * (size_t)C; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = (int)(i % (size_t)C) == labels[i / (size_t)C] ? (T)1 : (T)0;
+}
+
 template <typename T>
 __global__ void k_apply_gradient(T* __restrict__ p, const T* __restrict__ gsrc, T scale, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = p[i] - scale * gsrc[i];

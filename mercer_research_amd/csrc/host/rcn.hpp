@@ -140,25 +140,21 @@ public:
     std::vector<int64_t> train(const uint8_t* train_px, const int32_t* train_lab, size_t n_train, const uint8_t* test_px,
                                const int32_t* test_lab, size_t n_test, size_t batch_size, size_t epochs, double eta,
                                uint64_t shuffle_seed = 0, bool print = true) {
-        DataSet tr = load_data(train_px, train_lab, n_train);
-        DataSet te = load_data(test_px, test_lab, n_test);
+        // both sets stay resident in HBM (rcn_hip_load_data); an epoch is ONE call (device shuffle or the order drawn here,
+        // then chunks_exact over it), the evaluation another -- no per-step traffic over PCIe
+        double mean, sd;
+        check(rcn_hip_load_data(ctx_, 0, train_px, train_lab, n_train, &mean, &sd));      // rcn.rs:134-135
+        check(rcn_hip_load_data(ctx_, 1, test_px, test_lab, n_test, &mean, &sd));         // rcn.rs:136-137: scale_set = the TEST statistics
         if (!weights_loaded_) load_weights_and_bias();                       // rcn.rs:139-141
         std::mt19937_64 rng(shuffle_seed ? shuffle_seed : std::random_device{}());
-        std::vector<size_t> order(n_train);
+        std::vector<int32_t> order(n_train);
         std::iota(order.begin(), order.end(), 0);
-        std::vector<double> bx(batch_size * tr.features), by(batch_size * tr.classes);
         std::vector<int64_t> accepted;
         for (size_t e = 0; e < epochs; ++e) {                                // rcn.rs:144
             std::shuffle(order.begin(), order.end(), rng);                    // rcn.rs:146
-            for (size_t j = 0; j + batch_size <= n_train; j += batch_size) { // chunks_exact, rcn.rs:147
-                for (size_t i = 0; i < batch_size; ++i) {
-                    std::copy_n(&tr.x[order[j + i] * tr.features], tr.features, &bx[i * tr.features]);
-                    std::copy_n(&tr.y[order[j + i] * tr.classes], tr.classes, &by[i * tr.classes]);
-                }
-                train_batch(bx.data(), by.data(), batch_size, eta);
-            }
+            check(rcn_hip_train_set_epoch(ctx_, 0, order.data(), 0, batch_size, eta, nullptr));   // chunks_exact + train_batch, rcn.rs:147-149
             int64_t acc = 0;
-            check(rcn_hip_evaluate(ctx_, te.x.data(), te.y.data(), n_test, &acc));   // rcn.rs:152-157
+            check(rcn_hip_evaluate_set(ctx_, 1, &acc));                       // rcn.rs:152-157
             accepted.push_back(acc);
             if (print) std::printf("Epoch %zu: %lld/%zu [%.2f%%]\n", e, (long long)acc, n_test, (double)acc / (double)n_test * 100.0);
         }

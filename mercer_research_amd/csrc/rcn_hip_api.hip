@@ -114,6 +114,10 @@ struct rcn_hip_ctx {
         unsigned* err_host = nullptr;       // pinned copy, refreshed after every epoch call
         DevBuf raw, mism;
     } p2p;
+    struct ResidentSet {                     // rcn_hip_load_data: one of RCN::train's two data sets, kept in HBM (rcn.rs:134-137)
+        DevBuf imgs, X, Y, perm, loss;
+        size_t n = 0;
+    } sets[2];
     std::map<const void*, size_t> lds_attr;   // kernels whose dynamic-LDS limit was already raised
     std::string err;
     size_t esz() const { return dtype == RCN_HIP_F64 ? 8 : 4; }
@@ -1094,6 +1098,7 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
         for (DevBuf* b : {&c->slab, &c->xpack, &c->ypack, &c->p2buf, &c->params, &c->acts, &c->deltas, &c->loss_part, &c->grad, &c->xstage, &c->ystage, &c->ostage, &c->scratch0,
                           &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
             b->release();
+        for (auto& rs : c->sets) { rs.imgs.release(); rs.X.release(); rs.Y.release(); rs.perm.release(); rs.loss.release(); }
         if (c->pin_host) (void)hipHostFree(c->pin_host);
         c->pll.release();
         if (c->perr_dev) (void)hipFree(c->perr_dev);
@@ -2088,6 +2093,70 @@ int rcn_hip_dp_train_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, con
 int rcn_hip_dp_prepare_epoch_dev(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta,
                                  void* loss_dev) {
     return dp_epoch_impl(c, X, Y, perm, B, nb, eta, loss_dev, false);
+}
+
+// ---------------------------------------------------------------- RCN::train's data flow with the sets resident in HBM
+int rcn_hip_load_data(rcn_hip_ctx* c, int slot, const uint8_t* imgs, const int32_t* labels, size_t n, double* mean, double* sd) {
+    RCN_TRY(check_ctx(c));
+    if (slot < 0 || slot > 1) return fail(c, RCN_HIP_ERR_INVALID_ARG, "load_data: slot must be 0 (training set) or 1 (testing set)");
+    if (!imgs || !labels || n == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "load_data: empty set (gen_scales indexes iv[0], rcn.rs:233)");
+    RCN_TRY(need_dense(c));
+    const int Cc = c->nd.dims[c->nd.L];
+    for (size_t i = 0; i < n; ++i)
+        if (labels[i] < 0 || labels[i] >= Cc) return fail(c, RCN_HIP_ERR_SHAPE, "load_data: a label is not below `classes` (the one-hot vector of rcn.rs:466-471 would not match the output layer)");
+    DevGuard g(c->device);
+    auto& rs = c->sets[slot];
+    const size_t img_b = n * (size_t)c->fd.H * c->fd.W, F = (size_t)c->fd.F, es = c->esz();
+    drop_graphs(c);                                   // epoch graphs hold the old set's pointers
+    rs.n = 0;
+    HIP_TRY(c, rs.imgs.ensure(img_b));
+    HIP_TRY(c, rs.X.ensure(n * F * es));
+    HIP_TRY(c, rs.Y.ensure(n * (size_t)Cc * es));
+    HIP_TRY(c, rs.perm.ensure(n * sizeof(int32_t)));
+    HIP_TRY(c, hipMemcpyAsync(rs.imgs.p, imgs, img_b, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rs.perm.p, labels, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));     // staged in the index buffer
+    if (c->dtype == RCN_HIP_F64) hipLaunchKernelGGL((k_one_hot<double>), dim3(grid_for(n * Cc, 256)), dim3(256), 0, c->stream, (const int32_t*)rs.perm.p, n, Cc, (double*)rs.Y.p);
+    else hipLaunchKernelGGL((k_one_hot<float>), dim3(grid_for(n * Cc, 256)), dim3(256), 0, c->stream, (const int32_t*)rs.perm.p, n, Cc, (float*)rs.Y.p);
+    HIP_TRY(c, hipGetLastError());
+    RCN_TRY(rcn_hip_features_dev(c, (const uint8_t*)rs.imgs.p, n, rs.X.p, 0));           // rcn.rs:399-401
+    RCN_TRY(gen_scales_impl(c, rs.X.p, n * F, mean, sd));                                // rcn.rs:406 (overwrites scale_set; blocks)
+    RCN_TRY(rcn_hip_standardize_dev(c, rs.X.p, n * F));                                  // rcn.rs:407-412
+    rs.n = n;
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_train_set_epoch(rcn_hip_ctx* c, int slot, const int32_t* perm, uint64_t shuffle_seed, size_t B, double eta, double* loss_out) {
+    RCN_TRY(check_ctx(c));
+    if (slot < 0 || slot > 1 || c->sets[slot].n == 0) return fail(c, RCN_HIP_ERR_STATE, "train_set_epoch: rcn_hip_load_data has not filled this slot");
+    if (B == 0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_set_epoch: batch size 0 (chunks_exact panics, rcn.rs:147)");
+    auto& rs = c->sets[slot];
+    const size_t n = rs.n, nb = n / B;                 // chunks_exact drops the tail (rcn.rs:147)
+    if (perm)
+        for (size_t i = 0; i < nb * B; ++i)
+            if (perm[i] < 0 || (size_t)perm[i] >= n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_set_epoch: index out of range");
+    DevGuard g(c->device);
+    if (perm) HIP_TRY(c, hipMemcpyAsync(rs.perm.p, perm, nb * B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    else RCN_TRY(rcn_hip_shuffle_dev(c, (int32_t*)rs.perm.p, n, 1, shuffle_seed ? shuffle_seed : ((uint64_t)std::random_device{}() << 32) ^ std::random_device{}()));   // rcn.rs:146
+    if (nb == 0) return RCN_HIP_OK;
+    void* loss_dev = nullptr;
+    if (loss_out) { HIP_TRY(c, rs.loss.ensure(nb * c->esz())); loss_dev = rs.loss.p; }
+    RCN_TRY(rcn_hip_train_epoch_dev(c, rs.X.p, rs.Y.p, (const int32_t*)rs.perm.p, B, nb, eta, loss_dev));
+    if (loss_out) return download(c, loss_dev, loss_out, nb);
+    return RCN_HIP_OK;
+}
+
+int rcn_hip_evaluate_set(rcn_hip_ctx* c, int slot, int64_t* accepted) {
+    RCN_TRY(check_ctx(c));
+    if (!accepted) return fail(c, RCN_HIP_ERR_INVALID_ARG, "evaluate_set: NULL pointer");
+    if (slot < 0 || slot > 1 || c->sets[slot].n == 0) return fail(c, RCN_HIP_ERR_STATE, "evaluate_set: rcn_hip_load_data has not filled this slot");
+    RCN_TRY(need_params(c));
+    return rcn_hip_evaluate_dev(c, c->sets[slot].X.p, c->sets[slot].Y.p, c->sets[slot].n, accepted);
+}
+
+int rcn_hip_set_size(const rcn_hip_ctx* c, int slot, int64_t* n) {
+    if (!c || !n || slot < 0 || slot > 1) return RCN_HIP_ERR_INVALID_ARG;
+    *n = (int64_t)c->sets[slot].n;
+    return RCN_HIP_OK;
 }
 
 int rcn_hip_forward_dev(rcn_hip_ctx* c, const void* x, size_t n, void* out) {

@@ -273,21 +273,46 @@ class RCN:
         """RCN::train (rcn.rs:126-167) on decoded images: load both sets (test statistics end up in scale_set,
         SURVEY Q7), init weights if empty, then per epoch shuffle / chunks_exact / train_batch / evaluate."""
         rng = rng or np.random.default_rng()
-        x, y = self.load_data(train_imgs, train_labels)               # rcn.rs:134-135
-        tx, ty = self.load_data(test_imgs, test_labels)               # rcn.rs:136-137
+        n, nt = self.load_set(0, train_imgs, train_labels), self.load_set(1, test_imgs, test_labels)      # rcn.rs:134-137, resident in HBM
         if not self._weights_loaded:                                   # rcn.rs:139-141
             self.load_weights_and_bias()
         accepted = []
         for e in range(epochs):                                        # rcn.rs:144
-            order = rng.permutation(len(x))                            # rcn.rs:146
-            for j in range(len(x) // batch_size):                      # chunks_exact drops the tail, rcn.rs:147
-                sel = order[j * batch_size:(j + 1) * batch_size]
-                self.train_batch(x[sel], y[sel], eta)
-            acc = self.evaluate(tx, ty)                                # rcn.rs:152-157
+            order = rng.permutation(n).astype(np.int32)                # rcn.rs:146
+            self.train_set_epoch(0, batch_size, eta, perm=order)       # chunks_exact + train_batch, rcn.rs:147-149: one call per epoch
+            acc = self.evaluate_set(1)                                 # rcn.rs:152-157
             accepted.append(acc)
             if log:
-                log("Epoch {}: {}/{} [{:.2f}%]".format(e, acc, len(tx), acc / len(tx) * 100.0))   # rcn.rs:158-164
+                log("Epoch {}: {}/{} [{:.2f}%]".format(e, acc, nt, acc / nt * 100.0))   # rcn.rs:158-164
         return accepted
+
+    # ------------------------------------------------------------------ RCN::train's data flow with the sets resident in HBM
+    def load_set(self, slot: int, imgs_u8: np.ndarray, labels: np.ndarray) -> int:
+        """load_data after the decode (rcn.rs:399-414) into device slot 0 (training) / 1 (testing); overwrites scale_set."""
+        imgs = np.ascontiguousarray(imgs_u8, dtype=np.uint8)
+        lab = np.ascontiguousarray(labels, dtype=np.int32)
+        if imgs.ndim != 3 or tuple(imgs.shape[1:]) != self.input_shape or len(lab) != len(imgs):
+            raise ValueError(f"expected [n]{list(self.input_shape)} u8 images and n labels")
+        self._ck(self._lib.rcn_hip_load_data(self._ctx, slot, imgs.ctypes.data_as(C.POINTER(C.c_uint8)), lab.ctypes.data_as(C.POINTER(C.c_int32)), len(imgs), None, None))
+        return len(imgs)
+
+    def train_set_epoch(self, slot: int, batch_size: int, eta: float, perm: Optional[np.ndarray] = None, seed: int = 0, want_loss: bool = False):
+        """One pass of rcn.rs:146-149 over a loaded slot; perm = the shuffled order (or None: shuffled on the device with `seed`)."""
+        n = C.c_int64()
+        self._ck(self._lib.rcn_hip_set_size(self._ctx, slot, C.byref(n)))
+        nb = n.value // batch_size if batch_size else 0
+        p = np.ascontiguousarray(perm, dtype=np.int32) if perm is not None else None
+        if p is not None and p.size < nb * batch_size:
+            raise ValueError("perm shorter than the batches it has to cover")
+        loss = np.zeros(max(nb, 1)) if want_loss else None
+        self._ck(self._lib.rcn_hip_train_set_epoch(self._ctx, slot, p.ctypes.data_as(C.POINTER(C.c_int32)) if p is not None else None, seed & 0xFFFFFFFFFFFFFFFF,
+                                                   batch_size, float(eta), loss.ctypes.data_as(C.POINTER(C.c_double)) if want_loss else None))
+        return loss[:nb] if want_loss else None
+
+    def evaluate_set(self, slot: int) -> int:
+        acc = C.c_int64()
+        self._ck(self._lib.rcn_hip_evaluate_set(self._ctx, slot, C.byref(acc)))
+        return int(acc.value)
 
 
 # ---------------------------------------------------------------------------------------------------------------

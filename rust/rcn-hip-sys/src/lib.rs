@@ -19,6 +19,12 @@ pub const RCN_HIP_ERR_UNSUPPORTED: c_int = -3; // Pooling::Average -> panic!("No
 
 pub const RCN_HIP_F32: i32 = 0;
 pub const RCN_HIP_F64: i32 = 1;
+pub const RCN_HIP_LAYER_CONVOLVE2D: i32 = 0; // rcn.rs:35-38 (bincode variant indices)
+pub const RCN_HIP_LAYER_POOL2D: i32 = 1;
+pub const RCN_HIP_PAD_NONE: i32 = 0; // utils/kernel.rs:25-28
+pub const RCN_HIP_PAD_SAME: i32 = 1;
+pub const RCN_HIP_POOL_AVERAGE: i32 = 0; // utils/kernel.rs:32-35
+pub const RCN_HIP_POOL_MAX: i32 = 1;
 
 /// `RCNLayer::Convolve2D(Padding) | RCNLayer::Pool2D(Pooling)` (rcn.rs:35-38); tags = bincode variant indices.
 #[repr(C)]
@@ -117,6 +123,11 @@ extern "C" {
                                         eta: c_double, loss: *mut c_void) -> c_int;
     pub fn rcn_hip_dp_train_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b_shard: usize, n_batches: usize,
                                       eta: c_double, loss: *mut c_void) -> c_int;
+    // RCN::train's data flow with both sets resident in HBM (rcn.rs:126-167)
+    pub fn rcn_hip_load_data(ctx: *mut rcn_hip_ctx, slot: c_int, imgs: *const u8, labels: *const i32, n: usize, mean: *mut c_double, sd: *mut c_double) -> c_int;
+    pub fn rcn_hip_train_set_epoch(ctx: *mut rcn_hip_ctx, slot: c_int, perm: *const i32, shuffle_seed: u64, b: usize, eta: c_double, loss_out: *mut c_double) -> c_int;
+    pub fn rcn_hip_evaluate_set(ctx: *mut rcn_hip_ctx, slot: c_int, accepted: *mut i64) -> c_int;
+    pub fn rcn_hip_set_size(ctx: *const rcn_hip_ctx, slot: c_int, n: *mut i64) -> c_int;
     pub fn rcn_hip_forward(ctx: *mut rcn_hip_ctx, x: *const c_double, n: usize, out: *mut c_double) -> c_int;
     pub fn rcn_hip_forward_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, n: usize, out: *mut c_void) -> c_int;
     pub fn rcn_hip_classify(ctx: *mut rcn_hip_ctx, x: *const c_double, n: usize, class_out: *mut i32) -> c_int;
@@ -135,6 +146,14 @@ pub struct HipError {
     pub status: i32,
     pub message: String,
 }
+
+impl std::fmt::Display for HipError {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "rcn_hip status {}: {}", self.status, self.message)
+    }
+}
+
+impl std::error::Error for HipError {}
 
 /// Safe owner of one context.  `Send` but not `Sync`, like `RCN` behind `&mut self` (rcn.rs:126).
 pub struct Context {
@@ -221,6 +240,108 @@ impl Context {
 
     pub fn raw(&mut self) -> *mut rcn_hip_ctx {
         self.raw
+    }
+
+    // ---- operator API (traits Convolve2D / Pool2D, utils/kernel.rs:61-100, 219-236); matrices f64 column-major ----
+    /// Output shape of `convolve_2d`; panics exactly where the reference does (utils/kernel.rs:123-135).
+    pub fn conv_out_shape(&self, r: usize, c: usize, kr: usize, kc: usize, padding: i32) -> (usize, usize) {
+        let (mut or, mut oc) = (0 as c_int, 0 as c_int);
+        let st = unsafe { rcn_hip_conv_out_shape(r as c_int, c as c_int, kr as c_int, kc as c_int, padding, &mut or, &mut oc) };
+        if st != RCN_HIP_OK {
+            panic!("convolve_2d expects 'self.shape() >= kernel_shape() > 0' and an odd kernel under Padding::Same (utils/kernel.rs:123-135)");
+        }
+        (or as usize, oc as usize)
+    }
+
+    /// Output shape of `pool_2d`; panics for matrices below 2x2 (utils/kernel.rs:246-251).
+    pub fn pool_out_shape(&self, r: usize, c: usize, padding: i32) -> (usize, usize) {
+        let (mut or, mut oc) = (0 as c_int, 0 as c_int);
+        let st = unsafe { rcn_hip_pool_out_shape(r as c_int, c as c_int, padding, &mut or, &mut oc) };
+        if st != RCN_HIP_OK {
+            panic!("stride_2d expected a matrix with dimensions greater than (2, 2), got ({}, {})", r, c);
+        }
+        (or as usize, oc as usize)
+    }
+
+    #[allow(clippy::too_many_arguments)]
+    pub fn convolve_2d(&mut self, m: &[f64], r: usize, c: usize, kernel: &[f64], kr: usize, kc: usize, padding: i32, out: &mut [f64]) -> Result<(), HipError> {
+        let st = unsafe {
+            rcn_hip_convolve_2d(self.raw, m.as_ptr(), 1, r as c_int, c as c_int, kernel.as_ptr(), kr as c_int, kc as c_int, padding, out.as_mut_ptr())
+        };
+        self.check(st)
+    }
+
+    pub fn convolve_2d_separated(&mut self, m: &[f64], r: usize, c: usize, sep_op: i32, padding: i32, out: &mut [f64]) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_convolve_2d_separated(self.raw, m.as_ptr(), 1, r as c_int, c as c_int, sep_op, padding, out.as_mut_ptr()) };
+        self.check(st)
+    }
+
+    pub fn relu(&mut self, m: &[f64], out: &mut [f64]) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_relu(self.raw, m.as_ptr(), m.len(), out.as_mut_ptr()) };
+        self.check(st)
+    }
+
+    pub fn pool_2d(&mut self, m: &[f64], r: usize, c: usize, padding: i32, pooling: i32, out: &mut [f64]) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_pool_2d(self.raw, m.as_ptr(), 1, r as c_int, c as c_int, padding, pooling, out.as_mut_ptr()) };
+        self.check(st)
+    }
+
+    // ---- RCN::train's data flow with both sets resident in HBM (rcn.rs:126-167) ----
+    /// `load_data` after the image decode (rcn.rs:399-414) into slot 0 (training) / 1 (testing); returns the set's (mean, sd),
+    /// which is also the context's `scale_set` from now on (rcn.rs:249-250).
+    pub fn load_data(&mut self, slot: i32, pixels: &[u8], labels: &[i32]) -> Result<(f64, f64), HipError> {
+        let (mut mean, mut sd) = (0.0, 0.0);
+        let st = unsafe { rcn_hip_load_data(self.raw, slot, pixels.as_ptr(), labels.as_ptr(), labels.len(), &mut mean, &mut sd) };
+        self.check(st).map(|_| (mean, sd))
+    }
+
+    /// One pass of rcn.rs:146-149 over a loaded slot: `order` is the shuffled index list (`training_set.shuffle`), the
+    /// batches are `order.chunks_exact(batch_size)`.
+    pub fn train_set_epoch(&mut self, slot: i32, order: &[i32], batch_size: usize, eta: f64) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_train_set_epoch(self.raw, slot, order.as_ptr(), 0, batch_size, eta, std::ptr::null_mut()) };
+        self.check(st)
+    }
+
+    /// The accuracy count of rcn.rs:152-157 over a loaded slot.
+    pub fn evaluate_set(&mut self, slot: i32) -> Result<usize, HipError> {
+        let mut acc = 0i64;
+        let st = unsafe { rcn_hip_evaluate_set(self.raw, slot, &mut acc) };
+        self.check(st).map(|_| acc as usize)
+    }
+
+    /// `RCN::classify` minus the image decode (rcn.rs:84-97): features, standardise with `scale_set`, forward, last arg-max.
+    pub fn classify_image(&mut self, pixels: &[u8]) -> Result<usize, HipError> {
+        let mut cls = 0i32;
+        let st = unsafe { rcn_hip_classify_images(self.raw, pixels.as_ptr(), 1, &mut cls) };
+        self.check(st).map(|_| cls as usize)
+    }
+
+    /// `load_weights_and_bias` (rcn.rs:425-457); seed 0 = non-deterministic like `thread_rng`.
+    pub fn init_params(&mut self, seed: u64) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_init_params(self.raw, seed) };
+        self.check(st)
+    }
+
+    pub fn set_scale(&mut self, mean: f64, sd: f64) -> Result<(), HipError> {
+        let st = unsafe { rcn_hip_set_scale(self.raw, mean, sd) };
+        self.check(st)
+    }
+
+    pub fn scale(&self) -> (f64, f64) {
+        let (mut mean, mut sd) = (0.0, 0.0);
+        unsafe { rcn_hip_get_scale(self.raw, &mut mean, &mut sd) };
+        (mean, sd)
+    }
+
+    pub fn num_layers(&self) -> usize {
+        unsafe { rcn_hip_num_layers(self.raw) as usize }
+    }
+
+    /// (rows, cols) of `Weights` l: rows = outputs, cols = inputs (rcn.rs:502).
+    pub fn layer_dims(&self, layer: usize) -> (usize, usize) {
+        let (mut r, mut c) = (0i32, 0i32);
+        unsafe { rcn_hip_layer_dims(self.raw, layer as c_int, &mut r, &mut c) };
+        (r as usize, c as usize)
     }
 }
 

@@ -377,3 +377,77 @@ def test_init_params_draws_unscaled_standard_normals_w_then_b_per_layer(amd):
         assert np.array_equal(x.astype(np.float32).astype(np.float64), y)
     r.close()
     r32.close()
+
+
+# ------------------------------------------------------------------------------------------------ resident data sets
+
+@pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
+def test_resident_set_training_flow_equals_the_oracle_loop(amd, oracle, dtype):
+    """rcn_hip_load_data / rcn_hip_train_set_epoch / rcn_hip_evaluate_set -- what a host-language RCN::train calls (rust/rcn-hip,
+    csrc/host/rcn.hpp, rcn.py: train_arrays) -- against the oracle's restatement of rcn.rs:126-167 on the same pictures, the same
+    shuffles and the same initial parameters: scale_set ends up holding the TEST statistics (rcn.rs:134-137), chunks_exact drops the
+    tail (300 samples, batch 32 -> 9 steps), the accepted counts per epoch agree."""
+    B, epochs = 32, 3
+    imgs, labels = synthetic_images(300, seed=3)
+    timgs, tlabels = synthetic_images(120, seed=4)
+    ws, bs = synthetic_params(BENCH_DIMS, seed=21)
+    ws = [w * 0.05 for w in ws]
+    r = amd.RCN(10, amd.default_convpool(), [30], input_shape=(28, 28), dtype=dtype)
+    r.set_params(ws, bs)
+    assert r.load_set(0, imgs, labels) == 300 and r.load_set(1, timgs, tlabels) == 120
+    # oracle side
+    f, tf = oracle.features(imgs, DEFAULT_LAYERS), oracle.features(timgs, DEFAULT_LAYERS)
+    X = oracle.standardize(f, *oracle.gen_scales(f))
+    tm, ts = oracle.gen_scales(tf)
+    TX = oracle.standardize(tf, tm, ts)
+    Y, TY = one_hot(labels), one_hot(tlabels)
+    np.testing.assert_allclose(r.scale_set, (tm, ts), rtol=1e-12)          # the TEST set's statistics
+    rng = np.random.default_rng(99)
+    rw, rb = ws, bs
+    tol = 1e-10 if dtype == 1 else 2e-4
+    for e in range(epochs):
+        order = rng.permutation(300).astype(np.int32)
+        loss = r.train_set_epoch(0, B, 3.0, perm=order, want_loss=True)
+        assert loss.shape == (300 // B,)
+        costs = []
+        for j in range(300 // B):
+            sel = order[j * B:(j + 1) * B]
+            rw, rb, c = oracle.train_batch(rw, rb, X[sel], Y[sel], 3.0)
+            costs.append(c)
+        np.testing.assert_allclose(loss, costs, rtol=1e-9 if dtype == 1 else 2e-3)
+        out = oracle.classify_test(rw, rb, TX)
+        want = sum(oracle.eval_accept(out[i], TY[i]) for i in range(len(TX)))
+        got = r.evaluate_set(1)
+        assert got == want if dtype == 1 else abs(got - want) <= 2, (e, got, want)
+    gw, gb = r.get_params()
+    for a, b in zip(gw + gb, rw + rb):
+        assert np.all(np.abs(a - b) <= tol * np.abs(b) + tol * 0.1)
+    # a device-side shuffle instead of a host order: a permutation, deterministic per seed
+    l1 = r.train_set_epoch(0, B, 0.0, seed=7, want_loss=True)
+    l2 = r.train_set_epoch(0, B, 0.0, seed=7, want_loss=True)
+    l3 = r.train_set_epoch(0, B, 0.0, seed=8, want_loss=True)
+    assert np.array_equal(l1, l2) and not np.array_equal(l1, l3)
+    # error behaviour: unloaded slot, labels beyond the classes, batch size 0
+    r2 = amd.RCN(10, amd.default_convpool(), [30], input_shape=(28, 28), dtype=dtype)
+    r2.set_params(ws, bs)
+    with pytest.raises(amd.RcnHipError):
+        r2.evaluate_set(0)
+    with pytest.raises(amd.RcnPanic):
+        r2.load_set(0, imgs[:4], np.array([0, 1, 10, 2]))
+    r2.load_set(0, imgs[:40], labels[:40])
+    with pytest.raises(amd.RcnHipError):
+        r2.train_set_epoch(0, 0, 3.0)
+    assert r2.train_set_epoch(0, 64, 3.0, seed=1, want_loss=True).shape == (0,)      # fewer samples than one batch: no step (rcn.rs:147)
+    r.close(); r2.close()
+
+
+def test_train_arrays_runs_on_resident_sets_and_prints_the_reference_line(amd, oracle):
+    imgs, labels = synthetic_images(200, seed=5)
+    timgs, tlabels = synthetic_images(80, seed=6)
+    r = amd.RCN(10, amd.default_convpool(), [30], input_shape=(28, 28), dtype=amd.F64)
+    lines = []
+    acc = r.train_arrays(imgs, labels, timgs, tlabels, 10, 2, 3.0, rng=np.random.default_rng(1), log=lines.append)
+    assert len(acc) == 2 and all(0 <= a <= 80 for a in acc)
+    import re
+    assert all(re.fullmatch(r"Epoch \d+: \d+/80 \[\d+\.\d\d%\]", l) for l in lines), lines      # rcn.rs:158-164
+    r.close()
