@@ -274,14 +274,16 @@ int  rcn_hip_evaluate_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev
 int  rcn_hip_classify_images(rcn_hip_ctx* ctx, const uint8_t* imgs, size_t n, int32_t* class_out);
 
 /* ---------------------------------------------------------------- tuning / measurement aids */
-/* Which kernels implement train_batch / train_epoch: 0 = automatic (feature-sliced pipeline for batches <= 1024 when
- * the layer stack allows it, sample-tile kernels otherwise), 1 = always the sample-tile kernels, 2 = always the
- * feature-sliced pipeline, 3 = experimental: one resident kernel per epoch segment whose workgroups exchange results through
- * tagged words (f32, default shape class only; needs all its workgroups on the GPU at once -- a device shared with another
- * process can make a call fail with RCN_HIP_ERR_HIP instead; currently slower than mode 2), 4 = experimental:
- * one launch per step, the deltas handed from the sample groups to the feature slices inside the launch (f32, default shape
- * class only; bit-identical to mode 2 and as fast, no residency requirement; train_epoch calls only).  All compute the same
- * step (summation grouping differs, within the stated tolerances). */
+/* Which kernels implement train_batch / train_epoch: 0 = automatic (the feature-sliced pipeline for batches <= 1024 when the layer
+ * stack allows it -- as ONE resident kernel per epoch segment whose 32 workgroups share one XCD and hand over through its L2
+ * (csrc/dense_xcd.hpp) where that form applies: f32 context, one hidden layer <= 32, classes <= 16, batch 256, and a device on
+ * which a placement probe finds the blocks with blockIdx.x % 8 == 0 on one XCD; as two kernels per step (csrc/dense_p2.hpp,
+ * dense_pipe.hpp) otherwise -- and the sample-tile kernels for everything else), 1 = always the sample-tile kernels, 2 = the
+ * feature-sliced pipeline as two kernels per step, 5 = the resident one-XCD kernel (RCN_HIP_ERR_UNSUPPORTED where it does not
+ * apply; environment RCN_HIP_XCD=0 keeps mode 0 off it).  The resident kernel needs its 32 workgroups on the GPU at once: on a
+ * device shared with another process a call can fail with RCN_HIP_ERR_HIP (bounded waits; the failed segment is not applied).
+ * 3 and 4 are parked experiments compiled only into librcn_hip_exp.so.  All compute the same step (summation grouping differs,
+ * within the stated tolerances). */
 int  rcn_hip_set_dense_path(rcn_hip_ctx* ctx, int mode);
 /* Which kernel implements flatten_feature_set: 0 = automatic (the fused conv+pool kernel specialised for the default
  * stack conv(Same),pool(Max),conv(Same),pool(Max) on 28x28 input when the configuration is exactly that, the generic
@@ -297,7 +299,9 @@ int  rcn_hip_set_feature_kernel(rcn_hip_ctx* ctx, int mode);
  * rcn_hip_train_epoch_dev), successive launches walk that epoch's batches, so the timing includes the same cold reads as
  * the real loop.  us_pair (nullable) times `reps` repetitions of (first, second) alternating, as the real loop issues
  * them: the two kernels of a step cost more alternating than each back to back with itself (+1.7 us per pair measured),
- * so a profiler's per-dispatch average corresponds to us_pair split in the ratio us_first : us_second.  Blocks. */
+ * so a profiler's per-dispatch average corresponds to us_pair split in the ratio us_first : us_second.  Where the resident
+ * one-XCD kernel runs the step there is no first / second kernel: one launch runs all steps of the packed image's first
+ * segment; *us_first = 0 and *us_second = *us_pair = that launch's duration divided by its number of steps.  Blocks. */
 int  rcn_hip_time_kernels_dev(rcn_hip_ctx* ctx, const void* x_dev, const void* y_dev, size_t B, int reps,
                               double* us_first, double* us_second, double* us_pair /* nullable: the two alternating */);
 

@@ -1,0 +1,514 @@
+// dense_xcd.hpp -- the feature-sliced pipeline of dense_p2.hpp as ONE resident kernel per epoch segment whose workgroups all sit
+// on ONE XCD (f32, the reference's own network shape class, batch 256).
+//
+// Why.  The two-kernel step (k_p2_b, k_p2_a) is bound by what surrounds its arithmetic: two dependent launch boundaries (~1.5 us
+// each), W_0 and the batch leaving and re-entering the chip, and a 1.6 MB slab of partial sums written to and read back from
+// memory every step (3.9x the algorithmic traffic by PMC).  Round 1 tried the obvious fix -- keep the workgroups resident and hand
+// results over inside the launch -- and measured it SLOWER (11.7 us vs 9.6): its 85 workgroups were spread over all eight XCDs,
+// whose L2s are not coherent with each other, so every hand-off had to be written through to memory and read back with L2 misses.
+//
+// What is different here.  An XCD has 32 CUs behind ONE coherent 4 MiB L2.  Blocks are dealt round-robin over the XCDs, so the
+// blocks with blockIdx.x % 8 == 0 share one: the kernel is launched with 8 x 32 blocks, the 224 others return at once, and the 32
+// WORKERS (one per CU of that XCD: each asks for > 80 KB of LDS) hand over through that L2 -- payloads as PLAIN stores (they stay
+// dirty in L2 and are overwritten in place next step: no memory traffic at all), read with L1-bypassing (sc1) loads, announced by
+// one flag word per producer after its waves drained their stores.  tools/ubench_xcd_ring.hip measured the two hand-offs of a
+// step at 3.0-3.6 us together this way (5.3 us write-through, 5.9 us spread over the XCDs), with zero stale words in 2000 rounds;
+// plain stores between DIFFERENT XCDs are stale every time, so placement is part of correctness here: every worker publishes its
+// XCC_ID and checks all 32 before it trusts a plain store (a mismatch raises the sticky error word and nothing is written), and
+// the host probes the placement once per context before it ever selects this path.
+//
+// Roles.  Worker w plays, every step, in this order:
+//   sample group w   (all 32)          the work of k_p2_b for samples 8w..8w+7: wait for the slab parts of all feature workers and
+//                                      the tail parameters -> sum in producer order -> a_1, layer 2, cost part, delta_2, delta_1.
+//   feature worker w (w < NA)          the work of k_p2_a for the slice pair 2w, 2w+1 of W_0 (32 features): wait for delta_1 of all
+//                                      sample groups -> dW_0 slice over the whole batch (MFMA, K split over the 8 waves) -> update
+//                                      -> partial z_1 of the NEXT batch from the updated slice -> slab.  The slice of W_0 and the
+//                                      batch's features live in LDS: the slice never leaves the CU until the launch ends, and a
+//                                      batch is read from memory ONCE (for the forward of step j and the gradient of step j + 1),
+//                                      prefetched a whole step ahead.
+//   tail tile e      (w = NA + e)      db_0 or a 16-column tile of [W_1 | b_1]: gradient over the whole batch, update, and the new
+//                                      values scattered into the operand-fragment image the sample groups read (p2_frag_scatter).
+// Per step two hand-offs (slab: 25 producers -> 32 consumers; deltas / activations: 32 -> 28), no launch, no fence.
+// Summation orders are fixed (producer order across slab parts, wave order inside a workgroup): results are bit-reproducible and
+// agree with the two-kernel pipeline to f32 rounding of a different grouping (the oracle tolerances of tests/ hold for both).
+//
+// No hang by construction: every wait is bounded by the 100 MHz wall clock and raises a sticky error word that makes every
+// worker leave at its next wait; the parameters in memory are written only by a launch that ran to its end.
+#pragma once
+
+#include "dense_p2.hpp"
+
+namespace rcn {
+
+constexpr int kXcdWorkers = 32, kXcdThreads = 512, kXcdFlagStride = 32;      // flags: one 128-byte line each
+constexpr int kXcdSl = 2;                                                      // 16-feature slices per feature worker
+
+struct XcdBufs {
+    float* slab;       // [B/8][NA][8][32]   partial z_1 of one batch, consumer-major
+    float* d1;         // [B][32]            delta_1, a_1 [B][32], delta_2 [B][16], cost parts [B/8]: written by the sample groups
+    float* a1;
+    float* d2;
+    float* loss;
+    float* fragimg;    // [28][64]           tail parameters as the sample groups' MFMA operand fragments
+    unsigned* flagA;   // [32 x stride]      step tag of the newest complete slab part of feature worker w
+    unsigned* flagB;   // [32 x stride]      step tag of the newest complete outputs of sample group w
+    unsigned* flagT;   // [8 x stride]       step tag for which tail tile e's share of the fragment image is current
+    unsigned* xcc;     // [32 x stride]      (launch tag << 4) | XCC_ID of worker w
+};
+
+inline int xcd_na(const NetDesc& nd) { return (pipe_slices(nd) + kXcdSl - 1) / kXcdSl; }
+inline bool xcd_supported(const NetDesc& nd, size_t B) {
+    return p2_supported(nd, B) && B == 256 && xcd_na(nd) + pipe_extra_wgs(nd) <= kXcdWorkers && pipe_extra_wgs(nd) <= 8;
+}
+inline size_t xcd_buf_bytes(const NetDesc& nd, size_t B) {
+    const size_t NS = B / kP2Ts, NA = (size_t)xcd_na(nd);
+    return (NS * NA * kP2Ts * kP2H + 2 * B * kP2H + B * kP2C + NS + (size_t)kP2BFrag * 64) * sizeof(float) +
+           (size_t)(3 * kXcdWorkers + 8) * kXcdFlagStride * sizeof(unsigned) + 512;
+}
+// LDS (floats): two batch buffers of a slice pair, the K-split partials of both slices, the slice pair of W_0, and the sample
+// group's scratch (slab partial sums, a_1 / delta_2 tiles, target fragments)
+constexpr size_t kXcdXs = (size_t)kXcdSl * 256 * 16;
+constexpr size_t kXcdLdsFloats = 2 * kXcdXs + (size_t)kDenseWaves * kXcdSl * kMtp * kRedTile + (size_t)kXcdSl * 16 * kP2H +
+                                 (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + kP2C * kLd + (size_t)kP2BFrag * 64 + 64;
+
+using xu4 = __attribute__((ext_vector_type(4))) unsigned;
+#define XCD_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+// L1-bypassing (sc1, aux 16) reads of what another CU of this XCD stored in this launch; served by the shared L2
+__device__ inline Vec4<float>::type xcd_ld4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const xu4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    Vec4<float>::type f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+__device__ inline float xcd_ld1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16);
+    float f;
+    __builtin_memcpy(&f, &v, 4);
+    return f;
+}
+__device__ inline void xcd_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ inline void xcd_flag(unsigned* f, unsigned tag) { __hip_atomic_store(f, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ONE wave waits until every flag its lanes look at (lane < n0: f0[lane]; n0 <= lane < n0 + n1: f1[lane - n0]) carries a tag >= tag.
+// Bounded: gives up after `timeout` ticks of the 100 MHz clock or when another worker raised the sticky error word.
+__device__ inline bool xcd_wait(const unsigned* f0, int n0, const unsigned* f1, int n1, unsigned tag, long long timeout, const unsigned* err) {
+    const int lane = threadIdx.x & 63;
+    const unsigned* p = lane < n0 ? f0 + lane * kXcdFlagStride : (lane < n0 + n1 ? f1 + (lane - n0) * kXcdFlagStride : nullptr);
+    long long t0 = 0;
+    for (unsigned it = 0;; ++it) {
+        const unsigned f = p ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+        if (__all((int)(f - tag) >= 0)) return true;
+        if ((it & 255u) == 255u) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// nb consecutive train_batch steps (rcn.rs:176-223) over the packed batches xs[j] (slice-major, k_pack_epoch), ys[j]
+__global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
+    NetDesc nd, float* __restrict__ params, const float* __restrict__ xs_all, const float* __restrict__ ys_all, int B, int nb, int G, float scale,
+    float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout) {
+    using T = float;
+    using acc_t = Mfma16<T>::acc_t;
+    using vec4 = Vec4<T>::type;
+    if ((blockIdx.x & 7) != 0) return;                              // the other seven XCDs' blocks
+    const int w = (int)(blockIdx.x >> 3);
+    if (w >= kXcdWorkers) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    __shared__ int s_abort;
+    T* smem = reinterpret_cast<T*>(smem_dyn);
+    T* xbuf = smem;                                                 // [2][kXcdSl][B][16]
+    T* red = xbuf + 2 * kXcdXs;                                     // [wave][slice][mt][16 x kLd]
+    T* wsl = red + kDenseWaves * kXcdSl * kMtp * kRedTile;          // [slice][feature 0..15][32]
+    vec4* zred = reinterpret_cast<vec4*>(wsl + kXcdSl * 16 * kP2H); // [8 waves][64 lanes]
+    T* a1s = reinterpret_cast<T*>(zred) + kP2BWaves * 64 * 4;       // a_1 tile  [hidden 32][kLd]
+    T* d2s = a1s + kP2H * kLd;                                      // delta_2   [class 16][kLd]
+    T* frag = d2s + kP2C * kLd;                                     // [word][lane]: only the target words 20..23 are used
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
+    const int F = nd.dims[0], H = nd.dims[1], C = nd.dims[2];
+    const int NS = B / kP2Ts;                                       // 32 sample groups
+    const int NA = (G + kXcdSl - 1) / kXcdSl, NT = 1 + nd.tile_start[nd.L] - nd.tile_start[1];    // = pipe_extra_wgs(nd)
+    const bool is_a = w < NA, is_t = w >= NA && w < NA + NT;
+    const int e = w - NA;                                           // tail tile index when is_t
+    const int nsl = is_a ? (G - kXcdSl * w < kXcdSl ? G - kXcdSl * w : kXcdSl) : 0;
+    const size_t xs_stride = (size_t)G * B * 16, ys_stride = (size_t)B * C;
+    const auto r_slab = XCD_RSRC(bufs.slab, (size_t)NS * NA * kP2Ts * kP2H * 4);
+    const auto r_d1 = XCD_RSRC(bufs.d1, (size_t)B * kP2H * 4), r_a1 = XCD_RSRC(bufs.a1, (size_t)B * kP2H * 4);
+    const auto r_d2 = XCD_RSRC(bufs.d2, (size_t)B * kP2C * 4), r_loss = XCD_RSRC(bufs.loss, (size_t)NS * 4);
+    const auto r_img = XCD_RSRC(bufs.fragimg, (size_t)kP2BFrag * 64 * 4);
+
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+    // ---- placement: every worker says where it runs; nobody trusts a plain store before it has seen 32 equal answers
+    if (tid == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcd_flag(bufs.xcc + w * kXcdFlagStride, (tag0 << 4) | (id & 0xfu));
+    }
+    if (wave == 0) {
+        long long t0 = 0;
+        bool ok = true;
+        unsigned mine = 0, v = 0;
+        for (unsigned it = 0;; ++it) {
+            v = lane < kXcdWorkers ? __hip_atomic_load(bufs.xcc + lane * kXcdFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag0 << 4);
+            if (__all((v >> 4) == (tag0 & 0x0fffffffu))) break;
+            if ((it & 255u) == 255u) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        mine = __shfl(v, w < 64 ? w : 0, 64) & 0xfu;
+        const bool same = __all(lane >= kXcdWorkers || (v & 0xfu) == mine);
+        if (lane == 0 && !(ok && same)) {
+            s_abort = 1;
+            __hip_atomic_store(err, ok ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // 2: workers on different XCDs; 1: a wait expired
+        }
+    }
+    __syncthreads();
+    if (s_abort) return;
+
+    // ---- feature worker: its slice pair of W_0 into LDS and registers; the first two batches into the two LDS buffers
+    T* W0 = params + nd.w_off[0];
+    const int ml = tid & 15, cl = (tid >> 4) & 15, mt = tid >> 8, m = mt * 16 + ml;      // this thread's element (hidden m, feature cl) of each slice
+    T wcur[kXcdSl] = {0, 0};
+    bool wvalid[kXcdSl] = {false, false};
+    size_t woff[kXcdSl] = {0, 0};
+    if (is_a) {
+#pragma unroll
+        for (int sl = 0; sl < kXcdSl; ++sl) {
+            const int f0 = (kXcdSl * w + sl) * 16;
+            const int nf = sl < nsl ? (F - f0 < 16 ? F - f0 : 16) : 0;
+            wvalid[sl] = m < H && cl < nf;
+            woff[sl] = wvalid[sl] ? (size_t)(f0 + cl) * H + m : 0;
+            const T v = W0[woff[sl]];
+            wcur[sl] = wvalid[sl] ? v : (T)0;
+            wsl[(sl * 16 + cl) * kP2H + m] = wcur[sl];
+        }
+        // batches 0 and 1 of this launch: [slice pair][sample][16] is one contiguous run of nsl * B * 16 floats per batch
+        for (int b = 0; b < 2 && b < nb; ++b) {
+            const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)b * xs_stride + (size_t)(kXcdSl * w) * B * 16);
+            vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(b & 1) * kXcdXs);
+            for (int i = tid; i < nsl * B * 4; i += kXcdThreads) dst[i] = src[i];
+            for (int i = nsl * B * 4 + tid; i < kXcdSl * B * 4; i += kXcdThreads) dst[i] = vec4{0, 0, 0, 0};
+        }
+    }
+    // tail tile: this thread's parameter (column cc of [W_jl | b_jl], row tm), kept in a register until the launch ends
+    T tcur = 0;
+    size_t tp = 0;
+    bool tvalid = false;
+    if (is_t) {
+        const int jl = e == 0 ? 0 : 1, n0 = e == 0 ? F : (e - 1) * 16;
+        const int Kin = nd.dims[jl], M = nd.dims[jl + 1];
+        const int o = tid & 255, tm = mt * 16 + (o & 15), cc = n0 + (o >> 4);
+        tvalid = tm < M && cc <= Kin;
+        tp = tvalid ? (size_t)nd.w_off[jl] + (size_t)cc * M + tm : 0;
+        tcur = params[tp];
+    }
+    __syncthreads();
+
+    // partial z_1 of batch `jn` (LDS buffer jn & 1) from the slice pair in LDS -> this worker's part of the slab
+    auto forward = [&](int jn) {
+        const T* xb = xbuf + (size_t)(jn & 1) * kXcdXs;
+        T wf[kXcdSl][4][kMtp];
+#pragma unroll
+        for (int sl = 0; sl < kXcdSl; ++sl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) wf[sl][i][t] = wsl[(sl * 16 + 4 * g4 + i) * kP2H + t * 16 + n];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                                // B = 256: 16 sample tiles, two per wave
+            const int s = 16 * (wave + 8 * u) + n;
+            vec4 xv[kXcdSl];
+#pragma unroll
+            for (int sl = 0; sl < kXcdSl; ++sl) xv[sl] = *reinterpret_cast<const vec4*>(xb + ((size_t)sl * B + s) * 16 + 4 * g4);
+            acc_t acc[kMtp];
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int sl = 0; sl < kXcdSl; ++sl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(wf[sl][i][t], xv[sl][i], acc[t]);
+            T* dst = bufs.slab + (((size_t)(s >> 3) * NA + w) * kP2Ts + (s & 7)) * kP2H;
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) store4<T>(dst + t * 16, lane, acc[t]);
+        }
+        xcd_drain();                                                  // every storing wave, before the barrier in front of the flag
+    };
+
+    if (is_a) {
+        forward(0);
+        __syncthreads();
+        if (tid == 0) xcd_flag(bufs.flagA + w * kXcdFlagStride, tag0);
+    } else if (is_t) {
+        if (tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag0);   // the image the host built from the parameters is current
+    }
+
+    for (int j = 0; j < nb; ++j) {
+        const unsigned tag = tag0 + (unsigned)j;
+        const bool more = j + 1 < nb;
+        // (1) the batch after next, a whole step ahead: into registers now, into the LDS buffer step j's gradient frees
+        vec4 xr[4];
+        const bool pre = is_a && j + 2 < nb;
+        if (pre) {
+            const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)(j + 2) * xs_stride + (size_t)(kXcdSl * w) * B * 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = tid + r * kXcdThreads;
+                xr[r] = i < nsl * B * 4 ? src[i] : vec4{0, 0, 0, 0};
+            }
+        }
+
+        // =============================================================== sample group w: samples 8w .. 8w+7 of batch j
+        {
+            if (wave == 0 && !xcd_wait(bufs.flagA, NA, bufs.flagT, NT, tag, timeout, err) && lane == 0) {
+                s_abort = 1;
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (s_abort) return;
+            const int s0 = w * kP2Ts;
+            const T* Ys = ys_all + (size_t)j * ys_stride;
+            // slab: this group's NA x 1 KB, contiguous; wave q sums producers q, q + 8, q + 16, q + 24 in that order
+            vec4 z = vec4{0, 0, 0, 0};
+            {
+                vec4 t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = wave + kP2BWaves * q;
+                    t[q] = xcd_ld4(r_slab, (int)((((size_t)w * NA + (p < NA ? p : wave)) * 64 + lane) * 16));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (wave + kP2BWaves * q < NA) z += t[q];
+            }
+            T fr[kP2BFrag];
+            if (wave == 0) {
+#pragma unroll
+                for (int q = 0; q < kP2BFrag; ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1(r_img, (q * 64 + lane) * 4);
+            } else if (wave == 6) {                                   // targets per accumulator element
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = Mfma16<T>::row(lane, i);
+                    frag[(20 + i) * 64 + lane] = Ys[(size_t)(s0 + (n & 7)) * C + (c < C ? c : 0)];
+                }
+            }
+            zred[wave * 64 + lane] = z;
+            __syncthreads();
+            if (wave == 0) {
+                {   // fixed order across waves (as k_p2_b)
+                    typedef T h2 __attribute__((ext_vector_type(2)));
+                    vec4 r[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) r[q] = zred[q * 64 + lane];
+                    h2 lo[8], hi[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { lo[q] = h2{r[q][0], r[q][1]}; hi[q] = h2{r[q][2], r[q][3]}; }
+                    const h2 zl = ((lo[0] + lo[1]) + (lo[2] + lo[3])) + ((lo[4] + lo[5]) + (lo[6] + lo[7]));
+                    const h2 zh = ((hi[0] + hi[1]) + (hi[2] + hi[3])) + ((hi[4] + hi[5]) + (hi[6] + hi[7]));
+                    z = vec4{zl[0], zl[1], zh[0], zh[1]};
+                }
+#pragma unroll
+                for (int q = 20; q < 24; ++q) fr[q] = frag[q * 64 + lane];
+                // a_1 = sigmoid(z_1 + b_0); lane <- sample lane >> 3, hidden 4 (lane & 7) + i                        rcn.rs:287-289
+                {
+                    const int s = lane >> 3, h0 = 4 * (lane & 7);
+                    vec4 a;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const auto sg = sigmoid_fast(z[i] + fr[24 + i]);
+                        a[i] = (h0 + i < H) ? sg : (T)0;
+                        a1s[(h0 + i) * kLd + s] = a[i];
+                    }
+                    *reinterpret_cast<vec4*>(bufs.a1 + (size_t)(s0 + s) * kP2H + h0) = a;
+                }
+                // z_2 = W_1 a_1 + b_1, a_2 = sigmoid, delta_2 = (a_2 - y) (*) a_2 (1 - a_2)                          rcn.rs:287-289, 299
+                acc_t acc = acc_t{0, 0, 0, 0};
+                {
+                    T bv[8];
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) bv[ks] = a1s[(4 * ks + g4) * kLd + (n & 7)];
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) acc = Mfma16<T>::mfma(fr[ks], n < kP2Ts ? bv[ks] : (T)0, acc);
+                }
+                T lsum = 0;
+                acc_t dv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = Mfma16<T>::row(lane, i);
+                    const T a2 = sigmoid_fast(acc[i] + fr[16 + i]);
+                    const T diff = a2 - fr[20 + i];
+                    const bool ok = c < C && n < kP2Ts;
+                    dv[i] = ok ? diff * (a2 * ((T)1 - a2)) : (T)0;
+                    lsum += ok ? diff * diff : (T)0;
+                    d2s[c * kLd + n] = dv[i];
+                }
+                if (n < kP2Ts) store4<T>(bufs.d2 + (size_t)(s0 + n) * kP2C, lane, dv);
+                // delta_1 = (W_1^T delta_2) (*) a_1 (1 - a_1)                                                          rcn.rs:305-309
+                {
+                    T dvv[4], av[kMtp][4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) dvv[ks] = d2s[(4 * ks + g4) * kLd + n];
+#pragma unroll
+                    for (int t = 0; t < kMtp; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) av[t][i] = a1s[(t * 16 + Mfma16<T>::row(lane, i)) * kLd + (n & 7)];
+#pragma unroll
+                    for (int t = 0; t < kMtp; ++t) {
+                        acc_t ad = acc_t{0, 0, 0, 0};
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) ad = Mfma16<T>::mfma(fr[8 + t * 4 + ks], dvv[ks], ad);
+                        acc_t o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = ad[i] * (av[t][i] * ((T)1 - av[t][i]));
+                        if (n < kP2Ts) store4<T>(bufs.d1 + (size_t)(s0 + n) * kP2H + t * 16, lane, o);
+                    }
+                }
+                lsum = wave_sum_lane0(lsum);
+                if (lane == 0) bufs.loss[w] = lsum;
+                xcd_drain();                                              // only this wave stored
+                if (lane == 0) xcd_flag(bufs.flagB + w * kXcdFlagStride, tag);
+            }
+        }
+
+        // =============================================================== second half of step j: needs every sample group's outputs
+        if (is_a || is_t) {
+            if (wave == 1 && !xcd_wait(bufs.flagB, NS, nullptr, 0, tag, timeout, err) && lane == 0) {
+                s_abort = 1;
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();                                                   // (also orders wave 0's LDS scratch against the next step's)
+        if (s_abort) return;
+
+        if (is_a) {
+            // ---- U: dW_0[:, slice pair] = sum_s delta_1[s] (x) x_s[slice pair]; W_0 <- W_0 - (eta/B) dW_0            rcn.rs:310, 214
+            const T* xb = xbuf + (size_t)(j & 1) * kXcdXs;
+            acc_t acc[kXcdSl][kMtp];
+#pragma unroll
+            for (int sl = 0; sl < kXcdSl; ++sl)
+#pragma unroll
+                for (int t = 0; t < kMtp; ++t) acc[sl][t] = acc_t{0, 0, 0, 0};
+            {
+                const int kc = wave * (B >> 3);                            // 32 samples per wave: one chunk of 8 k-steps
+                T av[8][kMtp], bv[kXcdSl][8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int t = 0; t < kMtp; ++t) av[q][t] = xcd_ld1(r_d1, (int)((((size_t)(kc + g4 + 4 * q)) * kP2H + t * 16 + n) * 4));
+#pragma unroll
+                    for (int sl = 0; sl < kXcdSl; ++sl) bv[sl][q] = xb[((size_t)sl * B + kc + g4 + 4 * q) * 16 + n];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int sl = 0; sl < kXcdSl; ++sl)
+#pragma unroll
+                        for (int t = 0; t < kMtp; ++t) acc[sl][t] = Mfma16<T>::mfma(av[q][t], bv[sl][q], acc[sl][t]);
+            }
+#pragma unroll
+            for (int sl = 0; sl < kXcdSl; ++sl) store_partials<T>(red + (size_t)sl * kDenseWaves * kMtp * kRedTile, wave, lane, acc[sl]);
+            __syncthreads();
+#pragma unroll
+            for (int sl = 0; sl < kXcdSl; ++sl) {
+                const T wn = wcur[sl] - scale * sum_partials<T>(red + (size_t)sl * kDenseWaves * kMtp * kRedTile, mt, cl, ml);
+                wcur[sl] = wvalid[sl] ? wn : (T)0;
+                wsl[(sl * 16 + cl) * kP2H + m] = wcur[sl];
+            }
+            // the LDS buffer of batch j is free now: the batch after next moves in
+            if (pre) {
+                vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(j & 1) * kXcdXs);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[tid + r * kXcdThreads] = xr[r];
+            }
+            __syncthreads();
+            if (more) {
+                forward(j + 1);
+                __syncthreads();
+                if (tid == 0) xcd_flag(bufs.flagA + w * kXcdFlagStride, tag + 1);
+            }
+        } else if (is_t) {
+            // ---- tail tile e: e == 0 the bias column of W_0 (db_0 = sum_s delta_1); e >= 1 a 16-column tile of [W_1 | b_1]
+            if (e == 0 && tid == 0 && loss_dev) {
+                T t = 0;
+                for (int i = 0; i < NS; ++i) t += xcd_ld1(r_loss, i * 4);
+                loss_dev[j] = t * loss_scale;
+            }
+            const int jl = e == 0 ? 0 : 1, n0 = e == 0 ? F : (e - 1) * 16;
+            const int Kin = nd.dims[jl], M = nd.dims[jl + 1];
+            const int c = n0 + n;                                          // this lane's column of [W | b]
+            const auto r_act = e == 0 ? r_d1 : r_a1;                       // A_prev: unused for the bias-only tile (every column >= Kin)
+            const auto r_del = e == 0 ? r_d1 : r_d2;
+            const int ldD = e == 0 ? kP2H : kP2C, ldA = kP2H;
+            acc_t acc[kMtp];
+#pragma unroll
+            for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
+            {
+                const int kc = wave * (B >> 3);
+                const int cc_ld = (e != 0 && c < Kin) ? c : 0;
+                T bv[8], av[8][kMtp];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int s = kc + 4 * q + g4;
+                    bv[q] = xcd_ld1(r_act, (int)(((size_t)s * ldA + cc_ld) * 4));
+#pragma unroll
+                    for (int t = 0; t < kMtp; ++t) {
+                        const int row = t * 16 + n;
+                        av[q][t] = xcd_ld1(r_del, (int)(((size_t)s * ldD + (row < M ? row : M - 1)) * 4));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const T b = (e != 0 && c < Kin) ? bv[q] : (c == Kin ? (T)1 : (T)0);     // bias column: activation 1 (rcn.rs:302,309)
+#pragma unroll
+                    for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(t * 16 + n < M ? av[q][t] : (T)0, b, acc[t]);
+                }
+            }
+            store_partials<T>(red, wave, lane, acc);
+            __syncthreads();
+            {
+                const int o = tid & 255, tcl = o >> 4, tml = o & 15, tm = mt * 16 + tml, cc = n0 + tcl;
+                if (tvalid) {
+                    tcur -= scale * sum_partials<T>(red, mt, tcl, tml);      // rcn.rs:214,221
+                    p2_frag_scatter(jl, cc, tm, H, tcur, bufs.fragimg);
+                }
+            }
+            xcd_drain();
+            __syncthreads();
+            if (more && tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag + 1);
+        }
+    }
+
+    // ---- the slice pair of W_0 and the tail parameters go back to the parameter vector (only a launch that ran to its end gets here)
+    if (is_a) {
+#pragma unroll
+        for (int sl = 0; sl < kXcdSl; ++sl)
+            if (wvalid[sl]) W0[woff[sl]] = wcur[sl];
+    } else if (is_t && tvalid) {
+        params[tp] = tcur;
+    }
+}
+
+// placement probe: the same grid and LDS footprint as k_xcd_epoch; block b reports (XCC_ID, CU slot) -- the host selects the
+// resident kernel only if the 32 blocks with b % 8 == 0 report one XCC_ID
+__global__ __launch_bounds__(kXcdThreads) void k_xcd_probe(unsigned* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    if (threadIdx.x == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        smem_dyn[0] = (unsigned char)id;
+        out[blockIdx.x] = 0x100u | (id & 0xfu);
+    }
+}
+
+}  // namespace rcn

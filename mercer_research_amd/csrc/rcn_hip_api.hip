@@ -29,6 +29,7 @@
 #include "serve.hpp"
 #include "dp_p2p.hpp"
 #include "dense_p2_dp.hpp"
+#include "dense_xcd.hpp"
 // Parked experiments (a resident kernel per epoch segment, one launch per step, both step kernels as roles of one kernel object):
 // correct, measured, slower than or equal to the default two-kernel pipeline.  They are compiled only into
 // librcn_hip_exp.so (-DRCN_HIP_EXPERIMENTS; mercer_research_amd/build.py: build_experiments), which their tests and the stamp tools
@@ -114,6 +115,10 @@ struct rcn_hip_ctx {
         unsigned* err_host = nullptr;       // pinned copy, refreshed after every epoch call
         DevBuf raw, mism;
     } p2p;
+    DevBuf xcdbuf;                          // one-XCD resident epoch kernel (dense_xcd.hpp): slab, deltas, fragment image, flags
+    size_t xcd_B = 0;
+    unsigned xcd_tag = 0;                   // last step tag handed out; monotonic for the life of the buffer
+    int xcd_probe = 0;                      // 0 not probed, 1 the blocks with b % 8 == 0 share one XCD (and no other block does), -1 they do not
     struct ResidentSet {                     // rcn_hip_load_data: one of RCN::train's two data sets, kept in HBM (rcn.rs:134-137)
         DevBuf imgs, X, Y, perm, loss;
         size_t n = 0;
@@ -736,6 +741,120 @@ static bool use_step(const rcn_hip_ctx*, size_t) { return false; }
 static bool use_persist(const rcn_hip_ctx*, size_t) { return false; }
 #endif
 
+// ---- the resident one-XCD epoch kernel (dense_xcd.hpp) ------------------------------------------------------------------
+constexpr long long kXcdTimeoutTicks = 20000000LL;          // 0.2 s of the 100 MHz wall clock per wait
+
+// Are the 32 blocks with blockIdx.x % 8 == 0 of a 256-block launch with this LDS footprint on ONE XCD, and every other block
+// elsewhere?  Asked once per context, synchronously, before the resident kernel is ever selected (the kernel checks again itself).
+int xcd_probe(rcn_hip_ctx* c) {
+    if (c->xcd_probe != 0) return RCN_HIP_OK;
+    c->xcd_probe = -1;
+    const size_t lds = kXcdLdsFloats * sizeof(float);
+    RCN_TRY(set_dyn_lds(c, k_xcd_probe, lds));
+    RCN_TRY(set_dyn_lds(c, k_xcd_epoch, lds));
+    DevBuf out;
+    HIP_TRY(c, out.ensure(8 * kXcdWorkers * sizeof(unsigned)));
+    std::vector<unsigned> host(8 * kXcdWorkers);
+    int good = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIP_TRY(c, hipMemsetAsync(out.p, 0, host.size() * sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(k_xcd_probe, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, (unsigned*)out.p);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(host.data(), out.p, host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        bool ok = true;
+        for (size_t b = 0; b < host.size(); ++b) {
+            if (!(host[b] & 0x100u)) ok = false;
+            const bool worker = b % 8 == 0, same = (host[b] & 0xfu) == (host[0] & 0xfu);
+            if (worker != same) ok = false;
+        }
+        good += ok ? 1 : 0;
+    }
+    out.release();
+    if (good == 3) c->xcd_probe = 1;
+    return RCN_HIP_OK;
+}
+
+bool use_xcd(rcn_hip_ctx* c, size_t B) {
+    if (c->dtype != RCN_HIP_F32 || !xcd_supported(c->nd, B)) return false;
+    if (c->dense_path != 0 && c->dense_path != 5) return false;
+    static const int env = [] { const char* e = std::getenv("RCN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
+    if (c->dense_path == 0 && env == 0) return false;
+    if (c->xcd_probe == 0 && xcd_probe(c) != RCN_HIP_OK) return false;
+    return c->xcd_probe == 1;
+}
+
+int ensure_xcd_ws(rcn_hip_ctx* c, size_t B) {
+    if (!c->perr_dev) {
+        HIP_TRY(c, hipMalloc((void**)&c->perr_dev, 256));
+        HIP_TRY(c, hipHostMalloc((void**)&c->perr_host, 64, hipHostMallocDefault));
+        *c->perr_host = 0;
+        HIP_TRY(c, hipMemsetAsync(c->perr_dev, 0, 256, c->stream));
+    }
+    if (*c->perr_host != 0)
+        return fail(c, RCN_HIP_ERR_HIP, *c->perr_host == 2 ? "train_epoch: the resident kernel's workgroups did not share one XCD in an earlier call; nothing was "
+                                                             "updated by it.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline"
+                                                           : "train_epoch: a bounded wait inside the resident kernel expired in an earlier call (is the device shared?); "
+                                                             "that call's segment was not applied.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline");
+    const size_t bytes = xcd_buf_bytes(c->nd, B);
+    if (c->xcd_B != B || c->xcdbuf.cap < bytes) {
+        HIP_TRY(c, c->xcdbuf.ensure(bytes));
+        HIP_TRY(c, hipMemsetAsync(c->xcdbuf.p, 0, c->xcdbuf.cap, c->stream));      // flags 0: tags start at 1
+        c->xcd_B = B;
+        c->xcd_tag = 0;
+    }
+    return RCN_HIP_OK;
+}
+
+// nb consecutive steps over batches whose packed images are contiguous from xs / ys (one segment of the epoch image)
+int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, double eta, float* loss_dev) {
+    const NetDesc& nd = c->nd;
+    const size_t NS = B / kP2Ts, NA = (size_t)xcd_na(nd);
+    XcdBufs xb;
+    float* f = (float*)c->xcdbuf.p;
+    xb.slab = f; f += NS * NA * kP2Ts * kP2H;
+    xb.d1 = f;   f += B * kP2H;
+    xb.a1 = f;   f += B * kP2H;
+    xb.d2 = f;   f += B * kP2C;
+    xb.loss = f; f += NS;
+    xb.fragimg = f; f += (size_t)kP2BFrag * 64;
+    unsigned* u = (unsigned*)(((uintptr_t)f + 127) & ~(uintptr_t)127);
+    xb.flagA = u; u += kXcdWorkers * kXcdFlagStride;
+    xb.flagB = u; u += kXcdWorkers * kXcdFlagStride;
+    xb.xcc = u;   u += kXcdWorkers * kXcdFlagStride;
+    xb.flagT = u;
+    // the tail parameters as the sample groups' operand fragments: built from the parameter vector here, kept current by the tail tiles
+    hipLaunchKernelGGL(k_p2_fragimg, dim3(1), dim3(512), 0, c->stream, nd, (const float*)c->params.p, xb.fragimg);
+    HIP_TRY(c, hipGetLastError());
+    const unsigned tag0 = c->xcd_tag + 1;
+    hipLaunchKernelGGL(k_xcd_epoch, dim3(8 * kXcdWorkers), dim3(kXcdThreads), kXcdLdsFloats * sizeof(float), c->stream, nd, (float*)c->params.p, xs, ys, (int)B,
+                       (int)nb, pipe_slices(nd), (float)(eta / (double)B), (float)(1.0 / (2.0 * (double)B)), loss_dev, xb, tag0, c->perr_dev, kXcdTimeoutTicks);
+    HIP_TRY(c, hipGetLastError());
+    c->xcd_tag += (unsigned)nb;
+    return RCN_HIP_OK;
+}
+
+// a whole call on the resident kernel: batches [j0, j0 + nb) of the call, packed segment by segment (or already packed)
+int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool from_images,
+                      bool prepacked, size_t j0, size_t pre_seg) {
+    const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L];
+    const size_t seg = prepacked ? pre_seg : (nb <= pack_segment(c, B) ? nb : pack_segment(c, B));
+    auto slot = [&](size_t j) { return ((j / seg) % 2) * seg + j % seg; };
+    for (size_t j = prepacked ? j0 : 0, end = j + nb, k = 0; j < end;) {
+        const size_t in_seg = seg - j % seg, n = end - j < in_seg ? end - j : in_seg;       // up to the end of this segment of the image
+        if (!prepacked) {
+            const int half = (int)((j / seg) % 2);
+            RCN_TRY(from_images ? launch_feat_pack<float>(c, (const uint8_t*)X, Y, perm, B, j, n, half, seg) : launch_pack<float>(c, X, Y, perm, B, j, n, half, seg));
+        }
+        const float* xs = (const float*)c->xpack.p + slot(j) * G * B * 16;
+        const float* ys = (const float*)c->ypack.p + slot(j) * B * Cc;
+        RCN_TRY(enqueue_xcd_steps(c, xs, ys, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr));
+        j += n; k += n;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->perr_host, c->perr_dev, 4, hipMemcpyDeviceToHost, c->stream));     // looked at by the next call / synchronize
+    return RCN_HIP_OK;
+}
+
 // one train_batch (rcn.rs:176-223) on device-resident data; idx selects the batch's rows (or NULL)
 int enqueue_train_step(rcn_hip_ctx* c, const void* x, const void* y, const int32_t* idx, size_t B, double eta, void* loss_dev) {
     const double scale = eta / (double)B;                       // rcn.rs:214: eta / batch.len() as f64
@@ -1098,6 +1217,7 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
         for (DevBuf* b : {&c->slab, &c->xpack, &c->ypack, &c->p2buf, &c->params, &c->acts, &c->deltas, &c->loss_part, &c->grad, &c->xstage, &c->ystage, &c->ostage, &c->scratch0,
                           &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
             b->release();
+        c->xcdbuf.release();
         for (auto& rs : c->sets) { rs.imgs.release(); rs.X.release(); rs.Y.release(); rs.perm.release(); rs.loss.release(); }
         if (c->pin_host) (void)hipHostFree(c->pin_host);
         c->pll.release();
@@ -1129,13 +1249,23 @@ int rcn_hip_set_feature_kernel(rcn_hip_ctx* c, int mode) {
 
 int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
     RCN_TRY(check_ctx(c));
-    if (mode < 0 || mode > 4)
-        return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile), 2 (feature-sliced), 3 (resident epoch kernel) or 4 (one launch per step)");
+    if (mode < 0 || mode > 5)
+        return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_dense_path: mode must be 0 (auto), 1 (sample-tile), 2 (feature-sliced, two kernels per step), 5 (feature-sliced, resident "
+                                                "one-XCD kernel) -- or 3 / 4, parked experiments of librcn_hip_exp.so");
 #ifndef RCN_HIP_EXPERIMENTS
-    if (mode >= 3) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path: modes 3 and 4 are parked experiments, compiled only into librcn_hip_exp.so (RCN_HIP_EXPERIMENTS)");
+    if (mode == 3 || mode == 4) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path: modes 3 and 4 are parked experiments, compiled only into librcn_hip_exp.so (RCN_HIP_EXPERIMENTS)");
 #endif
     if (mode >= 2 && !pipe_supported(c->nd)) return fail(c, RCN_HIP_ERR_UNSUPPORTED, "feature-sliced path needs >= 2 dense layers whose tail fits LDS");
     DevGuard g(c->device);
+    if (mode == 5) {
+        if (c->dtype != RCN_HIP_F32 || !xcd_supported(c->nd, 256))
+            return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path(5): the resident one-XCD kernel covers the f32 context, one hidden layer <= 32, classes <= 16, "
+                                                      "at most 29 feature-slice pairs, batch 256");
+        RCN_TRY(xcd_probe(c));
+        if (c->xcd_probe != 1)
+            return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path(5): on this device the blocks with blockIdx.x % 8 == 0 do not share one XCD; the resident kernel "
+                                                      "cannot be used");
+    }
     drop_graphs(c);
     c->dense_path = mode;
     return RCN_HIP_OK;
@@ -1540,6 +1670,12 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
     if (from_images && !(use_pipe(c, B) && feat_is_cpcp28(c)))
         return fail(c, RCN_HIP_ERR_UNSUPPORTED, "train_epoch_images: needs the default conv/pool stack on 28x28 input and a layer stack / batch size the "
                                                   "feature-sliced pipeline covers; use rcn_hip_features_dev + rcn_hip_train_epoch_dev otherwise");
+    if (use_pipe(c, B) && use_xcd(c, B)) {
+        // one resident kernel per segment of the epoch image, all of its workgroups on one XCD (dense_xcd.hpp): nothing to capture
+        RCN_TRY(ensure_xcd_ws(c, B));
+        if (!launch) return RCN_HIP_OK;
+        return enqueue_xcd_epoch(c, X, Y, perm, B, nb, eta, loss_dev, from_images, false, 0, 0);
+    }
 #ifdef RCN_HIP_EXPERIMENTS
     if (use_persist(c, B) && !from_images) {
         // no graph: one resident kernel per segment of the epoch image runs all of its steps
@@ -1656,6 +1792,11 @@ static int epoch_steps_impl(rcn_hip_ctx* c, size_t j0, size_t n, double eta, voi
     DevGuard g(c->device);
     RCN_TRY(ensure_dense_ws(c, B));
     RCN_TRY(ensure_pipe_ws(c, B));
+    if (use_xcd(c, B)) {
+        RCN_TRY(ensure_xcd_ws(c, B));
+        if (!launch) return RCN_HIP_OK;
+        return enqueue_xcd_epoch(c, nullptr, nullptr, nullptr, B, n, eta, loss_dev, false, true, j0, seg);
+    }
     const EpochKey key{c->xpack.p, c->ypack.p, nullptr, B, n, eta, loss_dev, j0 + 1 + (seg << 32)};
     auto it = c->step_graphs.find(key);
     if (it == c->step_graphs.end()) {
@@ -2255,6 +2396,44 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
     HIP_TRY(c, c->grad.ensure((size_t)c->nd.P * c->esz()));
     const bool f64 = c->dtype == RCN_HIP_F64, pipe = use_pipe(c, B);
     if (pipe) RCN_TRY(ensure_pipe_ws(c, B));
+    if (pipe && use_xcd(c, B)) {
+        // the resident kernel: ONE launch runs every step of the image's first segment; timed as a whole (zero step: no drift), reported
+        // per step in *us_second and *us_pair (there is no first / second kernel)
+        RCN_TRY(ensure_xcd_ws(c, B));
+        size_t n = (c->packed_B == B && c->packed_nb >= 2) ? c->packed_nb : 0;
+        if (n == 0) {
+            RCN_TRY(ensure_pack_ws(c, B, 1));
+            RCN_TRY(launch_pack<float>(c, x, y, nullptr, B, 0, 1, 0, 1));
+            n = 1;
+        }
+        const size_t saved_nb = c->epoch_nb;      // timing on the image does not end a begun epoch (nothing is re-packed unless n was 0)
+        RCN_TRY(enqueue_xcd_steps(c, (const float*)c->xpack.p, (const float*)c->ypack.p, B, n, 0.0, nullptr));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipEvent_t e0, e1;
+        HIP_TRY(c, hipEventCreate(&e0));
+        HIP_TRY(c, hipEventCreate(&e1));
+        const int launches = (int)((reps + n - 1) / n) < 4 ? 4 : (int)((reps + n - 1) / n);
+        float best = 0.f, total = 0.f;
+        int st = RCN_HIP_OK;
+        for (int i = 0; i < launches && st == RCN_HIP_OK; ++i) {
+            hipError_t e = hipEventRecord(e0, c->stream);
+            if (e == hipSuccess) st = enqueue_xcd_steps(c, (const float*)c->xpack.p, (const float*)c->ypack.p, B, n, 0.0, nullptr);
+            if (e == hipSuccess && st == RCN_HIP_OK) e = hipEventRecord(e1, c->stream);
+            if (e == hipSuccess && st == RCN_HIP_OK) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess && st == RCN_HIP_OK) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess && st == RCN_HIP_OK) st = fail(c, RCN_HIP_ERR_HIP, hipGetErrorString(e));
+            total += ms;
+            (void)best;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (n > 1) c->epoch_nb = saved_nb;
+        *us_a = 0.0;
+        *us_b = (double)total * 1000.0 / ((double)launches * (double)n);
+        if (us_pair) *us_pair = *us_b;
+        return st;
+    }
     // which == 0: first kernel of a step (k_dense_fwd | k_pipe_b), which == 1: second (k_dense_wgrad | k_pipe_a).
     // Updates run with scale 0 / gradient-out so the parameters do not drift while timing.
     // Feature-sliced path: if the context still holds the packed image of a whole epoch at this batch size (the normal

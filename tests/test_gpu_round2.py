@@ -451,3 +451,127 @@ def test_train_arrays_runs_on_resident_sets_and_prints_the_reference_line(amd, o
     import re
     assert all(re.fullmatch(r"Epoch \d+: \d+/80 \[\d+\.\d\d%\]", l) for l in lines), lines      # rcn.rs:158-164
     r.close()
+
+
+# ------------------------------------------------------------------------------------------------ resident one-XCD kernel
+
+def _xcd_or_skip(d):
+    import mercer_research_amd as amd
+    try:
+        d.set_dense_path(5)
+    except amd.RcnHipError as e:
+        pytest.skip(f"the resident one-XCD kernel does not apply on this device: {e}")
+
+
+def test_resident_one_xcd_kernel_is_the_reference_loop(amd, oracle, monkeypatch):
+    """dense path 5 (csrc/dense_xcd.hpp): ONE resident kernel per epoch segment, its 32 workgroups on one XCD, slab / deltas handed over
+    through that XCD's L2.  Must be the reference's sequential train_batch loop (rcn.rs:147-149, 176-223): parameters and per-step costs
+    against the oracle (f32 tolerances of the two-kernel pipeline) and against the two-kernel pipeline itself; shuffled and stored
+    order, several launches per call (3 batches per segment of the epoch image), a second call continuing from the first, from u8
+    pictures, and a call of ONE step (nothing to prefetch, no next forward)."""
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(3 * 49 * 256 * 16 * 4))
+    B, nb, N = 256, 8, 2304
+    imgs, labels = synthetic_images(N, seed=41)
+    ws, bs = synthetic_params(BENCH_DIMS, seed=14)
+    ws = [w * 0.1 for w in ws]
+    perm = np.random.default_rng(5).permutation(N).astype(np.int32)
+    got = {}
+    for path in (5, 2):
+        d = DeviceRCN(dtype=0)
+        if path == 5:
+            _xcd_or_skip(d)
+        else:
+            d.set_dense_path(2)
+        d.set_params(ws, bs)
+        dev = d.to_device(imgs)
+        d.gen_scales(d.features(dev))
+        X = d.features(dev, standardize=True)
+        Y = d.to_device(one_hot(labels), d.tdtype)
+        permd = d.to_device(perm)
+        loss = d.empty(nb)
+        d.train_epoch(X, Y, permd, B, nb, 3.0, loss)                 # 3 + 3 + 2 steps: three launches of the resident kernel
+        d.synchronize()                                              # (the copies below run on torch's stream, not the context's)
+        l1 = loss.cpu().numpy().copy()
+        d.train_epoch(X, Y, None, B, 2, 3.0, None)                   # stored order, continues from the first call
+        d.train_epoch_images(dev, Y, permd, B, 4, 3.0, loss)         # straight from the pictures
+        d.synchronize()
+        l2 = loss.cpu().numpy()[:4].copy()
+        d.train_epoch(X, Y, permd[5 * B:], B, 1, 3.0, loss)          # a call of one step
+        d.synchronize()
+        l3 = float(loss.cpu().numpy()[0])
+        got[path] = (sum(d.get_params(), []), l1, l2, l3, X.double().cpu().numpy())
+        d.rcn.close()
+    # against the oracle's loop on the same (device-standardised) features
+    Xh, Yh = got[5][4], one_hot(labels)
+    rw, rb, c1, c2 = ws, bs, [], []
+    for j in range(nb):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, Xh[sel], Yh[sel], 3.0)
+        c1.append(c)
+    for j in range(2):
+        rw, rb, _ = oracle.train_batch(rw, rb, Xh[j * B:(j + 1) * B], Yh[j * B:(j + 1) * B], 3.0)
+    for j in range(4):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, Xh[sel], Yh[sel], 3.0)
+        c2.append(c)
+    sel = perm[5 * B:6 * B]
+    rw, rb, c3 = oracle.train_batch(rw, rb, Xh[sel], Yh[sel], 3.0)
+    for path in (5, 2):
+        np.testing.assert_allclose(got[path][1], c1, rtol=1e-3)
+        np.testing.assert_allclose(got[path][2], c2, rtol=2e-3)
+        assert abs(got[path][3] - c3) <= 2e-3 * c3
+        for a, b in zip(got[path][0], rw + rb):
+            assert np.all(np.abs(a - b) <= 5e-4 * np.abs(b) + 5e-5), path   # 15 chained f32 steps
+    for a, b in zip(got[5][0], got[2][0]):
+        assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)               # the two forms differ only in summation grouping
+
+
+def test_resident_one_xcd_kernel_first_step_tight_and_reproducible(amd, oracle):
+    """One step from identical parameters holds the one-step f32 tolerance of SURVEY §8(c) (1e-5 relative + 1e-6), N(0,1) un-scaled
+    parameters included, and two runs of the same epoch give the same bits (fixed summation orders; nothing depends on which
+    workgroup arrives first)."""
+    from mercer_research_amd.device import DeviceRCN
+    B, N = 256, 1024
+    rng = np.random.default_rng(2)
+    X, Y = np.maximum(rng.standard_normal((N, 784)), 0.0), one_hot(rng.integers(0, 10, N))
+    for wscale in (0.1, 1.0):
+        ws, bs = synthetic_params(BENCH_DIMS, seed=8)
+        ws = [w * wscale for w in ws]
+        runs = []
+        for rep in range(2):
+            d = DeviceRCN(dtype=0)
+            _xcd_or_skip(d)
+            d.set_params(ws, bs)
+            Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+            loss = d.empty(4)
+            d.train_epoch(Xd, Yd, None, B, 1, 3.0, loss)
+            p1 = sum(d.get_params(), [])
+            d.train_epoch(Xd[B:], Yd[B:], None, B, 3, 3.0, loss[1:])
+            d.synchronize()
+            runs.append((p1, sum(d.get_params(), []), loss.cpu().numpy().copy()))
+            d.rcn.close()
+        for a, b in zip(runs[0][1], runs[1][1]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(runs[0][2], runs[1][2])
+        Xf = X.astype(np.float32).astype(np.float64)
+        rw, rb, c = oracle.train_batch(ws, bs, Xf[:B], Y[:B], 3.0)
+        tol = (1e-5, 1e-6) if wscale < 1 else (1e-4, 1e-5)          # saturated sigmoids (un-scaled init): as test_unscaled_n01_init_default_net
+        for a, b in zip(runs[0][0], rw + rb):
+            assert np.all(np.abs(a - b) <= tol[0] * np.abs(b) + tol[1])
+        assert abs(runs[0][2][0] - c) <= 1e-5 * c if wscale < 1 else abs(runs[0][2][0] - c) <= 1e-4 * c
+
+
+def test_resident_kernel_is_what_auto_selects_for_the_bench_shape_and_not_for_others(amd):
+    from mercer_research_amd.device import DeviceRCN
+    d = DeviceRCN(dtype=0)
+    _xcd_or_skip(d)
+    d.rcn.close()
+    d64 = DeviceRCN(dtype=1)
+    with pytest.raises(amd.RcnHipError):
+        d64.set_dense_path(5)                                        # f64 context: two-kernel pipeline only
+    d64.rcn.close()
+    d3 = DeviceRCN(dtype=0, feedforward_cfg=[10, 10])
+    with pytest.raises(amd.RcnHipError):
+        d3.set_dense_path(5)                                         # two hidden layers: not the shape class
+    d3.rcn.close()
