@@ -65,11 +65,22 @@ inline size_t xcd_buf_bytes(const NetDesc& nd, size_t B) {
     return (NS * NA * kP2Ts * kP2H + 2 * B * kP2H + B * kP2C + NS + (size_t)kP2BFrag * 64) * sizeof(float) +
            (size_t)(3 * kXcdWorkers + 8) * kXcdFlagStride * sizeof(unsigned) + 512;
 }
-// LDS (floats): two batch buffers of a slice pair, the K-split partials of both slices, the slice pair of W_0, and the sample
-// group's scratch (slab partial sums, a_1 / delta_2 tiles, target fragments)
+// LDS (floats): two batch buffers of a slice pair, delta_1 of the whole batch (rows padded to 48: conflict-free MFMA operand reads),
+// the tail tiles' K-split partials, the second K-half's partial tiles of the slice gradient, the slice pair of W_0, and the sample
+// group's scratch (slab partial sums, a_1 / delta_2 tiles, target fragments): 151 KB of the CU's 160 -- one worker per CU
 constexpr size_t kXcdXs = (size_t)kXcdSl * 256 * 16;
-constexpr size_t kXcdLdsFloats = 2 * kXcdXs + (size_t)kDenseWaves * kXcdSl * kMtp * kRedTile + (size_t)kXcdSl * 16 * kP2H +
-                                 (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + kP2C * kLd + (size_t)kP2BFrag * 64 + 64;
+constexpr int kXcdD1Ld = 48;
+constexpr size_t kXcdLdsFloats = 2 * kXcdXs + (size_t)256 * kXcdD1Ld + (size_t)kDenseWaves * kMtp * kRedTile + (size_t)kXcdSl * kMtp * 256 +
+                                 (size_t)kXcdSl * 16 * kP2H + (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + kP2C * kLd + 4 * 64 + 64;
+
+// diagnostic build only (-DRCN_STAMPS, tools/stamps_xcd.py): where each worker is at each point of the launch's last-but-one step
+#ifdef RCN_STAMPS
+#define XSTAMP(i) do { if (j == nb - 2 && lane == 0) g_rcn_stamps[0][w][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define XCLOCK(k) do { if (lane == 0 && wave == 0) { g_rcn_stamps[1][w][2 * (k)] = __builtin_amdgcn_s_memtime(); g_rcn_stamps[1][w][2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define XSTAMP(i) do { } while (0)
+#define XCLOCK(k) do { } while (0)
+#endif
 
 using xu4 = __attribute__((ext_vector_type(4))) unsigned;
 #define XCD_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
@@ -87,7 +98,13 @@ __device__ inline float xcd_ld1(__amdgpu_buffer_rsrc_t r, int byte_off) {
     return f;
 }
 __device__ inline void xcd_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ inline void xcd_flag(unsigned* f, unsigned tag) { __hip_atomic_store(f, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A flag is a PLAIN store like the payload it announces: it stays in the XCD's L2, which is where the polls (sc1 loads) look;
+// a write-through (agent-scope atomic) store would drop the line from L2 and cost every poll a trip to memory (ubench: -0.2 us per
+// hand-off).  Legal only between workers that share one XCD -- checked through the xcc table, which IS written write-through.
+// (A workgroup-scope relaxed atomic store IS the plain global_store_dword; a `volatile` store compiles to a system-scope
+// write-through flat_store sc0 sc1 plus a wait.)
+__device__ inline void xcd_flag(unsigned* f, unsigned tag) { __hip_atomic_store(f, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void xcd_flag_wt(unsigned* f, unsigned v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ONE wave waits until every flag its lanes look at (lane < n0: f0[lane]; n0 <= lane < n0 + n1: f1[lane - n0]) carries a tag >= tag.
 // Bounded: gives up after `timeout` ticks of the 100 MHz clock or when another worker raised the sticky error word.
@@ -121,12 +138,14 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     __shared__ int s_abort;
     T* smem = reinterpret_cast<T*>(smem_dyn);
     T* xbuf = smem;                                                 // [2][kXcdSl][B][16]
-    T* red = xbuf + 2 * kXcdXs;                                     // [wave][slice][mt][16 x kLd]
-    T* wsl = red + kDenseWaves * kXcdSl * kMtp * kRedTile;          // [slice][feature 0..15][32]
+    T* d1s = xbuf + 2 * kXcdXs;                                     // delta_1 of the batch [B][48] (32 used)
+    T* red = d1s + 256 * kXcdD1Ld;                                  // tail tiles: [wave][mt][16 x kLd]
+    T* hred = red + kDenseWaves * kMtp * kRedTile;                  // second K-half's partial tile of the slice gradient: [tile][lane][4]
+    T* wsl = hred + kXcdSl * kMtp * 256;                            // [slice][feature 0..15][32]
     vec4* zred = reinterpret_cast<vec4*>(wsl + kXcdSl * 16 * kP2H); // [8 waves][64 lanes]
     T* a1s = reinterpret_cast<T*>(zred) + kP2BWaves * 64 * 4;       // a_1 tile  [hidden 32][kLd]
     T* d2s = a1s + kP2H * kLd;                                      // delta_2   [class 16][kLd]
-    T* frag = d2s + kP2C * kLd;                                     // [word][lane]: only the target words 20..23 are used
+    T* frag = d2s + kP2C * kLd;                                     // [4][lane]: the targets per accumulator element
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
     const int F = nd.dims[0], H = nd.dims[1], C = nd.dims[2];
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     if (tid == 0) {
         unsigned id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        xcd_flag(bufs.xcc + w * kXcdFlagStride, (tag0 << 4) | (id & 0xfu));
+        xcd_flag_wt(bufs.xcc + w * kXcdFlagStride, (tag0 << 4) | (id & 0xfu));
     }
     if (wave == 0) {
         long long t0 = 0;
@@ -173,22 +192,29 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     __syncthreads();
     if (s_abort) return;
 
-    // ---- feature worker: its slice pair of W_0 into LDS and registers; the first two batches into the two LDS buffers
+    // ---- feature worker: its slice pair of W_0 into LDS and registers; the first two batches into the two LDS buffers.
+    // The gradient of the slice pair is four 16 x 16 tiles (slice sl, hidden half mt); wave u owns tile u & 3 for the samples of K-half
+    // u >> 2, and waves 0..3 also own the tile's parameters, in the accumulator's layout: lane (n, g4), element i <-> hidden
+    // 16 mt + 4 g4 + i, feature 16 sl + n.
     T* W0 = params + nd.w_off[0];
-    const int ml = tid & 15, cl = (tid >> 4) & 15, mt = tid >> 8, m = mt * 16 + ml;      // this thread's element (hidden m, feature cl) of each slice
-    T wcur[kXcdSl] = {0, 0};
-    bool wvalid[kXcdSl] = {false, false};
-    size_t woff[kXcdSl] = {0, 0};
+    const int mt = tid >> 8;                                        // (tail tiles: M-tile of this thread's parameter)
+    const int tl = wave & 3, kh = wave >> 2, usl = tl >> 1, umt = tl & 1;
+    T wcur[4] = {0, 0, 0, 0};
+    bool wvalid[4] = {false, false, false, false};
+    size_t woff[4] = {0, 0, 0, 0};
     if (is_a) {
+        if (kh == 0) {
+            const int f0 = (kXcdSl * w + usl) * 16;
+            const int nf = usl < nsl ? (F - f0 < 16 ? F - f0 : 16) : 0;
 #pragma unroll
-        for (int sl = 0; sl < kXcdSl; ++sl) {
-            const int f0 = (kXcdSl * w + sl) * 16;
-            const int nf = sl < nsl ? (F - f0 < 16 ? F - f0 : 16) : 0;
-            wvalid[sl] = m < H && cl < nf;
-            woff[sl] = wvalid[sl] ? (size_t)(f0 + cl) * H + m : 0;
-            const T v = W0[woff[sl]];
-            wcur[sl] = wvalid[sl] ? v : (T)0;
-            wsl[(sl * 16 + cl) * kP2H + m] = wcur[sl];
+            for (int i = 0; i < 4; ++i) {
+                const int hid = umt * 16 + 4 * g4 + i;
+                wvalid[i] = hid < H && n < nf;
+                woff[i] = wvalid[i] ? (size_t)(f0 + n) * H + hid : 0;
+                const T v = W0[woff[i]];
+                wcur[i] = wvalid[i] ? v : (T)0;
+            }
+            *reinterpret_cast<vec4*>(wsl + (usl * 16 + n) * kP2H + umt * 16 + 4 * g4) = vec4{wcur[0], wcur[1], wcur[2], wcur[3]};
         }
         // batches 0 and 1 of this launch: [slice pair][sample][16] is one contiguous run of nsl * B * 16 floats per batch
         for (int b = 0; b < 2 && b < nb; ++b) {
@@ -254,6 +280,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 
     for (int j = 0; j < nb; ++j) {
         const unsigned tag = tag0 + (unsigned)j;
+        if (j == 8) XCLOCK(0);
+        if (j == nb - 8) XCLOCK(1);
         const bool more = j + 1 < nb;
         // (1) the batch after next, a whole step ahead: into registers now, into the LDS buffer step j's gradient frees
         vec4 xr[4];
@@ -269,14 +297,31 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 
         // =============================================================== sample group w: samples 8w .. 8w+7 of batch j
         {
-            if (wave == 0 && !xcd_wait(bufs.flagA, NA, bufs.flagT, NT, tag, timeout, err) && lane == 0) {
-                s_abort = 1;
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int s0 = w * kP2Ts;
+            const T* Ys = ys_all + (size_t)j * ys_stride;
+            T fr[kP2BFrag];
+            if (wave == 0) {
+                XSTAMP(0);
+                // the tail tiles finish well before the feature workers: their flags first, the 24 parameter words of the image
+                // fetched under the wait for the slab
+                bool ok = xcd_wait(bufs.flagT, NT, nullptr, 0, tag, timeout, err);
+#pragma unroll
+                for (int q = 0; q < kP2BFrag; ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1(r_img, (q * 64 + lane) * 4);
+                ok = ok && xcd_wait(bufs.flagA, NA, nullptr, 0, tag, timeout, err);
+                if (!ok && lane == 0) {
+                    s_abort = 1;
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                XSTAMP(1);
+            } else if (wave == 6) {                                   // targets per accumulator element: no flag to wait for
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = Mfma16<T>::row(lane, i);
+                    frag[i * 64 + lane] = Ys[(size_t)(s0 + (n & 7)) * C + (c < C ? c : 0)];
+                }
             }
             __syncthreads();
             if (s_abort) return;
-            const int s0 = w * kP2Ts;
-            const T* Ys = ys_all + (size_t)j * ys_stride;
             // slab: this group's NA x 1 KB, contiguous; wave q sums producers q, q + 8, q + 16, q + 24 in that order
             vec4 z = vec4{0, 0, 0, 0};
             {
@@ -290,20 +335,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 for (int q = 0; q < 4; ++q)
                     if (wave + kP2BWaves * q < NA) z += t[q];
             }
-            T fr[kP2BFrag];
-            if (wave == 0) {
-#pragma unroll
-                for (int q = 0; q < kP2BFrag; ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1(r_img, (q * 64 + lane) * 4);
-            } else if (wave == 6) {                                   // targets per accumulator element
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = Mfma16<T>::row(lane, i);
-                    frag[(20 + i) * 64 + lane] = Ys[(size_t)(s0 + (n & 7)) * C + (c < C ? c : 0)];
-                }
-            }
             zred[wave * 64 + lane] = z;
+            if (wave == 7) XSTAMP(2);
             __syncthreads();
             if (wave == 0) {
+                XSTAMP(3);
                 {   // fixed order across waves (as k_p2_b)
                     typedef T h2 __attribute__((ext_vector_type(2)));
                     vec4 r[8];
@@ -317,7 +353,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     z = vec4{zl[0], zl[1], zh[0], zh[1]};
                 }
 #pragma unroll
-                for (int q = 20; q < 24; ++q) fr[q] = frag[q * 64 + lane];
+                for (int q = 20; q < 24; ++q) fr[q] = frag[(q - 20) * 64 + lane];
                 // a_1 = sigmoid(z_1 + b_0); lane <- sample lane >> 3, hidden 4 (lane & 7) + i                        rcn.rs:287-289
                 {
                     const int s = lane >> 3, h0 = 4 * (lane & 7);
@@ -374,8 +410,10 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 }
                 lsum = wave_sum_lane0(lsum);
                 if (lane == 0) bufs.loss[w] = lsum;
+                XSTAMP(4);
                 xcd_drain();                                              // only this wave stored
                 if (lane == 0) xcd_flag(bufs.flagB + w * kXcdFlagStride, tag);
+                XSTAMP(5);
             }
         }
 
@@ -386,55 +424,84 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        if (wave == 1) XSTAMP(6);
         __syncthreads();                                                   // (also orders wave 0's LDS scratch against the next step's)
         if (s_abort) return;
+        if (wave == 1) XSTAMP(7);
 
         if (is_a) {
             // ---- U: dW_0[:, slice pair] = sum_s delta_1[s] (x) x_s[slice pair]; W_0 <- W_0 - (eta/B) dW_0            rcn.rs:310, 214
-            const T* xb = xbuf + (size_t)(j & 1) * kXcdXs;
-            acc_t acc[kXcdSl][kMtp];
-#pragma unroll
-            for (int sl = 0; sl < kXcdSl; ++sl)
-#pragma unroll
-                for (int t = 0; t < kMtp; ++t) acc[sl][t] = acc_t{0, 0, 0, 0};
+            // delta_1 of the whole batch into LDS first: 32 KB as 16-byte L1-bypassing loads, 4 per thread (as 4-byte loads straight
+            // into MFMA operands it was 16 per lane and the slower part of this phase)
             {
-                const int kc = wave * (B >> 3);                            // 32 samples per wave: one chunk of 8 k-steps
-                T av[8][kMtp], bv[kXcdSl][8];
+                vec4 dv[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int r = 0; r < 4; ++r) dv[r] = xcd_ld4(r_d1, (tid + r * kXcdThreads) * 16);
 #pragma unroll
-                    for (int t = 0; t < kMtp; ++t) av[q][t] = xcd_ld1(r_d1, (int)((((size_t)(kc + g4 + 4 * q)) * kP2H + t * 16 + n) * 4));
-#pragma unroll
-                    for (int sl = 0; sl < kXcdSl; ++sl) bv[sl][q] = xb[((size_t)sl * B + kc + g4 + 4 * q) * 16 + n];
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = tid + r * kXcdThreads;                 // vec4 index in [B][8]
+                    *reinterpret_cast<vec4*>(d1s + (idx >> 3) * kXcdD1Ld + (idx & 7) * 4) = dv[r];
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-#pragma unroll
-                    for (int sl = 0; sl < kXcdSl; ++sl)
-#pragma unroll
-                        for (int t = 0; t < kMtp; ++t) acc[sl][t] = Mfma16<T>::mfma(av[q][t], bv[sl][q], acc[sl][t]);
             }
-#pragma unroll
-            for (int sl = 0; sl < kXcdSl; ++sl) store_partials<T>(red + (size_t)sl * kDenseWaves * kMtp * kRedTile, wave, lane, acc[sl]);
             __syncthreads();
+            if (wave == 1) XSTAMP(8);
+            // Four 16 x 16 tiles, 64 k-steps each: 256 MFMAs = 2048 cycles of the CU's four matrix pipes whichever way they are cut.
+            // Waves 0..3 (one per SIMD) each run ONE tile over the WHOLE batch -- no K-split, so no cross-wave reduction, no partials
+            // in LDS, no second barrier -- on two interleaved accumulators (a single chain would be paced by the 40-cycle dependent
+            // latency instead of the 32-cycle issue rate).  Waves 4..7 have no arithmetic here; they move the prefetched batch into LDS.
+            if (kh == 0) {
+                const T* xb = xbuf + (size_t)(j & 1) * kXcdXs + (size_t)usl * B * 16;
+                acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
+                // hand-pipelined: the operands of block qb + 1 are requested before the MFMAs of block qb issue, and fences keep the
+                // scheduler from folding that back into load-wait-MFMA triples (which ran at ~100 cycles per MFMA instead of 32)
+                const T* ap = d1s + g4 * kXcdD1Ld + umt * 16 + n;
+                const T* bp = xb + g4 * 16 + n;
+                T av[2][8], bv[2][8];
 #pragma unroll
-            for (int sl = 0; sl < kXcdSl; ++sl) {
-                const T wn = wcur[sl] - scale * sum_partials<T>(red + (size_t)sl * kDenseWaves * kMtp * kRedTile, mt, cl, ml);
-                wcur[sl] = wvalid[sl] ? wn : (T)0;
-                wsl[(sl * 16 + cl) * kP2H + m] = wcur[sl];
+                for (int q = 0; q < 8; ++q) { av[0][q] = ap[4 * q * kXcdD1Ld]; bv[0][q] = bp[4 * q * 16]; }
+#pragma unroll
+                for (int qb = 0; qb < 8; ++qb) {
+                    if (qb + 1 < 8) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            av[(qb + 1) & 1][q] = ap[4 * (8 * (qb + 1) + q) * kXcdD1Ld];
+                            bv[(qb + 1) & 1][q] = bp[4 * (8 * (qb + 1) + q) * 16];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) {
+                        acc0 = Mfma16<T>::mfma(av[qb & 1][q], bv[qb & 1][q], acc0);
+                        acc1 = Mfma16<T>::mfma(av[qb & 1][q + 1], bv[qb & 1][q + 1], acc1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const T wn = wcur[i] - scale * (acc0[i] + acc1[i]);
+                    wcur[i] = wvalid[i] ? wn : (T)0;
+                }
+                *reinterpret_cast<vec4*>(wsl + (usl * 16 + n) * kP2H + umt * 16 + 4 * g4) = vec4{wcur[0], wcur[1], wcur[2], wcur[3]};
+                if (wave == 1) XSTAMP(9);
             }
-            // the LDS buffer of batch j is free now: the batch after next moves in
+            __syncthreads();
+            if (wave == 1) XSTAMP(10);
+            // the LDS buffer of batch j is free now (every wave is past its reads): the batch after next moves in; its first reader is
+            // the forward of the NEXT iteration, several barriers away
             if (pre) {
                 vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(j & 1) * kXcdXs);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[tid + r * kXcdThreads] = xr[r];
             }
-            __syncthreads();
             if (more) {
                 forward(j + 1);
+                if (wave == 1) XSTAMP(11);
+                if (wave == 0) XSTAMP(13);
+                if (wave == 4) XSTAMP(14);
+                if (wave == 7) XSTAMP(15);
                 __syncthreads();
                 if (tid == 0) xcd_flag(bufs.flagA + w * kXcdFlagStride, tag + 1);
+                if (wave == 0) XSTAMP(12);
             }
         } else if (is_t) {
             // ---- tail tile e: e == 0 the bias column of W_0 (db_0 = sum_s delta_1); e >= 1 a 16-column tile of [W_1 | b_1]
@@ -486,14 +553,15 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             xcd_drain();
             __syncthreads();
             if (more && tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag + 1);
+            if (wave == 0) XSTAMP(12);
         }
     }
 
     // ---- the slice pair of W_0 and the tail parameters go back to the parameter vector (only a launch that ran to its end gets here)
     if (is_a) {
 #pragma unroll
-        for (int sl = 0; sl < kXcdSl; ++sl)
-            if (wvalid[sl]) W0[woff[sl]] = wcur[sl];
+        for (int i = 0; i < 4; ++i)
+            if (wvalid[i]) W0[woff[i]] = wcur[i];
     } else if (is_t && tvalid) {
         params[tp] = tcur;
     }

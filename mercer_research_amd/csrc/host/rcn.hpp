@@ -145,7 +145,8 @@ public:
         double mean, sd;
         check(rcn_hip_load_data(ctx_, 0, train_px, train_lab, n_train, &mean, &sd));      // rcn.rs:134-135
         check(rcn_hip_load_data(ctx_, 1, test_px, test_lab, n_test, &mean, &sd));         // rcn.rs:136-137: scale_set = the TEST statistics
-        if (!weights_loaded_) load_weights_and_bias();                       // rcn.rs:139-141
+        // rcn.rs:139-141; a seeded run (tests, --seed) draws its parameters from the seed too -- the reference has no seeds at all
+        if (!weights_loaded_) load_weights_and_bias(shuffle_seed ? (shuffle_seed ^ 0x9E3779B97F4A7C15ULL) | 1ULL : 0);
         std::mt19937_64 rng(shuffle_seed ? shuffle_seed : std::random_device{}());
         std::vector<int32_t> order(n_train);
         std::iota(order.begin(), order.end(), 0);

@@ -36,7 +36,7 @@ __device__ inline bool wait_flags(const unsigned* flags, int n, unsigned it) {
     return false;
 }
 
-template <int ST_AUX, int T>
+template <int ST_AUX, int T, int FLAGP>
 __global__ __launch_bounds__(T) void k_ring(unsigned* slab, unsigned* dl, unsigned* flagA, unsigned* flagB, int NA, int NB, int stride8, int iters,
                                             unsigned* xcc, unsigned long long* bad, long long* ticks) {
     if (stride8 && (blockIdx.x & 7) != 0) return;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(T) void k_ring(unsigned* slab, unsigned* dl, unsign
             }
             drain();
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(flagA + w * 16, (unsigned)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) { if (FLAGP) { __hip_atomic_store(flagA + w * 16, (unsigned)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } else __hip_atomic_store(flagA + w * 16, (unsigned)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         if (w < NB) {                                                       // ---- phase 2: NA x 1 KB for me
             if (tid < 64) { const bool ok = wait_flags(flagA, NA, it); if (tid == 0) s_ok = ok; }
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(T) void k_ring(unsigned* slab, unsigned* dl, unsign
                 drain();
             }
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(flagB + w * 16, (unsigned)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) { if (FLAGP) { __hip_atomic_store(flagB + w * 16, (unsigned)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } else __hip_atomic_store(flagB + w * 16, (unsigned)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         if (w < NA) {                                                       // ---- phase 3: all NB x 1 KB
             if (tid < 64) { const bool ok = wait_flags(flagB, NB, it); if (tid == 0) s_ok = ok; }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(T) void k_ring(unsigned* slab, unsigned* dl, unsign
     if (w == 0 && tid == 0) *ticks = wall_clock64() - t0;
 }
 
-template <int ST_AUX, int T>
+template <int ST_AUX, int T, int FLAGP = 0>
 void run(const char* name, int NA, int NB, int stride8, int iters) {
     const int NW = NA > NB ? NA : NB;
     unsigned *slab, *dl, *fa, *fb, *xcc; unsigned long long* bad; long long* ticks;
@@ -103,7 +103,7 @@ void run(const char* name, int NA, int NB, int stride8, int iters) {
     hipMalloc(&fa, 64 * 64); hipMalloc(&fb, 64 * 64); hipMalloc(&xcc, 256); hipMalloc(&bad, 8); hipMalloc(&ticks, 8);
     hipMemset(slab, 0, (size_t)2 * NA * NB * 1024); hipMemset(dl, 0, (size_t)2 * NB * 1024);
     hipMemset(fa, 0, 64 * 64); hipMemset(fb, 0, 64 * 64); hipMemset(xcc, 0xff, 256); hipMemset(bad, 0, 8); hipMemset(ticks, 0, 8);
-    hipLaunchKernelGGL((k_ring<ST_AUX, T>), dim3(stride8 ? 8 * NW : NW), dim3(T), 0, 0, slab, dl, fa, fb, NA, NB, stride8, iters, xcc, bad, ticks);
+    hipLaunchKernelGGL((k_ring<ST_AUX, T, FLAGP>), dim3(stride8 ? 8 * NW : NW), dim3(T), 0, 0, slab, dl, fa, fb, NA, NB, stride8, iters, xcc, bad, ticks);
     hipError_t e = hipDeviceSynchronize();
     unsigned long long hb = 0; long long ht = 0; std::vector<unsigned> hx(64);
     hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost); hipMemcpy(&ht, ticks, 8, hipMemcpyDeviceToHost); hipMemcpy(hx.data(), xcc, 256, hipMemcpyDeviceToHost);
@@ -123,6 +123,8 @@ int main() {
         run<0, 512>("plain stores (ILLEGAL)", 28, 32, 0, iters);
         run<0, 1024>("plain stores, sc1 loads", 28, 32, 1, iters);
         run<16, 1024>("sc1 stores, sc1 loads", 28, 32, 1, iters);
+        run<0, 512, 1>("plain stores+flags, sc1 ld", 28, 32, 1, iters);
+        run<0, 1024, 1>("plain stores+flags, sc1 ld", 28, 32, 1, iters);
         run<0, 512>("plain stores, sc1 loads", 16, 16, 1, iters);
         run<0, 512>("plain stores, sc1 loads", 32, 32, 1, iters);
     }
