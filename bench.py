@@ -476,14 +476,18 @@ def main():
         # implementation traffic: they show up in `traffic` (PMC), not here.
         per_img_main = F * es + 2 * P * es / B
         per_img_tail = C * es
-        if args.path == 1:
+        resident = us_first == 0.0                  # the resident one-XCD kernel ran the step: one launch per epoch segment, no first / second kernel
+        if resident:
+            # k_xcd_epoch (csrc/dense_xcd.hpp) does the whole step; a launch processes `steps_per_launch` batches.  achieved = the
+            # step's algorithmic bytes x steps per launch / the launch's duration = per-step bytes / per-step time.
+            names, by, k = ("k_xcd_epoch", "k_xcd_epoch"), (B * (per_img_main + per_img_tail), B * (per_img_main + per_img_tail)), 1
+        elif args.path == 1:
             names, by = ("k_dense_fwd", "k_dense_wgrad"), (B * (F * es + C * es + P * es / B), B * (P * es / B))
+            k = 0 if us_first >= us_second else 1
         else:
             names, by = ("k_p2_b", "k_p2_a"), (B * per_img_tail, B * per_img_main)
-        k = 0 if us_first >= us_second else 1
-        if args.path != 1:
             k = 1                                   # k_p2_a owns the features and W_0; k_p2_b is the small tail kernel
-        us = us_pair * (us_first, us_second)[k] / (us_first + us_second)
+        us = us_second if resident else us_pair * (us_first, us_second)[k] / (us_first + us_second)
         flops_step = 2 * B * ((F * H + H * C) * 2 + H * C)
         traffic, traffic_src, traffic_stale = None, None, None
         pmc = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
@@ -495,15 +499,24 @@ def main():
                 traffic_stale = pj.get("csrc_sha16") != csrc_sha16()     # True: kernels changed since the counters were collected
             except Exception:
                 traffic = None
+        steps_per_launch = nb_epoch if resident else 1
         result["roofline"] = {"bound": "hbm", "kernel": names[k], "achieved": round(by[k] / us / 1e3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(by[k] / us / 1e3 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                              "frac": round(by[k] / us / 1e3 / HBM_PEAK_GBS, 5), "traffic": round(traffic) if traffic else None,
+                              "traffic_per_step": round(traffic / steps_per_launch) if traffic else None,
                               "traffic_source": traffic_src, "traffic_measured_on_other_kernel_sources": traffic_stale,
-                              "traffic_over_algorithmic": round(traffic / by[k], 2) if traffic else None,
-                              "algorithmic_bytes_per_launch": round(by[k]), "us_per_launch_hip_events": round(us, 3),
-                              "us_alternating_pair": round(us_pair, 3),
-                              "us_standalone_" + names[0]: round(us_first, 3), "us_standalone_" + names[1]: round(us_second, 3),
+                              "traffic_over_algorithmic": round(traffic / (by[k] * steps_per_launch), 2) if traffic else None,
+                              "steps_per_launch": steps_per_launch,
+                              "algorithmic_bytes_per_launch": round(by[k] * steps_per_launch), "algorithmic_bytes_per_step": round(by[k]) if resident else None,
+                              "us_per_launch_hip_events": round(us * steps_per_launch, 3), "us_per_step_hip_events": round(us, 3) if resident else None,
+                              "us_alternating_pair": None if resident else round(us_pair, 3),
+                              **({} if resident else {"us_standalone_" + names[0]: round(us_first, 3), "us_standalone_" + names[1]: round(us_second, 3)}),
                               "step_gflops_per_s": round(flops_step / (steady_el / steady_k) / 1e9, 1),
-                              "note": "one train_batch at B=256 is ~1 MB and ~25 MFLOP: bound by launch + dependent-latency floors "
+                              "mfma_floor_us_per_step": round(2 * 256 * 8 / 2.4e3, 3) if resident else None,
+                              "note": ("one train_batch at B=256 is ~1 MB and ~25 MFLOP.  The resident kernel keeps the step on the 32 CUs of one XCD: its floor is the 512 "
+                                       "f32 MFMAs per feature worker and step (8 cycles per CU each: 1.7 us) plus two in-launch hand-offs through that XCD's L2, "
+                                       "far from the HBM roof by construction -- the batch is read from memory exactly once per step, parameters and partial sums never leave the chip")
+                                      if resident else
+                                      "one train_batch at B=256 is ~1 MB and ~25 MFLOP: bound by launch + dependent-latency floors "
                                       "(1.6 us per dependent launch, >=1 us per global round trip), far from either roof"}
         if not use_dp and not args.no_e2e and args.dtype == "f32":
             # second kernel of the path with a roofline worth quoting: flatten_feature_set (conv, pool, conv, pool -> 784 features),
