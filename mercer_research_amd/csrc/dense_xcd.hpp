@@ -275,7 +275,15 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         __syncthreads();
         if (tid == 0) xcd_flag(bufs.flagA + w * kXcdFlagStride, tag0);
     } else if (is_t) {
-        if (tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag0);   // the image the host built from the parameters is current
+        // this tile's share of the operand-fragment image, from the parameter vector (the image's pads are the zeros it was created with)
+        if (tvalid) {
+            const int jl = e == 0 ? 0 : 1, n0 = e == 0 ? F : (e - 1) * 16;
+            const int o = tid & 255;
+            p2_frag_scatter(jl, n0 + (o >> 4), mt * 16 + (o & 15), H, tcur, bufs.fragimg);
+        }
+        xcd_drain();
+        __syncthreads();
+        if (tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag0);
     }
 
     for (int j = 0; j < nb; ++j) {

@@ -118,6 +118,8 @@ struct rcn_hip_ctx {
     DevBuf xcdbuf;                          // one-XCD resident epoch kernel (dense_xcd.hpp): slab, deltas, fragment image, flags
     size_t xcd_B = 0;
     unsigned xcd_tag = 0;                   // last step tag handed out; monotonic for the life of the buffer
+    unsigned* xerr_host = nullptr;          // its sticky error word: pinned host memory the kernel writes straight into (no copy-back in the stream)
+    unsigned* xerr_dev = nullptr;
     int xcd_probe = 0;                      // 0 not probed, 1 the blocks with b % 8 == 0 share one XCD (and no other block does), -1 they do not
     struct ResidentSet {                     // rcn_hip_load_data: one of RCN::train's two data sets, kept in HBM (rcn.rs:134-137)
         DevBuf imgs, X, Y, perm, loss;
@@ -785,14 +787,13 @@ bool use_xcd(rcn_hip_ctx* c, size_t B) {
 }
 
 int ensure_xcd_ws(rcn_hip_ctx* c, size_t B) {
-    if (!c->perr_dev) {
-        HIP_TRY(c, hipMalloc((void**)&c->perr_dev, 256));
-        HIP_TRY(c, hipHostMalloc((void**)&c->perr_host, 64, hipHostMallocDefault));
-        *c->perr_host = 0;
-        HIP_TRY(c, hipMemsetAsync(c->perr_dev, 0, 256, c->stream));
+    if (!c->xerr_host) {
+        HIP_TRY(c, hipHostMalloc((void**)&c->xerr_host, 64, hipHostMallocMapped));
+        *c->xerr_host = 0;
+        HIP_TRY(c, hipHostGetDevicePointer((void**)&c->xerr_dev, c->xerr_host, 0));
     }
-    if (*c->perr_host != 0)
-        return fail(c, RCN_HIP_ERR_HIP, *c->perr_host == 2 ? "train_epoch: the resident kernel's workgroups did not share one XCD in an earlier call; nothing was "
+    if (*c->xerr_host != 0)
+        return fail(c, RCN_HIP_ERR_HIP, *c->xerr_host == 2 ? "train_epoch: the resident kernel's workgroups did not share one XCD in an earlier call; nothing was "
                                                              "updated by it.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline"
                                                            : "train_epoch: a bounded wait inside the resident kernel expired in an earlier call (is the device shared?); "
                                                              "that call's segment was not applied.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline");
@@ -823,12 +824,11 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
     xb.flagB = u; u += kXcdWorkers * kXcdFlagStride;
     xb.xcc = u;   u += kXcdWorkers * kXcdFlagStride;
     xb.flagT = u;
-    // the tail parameters as the sample groups' operand fragments: built from the parameter vector here, kept current by the tail tiles
-    hipLaunchKernelGGL(k_p2_fragimg, dim3(1), dim3(512), 0, c->stream, nd, (const float*)c->params.p, xb.fragimg);
-    HIP_TRY(c, hipGetLastError());
+    // (the tail parameters as the sample groups' operand fragments -- xb.fragimg -- are written by the kernel's own tail tiles: at its
+    // start from the parameter vector, then after every update; its pads are the zeros the buffer was created with)
     const unsigned tag0 = c->xcd_tag + 1;
     hipLaunchKernelGGL(k_xcd_epoch, dim3(8 * kXcdWorkers), dim3(kXcdThreads), kXcdLdsFloats * sizeof(float), c->stream, nd, (float*)c->params.p, xs, ys, (int)B,
-                       (int)nb, pipe_slices(nd), (float)(eta / (double)B), (float)(1.0 / (2.0 * (double)B)), loss_dev, xb, tag0, c->perr_dev, kXcdTimeoutTicks);
+                       (int)nb, pipe_slices(nd), (float)(eta / (double)B), (float)(1.0 / (2.0 * (double)B)), loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks);
     HIP_TRY(c, hipGetLastError());
     c->xcd_tag += (unsigned)nb;
     return RCN_HIP_OK;
@@ -851,8 +851,7 @@ int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
         RCN_TRY(enqueue_xcd_steps(c, xs, ys, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr));
         j += n; k += n;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->perr_host, c->perr_dev, 4, hipMemcpyDeviceToHost, c->stream));     // looked at by the next call / synchronize
-    return RCN_HIP_OK;
+    return RCN_HIP_OK;                      // (the sticky error word lives in pinned host memory: current once the stream has drained)
 }
 
 // one train_batch (rcn.rs:176-223) on device-resident data; idx selects the batch's rows (or NULL)
@@ -889,6 +888,9 @@ int sticky_errors(rcn_hip_ctx* c) {
     }
     if (c->perr_host && *c->perr_host != 0)
         return fail(c, RCN_HIP_ERR_HIP, "a bounded wait inside the resident / one-launch step kernel expired; the last call's updates are incomplete");
+    if (c->xerr_host && *c->xerr_host != 0)
+        return fail(c, RCN_HIP_ERR_HIP, *c->xerr_host == 2 ? "the resident one-XCD kernel found its workgroups on different XCDs; the last call's segment was not applied"
+                                                           : "a bounded wait inside the resident one-XCD kernel expired; the last call's segment was not applied");
     return RCN_HIP_OK;
 }
 
@@ -1218,6 +1220,7 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
                           &c->scratch1, &c->scratch2, &c->redpart, &c->misc})
             b->release();
         c->xcdbuf.release();
+        if (c->xerr_host) (void)hipHostFree(c->xerr_host);
         for (auto& rs : c->sets) { rs.imgs.release(); rs.X.release(); rs.Y.release(); rs.perm.release(); rs.loss.release(); }
         if (c->pin_host) (void)hipHostFree(c->pin_host);
         c->pll.release();
@@ -1351,7 +1354,7 @@ int rcn_hip_params_dev(rcn_hip_ctx* c, void** p, int64_t* count) {
     if (!c || !p || !count) return RCN_HIP_ERR_INVALID_ARG;
     *p = c->params.p; *count = c->nd.P;
     c->params_set = true;      // the caller may fill the buffer directly (e.g. a DP broadcast)
-    if ((c->p2p.err_host && *c->p2p.err_host != 0) || (c->perr_host && *c->perr_host != 0)) return sticky_errors(c);   // no sync here: last known state
+    if ((c->p2p.err_host && *c->p2p.err_host != 0) || (c->perr_host && *c->perr_host != 0) || (c->xerr_host && *c->xerr_host != 0)) return sticky_errors(c);   // no sync here: last known state
     return RCN_HIP_OK;
 }
 
