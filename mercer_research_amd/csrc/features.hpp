@@ -236,10 +236,12 @@ struct Cpcp {
     // visible to every later read without a barrier; only the compiler must not reorder.  (__syncthreads() here would
     // also carry a workgroup-scope release -- an s_waitcnt vmcnt(0) that drains the previous picture's 16 global stores
     // and the prefetched loads once per picture: measured, that wait was the largest stall in the kernel.)
+    // More than one wave per picture: the stage boundary is a real barrier, but an LDS-only one -- every LDS operation of this wave
+    // retired (lgkmcnt), then s_barrier; the global stores of the previous picture and the prefetched loads stay in flight.
     template <int NT>
     __device__ static inline void sync() {
         if constexpr (NT <= 64) asm volatile("" ::: "memory");
-        else __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
     // one 4x4 window -> the four pooled operator responses (Top, Left, Right, Bottom) of its 2x2 cell.
@@ -360,29 +362,31 @@ struct Cpcp {
     }
 };
 
-template <int H, int W, typename TO, bool STD, bool FAST>
-__global__ __launch_bounds__(64) void k_features_cpcp(const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, TO mean, TO sd, TO rcp) {
+// NT = 64: one wave per picture (no barriers at all).  NT = 128: two waves share a picture's LDS image and split every stage's work
+// items -- the same 11 KB of LDS then carries twice the waves (28 per CU instead of 14), which is what hides the LDS and VALU
+// latencies of the other waves; stage boundaries are LDS-only barriers (Cpcp::sync).
+template <int H, int W, typename TO, bool STD, bool FAST, int NT = 64>
+__global__ __launch_bounds__(NT) void k_features_cpcp(const uint8_t* __restrict__ imgs, int n_img, TO* __restrict__ out, TO mean, TO sd, TO rcp) {
     using K = Cpcp<H, W>;
     __shared__ __attribute__((aligned(16))) float P0[K::N0];
     __shared__ __attribute__((aligned(16))) float P1[4 * K::N1];
     const int lane = threadIdx.x;
-    K::template init<64>(P0, P1, lane);
+    K::template init<NT>(P0, P1, lane);
     __syncthreads();
-    // the next picture's pixels are in flight while this one is computed (one wave per workgroup: nothing else hides
-    // the load's latency inside the wave)
-    auto nxt = K::template load_words<64>(imgs + (size_t)(blockIdx.x < n_img ? blockIdx.x : 0) * (H * W), lane);
+    // the next picture's pixels are in flight while this one is computed
+    auto nxt = K::template load_words<NT>(imgs + (size_t)(blockIdx.x < n_img ? blockIdx.x : 0) * (H * W), lane);
     for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
         TO* dst = out + (size_t)img * K::F;
         const auto cur = nxt;
         const int ni = img + (int)gridDim.x;
-        nxt = K::template load_words<64>(imgs + (size_t)(ni < n_img ? ni : img) * (H * W), lane);
-        K::template image<64>(P0, P1, cur, lane, [&](int ea, int eb, float fa, float fb) {
+        nxt = K::template load_words<NT>(imgs + (size_t)(ni < n_img ? ni : img) * (H * W), lane);
+        K::template image<NT>(P0, P1, cur, lane, [&](int ea, int eb, float fa, float fb) {
             TO va = (TO)fa, vb = (TO)fb;
             if constexpr (STD) standardise_clamp_pair<FAST>(va, vb, mean, sd, rcp);
             dst[ea] = va;
             dst[eb] = vb;
         });
-        K::template sync<64>();
+        K::template sync<NT>();
     }
 }
 

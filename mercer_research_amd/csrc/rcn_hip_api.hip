@@ -500,7 +500,7 @@ int launch_pack(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* per
 // once (CUs x resident workgroups per CU for that kernel's LDS footprint), so every image loop runs in a single pass --
 // a grid larger than that queues the excess behind the first pass and the tail runs on a part-empty chip.
 template <typename Kern>
-static int resident_grid(rcn_hip_ctx* c, Kern kern, size_t work) {
+static int resident_grid(rcn_hip_ctx* c, Kern kern, size_t work, int block = 64) {
     static std::map<std::pair<int, const void*>, int> cache;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
@@ -508,7 +508,7 @@ static int resident_grid(rcn_hip_ctx* c, Kern kern, size_t work) {
     auto it = cache.find(key);
     if (it == cache.end()) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, block, 0) != hipSuccess || per_cu < 1) per_cu = 8;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 256;
         it = cache.emplace(key, per_cu * cus).first;
     }
@@ -1480,11 +1480,20 @@ int rcn_hip_features_dev(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, void* ou
     // the default stack on MNIST-shaped input has its own kernel (features.hpp: k_features_cpcp)
     if (feat_is_cpcp28(c) && ((uintptr_t)imgs & 3) == 0) {
         const float rcp = c->dtype == RCN_HIP_F32 && standardize ? fast_standardise_rcp(c) : 0.f;
+        // RCN_HIP_FEAT_WAVES=2: two waves per picture (twice the waves per CU on the same LDS).  Measured neutral (144.8 vs 145.8 us per
+        // 131 072 pictures): the kernel is not short of waves to hide latency behind, it is short of issue slots -- kept for the record.
+        static const int two_waves = [] { const char* e = std::getenv("RCN_HIP_FEAT_WAVES"); return e ? std::atoi(e) : 1; }();
 #define RCN_CPCP(TT, STD, FAST, RCPV)                                                                                              \
     do {                                                                                                                          \
-        auto kern = k_features_cpcp<28, 28, TT, STD, FAST>;                                                                       \
-        hipLaunchKernelGGL(kern, dim3(resident_grid(c, kern, n)), dim3(64), 0, c->stream, imgs, (int)n, (TT*)out, (TT)c->mean,    \
-                           (TT)c->sd, (TT)(RCPV));                                                                                \
+        if (two_waves == 2) {                                                                                                     \
+            auto kern = k_features_cpcp<28, 28, TT, STD, FAST, 128>;                                                              \
+            hipLaunchKernelGGL(kern, dim3(resident_grid(c, kern, n, 128)), dim3(128), 0, c->stream, imgs, (int)n, (TT*)out,       \
+                               (TT)c->mean, (TT)c->sd, (TT)(RCPV));                                                               \
+        } else {                                                                                                                  \
+            auto kern = k_features_cpcp<28, 28, TT, STD, FAST, 64>;                                                               \
+            hipLaunchKernelGGL(kern, dim3(resident_grid(c, kern, n)), dim3(64), 0, c->stream, imgs, (int)n, (TT*)out, (TT)c->mean, \
+                               (TT)c->sd, (TT)(RCPV));                                                                            \
+        }                                                                                                                         \
     } while (0)
         if (c->dtype == RCN_HIP_F64) {
             if (standardize) RCN_CPCP(double, true, false, 0); else RCN_CPCP(double, false, false, 0);
