@@ -276,6 +276,9 @@ __global__ __launch_bounds__(256) void k_pack_epoch(const T* __restrict__ X, con
 }
 
 // One workgroup per 8 samples.  Ys: this batch's targets, packed [sample][classes].
+// (f32: sigmoid_fast -- v_exp_f32 / v_rcp_f32, ~1e-7 relative, inside the 2e-6 activation tolerance and what k_p2_b uses; the
+// libm-grade expf and the IEEE division of sigmoid_ref cost ~60 instructions per value, and the waves that evaluate it run alone on
+// their SIMD at ~5.6 cycles per instruction: by the stamps 0.6 us of this kernel's 1.0 us a_1 phase.  f64: unchanged.)
 template <typename T>
 __global__ __launch_bounds__(kPipeBThreads) void k_pipe_b(
     NetDesc nd, const T* __restrict__ params, const T* __restrict__ slab, int G, const T* __restrict__ Ys, int B,
@@ -306,6 +309,16 @@ __global__ __launch_bounds__(kPipeBThreads) void k_pipe_b(
     // deep (measured: 8.8 us for this kernel against 3.4 us for its specialised sibling).  Instead the slices are dealt over
     // NG = 256 / nq thread groups: group r sums slices r, r + NG, r + 2 NG, ... in that order (one round of loads in flight), and the
     // groups' partials meet in LDS and are added in group order -- a fixed order, so the result is bit-reproducible.
+    // the small parameters first (into registers: up to four values per thread, the usual case), so that their round trip runs
+    // under the slab's instead of behind it
+    constexpr int kPre = 4;
+    T pre[kPre], preb = 0;
+    const bool pre_ok = ntail <= kPre * kPipeBThreads && M <= kPipeBThreads;
+    if (pre_ok) {
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) { const int e = tid + q * kPipeBThreads; pre[q] = params[tail0 + (e < ntail ? e : 0)]; }
+        preb = params[nd.w_off[0] + (size_t)M * F + (tid < M ? tid : 0)];
+    }
     const int nq = kPipeTs * Mp / 4;                      // float4 groups per slice in this tile
     const int NG = kPipeBThreads / nq > 0 ? kPipeBThreads / nq : 1;
     {
@@ -332,8 +345,14 @@ __global__ __launch_bounds__(kPipeBThreads) void k_pipe_b(
             yv[u] = Ys[(size_t)(s0 + s < B ? s0 + s : B - 1) * C + (e - s * C)];
         }
     }
-    for (int e = tid; e < ntail; e += kPipeBThreads) wsm[e] = params[tail0 + e];
-    for (int e = tid; e < M; e += kPipeBThreads) b0[e] = params[nd.w_off[0] + (size_t)M * F + e];
+    if (pre_ok) {
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) { const int e = tid + q * kPipeBThreads; if (e < ntail) wsm[e] = pre[q]; }
+        if (tid < M) b0[tid] = preb;
+    } else {
+        for (int e = tid; e < ntail; e += kPipeBThreads) wsm[e] = params[tail0 + e];
+        for (int e = tid; e < M; e += kPipeBThreads) b0[e] = params[nd.w_off[0] + (size_t)M * F + e];
+    }
     RCN_STAMP(1, 1);
     __syncthreads();                                      // staged parameters visible
     RCN_STAMP(1, 2);
@@ -341,13 +360,20 @@ __global__ __launch_bounds__(kPipeBThreads) void k_pipe_b(
     // ---- a_1 = sigmoid(z_1 + b_0)                                                                 rcn.rs:287-289
     if (tid < nq) {
         vec4 z = zpart[tid];
-        for (int r = 1; r < NG; ++r) z += zpart[r * nq + tid];
+        for (int r0 = 1; r0 < NG; r0 += 8) {             // group order, eight partials per round of LDS reads
+            vec4 t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = zpart[(r0 + q < NG ? r0 + q : 0) * nq + tid];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r0 + q < NG) z += t[q];
+        }
         const int s = tid / (Mp / 4), m4 = (tid - s * (Mp / 4)) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m4 + i;
             if (m < M) {
-                const T a = sigmoid_ref(z[i] + b0[m]);
+                const T a = sigmoid_fast(z[i] + b0[m]);
                 act[s * M + m] = a;                       // act_off[1] == 0
                 if (s0 + s < B) acts[(size_t)B * nd.act_off[1] + (size_t)(s0 + s) * M + m] = a;
             }
@@ -379,7 +405,7 @@ __global__ __launch_bounds__(kPipeBThreads) void k_pipe_b(
                 for (int q = 0; q < 8; ++q)
                     if (k0 + q < dk) zz = (k0 + q == 0) ? w[q] * a[q] : w[q] * a[q] + zz;
             }
-            const T a = sigmoid_ref(zz + bj[m]);
+            const T a = sigmoid_fast(zz + bj[m]);
             an[s * dn + m] = a;
             if (j + 1 < L && s0 + s < B) acts[(size_t)B * nd.act_off[j + 1] + (size_t)(s0 + s) * dn + m] = a;
         }

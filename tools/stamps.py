@@ -13,10 +13,11 @@ _lib.LIB_PATH = out
 import torch
 from mercer_research_amd.device import DeviceRCN
 from mercer_research_amd.synth import synthetic_params
-d = DeviceRCN()
+hidden = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [30]
+d = DeviceRCN(feedforward_cfg=hidden)
 lib = d.lib
 lib.rcn_hip_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
-ws, bs = synthetic_params([784, 30, 10], seed=42)
+ws, bs = synthetic_params([784] + hidden + [10], seed=42)
 d.set_params(ws, bs)
 N, B = 16384, 256
 with torch.cuda.stream(d.stream):
