@@ -683,8 +683,12 @@ def trackx_leg(torch, dev):
     if os.path.exists(pm):
         try:
             pj = json.load(open(pm))
-            out["conv_fwd_mfma_busy"] = pj.get("conv_fwd_mfma_busy")
-            out["conv_fwd_mfma_busy_source"] = "profiles/r2_trackx_mfma_pmc.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES; tools/prof_trackx.sh)"
+            conv = {k: v["mfma_busy_fraction_of_simd_cycles"] for k, v in pj.items() if "k_conv_fwd<3, false" in k and "mfma_busy_fraction_of_simd_cycles" in v}
+            wg = {k: v["mfma_busy_fraction_of_simd_cycles"] for k, v in pj.items() if "k_conv_wgrad<3, false" in k and "mfma_busy_fraction_of_simd_cycles" in v}
+            out["conv_gemm_mfma_busy"] = {"forward_and_dgrad_kernels": conv, "wgrad_kernels": wg,
+                                          "source": "profiles/r2_trackx_mfma_pmc.json (tools/prof_trackx.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over "
+                                                    "bench_convnet.py --config cifar; fraction = MFMA-busy cycles / (GRBM_GUI_ACTIVE x 128), 1.0 = every SIMD's matrix pipe busy "
+                                                    "for the kernel's whole duration)"}
         except Exception:
             pass
     return out

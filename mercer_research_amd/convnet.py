@@ -150,6 +150,28 @@ class ConvNet:
         self._ck(self.lib.rcn_hipx_unpad_host(self.net, C.c_void_p(padded.data_ptr()), f.ctypes.data_as(C.POINTER(C.c_float))))
         return f
 
+    def step_hbm_floor_bytes(self, B: int) -> float:
+        """HBM floor of one training step with activations stored fp32: every layer's input read and output written once in the forward
+        pass; in the backward pass dZ read and dX written once by the input-gradient GEMM (not for the first layer) and the input and dZ
+        read once more by the weight-gradient GEMM; parameters read twice and written once.  Fusion (pool in the epilogue, ReLU masks in
+        the consumer) can go below it only by not materialising a tensor at all."""
+        H, W, Cc = self.in_shape
+        total, first = 0.0, True
+        for l in self.layers:
+            if l[0] == "conv":
+                i, o = H * W * Cc, H * W * l[1]
+                total += B * ((i + o) + (0 if first else (i + o)) + (i + o)) * 4 + 3 * (9 * Cc * l[1] + l[1]) * 4
+                Cc, first = l[1], False
+            elif l[0] == "pool":
+                i, o = H * W * Cc, (H // 2) * (W // 2) * Cc
+                total += B * 2 * (i + o) * 4
+                H, W = H // 2, W // 2
+            else:
+                i, o = H * W * Cc, l[1]
+                total += B * ((i + o) + (0 if first else (i + o)) + (i + o)) * 4 + 3 * (i * o + o) * 4
+                H, W, Cc, first = 1, 1, l[1], False
+        return total
+
     def step_flops(self, B: int) -> float:
         f = C.c_double()
         self._ck(self.lib.rcn_hipx_step_flops(self.net, B, C.byref(f)))
