@@ -217,7 +217,10 @@ def main():
         # begun["ok"]: the epoch image form (rcn_hip_epoch_begin_dev / _steps_dev) is available -- it is for the feature-sliced
         # pipeline; with --path 1 (sample-tile kernels) each piece gathers its rows by index instead.  live: the image holds the
         # session's current epoch.
-        begun = {"ok": True, "live": False}
+        # Where the resident kernel fetches its rows itself (rcn_hip_train_epoch_gathers) there is nothing to materialise: the session
+        # is shuffle + rcn_hip_train_epoch_dev over the shuffled order, one launch per piece.
+        gathers = bool(d.train_epoch_gathers(B))
+        begun = {"ok": not gathers, "live": False}
         with torch.cuda.stream(d.stream):
             perm.copy_(torch.arange(N_IMAGES, dtype=torch.int32, device=d.device))
 
@@ -266,6 +269,8 @@ def main():
             return bool(flag.item())
 
         def dp_kind():
+            if d.dp_p2p_mode() == 2 and d.dp_resident(B):
+                return "xgmi peer reads inside the resident one-XCD step kernel (csrc/dense_xcd.hpp, DP form: one launch per 64-step segment)"
             return {0: "ncclAllReduce (RCCL)", 1: "xgmi peer reads between kernels, fused with the update (csrc/dense_p2_dp.hpp, 3 kernels/step)",
                     2: "xgmi peer reads inside the gradient kernel (csrc/dense_p2_dp.hpp, 2 kernels/step)"}[d.dp_p2p_mode()]
 
@@ -324,8 +329,8 @@ def main():
             same = replicas_check() if flag.item() else False
             return bool(flag.item()) and same
 
-        # Rehearse before anything is timed, and step down together if the rehearsal fails: in-kernel xGMI exchange ->
-        # ncclAllReduce inside the library -> torch.distributed all_reduce.  Every rank takes the same branch (votes above).
+        # Rehearse before anything is timed, and step down together if the rehearsal fails: xGMI exchange inside the resident
+        # step kernel -> the same exchange inside the two-kernel pipeline's gradient kernel -> ncclAllReduce inside the library -> torch.distributed all_reduce.  Every rank takes the same branch (votes above).
         rehearsal = max(8, min(args.warmup, 64))
         while True:
             if args.dp_impl == "native":
@@ -341,6 +346,7 @@ def main():
             if args.dp_impl != "native":
                 raise SystemExit("[bench] the torch.distributed data-parallel loop failed its rehearsal too")
             was_p2p = d.dp_p2p_mode() != 0
+            was_resident = was_p2p and d.dp_p2p_mode() == 2 and d.dp_resident(B)
             try:
                 d.dp_finalize()
             except Exception as e:
@@ -348,7 +354,11 @@ def main():
             d.set_params(ws, bs)
             step_no[0] = 0
             epoch_no[0] = 0
-            if was_p2p:
+            if was_resident:
+                d.set_dense_path(2)                         # same exchange between the halves of the two-kernel pipeline
+                if not dp_native_setup():
+                    args.dp_impl = "torch"
+            elif was_p2p:
                 os.environ["RCN_HIP_DP_P2P"] = "0"          # same library loop on ncclAllReduce
                 if not dp_native_setup():
                     args.dp_impl = "torch"
@@ -446,8 +456,10 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": WORKLOAD,
                    "global_batch": B * world, "parallelism": f"dp{world}", "step_form": f"gradient -> exchange -> apply ({args.dp_impl} loop)" if use_dp else "fused update", "images_per_rank": N_IMAGES,
-                   "session": f"steps {args.warmup}..{args.warmup + args.steps} of one continuous training session (64 steps per epoch; device shuffle + one "
-                              f"gather of the shuffled order at every epoch boundary, inside the timed region whenever it is crossed)",
+                   "session": f"steps {args.warmup}..{args.warmup + args.steps} of one continuous training session (64 steps per epoch; device shuffle "
+                              + ("at every epoch boundary, rows fetched by the step kernel itself in the shuffled order -- no packed copy of the epoch"
+                                 if (not use_dp and gathers) else "+ one gather of the shuffled order at every epoch boundary")
+                              + ", inside the timed region whenever it is crossed)",
                    "device_ms_per_step_rank0": round(dev_ms / args.steps, 6), "final_cost_rank0": final_loss,
                    "steady_state_steps": steady_k,
                    "steady_state_images_per_s": round(steady_k * B * world / steady_el, 1),

@@ -166,6 +166,12 @@ int  rcn_hip_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_
  * pass into perm_dev (each pass is rcn.rs:146-149 once). */
 int  rcn_hip_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
                                size_t B, size_t n_batches, double eta, void* loss_dev);
+/* 1 when rcn_hip_train_epoch_dev at this batch size runs on the resident one-XCD kernel in its GATHER form: no packed epoch image is
+ * written -- one launch walks the whole call and every worker fetches its 128 bytes of each row of the batch after next while it
+ * works on the current one (csrc/dense_xcd.hpp).  The feature matrix is then read from memory exactly once per step and
+ * rcn_hip_epoch_begin_dev's one-off materialisation buys nothing; 0: the call packs its batches segment by segment.  (X_dev and
+ * Y_dev must each end within 4 GB of the pointer's allocation end for the form to apply; else the call packs, silently.) */
+int  rcn_hip_train_epoch_gathers(rcn_hip_ctx* ctx, size_t B);
 /* End to end: the same epoch straight from the resident u8 pictures (imgs_dev [N][H][W], perm_dev indexes pictures).  Per
  * segment of the epoch ONE kernel does flatten_feature_set (rcn.rs:317-356), the standardisation with the current scale_set
  * (rcn.rs:407-412) and the gather into the training kernels' layout -- no [N][F] feature matrix is ever written; results
@@ -247,6 +253,14 @@ int  rcn_hip_dp_p2p_selftest(rcn_hip_ctx* ctx, int iters, unsigned* mismatches, 
 typedef int (*rcn_hip_allgather_fn)(void* user, const void* mine, void* all, size_t bytes);
 typedef int (*rcn_hip_vote_min_fn)(void* user, int* v);
 int  rcn_hip_dp_p2p_admit(rcn_hip_ctx* ctx, int rank, int world, rcn_hip_allgather_fn allgather, rcn_hip_vote_min_fn vote_min, void* user);
+/* The data-parallel counterpart of rcn_hip_epoch_steps_dev: n_batches data-parallel steps over this rank's shard batches
+ * [first_batch, first_batch + n_batches) of the epoch image rcn_hip_epoch_begin_dev packed on THIS rank (every rank begins its own
+ * shard's epoch; nothing is gathered or packed inside the call, so an epoch is packed once however many calls walk it).  Collective
+ * like rcn_hip_dp_train_epoch_dev; available where rcn_hip_dp_resident says 1, RCN_HIP_ERR_UNSUPPORTED elsewhere. */
+int  rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* ctx, size_t first_batch, size_t n_batches, double eta, void* loss_dev);
+/* 1 when rcn_hip_dp_train_epoch_dev at this shard size runs the data-parallel step on the resident one-XCD kernel with the exchange
+ * inside it (csrc/dense_xcd.hpp, DP form: the in-kernel exchange was admitted and the single-GPU resident kernel applies), else 0 */
+int  rcn_hip_dp_resident(rcn_hip_ctx* ctx, size_t B_shard);
 int  rcn_hip_dp_p2p_active(const rcn_hip_ctx* ctx);   /* 0 ncclAllReduce, 1 peer exchange at kernel boundaries, 2 also inside the gradient kernel */
 /* ---- RCN::train's data flow with both data sets RESIDENT in HBM (rcn.rs:126-167): what a host-language `RCN::train` calls.
  * rcn_hip_load_data = the arithmetic of load_data after the image decode (rcn.rs:399-414) for `n` images: imgs n x in_h x in_w u8,

@@ -276,6 +276,44 @@ __device__ inline bool ll_gather_sum(const P2PDesc& d, size_t stride, size_t idx
     return true;
 }
 
+// Four consecutive values idx0 .. idx0 + 3 per lane (the resident kernel's accumulator layout: dense_xcd.hpp) gathered TOGETHER: every round polls every
+// outstanding (value, peer) pair, so the up-to 4 * (world - 1) xGMI reads of a lane are in flight at once and the exchange costs one
+// peer round trip, not four.  want[i] false: value i is not exchanged (its sum is left alone).  Sums in rank order, as above.
+__device__ inline bool ll_gather_sum4(const P2PDesc& d, size_t stride, size_t idx0, const bool (&want)[4], unsigned seq, float (&own)[4],
+                                      long long timeout_ticks) {
+    float v[4][kP2PMaxWorld];
+    unsigned ready[4];
+    const unsigned all = (1u << d.world) - 1u;
+    const size_t slot = (size_t)(seq & 1u) * stride + idx0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ready[i] = want[i] ? 1u << d.rank : all;
+    const long long t0 = wall_clock64();
+    while ((ready[0] & ready[1] & ready[2] & ready[3]) != all) {
+#pragma unroll
+        for (int q = 0; q < kP2PMaxWorld; ++q) {
+            if (q >= d.world) continue;
+            const u64* words = ll_region<float>(d.buf[q], stride);
+            float x[4];
+            bool got[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) got[i] = !((ready[i] >> q) & 1u) && ll_poll(words, slot + i, seq, x[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (got[i]) { v[i][q] = x[i]; ready[i] |= 1u << q; }
+        }
+        if ((ready[0] & ready[1] & ready[2] & ready[3]) != all && wall_clock64() - t0 > timeout_ticks) return false;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!want[i]) continue;
+        float g = 0;
+#pragma unroll
+        for (int q = 0; q < kP2PMaxWorld; ++q) g += q < d.world ? (q == d.rank ? own[i] : v[i][q]) : 0.f;
+        own[i] = g;
+    }
+    return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kDenseThreads) void k_p2_dp_fused(
     NetDesc nd, T* __restrict__ params, const T* __restrict__ Xp, const T* __restrict__ Xn, int B, const T* __restrict__ a1,

@@ -37,6 +37,7 @@
 #pragma once
 
 #include "dense_p2.hpp"
+#include "dense_p2_dp.hpp"
 
 namespace rcn {
 
@@ -106,6 +107,9 @@ __device__ inline void xcd_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memo
 __device__ inline void xcd_flag(unsigned* f, unsigned tag) { __hip_atomic_store(f, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void xcd_flag_wt(unsigned* f, unsigned v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// a workgroup barrier for data exchanged through LDS only: outstanding global stores are not waited for
+__device__ inline void xcd_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ONE wave waits until every flag its lanes look at (lane < n0: f0[lane]; n0 <= lane < n0 + n1: f1[lane - n0]) carries a tag >= tag.
 // Bounded: gives up after `timeout` ticks of the 100 MHz clock or when another worker raised the sticky error word.
 __device__ inline bool xcd_wait(const unsigned* f0, int n0, const unsigned* f1, int n1, unsigned tag, long long timeout, const unsigned* err) {
@@ -124,14 +128,24 @@ __device__ inline bool xcd_wait(const unsigned* f0, int n0, const unsigned* f1, 
     }
 }
 
-// nb consecutive train_batch steps (rcn.rs:176-223) over the packed batches xs[j] (slice-major, k_pack_epoch), ys[j]
+// nb consecutive train_batch steps (rcn.rs:176-223) over the packed batches xs[j] (slice-major, k_pack_epoch), ys[j].
+//
+// DP = true: the data-parallel step (one rank per GPU, this rank's shard of every global batch in xs / ys).  Between the gradient
+// MFMAs and the update every owner of a parameter -- the feature workers' waves 0..3 for their slice pair of W_0, the tail tiles'
+// threads for theirs -- publishes its shard's partial gradient as a self-validating {value, step} word in this rank's exported
+// buffer and polls the same word of every peer over xGMI (dense_p2_dp.hpp: ll_store / ll_gather_sum, the exchange k_p2_dp_fused
+// runs between the two-kernel pipeline's halves); sums are in rank order, so every rank applies the bit-identical update with the
+// GLOBAL batch length (`scale` = eta / (B * world)).  The cost travels the same way as element P.  xsel: which blocks are the
+// workers (blockIdx.x % 8 == xsel) -- 0 on a GPU of its own; the one-GPU test harness gives each rank another XCD.
+template <bool DP>
 __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     NetDesc nd, float* __restrict__ params, const float* __restrict__ xs_all, const float* __restrict__ ys_all, int B, int nb, int G, float scale,
-    float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout) {
+    float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, P2PDesc pd,
+    size_t pstride, unsigned seq0, long long ptimeout, int xsel, const int* __restrict__ gperm, int gather) {
     using T = float;
     using acc_t = Mfma16<T>::acc_t;
     using vec4 = Vec4<T>::type;
-    if ((blockIdx.x & 7) != 0) return;                              // the other seven XCDs' blocks
+    if ((int)(blockIdx.x & 7) != xsel) return;                      // the other seven XCDs' blocks
     const int w = (int)(blockIdx.x >> 3);
     if (w >= kXcdWorkers) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
@@ -196,12 +210,25 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     // The gradient of the slice pair is four 16 x 16 tiles (slice sl, hidden half mt); wave u owns tile u & 3 for the samples of K-half
     // u >> 2, and waves 0..3 also own the tile's parameters, in the accumulator's layout: lane (n, g4), element i <-> hidden
     // 16 mt + 4 g4 + i, feature 16 sl + n.
+    // gather form (no packed image: xs_all = X[rows][F] as stored, ys_all = Y[rows][C], gperm = the epoch's order or NULL for the
+    // stored order): element i of this worker's LDS image of batch b -- slice i / 4B of the pair, sample (i / 4) % B, 16-byte chunk
+    // i % 4 -- straight from row gperm[b B + sample]; four neighbouring threads fetch one 64-byte run of a row, and the sample's
+    // other slice comes from the same 128-byte line of that row (F % 4 == 0: a chunk is inside the row or past it)
+    auto xrow4 = [&](int b, int i) -> vec4 {
+        const int sl = i >> 10, smp = (i >> 2) & 255, col = (kXcdSl * w + sl) * 16 + 4 * (i & 3);      // B == 256
+        const unsigned at = (unsigned)(b * B + smp);
+        const unsigned row = gperm ? (unsigned)gperm[at] : at;
+        // 32-bit byte offsets from a uniform base (the host admits this form only for X / Y ranges below 4 GB): one address register
+        const unsigned off = (row * (unsigned)F + (unsigned)(col < F ? col : 0)) * 4u;
+        const vec4 v = *reinterpret_cast<const vec4*>(reinterpret_cast<const char*>(xs_all) + off);
+        return (sl < nsl && col < F) ? v : vec4{0, 0, 0, 0};
+    };
     T* W0 = params + nd.w_off[0];
     const int mt = tid >> 8;                                        // (tail tiles: M-tile of this thread's parameter)
     const int tl = wave & 3, kh = wave >> 2, usl = tl >> 1, umt = tl & 1;
     T wcur[4] = {0, 0, 0, 0};
     bool wvalid[4] = {false, false, false, false};
-    size_t woff[4] = {0, 0, 0, 0};
+    unsigned woff0 = 0;                                              // this lane's four parameters are consecutive in W_0 (hidden 4 g4 + i)
     if (is_a) {
         if (kh == 0) {
             const int f0 = (kXcdSl * w + usl) * 16;
@@ -210,18 +237,22 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             for (int i = 0; i < 4; ++i) {
                 const int hid = umt * 16 + 4 * g4 + i;
                 wvalid[i] = hid < H && n < nf;
-                woff[i] = wvalid[i] ? (size_t)(f0 + n) * H + hid : 0;
-                const T v = W0[woff[i]];
+                if (i == 0) woff0 = wvalid[0] ? (unsigned)((f0 + n) * H + hid) : 0u;      // (wvalid[0] false => all four are)
+                const T v = W0[wvalid[i] ? woff0 + i : 0u];
                 wcur[i] = wvalid[i] ? v : (T)0;
             }
             *reinterpret_cast<vec4*>(wsl + (usl * 16 + n) * kP2H + umt * 16 + 4 * g4) = vec4{wcur[0], wcur[1], wcur[2], wcur[3]};
         }
         // batches 0 and 1 of this launch: [slice pair][sample][16] is one contiguous run of nsl * B * 16 floats per batch
         for (int b = 0; b < 2 && b < nb; ++b) {
-            const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)b * xs_stride + (size_t)(kXcdSl * w) * B * 16);
             vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(b & 1) * kXcdXs);
-            for (int i = tid; i < nsl * B * 4; i += kXcdThreads) dst[i] = src[i];
-            for (int i = nsl * B * 4 + tid; i < kXcdSl * B * 4; i += kXcdThreads) dst[i] = vec4{0, 0, 0, 0};
+            if (gather) {
+                for (int i = tid; i < kXcdSl * B * 4; i += kXcdThreads) dst[i] = xrow4(b, i);
+            } else {
+                const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)b * xs_stride + (size_t)(kXcdSl * w) * B * 16);
+                for (int i = tid; i < nsl * B * 4; i += kXcdThreads) dst[i] = src[i];
+                for (int i = nsl * B * 4 + tid; i < kXcdSl * B * 4; i += kXcdThreads) dst[i] = vec4{0, 0, 0, 0};
+            }
         }
     }
     // tail tile: this thread's parameter (column cc of [W_jl | b_jl], row tm), kept in a register until the launch ends
@@ -286,6 +317,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         if (tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag0);
     }
 
+    unsigned yrow = 0;                                                // gather form: the row of this lane's sample (8 w + n % 8) in batch j
+    if (gather) {
+        const unsigned at = (unsigned)(w * kP2Ts + (n & 7));
+        yrow = gperm ? (unsigned)gperm[at] : at;
+    }
     for (int j = 0; j < nb; ++j) {
         const unsigned tag = tag0 + (unsigned)j;
         if (j == 8) XCLOCK(0);
@@ -295,18 +331,24 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         vec4 xr[4];
         const bool pre = is_a && j + 2 < nb;
         if (pre) {
-            const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)(j + 2) * xs_stride + (size_t)(kXcdSl * w) * B * 16);
+            if (gather) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = tid + r * kXcdThreads;
-                xr[r] = i < nsl * B * 4 ? src[i] : vec4{0, 0, 0, 0};
+                for (int r = 0; r < 4; ++r) xr[r] = xrow4(j + 2, tid + r * kXcdThreads);
+            } else {
+                const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)(j + 2) * xs_stride + (size_t)(kXcdSl * w) * B * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = tid + r * kXcdThreads;
+                    xr[r] = i < nsl * B * 4 ? src[i] : vec4{0, 0, 0, 0};
+                }
             }
         }
 
         // =============================================================== sample group w: samples 8w .. 8w+7 of batch j
         {
             const int s0 = w * kP2Ts;
-            const T* Ys = ys_all + (size_t)j * ys_stride;
+            const T* Ys = gather ? reinterpret_cast<const T*>(reinterpret_cast<const char*>(ys_all) + yrow * (unsigned)C * 4u)
+                                 : ys_all + (size_t)j * ys_stride + (size_t)(s0 + (n & 7)) * C;   // this lane's sample's targets
             T fr[kP2BFrag];
             if (wave == 0) {
                 XSTAMP(0);
@@ -325,7 +367,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = Mfma16<T>::row(lane, i);
-                    frag[i * 64 + lane] = Ys[(size_t)(s0 + (n & 7)) * C + (c < C ? c : 0)];
+                    frag[i * 64 + lane] = Ys[c < C ? c : 0];
+                }
+                if (gather && more) {                                 // the next step's row of this lane's sample: its index a step ahead
+                    const unsigned at = (unsigned)((j + 1) * B + s0 + (n & 7));
+                    yrow = gperm ? (unsigned)gperm[at] : at;
                 }
             }
             __syncthreads();
@@ -484,15 +530,41 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                T gsum[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gsum[i] = acc0[i] + acc1[i];
+                if constexpr (DP) {
+                    // publish this shard's four sums, then collect the peers' of the same parameters (rank order)
+                    const unsigned seq = seq0 + (unsigned)j;
+                    u64* mine = ll_region<T>(pd.buf[pd.rank], pstride) + (size_t)(seq & 1u) * pstride * LLWords<T>::n;
+                    bool ok = true;
+                    unsigned wo = woff0;                                     // opaque: the eight peers' addresses of these words are formed
+                    asm volatile("" : "+v"(wo));                             // here, per step, instead of living in 16 registers all loop long
+                    const size_t i0 = (size_t)nd.w_off[0] + wo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (wvalid[i]) ll_store(mine, i0 + i, gsum[i], seq);
+                    {
+                        const bool gw[4] = {wvalid[0], wvalid[1], wvalid[2], wvalid[3]};
+                        ok = ll_gather_sum4(pd, pstride, i0, gw, seq, gsum, ptimeout);   // the lane's four values in one round trip
+                    }
+                    if (!ok) {
+                        s_abort = 1;
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const T wn = wcur[i] - scale * (acc0[i] + acc1[i]);
+                    const T wn = wcur[i] - scale * gsum[i];
                     wcur[i] = wvalid[i] ? wn : (T)0;
                 }
                 *reinterpret_cast<vec4*>(wsl + (usl * 16 + n) * kP2H + umt * 16 + 4 * g4) = vec4{wcur[0], wcur[1], wcur[2], wcur[3]};
                 if (wave == 1) XSTAMP(9);
             }
-            __syncthreads();
+            // (DP: a barrier that orders LDS only -- __syncthreads would also wait for the exchange's system-scope stores to reach
+            // memory, 0.8 us on the step's critical path; they finish under the next forward and are covered by its drain)
+            if constexpr (DP) xcd_barrier_lds(); else __syncthreads();
+            if (DP && s_abort) return;
             if (wave == 1) XSTAMP(10);
             // the LDS buffer of batch j is free now (every wave is past its reads): the batch after next moves in; its first reader is
             // the forward of the NEXT iteration, several barriers away
@@ -513,10 +585,24 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             }
         } else if (is_t) {
             // ---- tail tile e: e == 0 the bias column of W_0 (db_0 = sum_s delta_1); e >= 1 a 16-column tile of [W_1 | b_1]
-            if (e == 0 && tid == 0 && loss_dev) {
-                T t = 0;
-                for (int i = 0; i < NS; ++i) t += xcd_ld1(r_loss, i * 4);
-                loss_dev[j] = t * loss_scale;
+            if (e == 0 && wave == 0 && (loss_dev || DP)) {
+                // the batch's cost: the sample groups' NS (<= 32) shares, one per lane, summed by a fixed butterfly (every lane ends
+                // with the same bits); lane 0 publishes.  One load latency, not NS of them, between flagB and this tile's gradient
+                T t = lane < NS ? xcd_ld1(r_loss, lane * 4) : (T)0;
+#pragma unroll
+                for (int sh = 16; sh >= 1; sh >>= 1) t += __shfl_xor(t, sh, 64);
+                t *= loss_scale;
+                if (lane == 0) {
+                if constexpr (DP) {                                          // the global cost: every shard's share, element P of the exchange
+                    const unsigned seq = seq0 + (unsigned)j;
+                    u64* mine = ll_region<T>(pd.buf[pd.rank], pstride) + (size_t)(seq & 1u) * pstride * LLWords<T>::n;
+                    ll_store(mine, (size_t)nd.P, t, seq);
+                    T g;
+                    if (ll_gather_sum<T>(pd, pstride, (size_t)nd.P, seq, t, ptimeout, g)) t = g;
+                    else { s_abort = 1; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                }
+                if (loss_dev) loss_dev[j] = t;
+                }
             }
             const int jl = e == 0 ? 0 : 1, n0 = e == 0 ? F : (e - 1) * 16;
             const int Kin = nd.dims[jl], M = nd.dims[jl + 1];
@@ -554,12 +640,26 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             {
                 const int o = tid & 255, tcl = o >> 4, tml = o & 15, tm = mt * 16 + tml, cc = n0 + tcl;
                 if (tvalid) {
-                    tcur -= scale * sum_partials<T>(red, mt, tcl, tml);      // rcn.rs:214,221
-                    p2_frag_scatter(jl, cc, tm, H, tcur, bufs.fragimg);
+                    T gsum = sum_partials<T>(red, mt, tcl, tml);
+                    if constexpr (DP) {
+                        const unsigned seq = seq0 + (unsigned)j;
+                        u64* mine = ll_region<T>(pd.buf[pd.rank], pstride) + (size_t)(seq & 1u) * pstride * LLWords<T>::n;
+                        size_t tpo = tp;                                     // (opaque, as in the feature workers' exchange)
+                        asm volatile("" : "+v"(tpo));
+                        ll_store(mine, tpo, gsum, seq);
+                        T g;
+                        if (ll_gather_sum<T>(pd, pstride, tpo, seq, gsum, ptimeout, g)) gsum = g;
+                        else { s_abort = 1; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    }
+                    tcur -= scale * gsum;                                    // rcn.rs:214,221
+                    int tmo = tm;                                            // opaque: the image addresses are recomputed per step, not
+                    asm volatile("" : "+v"(tmo));                            // kept in two dozen register pairs across the whole loop
+                    p2_frag_scatter(jl, cc, tmo, H, tcur, bufs.fragimg);
                 }
             }
             xcd_drain();
             __syncthreads();
+            if (DP && s_abort) return;
             if (more && tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag + 1);
             if (wave == 0) XSTAMP(12);
         }
@@ -569,7 +669,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     if (is_a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (wvalid[i]) W0[woff[i]] = wcur[i];
+            if (wvalid[i]) W0[woff0 + i] = wcur[i];
     } else if (is_t && tvalid) {
         params[tp] = tcur;
     }

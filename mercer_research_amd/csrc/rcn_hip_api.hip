@@ -120,7 +120,10 @@ struct rcn_hip_ctx {
     unsigned xcd_tag = 0;                   // last step tag handed out; monotonic for the life of the buffer
     unsigned* xerr_host = nullptr;          // its sticky error word: pinned host memory the kernel writes straight into (no copy-back in the stream)
     unsigned* xerr_dev = nullptr;
-    int xcd_probe = 0;                      // 0 not probed, 1 the blocks with b % 8 == 0 share one XCD (and no other block does), -1 they do not
+    struct { const float* X = nullptr; const float* Y = nullptr; const int32_t* perm = nullptr; size_t B = 0, nb = 0; } xg;   // the last call the resident
+                                            // kernel ran in its gather form (rcn_hip_time_kernels_dev times that form over the same rows)
+    bool xcd_dp_used = false;               // the resident kernel ran data-parallel steps since dp_init: dp_finalize clears its timeout word
+    int xcd_probe = 0;                      // 0 not probed, 1 the blocks with equal b % 8 share one XCD and the eight classes sit on eight XCDs, -1 not so
     struct ResidentSet {                     // rcn_hip_load_data: one of RCN::train's two data sets, kept in HBM (rcn.rs:134-137)
         DevBuf imgs, X, Y, perm, loss;
         size_t n = 0;
@@ -753,7 +756,8 @@ int xcd_probe(rcn_hip_ctx* c) {
     c->xcd_probe = -1;
     const size_t lds = kXcdLdsFloats * sizeof(float);
     RCN_TRY(set_dyn_lds(c, k_xcd_probe, lds));
-    RCN_TRY(set_dyn_lds(c, k_xcd_epoch, lds));
+    RCN_TRY(set_dyn_lds(c, k_xcd_epoch<false>, lds));
+    RCN_TRY(set_dyn_lds(c, k_xcd_epoch<true>, lds));
     DevBuf out;
     HIP_TRY(c, out.ensure(8 * kXcdWorkers * sizeof(unsigned)));
     std::vector<unsigned> host(8 * kXcdWorkers);
@@ -765,10 +769,10 @@ int xcd_probe(rcn_hip_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(host.data(), out.p, host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         bool ok = true;
-        for (size_t b = 0; b < host.size(); ++b) {
+        for (size_t b = 0; b < host.size(); ++b) {                       // block b sits on the XCD of block b % 8, and those eight differ
             if (!(host[b] & 0x100u)) ok = false;
-            const bool worker = b % 8 == 0, same = (host[b] & 0xfu) == (host[0] & 0xfu);
-            if (worker != same) ok = false;
+            for (size_t k = 0; k < 8; ++k)
+                if ((b % 8 == k) != ((host[b] & 0xfu) == (host[k] & 0xfu))) ok = false;
         }
         good += ok ? 1 : 0;
     }
@@ -807,8 +811,23 @@ int ensure_xcd_ws(rcn_hip_ctx* c, size_t B) {
     return RCN_HIP_OK;
 }
 
-// nb consecutive steps over batches whose packed images are contiguous from xs / ys (one segment of the epoch image)
-int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, double eta, float* loss_dev) {
+// Which blocks of the 256 are the workers: blockIdx.x % 8 == xcd_select().  0 on a GPU of its own; the one-GPU test harness gives every
+// rank process its own XCD (RCN_HIP_XCD_SELECT) so that two resident kernels can be on the device at once.
+static int xcd_select() {
+    const char* e = std::getenv("RCN_HIP_XCD_SELECT");
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 0 && v < 8 ? v : 0;
+}
+
+P2PDesc p2p_desc(const rcn_hip_ctx* c);
+long long p2p_timeout_ticks_fwd();
+
+// nb consecutive steps over batches whose packed images are contiguous from xs / ys (one segment of the epoch image).
+// dp: the data-parallel step -- B is this rank's shard, the update uses the global batch length, gradients meet inside the kernel.
+// gather: xs / ys are the caller's X[rows][F] / Y[rows][C] as stored and gperm the order of their rows (NULL: stored order) -- the kernel
+// fetches every batch's rows itself, a step ahead; else they are the packed epoch image (k_pack_epoch) and gperm is unused.
+int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, double eta, float* loss_dev, bool dp = false,
+                      const int32_t* gperm = nullptr, bool gather = false) {
     const NetDesc& nd = c->nd;
     const size_t NS = B / kP2Ts, NA = (size_t)xcd_na(nd);
     XcdBufs xb;
@@ -827,17 +846,59 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
     // (the tail parameters as the sample groups' operand fragments -- xb.fragimg -- are written by the kernel's own tail tiles: at its
     // start from the parameter vector, then after every update; its pads are the zeros the buffer was created with)
     const unsigned tag0 = c->xcd_tag + 1;
-    hipLaunchKernelGGL(k_xcd_epoch, dim3(8 * kXcdWorkers), dim3(kXcdThreads), kXcdLdsFloats * sizeof(float), c->stream, nd, (float*)c->params.p, xs, ys, (int)B,
-                       (int)nb, pipe_slices(nd), (float)(eta / (double)B), (float)(1.0 / (2.0 * (double)B)), loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks);
+    const double Bg = (double)B * (dp ? (double)c->dp_world : 1.0);          // the global batch.len() of rcn.rs:214
+    const float scale = (float)(eta / Bg), loss_scale = (float)(1.0 / (2.0 * Bg));
+    const size_t lds = kXcdLdsFloats * sizeof(float);
+    if (dp) {
+        hipLaunchKernelGGL(k_xcd_epoch<true>, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,
+                           pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks + 2 * p2p_timeout_ticks_fwd(), p2p_desc(c),
+                           c->p2p.stride, c->p2p.seq + 1, p2p_timeout_ticks_fwd(), xcd_select(), (const int*)gperm, gather ? 1 : 0);
+        c->p2p.seq += (unsigned)nb;
+        c->xcd_dp_used = true;
+    } else {
+        hipLaunchKernelGGL(k_xcd_epoch<false>, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,
+                           pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks, P2PDesc{}, (size_t)0, 0u, 0LL, xcd_select(),
+                           (const int*)gperm, gather ? 1 : 0);
+    }
     HIP_TRY(c, hipGetLastError());
     c->xcd_tag += (unsigned)nb;
     return RCN_HIP_OK;
 }
 
+// The gather form of the resident kernel (rows fetched by the workers themselves) applies to f32 feature vectors whose rows are
+// whole 16-byte chunks; RCN_HIP_XCD_GATHER=0 keeps the packed epoch image (A/B measurements).
+constexpr size_t kXcdMaxStepsPerLaunch = 1u << 20;
+static bool xcd_gather(const rcn_hip_ctx* c) {
+    static const int env = [] { const char* e = std::getenv("RCN_HIP_XCD_GATHER"); return e ? std::atoi(e) : 1; }();
+    return env != 0 && c->nd.dims[0] % 4 == 0;
+}
+// The kernel addresses rows by 32-bit byte offsets from X / Y: admitted only when the allocation holding the pointer ends within 4 GB
+// of it (the rows a device-side permutation may name are not known to the host; the allocation's end bounds them).
+static bool xcd_gather_range_ok(const void* p) {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const size_t left = (size_t)((const char*)base + size - (const char*)p);
+    return left <= 0xffffffffULL;
+}
+
 // a whole call on the resident kernel: batches [j0, j0 + nb) of the call, packed segment by segment (or already packed)
 int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool from_images,
-                      bool prepacked, size_t j0, size_t pre_seg) {
+                      bool prepacked, size_t j0, size_t pre_seg, bool dp = false) {
     const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L];
+    if (!prepacked && !from_images && xcd_gather(c) && xcd_gather_range_ok(X) && xcd_gather_range_ok(Y)) {
+        c->xg.X = (const float*)X; c->xg.Y = (const float*)Y; c->xg.perm = perm; c->xg.B = B; c->xg.nb = nb;
+        // feature vectors as stored: no packed image at all -- ONE launch walks the whole call, every worker gathering its 128 bytes of
+        // each row of the batch after next while it works on the current one (the bytes k_pack_epoch would read, write and hand back)
+        for (size_t k = 0; k < nb;) {
+            const size_t n = nb - k < kXcdMaxStepsPerLaunch ? nb - k : kXcdMaxStepsPerLaunch;
+            RCN_TRY(enqueue_xcd_steps(c, (const float*)X, (const float*)Y, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr, dp,
+                                      perm ? perm + k * B : nullptr, true));
+            if (!perm) { X = (const float*)X + n * B * c->nd.dims[0]; Y = (const float*)Y + n * B * Cc; }
+            k += n;
+        }
+        return RCN_HIP_OK;
+    }
     const size_t seg = prepacked ? pre_seg : (nb <= pack_segment(c, B) ? nb : pack_segment(c, B));
     auto slot = [&](size_t j) { return ((j / seg) % 2) * seg + j % seg; };
     for (size_t j = prepacked ? j0 : 0, end = j + nb, k = 0; j < end;) {
@@ -848,7 +909,7 @@ int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
         }
         const float* xs = (const float*)c->xpack.p + slot(j) * G * B * 16;
         const float* ys = (const float*)c->ypack.p + slot(j) * B * Cc;
-        RCN_TRY(enqueue_xcd_steps(c, xs, ys, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr));
+        RCN_TRY(enqueue_xcd_steps(c, xs, ys, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr, dp));
         j += n; k += n;
     }
     return RCN_HIP_OK;                      // (the sticky error word lives in pinned host memory: current once the stream has drained)
@@ -992,6 +1053,7 @@ static long long p2p_timeout_ticks() {
     const long long t = e ? std::atoll(e) : 0;
     return t > 0 ? t : 100000000LL;
 }
+long long p2p_timeout_ticks_fwd() { return p2p_timeout_ticks(); }
 
 // one all-reduce step on the context's stream; mode 0 applies the update, mode 1 writes the raw sums to p2p.raw
 template <typename T>
@@ -2036,6 +2098,13 @@ int rcn_hip_dp_init(rcn_hip_ctx* c, const void* id_bytes, int rank, int world) {
     return RCN_HIP_OK;
 }
 
+// A peer wait that expired inside the resident kernel's data-parallel form is a property of the group just torn down (a peer that
+// left), not of this context's single-GPU resident path: reported by dp_finalize, then cleared with the group.
+static void clear_xcd_dp_timeout(rcn_hip_ctx* c) {
+    if (c->xcd_dp_used && c->xerr_host && *c->xerr_host == 1u) *c->xerr_host = 0;
+    c->xcd_dp_used = false;
+}
+
 int rcn_hip_dp_finalize(rcn_hip_ctx* c) {
     RCN_TRY(check_ctx(c));
     DevGuard g(c->device);
@@ -2045,6 +2114,7 @@ int rcn_hip_dp_finalize(rcn_hip_ctx* c) {
             const int sticky = sticky_errors(c);
             const std::string sticky_msg = c->err;
             p2p_release(c); c->dp_rank = 0; c->dp_world = 1;
+            clear_xcd_dp_timeout(c);
             if (sticky != RCN_HIP_OK) return fail(c, sticky, sticky_msg);
         }
         return RCN_HIP_OK;
@@ -2057,6 +2127,7 @@ int rcn_hip_dp_finalize(rcn_hip_ctx* c) {
     p2p_release(c);
     c->dp_rank = 0;
     c->dp_world = 1;
+    clear_xcd_dp_timeout(c);
     if (sticky != RCN_HIP_OK) return fail(c, sticky, sticky_msg);
     return RCN_HIP_OK;
 }
@@ -2119,6 +2190,40 @@ int rcn_hip_dp_p2p_admit(rcn_hip_ctx* c, int rank, int world, rcn_hip_allgather_
 
 int rcn_hip_dp_p2p_active(const rcn_hip_ctx* c) { return c && c->p2p.on ? (c->p2p.fused ? 2 : 1) : 0; }
 
+int rcn_hip_train_epoch_gathers(rcn_hip_ctx* c, size_t B) {
+    if (!c) return 0;
+    DevGuard g(c->device);
+    return use_xcd(c, B) && xcd_gather(c) ? 1 : 0;
+}
+
+int rcn_hip_dp_resident(rcn_hip_ctx* c, size_t B_shard) {
+    if (!c) return 0;
+    DevGuard g(c->device);
+    return c->p2p.on && c->p2p.fused && c->dtype == RCN_HIP_F32 && use_xcd(c, B_shard) ? 1 : 0;
+}
+
+int rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* c, size_t first_batch, size_t n_batches, double eta, void* loss_dev) {
+    RCN_TRY(check_ctx(c));
+    if (!c->comm && !c->p2p.on) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_epoch_steps: rcn_hip_dp_init was not called");
+    if (c->p2p.on && *c->p2p.err_host != 0)
+        return fail(c, RCN_HIP_ERR_HIP, "dp_epoch_steps: the peer exchange timed out in an earlier call; the replicas are no longer in step");
+    if (c->epoch_nb == 0) return fail(c, RCN_HIP_ERR_STATE, "dp_epoch_steps: no epoch begun (rcn_hip_epoch_begin_dev), or another training call has re-packed the image since");
+    if (first_batch > c->epoch_nb || n_batches > c->epoch_nb - first_batch) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_epoch_steps: batches beyond the begun epoch");
+    if (n_batches == 0) return RCN_HIP_OK;
+    RCN_TRY(need_params(c));
+    const size_t B = c->epoch_B, seg = c->epoch_seg;
+    DevGuard g(c->device);
+    if (!(c->p2p.on && c->p2p.fused && c->dtype == RCN_HIP_F32 && use_xcd(c, B)))
+        return fail(c, RCN_HIP_ERR_UNSUPPORTED, "dp_epoch_steps: only where the data-parallel step runs on the resident kernel (rcn_hip_dp_resident); "
+                                                "rcn_hip_dp_train_epoch_dev packs and runs its batches itself on every form");
+    RCN_TRY(ensure_dense_ws(c, B));
+    RCN_TRY(ensure_pipe_ws(c, B));
+    RCN_TRY(ensure_xcd_ws(c, B));
+    RCN_TRY(enqueue_xcd_epoch(c, nullptr, nullptr, nullptr, B, n_batches, eta, loss_dev, false, true, first_batch, seg, true));
+    HIP_TRY(c, hipMemcpyAsync(c->p2p.err_host, c->p2p.err_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    return RCN_HIP_OK;
+}
+
 int rcn_hip_dp_world(const rcn_hip_ctx* c) { return c ? c->dp_world : 0; }
 int rcn_hip_dp_rank(const rcn_hip_ctx* c) { return c ? c->dp_rank : -1; }
 
@@ -2153,6 +2258,17 @@ static int dp_epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int
     char* gbuf = (char*)c->grad.p;
     void* lslot = gbuf + P * es;
     const bool f64 = c->dtype == RCN_HIP_F64;
+    if (c->p2p.on && c->p2p.fused && !f64 && use_xcd(c, B)) {
+        // the resident one-XCD kernel with the exchange between its gradient MFMAs and its update (dense_xcd.hpp, DP = true): one
+        // launch per segment of the epoch image, nothing to capture
+        RCN_TRY(ensure_pipe_ws(c, B));
+        RCN_TRY(ensure_pack_ws(c, B, nb));
+        RCN_TRY(ensure_xcd_ws(c, B));
+        if (!launch) return RCN_HIP_OK;
+        RCN_TRY(enqueue_xcd_epoch(c, X, Y, perm, B, nb, eta, loss_dev, false, false, 0, 0, true));
+        HIP_TRY(c, hipMemcpyAsync(c->p2p.err_host, c->p2p.err_dev, 4, hipMemcpyDeviceToHost, c->stream));
+        return RCN_HIP_OK;
+    }
     if (c->p2p.on && c->dense_path != 1 && p2_supported(c->nd, B)) {
         // the lean pipeline with the exchange inside its third kernel (dense_p2_dp.hpp)
         RCN_TRY(ensure_pipe_ws(c, B));
@@ -2412,14 +2528,20 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
         // the resident kernel: ONE launch runs every step of the image's first segment; timed as a whole (zero step: no drift), reported
         // per step in *us_second and *us_pair (there is no first / second kernel)
         RCN_TRY(ensure_xcd_ws(c, B));
-        size_t n = (c->packed_B == B && c->packed_nb >= 2) ? c->packed_nb : 0;
+        // the form the last training call ran in: rows gathered by the kernel itself (over that call's rows), or the packed image
+        const bool tg = xcd_gather(c) && c->xg.B == B && c->xg.nb >= 2;
+        size_t n = tg ? (c->xg.nb < 64 ? c->xg.nb : 64) : ((c->packed_B == B && c->packed_nb >= 2) ? c->packed_nb : 0);
+        auto timed_launch = [&]() {
+            return tg ? enqueue_xcd_steps(c, c->xg.X, c->xg.Y, B, n, 0.0, nullptr, false, c->xg.perm, true)
+                      : enqueue_xcd_steps(c, (const float*)c->xpack.p, (const float*)c->ypack.p, B, n, 0.0, nullptr);
+        };
         if (n == 0) {
             RCN_TRY(ensure_pack_ws(c, B, 1));
             RCN_TRY(launch_pack<float>(c, x, y, nullptr, B, 0, 1, 0, 1));
             n = 1;
         }
         const size_t saved_nb = c->epoch_nb;      // timing on the image does not end a begun epoch (nothing is re-packed unless n was 0)
-        RCN_TRY(enqueue_xcd_steps(c, (const float*)c->xpack.p, (const float*)c->ypack.p, B, n, 0.0, nullptr));
+        RCN_TRY(timed_launch());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         hipEvent_t e0, e1;
         HIP_TRY(c, hipEventCreate(&e0));
@@ -2429,7 +2551,7 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
         int st = RCN_HIP_OK;
         for (int i = 0; i < launches && st == RCN_HIP_OK; ++i) {
             hipError_t e = hipEventRecord(e0, c->stream);
-            if (e == hipSuccess) st = enqueue_xcd_steps(c, (const float*)c->xpack.p, (const float*)c->ypack.p, B, n, 0.0, nullptr);
+            if (e == hipSuccess) st = timed_launch();
             if (e == hipSuccess && st == RCN_HIP_OK) e = hipEventRecord(e1, c->stream);
             if (e == hipSuccess && st == RCN_HIP_OK) e = hipEventSynchronize(e1);
             float ms = 0.f;
@@ -2440,7 +2562,7 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        if (n > 1) c->epoch_nb = saved_nb;
+        if (n > 1 && !tg) c->epoch_nb = saved_nb;
         *us_a = 0.0;
         *us_b = (double)total * 1000.0 / ((double)launches * (double)n);
         if (us_pair) *us_pair = *us_b;

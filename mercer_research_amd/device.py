@@ -203,6 +203,18 @@ class DeviceRCN:
         """0 ncclAllReduce; 1 peer exchange between kernels; 2 peer exchange inside the gradient kernel (two kernels per step)."""
         return int(self.lib.rcn_hip_dp_p2p_active(self.ctx))
 
+    def dp_epoch_steps(self, first_batch: int, n_batches: int, eta: float, loss: Optional[torch.Tensor] = None):
+        """Data-parallel steps over this rank's batches first_batch .. of the epoch epoch_begin packed here (where dp_resident)."""
+        self._ck(self.lib.rcn_hip_dp_epoch_steps_dev(self.ctx, first_batch, n_batches, float(eta), _p(loss)))
+
+    def train_epoch_gathers(self, B: int) -> bool:
+        """True when train_epoch at this batch size fetches its rows inside the resident kernel (no packed epoch image)."""
+        return bool(self.lib.rcn_hip_train_epoch_gathers(self.ctx, B))
+
+    def dp_resident(self, B_shard: int) -> bool:
+        """True when dp_train_epoch at this shard size runs on the resident one-XCD kernel with the exchange inside it."""
+        return bool(self.lib.rcn_hip_dp_resident(self.ctx, B_shard))
+
     def dp_p2p_setup(self, group=None, selftest_iters: int = 8):
         """The peer all-reduce with the handle exchange carried by torch.distributed (any backend, e.g. gloo) instead of
         RCCL: export -> all_gather -> attach -> known-answer self-test.  Collective.  Returns (mismatches, timed_out)."""

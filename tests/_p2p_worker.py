@@ -26,6 +26,9 @@ def main():
     rank, world, port, dtype, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     case_name = sys.argv[6] if len(sys.argv) > 6 else "default"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # ranks share one GPU here: were the resident one-XCD kernel chosen, every rank's workers must sit on an XCD of their own (two
+    # resident kernels cannot share compute units: each workgroup takes a whole CU's LDS).  On a node every rank has its GPU and XCD 0.
+    os.environ.setdefault("RCN_HIP_XCD_SELECT", str(rank))
     import torch
     import torch.distributed as dist
     import mercer_research_amd as amd
@@ -44,13 +47,21 @@ def main():
     if case_name == "sticky":
         mode = d.dp_p2p_admit()
         assert mode != 0, "the peer exchange was not admitted"
-        d.dp_train_epoch(X, Y, None, Bs, 1, 3.0, None)             # one healthy step on both ranks
+        resident = d.dp_resident(Bs)
+        if resident:                # no healthy step first: two resident kernels on ONE device need launch luck (see below); one does not
+            d.epoch_begin(X, Y, d.to_device(np.arange(Bs * nb, dtype=np.int32)), Bs, nb)
+        else:
+            d.dp_train_epoch(X, Y, None, Bs, 1, 3.0, None)         # one healthy step on both ranks
         d.synchronize()
         dist.barrier()
         said = {}
         if rank == 0:
+            print(f"RESIDENT {int(resident)}", flush=True)
             os.environ["RCN_HIP_DP_TIMEOUT_TICKS"] = "2000000"     # 20 ms of the 100 MHz clock, read when the next call is enqueued
-            d.dp_train_epoch(X, Y, None, Bs, 1, 3.0, None)         # rank 1 never runs this step
+            if resident:
+                d.dp_epoch_steps(0, 1, 3.0, None)                  # rank 1 never runs this step
+            else:
+                d.dp_train_epoch(X, Y, None, Bs, 1, 3.0, None)
             for name, fn in (("synchronize", d.synchronize), ("get_params", d.get_params), ("finalize", d.dp_finalize)):
                 try:
                     fn()
@@ -76,7 +87,22 @@ def main():
         bad, timed_out = d.dp_p2p_setup(selftest_iters=12)
         mode = d.dp_p2p_mode()
 
-    if mode != 0:
+    resident = int(d.dp_resident(Bs))
+    if mode != 0 and resident:
+        # Ranks that SHARE a GPU: a resident kernel holds its XCD's compute units for a whole call, so no rank may have a kernel that
+        # needs a place on every XCD (the batch gather) queued while a peer's resident kernel waits for it -- pack first, meet, then
+        # step (rcn_hip_epoch_begin_dev + rcn_hip_dp_epoch_steps_dev), and let every kernel of a call drain before the next call.
+        # With a GPU per rank none of this matters and rcn_hip_dp_train_epoch_dev does both.
+        order = d.to_device(np.arange(Bs * nb, dtype=np.int32))
+        for ep, (first, n, ls) in enumerate(((0, nb, loss), (0, 2, None), (2, nb - 2, None))):   # the second epoch in two calls
+            if first == 0:
+                d.epoch_begin(X, Y, order, Bs, nb)
+            d.synchronize()
+            dist.barrier()
+            d.dp_epoch_steps(first, n, 3.0, ls)
+            d.synchronize()
+            dist.barrier()
+    elif mode != 0:
         d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, loss)
         d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, None)           # a second call: sequence numbers carry over
     else:
@@ -97,7 +123,7 @@ def main():
                 d.apply_gradient(grad, 3.0 / (Bs * world))
     gw, gb = d.get_params()
     d.synchronize()
-    np.savez(os.path.join(outdir, f"out{rank}.npz"), bad=bad, timed_out=timed_out, active=mode, loss=loss.cpu().numpy(),
+    np.savez(os.path.join(outdir, f"out{rank}.npz"), bad=bad, timed_out=timed_out, active=mode, resident=resident, loss=loss.cpu().numpy(),
              **{f"w{i}": w for i, w in enumerate(gw)}, **{f"b{i}": b for i, b in enumerate(gb)})
     dist.barrier()                                             # nobody unmaps while a peer may still read
     d.dp_finalize()

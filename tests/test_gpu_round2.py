@@ -255,12 +255,14 @@ def _spawn_ranks(tmp_path, world, dtype, case_name, env_extra, dims=(784, 30, 10
     return Xs, Ys, logs
 
 
-def test_sticky_timeout_of_the_peer_exchange_surfaces_from_synchronize_and_get_params(amd, tmp_path):
+@pytest.mark.parametrize("xcd", ["0", "1"], ids=["two-kernel-pipeline", "resident-one-xcd-kernel"])
+def test_sticky_timeout_of_the_peer_exchange_surfaces_from_synchronize_and_get_params(amd, tmp_path, xcd):
     """a peer wait that times out in the LAST call used to go unnoticed (the word was only looked at by the next
     epoch call).  Two ranks on this GPU; rank 1 stops after one step, rank 0's second step waits (20 ms bound) for data that never
     comes: rcn_hip_synchronize, rcn_hip_get_params and rcn_hip_dp_finalize must each report it."""
-    _, _, logs = _spawn_ranks(tmp_path, 2, 0, "sticky", {})
+    _, _, logs = _spawn_ranks(tmp_path, 2, 0, "sticky", {"RCN_HIP_XCD": xcd})
     assert "STICKY synchronize=error get_params=error finalize=error" in logs[0], logs[0]
+    assert f"RESIDENT {xcd}" in logs[0], logs[0]                    # ... on the step kernel this case is about
 
 
 # (fault, the form every rank must land on).  No fault: the in-kernel exchange.  A rank that cannot export / map its peers / gets a
@@ -575,3 +577,46 @@ def test_resident_kernel_is_what_auto_selects_for_the_bench_shape_and_not_for_ot
     with pytest.raises(amd.RcnHipError):
         d3.set_dense_path(5)                                         # two hidden layers: not the shape class
     d3.rcn.close()
+
+
+def test_resident_kernel_data_parallel_form_at_world_one_is_the_single_gpu_kernel_bit_for_bit(amd, monkeypatch):
+    """The DP instantiation of the resident kernel (k_xcd_epoch<true>: publish / gather between the gradient MFMAs and the update)
+    with a group of ONE rank: the gathered sum is the rank's own partial, so parameters and per-step costs must equal the
+    single-GPU instantiation bit for bit -- every line of the exchange except the peer polls runs (bootstrap over RCCL forced on,
+    as in test_peer_allreduce_bootstrap_over_rccl_world1), several launches per call, and a second call carries the sequence on."""
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(3 * 49 * 256 * 16 * 4))
+    monkeypatch.setenv("RCN_HIP_DP_P2P", "2")
+    B, nb, N = 256, 7, 2048
+    rng = np.random.default_rng(12)
+    X = np.maximum(rng.standard_normal((N, 784)), 0.0).astype(np.float32)
+    Y = one_hot(rng.integers(0, 10, N)).astype(np.float32)
+    ws, bs = synthetic_params(BENCH_DIMS, seed=3)
+    ws = [w * 0.1 for w in ws]
+    perm = np.random.default_rng(6).permutation(N).astype(np.int32)
+    got = {}
+    for form in ("dp", "single"):
+        d = DeviceRCN(dtype=0)
+        _xcd_or_skip(d)
+        d.set_params(ws, bs)
+        Xd, Yd, permd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype), d.to_device(perm)
+        loss, loss2 = d.empty(nb), d.empty(2)
+        if form == "dp":
+            try:
+                assert d.dp_init() == (0, 1)
+            except amd.RcnHipError as e:
+                pytest.skip(f"no RCCL bootstrap on this box: {e}")
+            assert d.dp_p2p_mode() == 2 and d.dp_resident(B)
+            d.dp_train_epoch(Xd, Yd, permd, B, nb, 3.0, loss)
+            d.dp_train_epoch(Xd, Yd, None, B, 2, 3.0, loss2)
+        else:
+            d.train_epoch(Xd, Yd, permd, B, nb, 3.0, loss)
+            d.train_epoch(Xd, Yd, None, B, 2, 3.0, loss2)
+        d.synchronize()
+        got[form] = (sum(d.get_params(), []), loss.cpu().numpy().copy(), loss2.cpu().numpy().copy())
+        if form == "dp":
+            d.dp_finalize()
+        d.rcn.close()
+    for a, b in zip(got["dp"][0], got["single"][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(got["dp"][1], got["single"][1]) and np.array_equal(got["dp"][2], got["single"][2])

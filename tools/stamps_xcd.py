@@ -25,9 +25,14 @@ with torch.cuda.stream(d.stream):
     perm = torch.randperm(N, device=d.device).int()
 d.set_dense_path(5)
 d.synchronize()
+DP = os.environ.get("STAMPS_DP", "0") == "1"            # the data-parallel instantiation at a group of one (bootstrap over RCCL forced on)
+if DP:
+    d.dp_init()
+    assert d.dp_resident(B), "the data-parallel step does not run on the resident kernel here"
 for it in range(3):
-    d.train_epoch(X, Y, perm, B, 64, 3.0, None)
+    (d.dp_train_epoch if DP else d.train_epoch)(X, Y, perm, B, 64, 3.0, None)
 d.synchronize()
+print("data-parallel instantiation (world 1)" if DP else "single-GPU instantiation")
 st = np.zeros((2, 512, 16), dtype=np.uint64)
 lib.rcn_hip_debug_read_stamps(d.ctx, st.ctypes.data_as(C.c_void_p))
 r = st[0].astype(np.int64)[:32, :16]
