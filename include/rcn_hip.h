@@ -166,11 +166,11 @@ int  rcn_hip_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_
  * pass into perm_dev (each pass is rcn.rs:146-149 once). */
 int  rcn_hip_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
                                size_t B, size_t n_batches, double eta, void* loss_dev);
-/* 1 when rcn_hip_train_epoch_dev at this batch size runs on the resident one-XCD kernel in its GATHER form: no packed epoch image is
+/* (Opt-in form, RCN_HIP_XCD_GATHER=1 in the environment; measured slower than the packed image on MI355X -- csrc/rcn_hip_api.hip.)
+ * 1 when rcn_hip_train_epoch_dev at this batch size runs on the resident one-XCD kernel in its GATHER form: no packed epoch image is
  * written -- one launch walks the whole call and every worker fetches its 128 bytes of each row of the batch after next while it
  * works on the current one (csrc/dense_xcd.hpp).  The feature matrix is then read from memory exactly once per step and
- * rcn_hip_epoch_begin_dev's one-off materialisation buys nothing; 0: the call packs its batches segment by segment.  (X_dev and
- * Y_dev must each end within 4 GB of the pointer's allocation end for the form to apply; else the call packs, silently.) */
+ * rcn_hip_epoch_begin_dev's one-off materialisation buys nothing; 0: the call packs its batches segment by segment. */
 int  rcn_hip_train_epoch_gathers(rcn_hip_ctx* ctx, size_t B);
 /* End to end: the same epoch straight from the resident u8 pictures (imgs_dev [N][H][W], perm_dev indexes pictures).  Per
  * segment of the epoch ONE kernel does flatten_feature_set (rcn.rs:317-356), the standardisation with the current scale_set

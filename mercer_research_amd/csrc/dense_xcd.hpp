@@ -218,9 +218,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         const int sl = i >> 10, smp = (i >> 2) & 255, col = (kXcdSl * w + sl) * 16 + 4 * (i & 3);      // B == 256
         const unsigned at = (unsigned)(b * B + smp);
         const unsigned row = gperm ? (unsigned)gperm[at] : at;
-        // 32-bit byte offsets from a uniform base (the host admits this form only for X / Y ranges below 4 GB): one address register
-        const unsigned off = (row * (unsigned)F + (unsigned)(col < F ? col : 0)) * 4u;
-        const vec4 v = *reinterpret_cast<const vec4*>(reinterpret_cast<const char*>(xs_all) + off);
+        const vec4 v = *reinterpret_cast<const vec4*>(xs_all + (size_t)row * F + (col < F ? col : 0));
         return (sl < nsl && col < F) ? v : vec4{0, 0, 0, 0};
     };
     T* W0 = params + nd.w_off[0];
@@ -347,7 +345,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         // =============================================================== sample group w: samples 8w .. 8w+7 of batch j
         {
             const int s0 = w * kP2Ts;
-            const T* Ys = gather ? reinterpret_cast<const T*>(reinterpret_cast<const char*>(ys_all) + yrow * (unsigned)C * 4u)
+            const T* Ys = gather ? ys_all + (size_t)yrow * C
                                  : ys_all + (size_t)j * ys_stride + (size_t)(s0 + (n & 7)) * C;   // this lane's sample's targets
             T fr[kP2BFrag];
             if (wave == 0) {

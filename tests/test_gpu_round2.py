@@ -620,3 +620,54 @@ def test_resident_kernel_data_parallel_form_at_world_one_is_the_single_gpu_kerne
     for a, b in zip(got["dp"][0], got["single"][0]):
         assert np.array_equal(a, b)
     assert np.array_equal(got["dp"][1], got["single"][1]) and np.array_equal(got["dp"][2], got["single"][2])
+
+
+_GATHER_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import mercer_research_amd as amd
+from mercer_research_amd.device import DeviceRCN
+from mercer_research_amd.synth import synthetic_params
+case = np.load(sys.argv[2])
+d = DeviceRCN(dtype=0)
+try:
+    d.set_dense_path(5)
+except amd.RcnHipError:
+    np.savez(sys.argv[3], skipped=1); sys.exit(0)
+ws, bs = synthetic_params([784, 30, 10], seed=8)
+d.set_params([w * 0.1 for w in ws], bs)
+X, Y, perm = d.to_device(case["X"], d.tdtype), d.to_device(case["Y"], d.tdtype), d.to_device(case["perm"])
+B, nb = 256, int(case["nb"])
+loss, loss2 = d.empty(nb), d.empty(3)
+d.train_epoch(X, Y, perm, B, nb, 3.0, loss)          # shuffled order
+d.train_epoch(X, Y, None, B, 3, 3.0, loss2)          # stored order, continues
+d.train_epoch(X, Y, perm[B:], B, 1, 3.0, None)       # a call of one step
+d.synchronize()
+gw, gb = d.get_params()
+np.savez(sys.argv[3], skipped=0, gathers=int(d.train_epoch_gathers(B)), loss=loss.cpu().numpy(), loss2=loss2.cpu().numpy(),
+         **{f"p{i}": p for i, p in enumerate(gw + gb)})
+"""
+
+
+def test_resident_kernel_gather_form_equals_the_packed_image_bit_for_bit(amd, tmp_path):
+    """RCN_HIP_XCD_GATHER=1 (opt-in; measured slower, csrc/rcn_hip_api.hip): the resident kernel fetches every batch's rows itself --
+    no k_pack_epoch, one launch per call.  Same loads, same arithmetic: parameters and per-step costs must equal the default
+    (packed image) form bit for bit, in shuffled and stored order and for a one-step call.  The form is chosen per process
+    (environment), hence two child processes."""
+    rng = np.random.default_rng(77)
+    N, nb = 2048, 7
+    np.savez(tmp_path / "case.npz", X=np.maximum(rng.standard_normal((N, 784)), 0.0).astype(np.float32),
+             Y=one_hot(rng.integers(0, 10, N)).astype(np.float32), perm=rng.permutation(N).astype(np.int32), nb=nb)
+    outs = {}
+    for g in ("0", "1"):
+        out = tmp_path / f"out{g}.npz"
+        pr = subprocess.run([sys.executable, "-c", _GATHER_SCRIPT, ROOT, str(tmp_path / "case.npz"), str(out)],
+                            env=dict(os.environ, RCN_HIP_XCD_GATHER=g), capture_output=True, timeout=240)
+        assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+        outs[g] = np.load(out)
+        if int(outs[g]["skipped"]):
+            pytest.skip("the resident one-XCD kernel does not apply on this device")
+    assert int(outs["0"]["gathers"]) == 0 and int(outs["1"]["gathers"]) == 1
+    for k in outs["0"].files:
+        if k not in ("gathers", "skipped"):
+            assert np.array_equal(outs["0"][k], outs["1"][k]), k
