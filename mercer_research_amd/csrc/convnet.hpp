@@ -99,7 +99,7 @@ __device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape&
 // EPI: 0 = raw, 1 = + bias, 2 = + bias, ReLU, 3 = raw gated by (G > 0) where `bias` points at a tensor G shaped like Y (the
 // input-gradient pass writes dZ of the layer below directly: G = that layer's post-ReLU output)
 template <int KS, bool SMALLC, int BN, int EPI>
-__global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__ X, const float* __restrict__ Wk,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_conv_fwd(const float* __restrict__ X, const float* __restrict__ Wk,
                                                        const float* __restrict__ bias, float* __restrict__ Y, ConvShape s) {
     constexpr int kLdB = BN + 1, NT = BN / 32;
     __shared__ float As[2][kBM * kLdA];
@@ -121,44 +121,36 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    f32x4 av[4];
-    f32x4 bv[BN / 32];                                   // B tile: 32 x BN floats = 8*BN float4 / 256 threads
-    auto load_b = [&](int kt) {
+    // Two register stages: the global loads of K-tile kt + 2 are issued before tile kt is contracted and waited for only when tile
+    // kt + 1 has been contracted too -- two tiles of MFMA work (4096 cycles per wave at BN = 64) under every load instead of one.
+    // (PMC, CIFAR shape, one stage: SQ_WAIT_INST_ANY 48 % of the wave cycles, SQ_WAIT_INST_LDS 2 %: the waves sat on vmcnt.)
+    f32x4 av[2][4];
+    f32x4 bv[2][BN / 32];                                // B tile: 32 x BN floats = 8*BN float4 / 256 threads
+    auto load_b = [&](int kt, f32x4 (&b)[BN / 32]) {
 #pragma unroll
         for (int q = 0; q < BN / 32; ++q) {
             const int e = tid + kThreads * q;            // float4 index in the 32 x (BN/4) tile
             const int kr = e / (BN / 4), c4 = (e - kr * (BN / 4)) * 4;
             const int k = kt * kBK + kr;
-            bv[q] = (k < K) ? *reinterpret_cast<const f32x4*>(Wk + (long long)k * s.Cout + n0 + c4) : f32x4{0, 0, 0, 0};
+            b[q] = (k < K) ? *reinterpret_cast<const f32x4*>(Wk + (long long)k * s.Cout + n0 + c4) : f32x4{0, 0, 0, 0};
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const f32x4 (&a)[4], const f32x4 (&b)[BN / 32]) {
         const int c4 = (tid & 7) * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float* d = &As[buf][((tid >> 3) + 32 * q) * kLdA + c4];
-            d[0] = av[q][0]; d[1] = av[q][1]; d[2] = av[q][2]; d[3] = av[q][3];
+            d[0] = a[q][0]; d[1] = a[q][1]; d[2] = a[q][2]; d[3] = a[q][3];
         }
 #pragma unroll
         for (int q = 0; q < BN / 32; ++q) {
             const int e = tid + kThreads * q;
             const int kr = e / (BN / 4), c4b = (e - kr * (BN / 4)) * 4;
             float* d = &Bs[buf][kr * kLdB + c4b];
-            d[0] = bv[q][0]; d[1] = bv[q][1]; d[2] = bv[q][2]; d[3] = bv[q][3];
+            d[0] = b[q][0]; d[1] = b[q][1]; d[2] = b[q][2]; d[3] = b[q][3];
         }
     };
-
-    const ARows rows = decode_rows(s, M, m0, tid);
-    load_a_regs<KS, SMALLC>(X, s, rows, kt0, tid, av);
-    load_b(kt0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) {                              // next tile's global loads fly while this tile computes
-            load_a_regs<KS, SMALLC>(X, s, rows, kt0 + kt + 1, tid, av);
-            load_b(kt0 + kt + 1);
-        }
+    auto contract = [&](int cur) {
         const float* a = &As[cur][(wave * 32 + (lane & 31)) * kLdA + (lane >> 5)];
         const float* b = &Bs[cur][(lane >> 5) * kLdB + (lane & 31)];
 #pragma unroll
@@ -167,9 +159,36 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd(const float* __restrict__
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, b[2 * ks * kLdB + 32 * t], acc[t], 0, 0, 0);
         }
+    };
+
+    const ARows rows = decode_rows(s, M, m0, tid);
+    load_a_regs<KS, SMALLC>(X, s, rows, kt0, tid, av[0]);
+    load_b(kt0, bv[0]);
+    if (nkt > 1) {
+        load_a_regs<KS, SMALLC>(X, s, rows, kt0 + 1, tid, av[1]);
+        load_b(kt0 + 1, bv[1]);
+    }
+    store_tiles(0, av[0], bv[0]);
+    __syncthreads();
+    // tile kt sits in LDS buffer kt & 1 and came through register stage kt & 1: that stage is free for tile kt + 2
+    for (int kt = 0; kt < nkt; kt += 2) {
+        if (kt + 2 < nkt) {
+            load_a_regs<KS, SMALLC>(X, s, rows, kt0 + kt + 2, tid, av[0]);
+            load_b(kt0 + kt + 2, bv[0]);
+        }
+        contract(0);
         if (kt + 1 < nkt) {
-            store_tiles(cur ^ 1);
+            store_tiles(1, av[1], bv[1]);
             __syncthreads();
+            if (kt + 3 < nkt) {
+                load_a_regs<KS, SMALLC>(X, s, rows, kt0 + kt + 3, tid, av[1]);
+                load_b(kt0 + kt + 3, bv[1]);
+            }
+            contract(1);
+            if (kt + 2 < nkt) {
+                store_tiles(0, av[0], bv[0]);
+                __syncthreads();
+            }
         }
     }
     // epilogue: lane holds column co = n0 + 32 t + (lane & 31), 16 rows
