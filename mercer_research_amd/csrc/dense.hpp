@@ -325,6 +325,22 @@ __device__ inline void p2_frag_scatter(int jl, int cc, int m, int H, float v, fl
 }
 __device__ inline void p2_frag_scatter(int, int, int, int, double, double*) {}    // the f64 context builds its fragments in the kernel
 
+// Two hidden layers (the reference's own test net 784-10-10-10, rcn.rs:558,577; resident kernel only): the image grows by the
+// third dense layer's parameters -- words 28..31 W_2 as A[m = c][k = h2], 32..35 W_2^T as A[m = h2][k = c], 36..39 b_2 per
+// accumulator element -- and layer 1 of p2_frag_scatter is then the 32 -> 16 layer in the middle (its "classes" are the h2 units).
+constexpr int kP3BFrag = 40;
+__device__ inline void p3_frag_scatter(int cc, int m, int H2, float v, float* __restrict__ img) {
+    if (cc < H2) {
+        const int h2 = cc, c = m;
+        img[(28 + (h2 >> 2)) * 64 + (h2 & 3) * 16 + c] = v;
+        img[(32 + (c >> 2)) * 64 + (c & 3) * 16 + h2] = v;
+    } else {
+        const int c = m;                                                          // b_2[c]
+#pragma unroll
+        for (int nn = 0; nn < 16; ++nn) img[(36 + (c & 3)) * 64 + (c >> 2) * 16 + nn] = v;
+    }
+}
+
 // One 16-column tile (columns n0..n0+15) of [W_j | b_j]: dW = Delta_{j+1} . [A_j | 1]^T summed over the whole batch
 // (the MFMA contraction index is the sample), then either the SGD update or the raw gradient.
 template <typename T, bool APPLY>

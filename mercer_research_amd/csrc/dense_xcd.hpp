@@ -50,7 +50,9 @@ struct XcdBufs {
     float* a1;
     float* d2;
     float* loss;
-    float* fragimg;    // [28][64]           tail parameters as the sample groups' MFMA operand fragments
+    float* a2;         // [B][16]            two hidden layers only: a_2 and delta_3 (then d2 holds delta_2 of the middle layer)
+    float* d3;
+    float* fragimg;    // [28 | 40][64]      tail parameters as the sample groups' MFMA operand fragments
     unsigned* flagA;   // [32 x stride]      step tag of the newest complete slab part of feature worker w
     unsigned* flagB;   // [32 x stride]      step tag of the newest complete outputs of sample group w
     unsigned* flagT;   // [8 x stride]       step tag for which tail tile e's share of the fragment image is current
@@ -58,12 +60,16 @@ struct XcdBufs {
 };
 
 inline int xcd_na(const NetDesc& nd) { return (pipe_slices(nd) + kXcdSl - 1) / kXcdSl; }
+// one hidden layer (<= 32 units, <= 16 classes: the shape class of the two-kernel pipeline), or two (<= 32, <= 16 units, <= 16 classes)
+inline bool xcd_two_hidden(const NetDesc& nd) {
+    return nd.L == 3 && nd.dims[1] <= kP2H && nd.dims[2] <= kP2C && nd.dims[3] <= kP2C && pipe_slices(nd) <= kP2MaxSlices;
+}
 inline bool xcd_supported(const NetDesc& nd, size_t B) {
-    return p2_supported(nd, B) && B == 256 && xcd_na(nd) + pipe_extra_wgs(nd) <= kXcdWorkers && pipe_extra_wgs(nd) <= 8;
+    return (p2_supported(nd, B) || xcd_two_hidden(nd)) && B == 256 && xcd_na(nd) + pipe_extra_wgs(nd) <= kXcdWorkers && pipe_extra_wgs(nd) <= 8;
 }
 inline size_t xcd_buf_bytes(const NetDesc& nd, size_t B) {
     const size_t NS = B / kP2Ts, NA = (size_t)xcd_na(nd);
-    return (NS * NA * kP2Ts * kP2H + 2 * B * kP2H + B * kP2C + NS + (size_t)kP2BFrag * 64) * sizeof(float) +
+    return (NS * NA * kP2Ts * kP2H + 2 * B * kP2H + 3 * B * kP2C + NS + (size_t)kP3BFrag * 64) * sizeof(float) +
            (size_t)(3 * kXcdWorkers + 8) * kXcdFlagStride * sizeof(unsigned) + 512;
 }
 // LDS (floats): two batch buffers of a slice pair, delta_1 of the whole batch (rows padded to 48: conflict-free MFMA operand reads),
@@ -72,7 +78,7 @@ inline size_t xcd_buf_bytes(const NetDesc& nd, size_t B) {
 constexpr size_t kXcdXs = (size_t)kXcdSl * 256 * 16;
 constexpr int kXcdD1Ld = 48;
 constexpr size_t kXcdLdsFloats = 2 * kXcdXs + (size_t)256 * kXcdD1Ld + (size_t)kDenseWaves * kMtp * kRedTile + (size_t)kXcdSl * kMtp * 256 +
-                                 (size_t)kXcdSl * 16 * kP2H + (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + kP2C * kLd + 4 * 64 + 64;
+                                 (size_t)kXcdSl * 16 * kP2H + (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + 3 * kP2C * kLd + 4 * 64 + 64;
 
 // diagnostic build only (-DRCN_STAMPS, tools/stamps_xcd.py): where each worker is at each point of the launch's last-but-one step
 #ifdef RCN_STAMPS
@@ -137,7 +143,10 @@ __device__ inline bool xcd_wait(const unsigned* f0, int n0, const unsigned* f1, 
 // runs between the two-kernel pipeline's halves); sums are in rank order, so every rank applies the bit-identical update with the
 // GLOBAL batch length (`scale` = eta / (B * world)).  The cost travels the same way as element P.  xsel: which blocks are the
 // workers (blockIdx.x % 8 == xsel) -- 0 on a GPU of its own; the one-GPU test harness gives each rank another XCD.
-template <bool DP>
+// L3 = true: two hidden layers (dims F, H <= 32, H2 <= 16, C <= 16 -- the reference's own test net 784-10-10-10): the sample group
+// runs one more 16 x 16 layer forward and backward (a_2, delta_3 through LDS; fragment words 28..39), the tail tiles cover
+// [W_2 | b_2] as well (from a_2 / delta_3); everything about the big first layer is unchanged.
+template <bool DP, bool L3 = false>
 __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     NetDesc nd, float* __restrict__ params, const float* __restrict__ xs_all, const float* __restrict__ ys_all, int B, int nb, int G, float scale,
     float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, P2PDesc pd,
@@ -160,9 +169,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     T* a1s = reinterpret_cast<T*>(zred) + kP2BWaves * 64 * 4;       // a_1 tile  [hidden 32][kLd]
     T* d2s = a1s + kP2H * kLd;                                      // delta_2   [class 16][kLd]
     T* frag = d2s + kP2C * kLd;                                     // [4][lane]: the targets per accumulator element
+    T* a2s = frag + 4 * 64;                                         // two hidden layers: a_2 [h2 16][kLd], delta_3 [class 16][kLd]
+    T* d3s = a2s + kP2C * kLd;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
-    const int F = nd.dims[0], H = nd.dims[1], C = nd.dims[2];
+    const int F = nd.dims[0], H = nd.dims[1], Cm = nd.dims[2], C = nd.dims[L3 ? 3 : 2];     // Cm: the units after W_1 (the classes, or h2)
     const int NS = B / kP2Ts;                                       // 32 sample groups
     const int NA = (G + kXcdSl - 1) / kXcdSl, NT = 1 + nd.tile_start[nd.L] - nd.tile_start[1];    // = pipe_extra_wgs(nd)
     const bool is_a = w < NA, is_t = w >= NA && w < NA + NT;
@@ -172,7 +183,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     const auto r_slab = XCD_RSRC(bufs.slab, (size_t)NS * NA * kP2Ts * kP2H * 4);
     const auto r_d1 = XCD_RSRC(bufs.d1, (size_t)B * kP2H * 4), r_a1 = XCD_RSRC(bufs.a1, (size_t)B * kP2H * 4);
     const auto r_d2 = XCD_RSRC(bufs.d2, (size_t)B * kP2C * 4), r_loss = XCD_RSRC(bufs.loss, (size_t)NS * 4);
-    const auto r_img = XCD_RSRC(bufs.fragimg, (size_t)kP2BFrag * 64 * 4);
+    const auto r_img = XCD_RSRC(bufs.fragimg, (size_t)(L3 ? kP3BFrag : kP2BFrag) * 64 * 4);
+    const auto r_a2 = XCD_RSRC(bufs.a2, (size_t)B * kP2C * 4), r_d3 = XCD_RSRC(bufs.d3, (size_t)B * kP2C * 4);
 
     if (tid == 0) s_abort = 0;
     __syncthreads();
@@ -257,8 +269,16 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     T tcur = 0;
     size_t tp = 0;
     bool tvalid = false;
+    // tail tile e -> (layer jl, first column n0 of [W_jl | b_jl]): e == 0 the bias column of W_0, then the tiles of layer 1, then of layer 2
+    const int nt1 = nd.tile_start[2] - nd.tile_start[1];            // 16-column tiles of [W_1 | b_1]
+    auto tile_of = [&](int& jl, int& n0) {
+        if (e == 0) { jl = 0; n0 = F; }
+        else if (!L3 || e - 1 < nt1) { jl = 1; n0 = (e - 1) * 16; }
+        else { jl = 2; n0 = (e - 1 - nt1) * 16; }
+    };
     if (is_t) {
-        const int jl = e == 0 ? 0 : 1, n0 = e == 0 ? F : (e - 1) * 16;
+        int jl, n0;
+        tile_of(jl, n0);
         const int Kin = nd.dims[jl], M = nd.dims[jl + 1];
         const int o = tid & 255, tm = mt * 16 + (o & 15), cc = n0 + (o >> 4);
         tvalid = tm < M && cc <= Kin;
@@ -306,9 +326,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     } else if (is_t) {
         // this tile's share of the operand-fragment image, from the parameter vector (the image's pads are the zeros it was created with)
         if (tvalid) {
-            const int jl = e == 0 ? 0 : 1, n0 = e == 0 ? F : (e - 1) * 16;
+            int jl, n0;
+            tile_of(jl, n0);
             const int o = tid & 255;
-            p2_frag_scatter(jl, n0 + (o >> 4), mt * 16 + (o & 15), H, tcur, bufs.fragimg);
+            if (L3 && jl == 2) p3_frag_scatter(n0 + (o >> 4), mt * 16 + (o & 15), Cm, tcur, bufs.fragimg);
+            else p2_frag_scatter(jl, n0 + (o >> 4), mt * 16 + (o & 15), H, tcur, bufs.fragimg);
         }
         xcd_drain();
         __syncthreads();
@@ -347,14 +369,14 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             const int s0 = w * kP2Ts;
             const T* Ys = gather ? ys_all + (size_t)yrow * C
                                  : ys_all + (size_t)j * ys_stride + (size_t)(s0 + (n & 7)) * C;   // this lane's sample's targets
-            T fr[kP2BFrag];
+            T fr[L3 ? kP3BFrag : kP2BFrag];
             if (wave == 0) {
                 XSTAMP(0);
                 // the tail tiles finish well before the feature workers: their flags first, the 24 parameter words of the image
                 // fetched under the wait for the slab
                 bool ok = xcd_wait(bufs.flagT, NT, nullptr, 0, tag, timeout, err);
 #pragma unroll
-                for (int q = 0; q < kP2BFrag; ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1(r_img, (q * 64 + lane) * 4);
+                for (int q = 0; q < (L3 ? kP3BFrag : kP2BFrag); ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1(r_img, (q * 64 + lane) * 4);
                 ok = ok && xcd_wait(bufs.flagA, NA, nullptr, 0, tag, timeout, err);
                 if (!ok && lane == 0) {
                     s_abort = 1;
@@ -429,15 +451,64 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 }
                 T lsum = 0;
                 acc_t dv;
+                if constexpr (!L3) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = Mfma16<T>::row(lane, i);
-                    const T a2 = sigmoid_fast(acc[i] + fr[16 + i]);
-                    const T diff = a2 - fr[20 + i];
-                    const bool ok = c < C && n < kP2Ts;
-                    dv[i] = ok ? diff * (a2 * ((T)1 - a2)) : (T)0;
-                    lsum += ok ? diff * diff : (T)0;
-                    d2s[c * kLd + n] = dv[i];
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = Mfma16<T>::row(lane, i);
+                        const T a2 = sigmoid_fast(acc[i] + fr[16 + i]);
+                        const T diff = a2 - fr[20 + i];
+                        const bool ok = c < C && n < kP2Ts;
+                        dv[i] = ok ? diff * (a2 * ((T)1 - a2)) : (T)0;
+                        lsum += ok ? diff * diff : (T)0;
+                        d2s[c * kLd + n] = dv[i];
+                    }
+                } else {
+                    // a_2 = sigmoid(z_2 + b_1): element i of the accumulator is unit h2 = 4 g4 + i of sample n                 rcn.rs:287-289
+                    acc_t a2r;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int h2 = Mfma16<T>::row(lane, i);
+                        const T a = sigmoid_fast(acc[i] + fr[16 + i]);
+                        a2r[i] = (h2 < Cm && n < kP2Ts) ? a : (T)0;
+                        a2s[h2 * kLd + n] = a2r[i];
+                    }
+                    if (n < kP2Ts) store4<T>(bufs.a2 + (size_t)(s0 + n) * kP2C, lane, a2r);
+                    // z_3 = W_2 a_2 + b_2, a_3 = sigmoid, delta_3 = (a_3 - y) (*) a_3 (1 - a_3)                               rcn.rs:287-289, 299
+                    acc_t acc3 = acc_t{0, 0, 0, 0};
+                    {
+                        T bv[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) bv[ks] = a2s[(4 * ks + g4) * kLd + (n & 7)];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) acc3 = Mfma16<T>::mfma(fr[28 + ks], n < kP2Ts ? bv[ks] : (T)0, acc3);
+                    }
+                    acc_t d3v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = Mfma16<T>::row(lane, i);
+                        const T a3 = sigmoid_fast(acc3[i] + fr[36 + i]);
+                        const T diff = a3 - fr[20 + i];
+                        const bool ok = c < C && n < kP2Ts;
+                        d3v[i] = ok ? diff * (a3 * ((T)1 - a3)) : (T)0;
+                        lsum += ok ? diff * diff : (T)0;
+                        d3s[c * kLd + n] = d3v[i];
+                    }
+                    if (n < kP2Ts) store4<T>(bufs.d3 + (size_t)(s0 + n) * kP2C, lane, d3v);
+                    // delta_2 = (W_2^T delta_3) (*) a_2 (1 - a_2)                                                              rcn.rs:305-309
+                    acc_t ad2 = acc_t{0, 0, 0, 0};
+                    {
+                        T dvv[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) dvv[ks] = d3s[(4 * ks + g4) * kLd + n];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) ad2 = Mfma16<T>::mfma(fr[32 + ks], dvv[ks], ad2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int h2 = Mfma16<T>::row(lane, i);
+                        dv[i] = ad2[i] * (a2r[i] * ((T)1 - a2r[i]));                 // a2r is zero outside the live units / samples
+                        d2s[h2 * kLd + n] = dv[i];
+                    }
                 }
                 if (n < kP2Ts) store4<T>(bufs.d2 + (size_t)(s0 + n) * kP2C, lane, dv);
                 // delta_1 = (W_1^T delta_2) (*) a_1 (1 - a_1)                                                          rcn.rs:305-309
@@ -602,12 +673,13 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 if (loss_dev) loss_dev[j] = t;
                 }
             }
-            const int jl = e == 0 ? 0 : 1, n0 = e == 0 ? F : (e - 1) * 16;
+            int jl, n0;
+            tile_of(jl, n0);
             const int Kin = nd.dims[jl], M = nd.dims[jl + 1];
             const int c = n0 + n;                                          // this lane's column of [W | b]
-            const auto r_act = e == 0 ? r_d1 : r_a1;                       // A_prev: unused for the bias-only tile (every column >= Kin)
-            const auto r_del = e == 0 ? r_d1 : r_d2;
-            const int ldD = e == 0 ? kP2H : kP2C, ldA = kP2H;
+            const auto r_act = e == 0 ? r_d1 : ((L3 && jl == 2) ? r_a2 : r_a1);    // A_prev: unused for the bias-only tile (every column >= Kin)
+            const auto r_del = e == 0 ? r_d1 : ((L3 && jl == 2) ? r_d3 : r_d2);
+            const int ldD = e == 0 ? kP2H : kP2C, ldA = (L3 && jl == 2) ? kP2C : kP2H;
             acc_t acc[kMtp];
 #pragma unroll
             for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
@@ -652,7 +724,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     tcur -= scale * gsum;                                    // rcn.rs:214,221
                     int tmo = tm;                                            // opaque: the image addresses are recomputed per step, not
                     asm volatile("" : "+v"(tmo));                            // kept in two dozen register pairs across the whole loop
-                    p2_frag_scatter(jl, cc, tmo, H, tcur, bufs.fragimg);
+                    if (L3 && jl == 2) p3_frag_scatter(cc, tmo, Cm, tcur, bufs.fragimg);
+                    else p2_frag_scatter(jl, cc, tmo, H, tcur, bufs.fragimg);
                 }
             }
             xcd_drain();

@@ -758,6 +758,7 @@ int xcd_probe(rcn_hip_ctx* c) {
     RCN_TRY(set_dyn_lds(c, k_xcd_probe, lds));
     RCN_TRY(set_dyn_lds(c, k_xcd_epoch<false>, lds));
     RCN_TRY(set_dyn_lds(c, k_xcd_epoch<true>, lds));
+    RCN_TRY(set_dyn_lds(c, (k_xcd_epoch<false, true>), lds));
     DevBuf out;
     HIP_TRY(c, out.ensure(8 * kXcdWorkers * sizeof(unsigned)));
     std::vector<unsigned> host(8 * kXcdWorkers);
@@ -836,8 +837,10 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
     xb.d1 = f;   f += B * kP2H;
     xb.a1 = f;   f += B * kP2H;
     xb.d2 = f;   f += B * kP2C;
+    xb.a2 = f;   f += B * kP2C;
+    xb.d3 = f;   f += B * kP2C;
     xb.loss = f; f += NS;
-    xb.fragimg = f; f += (size_t)kP2BFrag * 64;
+    xb.fragimg = f; f += (size_t)kP3BFrag * 64;
     unsigned* u = (unsigned*)(((uintptr_t)f + 127) & ~(uintptr_t)127);
     xb.flagA = u; u += kXcdWorkers * kXcdFlagStride;
     xb.flagB = u; u += kXcdWorkers * kXcdFlagStride;
@@ -855,6 +858,10 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
                            c->p2p.stride, c->p2p.seq + 1, p2p_timeout_ticks_fwd(), xcd_select(), (const int*)gperm, gather ? 1 : 0);
         c->p2p.seq += (unsigned)nb;
         c->xcd_dp_used = true;
+    } else if (nd.L == 3) {
+        hipLaunchKernelGGL((k_xcd_epoch<false, true>), dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,
+                           pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks, P2PDesc{}, (size_t)0, 0u, 0LL, xcd_select(),
+                           (const int*)gperm, gather ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_xcd_epoch<false>, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,
                            pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks, P2PDesc{}, (size_t)0, 0u, 0LL, xcd_select(),
@@ -1318,7 +1325,7 @@ int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
     DevGuard g(c->device);
     if (mode == 5) {
         if (c->dtype != RCN_HIP_F32 || !xcd_supported(c->nd, 256))
-            return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path(5): the resident one-XCD kernel covers the f32 context, one hidden layer <= 32, classes <= 16, "
+            return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path(5): the resident one-XCD kernel covers the f32 context, one hidden layer <= 32 (or two: <= 32, <= 16), classes <= 16, "
                                                       "at most 29 feature-slice pairs, batch 256");
         RCN_TRY(xcd_probe(c));
         if (c->xcd_probe != 1)
@@ -2193,7 +2200,7 @@ int rcn_hip_train_epoch_gathers(rcn_hip_ctx* c, size_t B) {
 int rcn_hip_dp_resident(rcn_hip_ctx* c, size_t B_shard) {
     if (!c) return 0;
     DevGuard g(c->device);
-    return c->p2p.on && c->p2p.fused && c->dtype == RCN_HIP_F32 && use_xcd(c, B_shard) ? 1 : 0;
+    return c->p2p.on && c->p2p.fused && c->dtype == RCN_HIP_F32 && c->nd.L == 2 && use_xcd(c, B_shard) ? 1 : 0;
 }
 
 int rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* c, size_t first_batch, size_t n_batches, double eta, void* loss_dev) {
@@ -2207,7 +2214,7 @@ int rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* c, size_t first_batch, size_t n_batc
     RCN_TRY(need_params(c));
     const size_t B = c->epoch_B, seg = c->epoch_seg;
     DevGuard g(c->device);
-    if (!(c->p2p.on && c->p2p.fused && c->dtype == RCN_HIP_F32 && use_xcd(c, B)))
+    if (!(c->p2p.on && c->p2p.fused && c->dtype == RCN_HIP_F32 && c->nd.L == 2 && use_xcd(c, B)))
         return fail(c, RCN_HIP_ERR_UNSUPPORTED, "dp_epoch_steps: only where the data-parallel step runs on the resident kernel (rcn_hip_dp_resident); "
                                                 "rcn_hip_dp_train_epoch_dev packs and runs its batches itself on every form");
     RCN_TRY(ensure_dense_ws(c, B));
@@ -2252,7 +2259,7 @@ static int dp_epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int
     char* gbuf = (char*)c->grad.p;
     void* lslot = gbuf + P * es;
     const bool f64 = c->dtype == RCN_HIP_F64;
-    if (c->p2p.on && c->p2p.fused && !f64 && use_xcd(c, B)) {
+    if (c->p2p.on && c->p2p.fused && !f64 && c->nd.L == 2 && use_xcd(c, B)) {
         // the resident one-XCD kernel with the exchange between its gradient MFMAs and its update (dense_xcd.hpp, DP = true): one
         // launch per segment of the epoch image, nothing to capture
         RCN_TRY(ensure_pipe_ws(c, B));

@@ -574,9 +574,13 @@ def test_resident_kernel_is_what_auto_selects_for_the_bench_shape_and_not_for_ot
         d64.set_dense_path(5)                                        # f64 context: two-kernel pipeline only
     d64.rcn.close()
     d3 = DeviceRCN(dtype=0, feedforward_cfg=[10, 10])
-    with pytest.raises(amd.RcnHipError):
-        d3.set_dense_path(5)                                         # two hidden layers: not the shape class
+    d3.set_dense_path(5)                                             # two hidden layers <= 32, <= 16: the kernel's second instantiation
     d3.rcn.close()
+    for cfg in ([10, 10, 10], [40], [30, 20]):                       # three hidden layers; hidden > 32; second hidden > 16
+        dn = DeviceRCN(dtype=0, feedforward_cfg=cfg)
+        with pytest.raises(amd.RcnHipError):
+            dn.set_dense_path(5)
+        dn.rcn.close()
 
 
 def test_resident_kernel_data_parallel_form_at_world_one_is_the_single_gpu_kernel_bit_for_bit(amd, monkeypatch):
@@ -671,3 +675,81 @@ def test_resident_kernel_gather_form_equals_the_packed_image_bit_for_bit(amd, tm
     for k in outs["0"].files:
         if k not in ("gathers", "skipped"):
             assert np.array_equal(outs["0"][k], outs["1"][k]), k
+
+
+@pytest.mark.parametrize("hidden", [[10, 10], [30, 12], [32, 16], [7, 3]], ids=["reference-test-net-784-10-10-10", "784-30-12-10", "784-32-16-10", "784-7-3-10"])
+def test_resident_kernel_with_two_hidden_layers_is_the_reference_loop(amd, oracle, monkeypatch, hidden):
+    """k_xcd_epoch<false, true> (csrc/dense_xcd.hpp): the resident kernel for TWO hidden layers -- the reference's own test net is
+    784-10-10-10 (rcn.rs:558,577).  The sample group runs one more small layer forward and backward, the tail tiles cover [W_2 | b_2];
+    against the oracle's sequential train_batch (f32 tolerances of the resident kernel) and against the generic two-kernel pipeline:
+    shuffled and stored order, several launches per call, a call of one step, per-step costs."""
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(3 * 49 * 256 * 16 * 4))
+    dims = [784] + hidden + [10]
+    B, nb, N = 256, 7, 2048
+    rng = np.random.default_rng(21)
+    X = np.maximum(rng.standard_normal((N, 784)), 0.0).astype(np.float32)
+    labels = rng.integers(0, 10, N)
+    Y = one_hot(labels).astype(np.float32)
+    ws, bs = synthetic_params(dims, seed=33)
+    ws = [w * 0.1 for w in ws]
+    perm = np.random.default_rng(9).permutation(N).astype(np.int32)
+    got = {}
+    for path in (5, 2):
+        d = DeviceRCN(dtype=0, feedforward_cfg=hidden)
+        if path == 5:
+            _xcd_or_skip(d)
+        else:
+            d.set_dense_path(2)
+        d.set_params(ws, bs)
+        Xd, Yd, permd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype), d.to_device(perm)
+        loss, loss1 = d.empty(nb), d.empty(1)
+        d.train_epoch(Xd, Yd, permd, B, nb, 3.0, loss)               # 3 + 3 + 1 steps: three launches
+        d.train_epoch(Xd, Yd, None, B, 2, 3.0, None)                 # stored order, continues
+        d.train_epoch(Xd, Yd, permd[5 * B:], B, 1, 3.0, loss1)       # a call of one step
+        d.synchronize()
+        got[path] = (sum(d.get_params(), []), loss.cpu().numpy().copy(), float(loss1.cpu().numpy()[0]))
+        d.rcn.close()
+    Xh, Yh = X.astype(np.float64), Y.astype(np.float64)
+    rw, rb, c1 = ws, bs, []
+    for j in range(nb):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, Xh[sel], Yh[sel], 3.0)
+        c1.append(c)
+    for j in range(2):
+        rw, rb, _ = oracle.train_batch(rw, rb, Xh[j * B:(j + 1) * B], Yh[j * B:(j + 1) * B], 3.0)
+    sel = perm[5 * B:6 * B]
+    rw, rb, c3 = oracle.train_batch(rw, rb, Xh[sel], Yh[sel], 3.0)
+    for path in (5, 2):
+        np.testing.assert_allclose(got[path][1], c1, rtol=1e-3)
+        assert abs(got[path][2] - c3) <= 2e-3 * c3
+        for a, b in zip(got[path][0], rw + rb):
+            assert np.all(np.abs(a - b) <= 5e-4 * np.abs(b) + 5e-5), path   # 10 chained f32 steps
+    for a, b in zip(got[5][0], got[2][0]):
+        assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)
+
+
+def test_resident_kernel_is_what_auto_selects_for_the_reference_test_net(amd):
+    """784-10-10-10 at B = 256 in the f32 context lands on the resident kernel by default (rcn_hip_time_kernels_dev reports no
+    first / second kernel), and the step is faster than the generic two-kernel pipeline it replaces there."""
+    from mercer_research_amd.device import DeviceRCN
+    import torch
+    res = {}
+    for path in (0, 2):
+        d = DeviceRCN(dtype=0, feedforward_cfg=[10, 10])
+        ws, bs = synthetic_params([784, 10, 10, 10], seed=5)
+        d.set_params(ws, bs)
+        if path:
+            d.set_dense_path(path)
+        with torch.cuda.stream(d.stream):
+            X = torch.rand(4096, 784, device=d.device)
+            Y = torch.zeros(4096, 10, device=d.device); Y[:, 1] = 1
+        d.synchronize()
+        for _ in range(2):
+            d.train_epoch(X, Y, None, 256, 16, 3.0, None)
+        d.synchronize()
+        res[path] = d.time_kernels(X[:256], Y[:256], reps=128)
+        d.rcn.close()
+    if res[0][0] != 0.0:
+        pytest.skip("the resident one-XCD kernel does not apply on this device")
+    assert res[0][2] < res[2][2], res

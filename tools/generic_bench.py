@@ -15,7 +15,7 @@ with torch.cuda.stream(d.stream):
     Y = torch.zeros(N, 10, device=d.device); Y[:, 3] = 1
     perm = torch.randperm(N, device=d.device).int()
 res = {}
-for path in (2, 1):
+for path in (0, 2, 1):
     d.set_dense_path(path)
     for _ in range(3):
         d.train_epoch(X, Y, perm, B, 64, 3.0, None)
@@ -28,5 +28,5 @@ for path in (2, 1):
     d.synchronize()
     us = a.elapsed_time(b) * 1e3 / (16 * 64)
     k1, k2, kp = d.time_kernels(X[:B], Y[:B], reps=256)
-    res["pipeline" if path == 2 else "sample-tile"] = {"us_per_step_epoch_loop": round(us, 2), "us_first": round(k1, 2), "us_second": round(k2, 2), "us_pair": round(kp, 2)}
+    res[{0: "auto", 2: "pipeline", 1: "sample-tile"}[path]] = {"us_per_step_epoch_loop": round(us, 2), "us_first": round(k1, 2), "us_second": round(k2, 2), "us_pair": round(kp, 2)}
 print(json.dumps({"dims": dims, "B": B, **res}))
