@@ -560,6 +560,11 @@ def main():
                 result["config"].update(f64_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, local_rank))
             except Exception as ex:
                 result["config"]["f64_error"] = str(ex)[:200]
+        if extras and args.dtype == "f32":
+            try:
+                result["config"]["reference_test_net"] = test_net_leg(torch, amd, DeviceRCN, imgs_d, labels_d, local_rank)
+            except Exception as ex:
+                result["config"]["reference_test_net"] = {"error": str(ex)[:200]}
         if extras:
             try:
                 result["config"]["loss_curve"] = loss_curve_leg(torch, amd, DeviceRCN, imgs, labels, imgs_d, labels_d, ws, bs, local_rank, dtype)
@@ -614,6 +619,41 @@ def f64_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, dev):
     us = a.elapsed_time(b) * 1e3 / (n * nb)
     d.rcn.close()
     return {"f64_images_per_s": round(B / us * 1e6, 1), "f64_us_per_step": round(us, 4), "f64_steps": n * nb}
+
+
+def test_net_leg(torch, amd, DeviceRCN, imgs_d, labels_d, dev):
+    """The reference's OWN test net (two hidden layers of ten, rcn.rs:558,577) on the same data and session shape: device-timed
+    steps on the default path (the resident kernel's two-hidden-layer instantiation where it applies) and on the generic two-kernel
+    pipeline it replaces there."""
+    from mercer_research_amd.synth import synthetic_params
+    nb, B = N_IMAGES // B_PER_GPU, B_PER_GPU
+    out = {"dims": [784, 10, 10, 10]}
+    for name, path in (("default_path", 0), ("generic_pipeline", 2)):
+        d = DeviceRCN(classes=10, feedforward_cfg=[10, 10], input_shape=(28, 28), dtype=amd.F32, device=dev)
+        ws, bs = synthetic_params([784, 10, 10, 10], seed=42)
+        d.set_params(ws, bs)
+        if path:
+            d.set_dense_path(path)
+        X, Y = d.load_data(imgs_d, labels_d)
+        perm = torch.empty(N_IMAGES, dtype=torch.int32, device=d.device)
+
+        def epochs(n, seed0):
+            for e in range(n):
+                d.shuffle(perm, N_IMAGES, 1, seed=seed0 + e)
+                d.train_epoch(X, Y, perm, B, nb, ETA, None)
+        epochs(2, 11)
+        d.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 16
+        a.record(d.stream)
+        epochs(n, 100)
+        b.record(d.stream)
+        d.synchronize()
+        us = a.elapsed_time(b) * 1e3 / (n * nb)
+        k1, _, kp = d.time_kernels(X[:B], Y[:B], reps=128)
+        out[name] = {"us_per_step": round(us, 3), "images_per_s": round(B / us * 1e6, 1), "resident_kernel": k1 == 0.0, "steps": n * nb}
+        d.rcn.close()
+    return out
 
 
 def loss_curve_leg(torch, amd, DeviceRCN, imgs, labels, imgs_d, labels_d, ws, bs, dev, dtype, steps: int = 256):

@@ -753,3 +753,43 @@ def test_resident_kernel_is_what_auto_selects_for_the_reference_test_net(amd):
     if res[0][0] != 0.0:
         pytest.skip("the resident one-XCD kernel does not apply on this device")
     assert res[0][2] < res[2][2], res
+
+
+def test_resident_set_flow_of_the_reference_test_net_at_batch_256(amd, oracle):
+    """RCN::train's flow (rcn.rs:126-167: load both sets, shuffle, chunks_exact, train_batch, classify_test) for the reference's own
+    test net -- two hidden layers of ten (rcn.rs:558,577) -- at the batch size of BASELINE's metric, f32: the steps run on the resident
+    kernel's two-hidden-layer instantiation (where the device has it) and must follow the oracle's restatement on the same pictures,
+    shuffles and initial parameters: per-step costs, final parameters, accepted counts."""
+    B, epochs, N = 256, 2, 600
+    dims = [784, 10, 10, 10]
+    imgs, labels = synthetic_images(N, seed=13)
+    timgs, tlabels = synthetic_images(160, seed=14)
+    ws, bs = synthetic_params(dims, seed=22)
+    ws = [w * 0.05 for w in ws]
+    r = amd.RCN(10, amd.default_convpool(), [10, 10], input_shape=(28, 28), dtype=0)
+    r.set_params(ws, bs)
+    assert r.load_set(0, imgs, labels) == N and r.load_set(1, timgs, tlabels) == 160
+    f, tf = oracle.features(imgs, DEFAULT_LAYERS), oracle.features(timgs, DEFAULT_LAYERS)
+    tm, ts = oracle.gen_scales(tf)
+    X = oracle.standardize(f, *oracle.gen_scales(f))
+    TX = oracle.standardize(tf, tm, ts)
+    Y, TY = one_hot(labels), one_hot(tlabels)
+    rng = np.random.default_rng(5)
+    rw, rb = ws, bs
+    for e in range(epochs):
+        order = rng.permutation(N).astype(np.int32)
+        loss = r.train_set_epoch(0, B, 3.0, perm=order, want_loss=True)
+        assert loss.shape == (N // B,)                                   # chunks_exact: 600 -> two batches, the tail is dropped
+        costs = []
+        for j in range(N // B):
+            sel = order[j * B:(j + 1) * B]
+            rw, rb, c = oracle.train_batch(rw, rb, X[sel], Y[sel], 3.0)
+            costs.append(c)
+        np.testing.assert_allclose(loss, costs, rtol=2e-3)
+        out = oracle.classify_test(rw, rb, TX)
+        want = sum(oracle.eval_accept(out[i], TY[i]) for i in range(len(TX)))
+        assert abs(r.evaluate_set(1) - want) <= 2, e
+    gw, gb = r.get_params()
+    for a, b in zip(gw + gb, rw + rb):
+        assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)
+    r.close()
