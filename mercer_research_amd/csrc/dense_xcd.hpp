@@ -143,14 +143,24 @@ __device__ inline bool xcd_wait(const unsigned* f0, int n0, const unsigned* f1, 
 // runs between the two-kernel pipeline's halves); sums are in rank order, so every rank applies the bit-identical update with the
 // GLOBAL batch length (`scale` = eta / (B * world)).  The cost travels the same way as element P.  xsel: which blocks are the
 // workers (blockIdx.x % 8 == xsel) -- 0 on a GPU of its own; the one-GPU test harness gives each rank another XCD.
+// the data-parallel form's arguments; the single-GPU instantiations carry an empty struct instead (no kernel-argument registers)
+struct XcdDpOn { P2PDesc pd; size_t pstride; unsigned seq0; long long ptimeout; };
+struct XcdDpOff {};
+template <bool DP> struct XcdDpSel { using type = XcdDpOff; };
+template <> struct XcdDpSel<true> { using type = XcdDpOn; };
+template <bool DP> using XcdDpArgs = typename XcdDpSel<DP>::type;
+
 // L3 = true: two hidden layers (dims F, H <= 32, H2 <= 16, C <= 16 -- the reference's own test net 784-10-10-10): the sample group
 // runs one more 16 x 16 layer forward and backward (a_2, delta_3 through LDS; fragment words 28..39), the tail tiles cover
 // [W_2 | b_2] as well (from a_2 / delta_3); everything about the big first layer is unchanged.
-template <bool DP, bool L3 = false>
+// GA = true: the gather form (rows fetched by the workers; opt-in, see below) -- its own instantiation, so that the default kernels do
+// not carry its registers and branches.
+template <bool DP, bool L3 = false, bool GA = false>
 __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     NetDesc nd, float* __restrict__ params, const float* __restrict__ xs_all, const float* __restrict__ ys_all, int B, int nb, int G, float scale,
-    float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, P2PDesc pd,
-    size_t pstride, unsigned seq0, long long ptimeout, int xsel, const int* __restrict__ gperm, int gather) {
+    float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, XcdDpArgs<DP> dp,
+    int xsel, const int* __restrict__ gperm) {
+    constexpr bool gather = GA;
     using T = float;
     using acc_t = Mfma16<T>::acc_t;
     using vec4 = Vec4<T>::type;
@@ -604,8 +614,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 for (int i = 0; i < 4; ++i) gsum[i] = acc0[i] + acc1[i];
                 if constexpr (DP) {
                     // publish this shard's four sums, then collect the peers' of the same parameters (rank order)
-                    const unsigned seq = seq0 + (unsigned)j;
-                    u64* mine = ll_region<T>(pd.buf[pd.rank], pstride) + (size_t)(seq & 1u) * pstride * LLWords<T>::n;
+                    const unsigned seq = dp.seq0 + (unsigned)j;
+                    u64* mine = ll_region<T>(dp.pd.buf[dp.pd.rank], dp.pstride) + (size_t)(seq & 1u) * dp.pstride * LLWords<T>::n;
                     bool ok = true;
                     unsigned wo = woff0;                                     // opaque: the eight peers' addresses of these words are formed
                     asm volatile("" : "+v"(wo));                             // here, per step, instead of living in 16 registers all loop long
@@ -615,7 +625,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                         if (wvalid[i]) ll_store(mine, i0 + i, gsum[i], seq);
                     {
                         const bool gw[4] = {wvalid[0], wvalid[1], wvalid[2], wvalid[3]};
-                        ok = ll_gather_sum4(pd, pstride, i0, gw, seq, gsum, ptimeout);   // the lane's four values in one round trip
+                        ok = ll_gather_sum4(dp.pd, dp.pstride, i0, gw, seq, gsum, dp.ptimeout);   // the lane's four values in one round trip
                     }
                     if (!ok) {
                         s_abort = 1;
@@ -663,11 +673,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 t *= loss_scale;
                 if (lane == 0) {
                 if constexpr (DP) {                                          // the global cost: every shard's share, element P of the exchange
-                    const unsigned seq = seq0 + (unsigned)j;
-                    u64* mine = ll_region<T>(pd.buf[pd.rank], pstride) + (size_t)(seq & 1u) * pstride * LLWords<T>::n;
+                    const unsigned seq = dp.seq0 + (unsigned)j;
+                    u64* mine = ll_region<T>(dp.pd.buf[dp.pd.rank], dp.pstride) + (size_t)(seq & 1u) * dp.pstride * LLWords<T>::n;
                     ll_store(mine, (size_t)nd.P, t, seq);
                     T g;
-                    if (ll_gather_sum<T>(pd, pstride, (size_t)nd.P, seq, t, ptimeout, g)) t = g;
+                    if (ll_gather_sum<T>(dp.pd, dp.pstride, (size_t)nd.P, seq, t, dp.ptimeout, g)) t = g;
                     else { s_abort = 1; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 }
                 if (loss_dev) loss_dev[j] = t;
@@ -712,13 +722,13 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 if (tvalid) {
                     T gsum = sum_partials<T>(red, mt, tcl, tml);
                     if constexpr (DP) {
-                        const unsigned seq = seq0 + (unsigned)j;
-                        u64* mine = ll_region<T>(pd.buf[pd.rank], pstride) + (size_t)(seq & 1u) * pstride * LLWords<T>::n;
+                        const unsigned seq = dp.seq0 + (unsigned)j;
+                        u64* mine = ll_region<T>(dp.pd.buf[dp.pd.rank], dp.pstride) + (size_t)(seq & 1u) * dp.pstride * LLWords<T>::n;
                         size_t tpo = tp;                                     // (opaque, as in the feature workers' exchange)
                         asm volatile("" : "+v"(tpo));
                         ll_store(mine, tpo, gsum, seq);
                         T g;
-                        if (ll_gather_sum<T>(pd, pstride, tpo, seq, gsum, ptimeout, g)) gsum = g;
+                        if (ll_gather_sum<T>(dp.pd, dp.pstride, tpo, seq, gsum, dp.ptimeout, g)) gsum = g;
                         else { s_abort = 1; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     }
                     tcur -= scale * gsum;                                    // rcn.rs:214,221

@@ -759,6 +759,7 @@ int xcd_probe(rcn_hip_ctx* c) {
     RCN_TRY(set_dyn_lds(c, k_xcd_epoch<false>, lds));
     RCN_TRY(set_dyn_lds(c, k_xcd_epoch<true>, lds));
     RCN_TRY(set_dyn_lds(c, (k_xcd_epoch<false, true>), lds));
+    RCN_TRY(set_dyn_lds(c, (k_xcd_epoch<false, false, true>), lds));
     DevBuf out;
     HIP_TRY(c, out.ensure(8 * kXcdWorkers * sizeof(unsigned)));
     std::vector<unsigned> host(8 * kXcdWorkers);
@@ -852,21 +853,23 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
     const double Bg = (double)B * (dp ? (double)c->dp_world : 1.0);          // the global batch.len() of rcn.rs:214
     const float scale = (float)(eta / Bg), loss_scale = (float)(1.0 / (2.0 * Bg));
     const size_t lds = kXcdLdsFloats * sizeof(float);
+    // instantiations: one hidden layer (single-GPU, data-parallel, gather form), two hidden layers (single-GPU)
+#define RCN_XCD_LAUNCH(KERN, DPARG)                                                                                                                  \
+    hipLaunchKernelGGL(KERN, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb, pipe_slices(nd), \
+                       scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, dp ? kXcdTimeoutTicks + 2 * p2p_timeout_ticks_fwd() : kXcdTimeoutTicks, DPARG,  \
+                       xcd_select(), (const int*)gperm)
     if (dp) {
-        hipLaunchKernelGGL(k_xcd_epoch<true>, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,
-                           pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks + 2 * p2p_timeout_ticks_fwd(), p2p_desc(c),
-                           c->p2p.stride, c->p2p.seq + 1, p2p_timeout_ticks_fwd(), xcd_select(), (const int*)gperm, gather ? 1 : 0);
+        RCN_XCD_LAUNCH((k_xcd_epoch<true>), (XcdDpOn{p2p_desc(c), c->p2p.stride, c->p2p.seq + 1, p2p_timeout_ticks_fwd()}));
         c->p2p.seq += (unsigned)nb;
         c->xcd_dp_used = true;
     } else if (nd.L == 3) {
-        hipLaunchKernelGGL((k_xcd_epoch<false, true>), dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,
-                           pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks, P2PDesc{}, (size_t)0, 0u, 0LL, xcd_select(),
-                           (const int*)gperm, gather ? 1 : 0);
+        RCN_XCD_LAUNCH((k_xcd_epoch<false, true>), XcdDpOff{});
+    } else if (gather) {
+        RCN_XCD_LAUNCH((k_xcd_epoch<false, false, true>), XcdDpOff{});
     } else {
-        hipLaunchKernelGGL(k_xcd_epoch<false>, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,
-                           pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, kXcdTimeoutTicks, P2PDesc{}, (size_t)0, 0u, 0LL, xcd_select(),
-                           (const int*)gperm, gather ? 1 : 0);
+        RCN_XCD_LAUNCH((k_xcd_epoch<false>), XcdDpOff{});
     }
+#undef RCN_XCD_LAUNCH
     HIP_TRY(c, hipGetLastError());
     c->xcd_tag += (unsigned)nb;
     return RCN_HIP_OK;
@@ -880,14 +883,14 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
 constexpr size_t kXcdMaxStepsPerLaunch = 1u << 20;
 static bool xcd_gather(const rcn_hip_ctx* c) {
     static const int env = [] { const char* e = std::getenv("RCN_HIP_XCD_GATHER"); return e ? std::atoi(e) : 0; }();
-    return env != 0 && c->nd.dims[0] % 4 == 0;
+    return env != 0 && c->nd.dims[0] % 4 == 0 && c->nd.L == 2;
 }
 
 // a whole call on the resident kernel: batches [j0, j0 + nb) of the call, packed segment by segment (or already packed)
 int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool from_images,
                       bool prepacked, size_t j0, size_t pre_seg, bool dp = false) {
     const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L];
-    if (!prepacked && !from_images && xcd_gather(c)) {
+    if (!prepacked && !from_images && !dp && xcd_gather(c)) {
         c->xg.X = (const float*)X; c->xg.Y = (const float*)Y; c->xg.perm = perm; c->xg.B = B; c->xg.nb = nb;
         // feature vectors as stored: no packed image at all -- ONE launch walks the whole call, every worker gathering its 128 bytes of
         // each row of the batch after next while it works on the current one (the bytes k_pack_epoch would read, write and hand back)
@@ -2530,7 +2533,8 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
         // per step in *us_second and *us_pair (there is no first / second kernel)
         RCN_TRY(ensure_xcd_ws(c, B));
         // the form the last training call ran in: rows gathered by the kernel itself (over that call's rows), or the packed image
-        const bool tg = xcd_gather(c) && c->xg.B == B && c->xg.nb >= 2;
+        // (only over the matrix the caller hands in now: the remembered pointers are not trusted to be alive otherwise)
+        const bool tg = xcd_gather(c) && c->xg.B == B && c->xg.nb >= 2 && c->xg.X == (const float*)x && c->xg.Y == (const float*)y;
         size_t n = tg ? (c->xg.nb < 64 ? c->xg.nb : 64) : ((c->packed_B == B && c->packed_nb >= 2) ? c->packed_nb : 0);
         auto timed_launch = [&]() {
             return tg ? enqueue_xcd_steps(c, c->xg.X, c->xg.Y, B, n, 0.0, nullptr, false, c->xg.perm, true)
