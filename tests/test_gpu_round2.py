@@ -61,16 +61,29 @@ F32_CURVE_RTOL, F32_MEAN_RTOL = 5e-2, 5e-3
 
 
 @pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
+def test_loss_curve_256_steps_of_the_reference_test_net_matches_the_cpu_restatement(amd, oracle, bench_workload, dtype):
+    """The same 256-step curve for the reference's own test net, two hidden layers of ten (rcn.rs:558,577): in the f32 context these
+    steps run on the resident kernel's two-hidden-layer instantiation, in the f64 context on the generic pipeline."""
+    _loss_curve_case(amd, oracle, bench_workload, dtype, [784, 10, 10, 10])
+
+
+@pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
 def test_loss_curve_256_steps_on_the_bench_workload_matches_the_cpu_restatement(amd, oracle, bench_workload, dtype):
     """256 consecutive train_batch steps of bench.py's workload (B = 256, eta = 3.0, synthetic_params(seed = 42), 16 384 synthetic
     pictures, four device-shuffled epochs through rcn_hip_epoch_begin_dev / rcn_hip_epoch_steps_dev -- the loop bench.py times) with
     the per-step quadratic cost recorded, against oracle/rcn_oracle.c's train_batch (rcn.rs:176-223, f64) on the identical
     batches in the identical order.  f64 context: <= 1e-9 relative at every step and on the final parameters."""
+    _loss_curve_case(amd, oracle, bench_workload, dtype, BENCH_DIMS)
+
+
+def _loss_curve_case(amd, oracle, bench_workload, dtype, dims):
     import torch
     from mercer_research_amd.device import DeviceRCN
     imgs, labels, X, Y, ws, bs = bench_workload
+    if dims != BENCH_DIMS:
+        ws, bs = synthetic_params(dims, seed=42)
     B, nb, steps = BENCH_B, BENCH_N // BENCH_B, 256
-    d = DeviceRCN(dtype=dtype)
+    d = DeviceRCN(dtype=dtype, feedforward_cfg=dims[1:-1])
     d.set_params(ws, bs)
     imgs_d, labels_d = d.to_device(imgs), d.to_device(labels)
     Xd, Yd = d.load_data(imgs_d, labels_d)                      # HIP features + gen_scales + standardise
@@ -100,8 +113,11 @@ def test_loss_curve_256_steps_on_the_bench_workload_matches_the_cpu_restatement(
         assert rel[:F32_TIGHT_STEPS].max() <= F32_TIGHT_RTOL, (rel[:F32_TIGHT_STEPS].max(), int(rel[:F32_TIGHT_STEPS].argmax()))
         assert rel.max() <= F32_CURVE_RTOL, (rel.max(), int(rel.argmax()))
         assert abs(gpu.mean() - cpu.mean()) <= F32_MEAN_RTOL * cpu.mean()
-    # the curve is a training curve: the cost at the end is below the cost at the start on both sides
-    assert gpu[-16:].mean() < gpu[:16].mean() and cpu[-16:].mean() < cpu[:16].mean()
+    # the curve is a training curve: the cost at the end is below the cost at the start on both sides (the bench net; the ten-unit
+    # test net at eta = 3 on un-scaled parameters need not descend -- then both sides must agree that it does not)
+    assert (gpu[-16:].mean() < gpu[:16].mean()) == (cpu[-16:].mean() < cpu[:16].mean())
+    if dims == BENCH_DIMS:
+        assert cpu[-16:].mean() < cpu[:16].mean()
 
 
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "f64"])
