@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace rcnx {
 
@@ -76,20 +77,35 @@ __device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape&
             v[q] = ok ? val : f32x4{0, 0, 0, 0};
         }
     } else {
+        // whole K (= KS*KS*Cin <= 32) in one tile.  The tap of column k does not depend on the row: decoded ONCE per thread (four
+        // columns), with the division by a compile-time 3 for RGB input -- as a per-element k / s.Cin this loader issued ~100 VALU
+        // instructions per MFMA of the first layer (PMC, CIFAR shape).
+        int dh[4], dw[4], off[4];
+        bool kv[4];
+        auto decode = [&](auto cin_c) {
+            constexpr int CC = decltype(cin_c)::value;
+            const int Cin = CC ? CC : s.Cin;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = c4 + i;
+                const int tap = k / Cin, ci = k - tap * Cin;
+                kv[i] = k < KS * KS * Cin;
+                dh[i] = tap / KS - KS / 2;
+                dw[i] = tap % KS - KS / 2;
+                off[i] = (dh[i] * s.W + dw[i]) * Cin + ci;
+            }
+        };
+        if (s.Cin == 3) decode(std::integral_constant<int, 3>{});
+        else if (s.Cin == 1) decode(std::integral_constant<int, 1>{});
+        else decode(std::integral_constant<int, 0>{});
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 val = f32x4{0, 0, 0, 0};
-            if (rows.base[q] >= 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = c4 + i;                           // whole K (= KS*KS*Cin <= 32) in one tile
-                    if (k < KS * KS * s.Cin) {
-                        const int tap = k / s.Cin, ci = k - tap * s.Cin;
-                        const int dh = tap / KS - KS / 2, dw = tap % KS - KS / 2;
-                        if ((unsigned)(rows.oh[q] + dh) < (unsigned)s.H && (unsigned)(rows.ow[q] + dw) < (unsigned)s.W)
-                            val[i] = X[rows.base[q] + ((long long)dh * s.W + dw) * s.Cin + ci];
-                    }
-                }
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = rows.base[q] >= 0 && kv[i] && (unsigned)(rows.oh[q] + dh[i]) < (unsigned)s.H && (unsigned)(rows.ow[q] + dw[i]) < (unsigned)s.W;
+                const float x = X[ok ? rows.base[q] + off[i] : 0];                  // unconditional load, masked by value
+                val[i] = ok ? x : 0.f;
             }
             v[q] = val;
         }
@@ -281,6 +297,27 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
         dh = tap / KS - KS / 2; dw = tap % KS - KS / 2;
         toff = ((long long)dh * s.W + dw) * s.Cin + (k0 - tap * s.Cin) + c4;
     }
+    // SMALLC: the taps of this thread's four columns (row-independent), decoded once; division by a compile-time 3 for RGB input
+    int sdh[4] = {0, 0, 0, 0}, sdw[4] = {0, 0, 0, 0}, soff[4] = {0, 0, 0, 0};
+    bool skv[4] = {false, false, false, false};
+    if (SMALLC) {
+        auto decode = [&](auto cin_c) {
+            constexpr int CC = decltype(cin_c)::value;
+            const int Cin = CC ? CC : s.Cin;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = c4 + i;
+                const int tap = k / Cin, ci = k - tap * Cin;
+                skv[i] = k < KS * KS * Cin;
+                sdh[i] = tap / KS - KS / 2;
+                sdw[i] = tap % KS - KS / 2;
+                soff[i] = (sdh[i] * s.W + sdw[i]) * Cin + ci;
+            }
+        };
+        if (s.Cin == 3) decode(std::integral_constant<int, 3>{});
+        else if (s.Cin == 1) decode(std::integral_constant<int, 1>{});
+        else decode(std::integral_constant<int, 0>{});
+    }
     f32x4 xv[4], dv[BN / 8];                             // 128 x 32 floats / 256 thr = 4 float4; 128 x BN / 256 = BN/8 float4
     // The thread's X rows are pixels m_first, m_first + 32, ... across q AND across stages (128 = 4 * 32): (oh, ow) of the next
     // row is running state advanced by 32 pixels per load -- one 32-bit division per kernel instead of two 64-bit ones per load.
@@ -302,17 +339,11 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
                 xv[q] = ok ? val : f32x4{0, 0, 0, 0};
             } else {
                 f32x4 val = f32x4{0, 0, 0, 0};
-                if (in) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int k = c4 + i;
-                        if (k < K) {
-                            const int tap = k / s.Cin, ci = k - tap * s.Cin;
-                            const int eh = tap / KS - KS / 2, ew = tap % KS - KS / 2;
-                            if ((unsigned)(oh + eh) < (unsigned)s.H && (unsigned)(ow + ew) < (unsigned)s.W)
-                                val[i] = X[mc * (long long)s.Cin + ((long long)eh * s.W + ew) * s.Cin + ci];
-                        }
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = in && skv[i] && (unsigned)(oh + sdh[i]) < (unsigned)s.H && (unsigned)(ow + sdw[i]) < (unsigned)s.W;
+                    const float x = X[ok ? mc * (long long)s.Cin + soff[i] : 0];
+                    val[i] = ok ? x : 0.f;
                 }
                 xv[q] = val;
             }
