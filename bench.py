@@ -213,6 +213,7 @@ def main():
         return out
 
     allreduce_kind = None
+    dp_form_trial = None
     if not use_dp:
         # begun["ok"]: the epoch image form (rcn_hip_epoch_begin_dev / _steps_dev) is available -- it is for the feature-sliced
         # pipeline; with --path 1 (sample-tile kernels) each piece gathers its rows by index instead.  live: the image holds the
@@ -365,6 +366,61 @@ def main():
             else:
                 args.dp_impl = "torch"
 
+        # Two forms carry the same in-kernel exchange: the resident one-XCD kernel and the two-kernel pipeline.  Which is faster over
+        # real xGMI links has never been measured on the dev box (one GPU), so the bench tries both for a short, untimed stretch and
+        # keeps the faster -- the maximum over the ranks decides, identically on every rank -- before anything is timed.
+        if args.dp_impl == "native" and d.dp_p2p_mode() == 2 and d.dp_resident(B):
+            def trial(k: int) -> float:
+                prime(k)
+                d.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(k)
+                d.synchronize(); dist.barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=d.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item()) * 1e6 / k
+            try:
+                trial_steps = 2 * nb_epoch
+                t_res = trial(trial_steps)
+                d.set_dense_path(2)
+                ok2 = healthy(rehearsal)
+                t_two = trial(trial_steps) if ok2 else float("inf")
+                dp_form_trial = {"resident_us_per_step": round(t_res, 3), "two_kernel_us_per_step": round(t_two, 3) if ok2 else None, "steps": trial_steps}
+                if not ok2:
+                    # the other form failed its own rehearsal (its sticky time-out word stays set): a fresh group, resident form again
+                    try:
+                        d.dp_finalize()
+                    except Exception as e:
+                        print(f"[bench] rank {rank}: dp_finalize after the two-kernel trial: {e}", file=sys.stderr, flush=True)
+                    d.set_dense_path(0)
+                    if not dp_native_setup():
+                        raise RuntimeError("the data-parallel group could not be set up again after the two-kernel trial")
+                elif not t_two < t_res:
+                    d.set_dense_path(0)
+                dp_form_trial["kept"] = "two-kernel pipeline" if (ok2 and t_two < t_res) else "resident kernel"
+                allreduce_kind = dp_kind()
+            except Exception as e:                   # a failed trial must not cost the run: a fresh group on the default form, or the torch loop
+                print(f"[bench] rank {rank}: exchange-form trial: {e}", file=sys.stderr, flush=True)
+                dp_form_trial = {"error": str(e)[:200]}
+                try:
+                    d.dp_finalize()
+                except Exception:
+                    pass
+                d.set_dense_path(0)
+                if dp_native_setup():
+                    allreduce_kind = dp_kind()
+                else:
+                    args.dp_impl = "torch"
+                    allreduce_kind = "torch.distributed all_reduce (RCCL)"
+                    dp = DataParallelStep(d)
+            d.set_params(ws, bs)                     # the timed session starts from the common initial state again
+            if args.dp_impl == "native":
+                d.dp_broadcast_params(0)
+            else:
+                dp.broadcast_params(0)
+            step_no[0] = 0
+            epoch_no[0] = 0
+
     def sync():
         d.synchronize()
         torch.cuda.synchronize()
@@ -467,7 +523,7 @@ def main():
                    "steady_state_device_us_per_step_rank0": round(steady_dev_ms * 1e3 / steady_k, 4),
                    "end_to_end_images_per_s": round(e2e, 1) if e2e else None,
                    "allreduce": allreduce_kind if use_dp else None, "replicas_identical": replicas_identical,
-                   "dp_fallbacks_taken": fallbacks if use_dp else None},
+                   "dp_fallbacks_taken": fallbacks if use_dp else None, "dp_form_trial": dp_form_trial},
     }
 
     if rank == 0:
