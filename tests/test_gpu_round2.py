@@ -809,3 +809,49 @@ def test_resident_set_flow_of_the_reference_test_net_at_batch_256(amd, oracle):
     for a, b in zip(gw + gb, rw + rb):
         assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)
     r.close()
+
+
+def test_resident_kernel_many_segments_of_the_epoch_image(amd, oracle, monkeypatch):
+    """A call of many segments of the epoch image (2 batches each here, 17 batches: nine launches): the halves of the image are reused
+    every second segment -- a pack that ran over a half still being read, or steps on a half not yet packed, would train on the
+    wrong batches.  Per-step costs and parameters against the oracle's sequential loop, twice in a row, then once more from u8
+    pictures (the fused feature + pack kernel) for the same costs bit for bit."""
+    from mercer_research_amd.device import DeviceRCN
+    monkeypatch.setenv("RCN_HIP_PACK_SEGMENT_BYTES", str(2 * 49 * 256 * 16 * 4))
+    B, nb, N = 256, 17, 4608
+    imgs, labels = synthetic_images(N, seed=61)
+    ws, bs = synthetic_params(BENCH_DIMS, seed=15)
+    ws = [w * 0.1 for w in ws]
+    perm = np.random.default_rng(8).permutation(N).astype(np.int32)
+    d = DeviceRCN(dtype=0)
+    _xcd_or_skip(d)
+    d.set_dense_path(0)
+    d.set_params(ws, bs)
+    dev = d.to_device(imgs)
+    d.gen_scales(d.features(dev))
+    X = d.features(dev, standardize=True)
+    Y = d.to_device(one_hot(labels), d.tdtype)
+    permd = d.to_device(perm)
+    loss, loss2, loss3 = d.empty(nb), d.empty(nb), d.empty(nb)
+    d.train_epoch(X, Y, permd, B, nb, 3.0, loss)
+    d.train_epoch(X, Y, None, B, nb, 3.0, loss2)
+    d.synchronize()
+    p_after_two = sum(d.get_params(), [])
+    d.set_params(ws, bs)
+    d.train_epoch_images(dev, Y, permd, B, nb, 3.0, loss3)
+    d.synchronize()
+    Xh, Yh = X.double().cpu().numpy(), one_hot(labels)
+    rw, rb, c1, c2 = ws, bs, [], []
+    for j in range(nb):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, Xh[sel], Yh[sel], 3.0)
+        c1.append(c)
+    for j in range(nb):
+        rw, rb, c = oracle.train_batch(rw, rb, Xh[j * B:(j + 1) * B], Yh[j * B:(j + 1) * B], 3.0)
+        c2.append(c)
+    np.testing.assert_allclose(loss.cpu().numpy(), c1, rtol=2e-3)
+    np.testing.assert_allclose(loss2.cpu().numpy(), c2, rtol=5e-3)
+    for a, b in zip(p_after_two, rw + rb):
+        assert np.all(np.abs(a - b) <= 1e-3 * np.abs(b) + 1e-4)            # 34 chained f32 steps
+    assert np.array_equal(loss3.cpu().numpy(), loss.cpu().numpy())          # the in-line pack from pictures: the same batches, bit for bit
+    d.rcn.close()
