@@ -442,8 +442,12 @@ def main():
         sync()
         t0 = time.perf_counter()
         run(k)
-        sync()
+        torch.cuda.synchronize()          # every stream of the device, the library's included
+        if use_dp:
+            dist.barrier()
+            torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        d.synchronize()                   # (outside the bracket: reports a sticky in-kernel time-out of the timed steps, if any)
         # the device-side time of the same k steps, from a second pass of the session (event records are host calls of several
         # microseconds each: kept out of the wall-clock bracket above, which is the contract's figure)
         prime(k)
@@ -529,8 +533,9 @@ def main():
         sync()
         t0 = time.perf_counter()
         e2e_steps(args.steps, 0xE2E1000)
-        sync()
+        torch.cuda.synchronize()                                 # the same end of the bracket as in timed()
         e2e = args.steps * B / (time.perf_counter() - t0)
+        d.synchronize()
 
     # data-parallel runs: every rank must hold bit-identical parameters (identical update from rank-ordered sums); a stale or
     # torn read in the exchange would show up here as diverged replicas
