@@ -443,10 +443,10 @@ def main():
         t0 = time.perf_counter()
         run(k)
         torch.cuda.synchronize()          # every stream of the device, the library's included
+        el = time.perf_counter() - t0     # this rank's K steps are done; the MAX over the ranks (below) is the job's time
         if use_dp:
-            dist.barrier()
-            torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+            dist.barrier()                # the closing barrier + synchronise of the bracket: the slowest rank's clock has stopped by now,
+            torch.cuda.synchronize()      # and the barrier's own latency (an all-reduce launch) is not training time
         d.synchronize()                   # (outside the bracket: reports a sticky in-kernel time-out of the timed steps, if any)
         # the device-side time of the same k steps, from a second pass of the session (event records are host calls of several
         # microseconds each: kept out of the wall-clock bracket above, which is the contract's figure)
@@ -561,7 +561,9 @@ def main():
                    "end_to_end_images_per_s": round(e2e, 1) if e2e else None,                       # same steps, bracket and clock as `value`
                    "end_to_end_steady_state_images_per_s": round(e2e_steady, 1) if e2e_steady else None,   # 32 passes over the set, device-timed
                    "allreduce": allreduce_kind if use_dp else None, "replicas_identical": replicas_identical,
-                   "dp_fallbacks_taken": fallbacks if use_dp else None, "dp_form_trial": dp_form_trial},
+                   "dp_fallbacks_taken": fallbacks if use_dp else None, "dp_form_trial": dp_form_trial,
+                   "timing": ("barrier + synchronise, clock started on every rank; K steps; synchronise, clock stopped on every rank, closing barrier + "
+                              "synchronise; value uses the MAX over the ranks") if use_dp else "synchronise; K steps; one device-wide synchronise"},
     }
 
     if rank == 0:
