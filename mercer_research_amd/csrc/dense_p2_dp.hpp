@@ -259,15 +259,22 @@ __device__ inline bool ll_gather_sum(const P2PDesc& d, size_t stride, size_t idx
     unsigned ready = 1u << d.rank;
     const unsigned all = (1u << d.world) - 1u;
     const size_t at = (size_t)(seq & 1u) * stride + idx;
-    const long long t0 = wall_clock64();
-    while (ready != all) {
+    // The clock is read only while a word is still missing, and then every 32nd round: s_memrealtime is a scalar memory access of the
+    // better part of a microsecond -- read up front it sat between the publish and the first poll of EVERY exchange (0.9 us per step
+    // of the resident kernel at a group of one, by the phase stamps), and once per round it would halve the polling rate.
+    long long t0 = 0;
+    for (unsigned it = 0; ready != all; ++it) {
 #pragma unroll
         for (int q = 0; q < kP2PMaxWorld; ++q)
             if (q < d.world && !((ready >> q) & 1u)) {
                 T x;
                 if (ll_poll(ll_region<T>(d.buf[q], stride), at, seq, x)) { v[q] = x; ready |= 1u << q; }
             }
-        if (ready != all && wall_clock64() - t0 > timeout_ticks) return false;
+        if (ready != all && (it & 31u) == 31u) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > timeout_ticks) return false;
+        }
     }
     T g = 0;
 #pragma unroll
@@ -287,8 +294,8 @@ __device__ inline bool ll_gather_sum4(const P2PDesc& d, size_t stride, size_t id
     const size_t slot = (size_t)(seq & 1u) * stride + idx0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) ready[i] = want[i] ? 1u << d.rank : all;
-    const long long t0 = wall_clock64();
-    while ((ready[0] & ready[1] & ready[2] & ready[3]) != all) {
+    long long t0 = 0;                                                 // (read lazily: see ll_gather_sum)
+    for (unsigned it = 0; (ready[0] & ready[1] & ready[2] & ready[3]) != all; ++it) {
 #pragma unroll
         for (int q = 0; q < kP2PMaxWorld; ++q) {
             if (q >= d.world) continue;
@@ -301,7 +308,11 @@ __device__ inline bool ll_gather_sum4(const P2PDesc& d, size_t stride, size_t id
             for (int i = 0; i < 4; ++i)
                 if (got[i]) { v[i][q] = x[i]; ready[i] |= 1u << q; }
         }
-        if ((ready[0] & ready[1] & ready[2] & ready[3]) != all && wall_clock64() - t0 > timeout_ticks) return false;
+        if ((ready[0] & ready[1] & ready[2] & ready[3]) != all && (it & 31u) == 31u) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > timeout_ticks) return false;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
