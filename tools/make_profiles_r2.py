@@ -7,7 +7,7 @@ G = "gpurun_out"
 def one(pat):
     m = glob.glob(pat, recursive=True)
     assert m, pat
-    return m[0]
+    return max(m, key=os.path.getmtime)          # gpurun merges every call's files into the same directory: the newest run counts
 def csrc_sha16():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mercer_research_amd", "csrc")

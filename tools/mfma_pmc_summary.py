@@ -3,7 +3,8 @@
 median over dispatches; fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 128), the normalisation under which a kernel that keeps every
 SIMD's matrix pipe busy for its whole duration reads 1.0 on gfx950 (same as profiles/r1_trackx_mfma_pmc.json).  usage: mfma_pmc_summary.py <dir> <out.json>"""
 import csv, glob, json, statistics, sys
-rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)[0])))
+import os
+rows = list(csv.DictReader(open(max(glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime))))   # newest run
 acc = {}
 for r in rows:
     if 'rcnx::' not in r['Kernel_Name']:
