@@ -253,22 +253,52 @@ __device__ inline bool ll_poll(const u64* words, size_t idx, unsigned seq, doubl
 
 // value `idx` of slot `seq & 1` summed over the ranks in rank order: own from the register, the peers' polled out of their
 // HBM.  false: a peer's word did not arrive within the timeout.
+// raw tagged word(s) of value idx: issued without looking at the answer, so that a round's loads are all in flight before the first use
+template <typename T> struct LLRaw;
+template <> struct LLRaw<float> { u64 w; };
+template <> struct LLRaw<double> { u64 lo, hi; };
+__device__ inline void ll_load(const u64* words, size_t idx, LLRaw<float>& r) { r.w = __hip_atomic_load(words + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline void ll_load(const u64* words, size_t idx, LLRaw<double>& r) {
+    r.lo = __hip_atomic_load(words + 2 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    r.hi = __hip_atomic_load(words + 2 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline bool ll_take(const LLRaw<float>& r, unsigned seq, float& out) {
+    const unsigned b = (unsigned)r.w;
+    __builtin_memcpy(&out, &b, 4);
+    return (unsigned)(r.w >> 32) == seq;
+}
+__device__ inline bool ll_take(const LLRaw<double>& r, unsigned seq, double& out) {
+    const u64 b = (r.lo & 0xffffffffull) | (r.hi << 32);
+    __builtin_memcpy(&out, &b, 8);
+    return (unsigned)(r.lo >> 32) == seq && (unsigned)(r.hi >> 32) == seq;
+}
+
 template <typename T>
 __device__ inline bool ll_gather_sum(const P2PDesc& d, size_t stride, size_t idx, unsigned seq, T own, long long timeout_ticks, T& sum) {
     T v[kP2PMaxWorld];
     unsigned ready = 1u << d.rank;
     const unsigned all = (1u << d.world) - 1u;
     const size_t at = (size_t)(seq & 1u) * stride + idx;
+    // A round has two phases: first the loads of every peer still missing, then the answers.  Written as one loop -- load a word,
+    // look at it -- the compiler put an s_waitcnt vmcnt(0) behind every single load: up to seven xGMI round trips in a row per round
+    // where one is enough (read off the ISA; invisible at a group of one).  Words that have arrived are not read again: every thread
+    // of every rank polls, and re-reading everything every round saturates the memory of four ranks that share one GPU (measured:
+    // time-outs) and would waste most of the link otherwise.
     // The clock is read only while a word is still missing, and then every 32nd round: s_memrealtime is a scalar memory access of the
-    // better part of a microsecond -- read up front it sat between the publish and the first poll of EVERY exchange (0.9 us per step
-    // of the resident kernel at a group of one, by the phase stamps), and once per round it would halve the polling rate.
+    // better part of a microsecond -- read up front it sat between the publish and the first poll of EVERY exchange, and once per
+    // round it would halve the polling rate.
     long long t0 = 0;
     for (unsigned it = 0; ready != all; ++it) {
+        LLRaw<T> raw[kP2PMaxWorld];
+        const unsigned miss = all & ~ready;
 #pragma unroll
-        for (int q = 0; q < kP2PMaxWorld; ++q)
-            if (q < d.world && !((ready >> q) & 1u)) {
+        for (int q = 0; q < kP2PMaxWorld; ++q)                       // phase 1: the loads of the peers still missing, nothing looked at
+            if ((miss >> q) & 1u) ll_load(ll_region<T>(d.buf[q], stride), at, raw[q]);
+#pragma unroll
+        for (int q = 0; q < kP2PMaxWorld; ++q)                       // phase 2: the answers
+            if ((miss >> q) & 1u) {
                 T x;
-                if (ll_poll(ll_region<T>(d.buf[q], stride), at, seq, x)) { v[q] = x; ready |= 1u << q; }
+                if (ll_take(raw[q], seq, x)) { v[q] = x; ready |= 1u << q; }
             }
         if (ready != all && (it & 31u) == 31u) {
             const long long now = wall_clock64();
@@ -288,40 +318,56 @@ __device__ inline bool ll_gather_sum(const P2PDesc& d, size_t stride, size_t idx
 // peer round trip, not four.  want[i] false: value i is not exchanged (its sum is left alone).  Sums in rank order, as above.
 __device__ inline bool ll_gather_sum4(const P2PDesc& d, size_t stride, size_t idx0, const bool (&want)[4], unsigned seq, float (&own)[4],
                                       long long timeout_ticks) {
-    float v[4][kP2PMaxWorld];
-    unsigned ready[4];
-    const unsigned all = (1u << d.world) - 1u;
     const size_t slot = (size_t)(seq & 1u) * stride + idx0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ready[i] = want[i] ? 1u << d.rank : all;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     long long t0 = 0;                                                 // (read lazily: see ll_gather_sum)
-    for (unsigned it = 0; (ready[0] & ready[1] & ready[2] & ready[3]) != all; ++it) {
+    unsigned it = 0;
+    const unsigned peers = ((1u << d.world) - 1u) & ~(1u << d.rank);
+    // Two batches of four ranks, in rank order: up to sixteen words in flight per round (phase 1: the loads of the words still missing;
+    // phase 2: the answers -- see ll_gather_sum); a batch is added, in rank order and with this rank's own values at its own place,
+    // once all of its words carry this step's tag.  Every rank publishes at about the same time, so the second batch is normally
+    // complete one round trip after the first.
 #pragma unroll
-        for (int q = 0; q < kP2PMaxWorld; ++q) {
-            if (q >= d.world) continue;
-            const u64* words = ll_region<float>(d.buf[q], stride);
-            float x[4];
-            bool got[4];
+    for (int q0 = 0; q0 < kP2PMaxWorld; q0 += 4) {
+        if (q0 >= d.world) break;                                     // (uniform)
+        float x[4][4];
+        unsigned miss[4];                                             // per value: the ranks of this batch whose word is still missing
 #pragma unroll
-            for (int i = 0; i < 4; ++i) got[i] = !((ready[i] >> q) & 1u) && ll_poll(words, slot + i, seq, x[i]);
+        for (int i = 0; i < 4; ++i) miss[i] = want[i] ? (peers >> q0) & 15u : 0u;
+        for (; (miss[0] | miss[1] | miss[2] | miss[3]) != 0u; ++it) {
+            u64 w[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (got[i]) { v[i][q] = x[i]; ready[i] |= 1u << q; }
+            for (int qq = 0; qq < 4; ++qq) {
+                const u64* words = ll_region<float>(d.buf[(q0 + qq) < d.world ? q0 + qq : 0], stride) + slot;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if ((miss[i] >> qq) & 1u) w[i][qq] = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (((miss[i] >> qq) & 1u) && (unsigned)(w[i][qq] >> 32) == seq) {
+                        const unsigned b = (unsigned)w[i][qq];
+                        __builtin_memcpy(&x[i][qq], &b, 4);
+                        miss[i] &= ~(1u << qq);
+                    }
+            if ((miss[0] | miss[1] | miss[2] | miss[3]) != 0u && (it & 31u) == 31u) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > timeout_ticks) return false;
+            }
         }
-        if ((ready[0] & ready[1] & ready[2] & ready[3]) != all && (it & 31u) == 31u) {
-            const long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            else if (now - t0 > timeout_ticks) return false;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int q = q0 + qq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += q < d.world ? (q == d.rank ? own[i] : x[i][qq]) : 0.f;
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!want[i]) continue;
-        float g = 0;
-#pragma unroll
-        for (int q = 0; q < kP2PMaxWorld; ++q) g += q < d.world ? (q == d.rank ? own[i] : v[i][q]) : 0.f;
-        own[i] = g;
-    }
+    for (int i = 0; i < 4; ++i)
+        if (want[i]) own[i] = acc[i];
     return true;
 }
 
