@@ -166,7 +166,7 @@ int  rcn_hip_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_
  * pass into perm_dev (each pass is rcn.rs:146-149 once). */
 int  rcn_hip_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
                                size_t B, size_t n_batches, double eta, void* loss_dev);
-/* (Opt-in form, RCN_HIP_XCD_GATHER=1 in the environment; measured slower than the packed image on MI355X -- csrc/rcn_hip_api.hip.)
+/* (Opt-in form, option "xcd_gather" = 1; measured slower than the packed image on MI355X -- csrc/rcn_hip_api.hip.)
  * 1 when rcn_hip_train_epoch_dev at this batch size runs on the resident one-XCD kernel in its GATHER form: no packed epoch image is
  * written -- one launch walks the whole call and every worker fetches its 128 bytes of each row of the batch after next while it
  * works on the current one (csrc/dense_xcd.hpp).  The feature matrix is then read from memory exactly once per step and
@@ -233,8 +233,8 @@ int  rcn_hip_dp_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const voi
 /* The all-reduce of that loop.  For 2..8 ranks of one node rcn_hip_dp_init also sets up a one-shot PEER-READ all-reduce
  * over xGMI (every rank reads all ranks' gradient buffers through hipIpc mappings, adds them in rank order and applies
  * the update in the same kernel; csrc/dp_p2p.hpp) and keeps it only if every rank mapped every peer and a known-answer
- * exchange came back exact on every rank; otherwise, or with RCN_HIP_DP_P2P=0 in the environment, the loop uses
- * ncclAllReduce (RCN_HIP_DP_P2P=2 also sets it up for a single rank, for tests).  rcn_hip_dp_p2p_active tells which.  The three calls below are the same set-up with the handle exchange
+ * exchange came back exact on every rank; otherwise, or with option "dp_p2p" = 0, the loop uses
+ * ncclAllReduce ("dp_p2p" = 2 also sets it up for a single rank, for tests).  rcn_hip_dp_p2p_active tells which.  The three calls below are the same set-up with the handle exchange
  * done by the caller instead of RCCL (any transport; used by the tests): export -> gather every rank's
  * RCN_HIP_DP_P2P_HANDLE_BYTES in rank order -> attach (collective; after it rcn_hip_dp_train_epoch_dev uses the peer
  * all-reduce and needs no RCCL communicator) -> optionally selftest (collective; counts wrong sums over `iters` exchanges
@@ -289,16 +289,48 @@ int  rcn_hip_classify_images(rcn_hip_ctx* ctx, const uint8_t* imgs, size_t n, in
 
 /* ---------------------------------------------------------------- tuning / measurement aids */
 /* Which kernels implement train_batch / train_epoch: 0 = automatic (the feature-sliced pipeline for batches <= 1024 when the layer
- * stack allows it -- as ONE resident kernel per epoch segment whose 32 workgroups share one XCD and hand over through its L2
- * (csrc/dense_xcd.hpp) where that form applies: f32 context, one hidden layer <= 32, classes <= 16, batch 256, and a device on
- * which a placement probe finds the blocks with blockIdx.x % 8 == 0 on one XCD; as two kernels per step (csrc/dense_p2.hpp,
- * dense_pipe.hpp) otherwise -- and the sample-tile kernels for everything else), 1 = always the sample-tile kernels, 2 = the
- * feature-sliced pipeline as two kernels per step, 5 = the resident one-XCD kernel (RCN_HIP_ERR_UNSUPPORTED where it does not
- * apply; environment RCN_HIP_XCD=0 keeps mode 0 off it).  The resident kernel needs its 32 workgroups on the GPU at once: on a
- * device shared with another process a call can fail with RCN_HIP_ERR_HIP (bounded waits; the failed segment is not applied).
+ * stack allows it -- as ONE resident kernel per epoch segment whose workgroups share one XCD and hand over through its L2
+ * (csrc/dense_xcd.hpp) where that form applies: f32 context, one hidden layer <= 32 (or two: <= 32, <= 16), classes <= 16, ANY
+ * batch of 1..256 samples (the reference trains at batch_size 10, rcn/src/main.rs:36-37; instantiations for 32 / 64 / 128 / 256,
+ * smaller batches padded with masked samples), and a device on which a placement probe finds the blocks with blockIdx.x % 8 == 0
+ * on one XCD; as two kernels per step (csrc/dense_p2.hpp, dense_pipe.hpp) otherwise -- and the sample-tile kernels for everything
+ * else), 1 = always the sample-tile kernels, 2 = the feature-sliced pipeline as two kernels per step, 5 = the resident one-XCD
+ * kernel (RCN_HIP_ERR_UNSUPPORTED where it does not apply; option "xcd" = 0 keeps mode 0 off it).
+ * The resident kernel needs its workgroups on the GPU at once.  On a device shared with another process one of its bounded waits
+ * can expire; nothing such a launch computed reaches the parameters, and a single-GPU context then STEPS DOWN by itself: at the
+ * next point where the library drains the stream (rcn_hip_synchronize, rcn_hip_get_params, rcn_hip_evaluate*, a call that returns
+ * costs to the host, or the next training call that finds the failure) it clears the error, selects the two-kernel pipeline for the
+ * rest of the context's life and re-runs there every step that was not applied, from the arguments the calls were given -- index
+ * rows the library shuffled or uploaded itself are re-created, everything else those calls read must be unchanged, the usual
+ * contract of an asynchronous call.  rcn_hip_fallbacks_taken counts these step-downs; option "xcd_auto_fallback" = 0 restores the
+ * sticky RCN_HIP_ERR_HIP (cleared by rcn_hip_set_params / rcn_hip_init_params / rcn_hip_set_dense_path(ctx, 1 or 2)).
  * 3 and 4 are parked experiments compiled only into librcn_hip_exp.so.  All compute the same step (summation grouping differs,
  * within the stated tolerances). */
 int  rcn_hip_set_dense_path(rcn_hip_ctx* ctx, int mode);
+int  rcn_hip_fallbacks_taken(const rcn_hip_ctx* ctx);      /* not a status: the number of step-downs described above */
+
+/* Per-context options.  The environment variable named beside an option only seeds its default when the context is created; nothing
+ * reads the environment afterwards, so two contexts of one process can differ.  RCN_HIP_ERR_INVALID_ARG for an unknown name or a value
+ * out of range.  Changing an option drops the context's captured graphs.
+ *   "xcd"                 RCN_HIP_XCD                 0 | 1     dense path 0 may select the resident one-XCD kernel (1)
+ *   "xcd_select"          RCN_HIP_XCD_SELECT          0..7      which blocks of a resident launch are its workers (blockIdx.x % 8); tests
+ *   "xcd_gather"          RCN_HIP_XCD_GATHER          0 | 1     rows fetched by the resident kernel itself, batch 256 (measured slower; 0)
+ *   "xcd_timeout_ticks"   RCN_HIP_XCD_TIMEOUT_TICKS   >= 1      bound of every wait inside the resident kernel, 100 MHz ticks (20000000 = 0.2 s)
+ *   "xcd_exact_lds"       RCN_HIP_XCD_EXACT_LDS       0 | 1     the resident kernel asks for exactly the LDS it uses, so that two contexts'
+ *                                                               kernels fit on one device at batches <= 64 (0: one worker per CU)
+ *   "xcd_auto_fallback"   RCN_HIP_XCD_AUTO_FALLBACK   0 | 1     self-healing step-down of the single-GPU resident kernel (1)
+ *   "xcd_fault_launch"    RCN_HIP_XCD_FAULT_LAUNCH    >= 0      test hook: the n-th resident launch of the context loses a worker and fails (0: none)
+ *   "dp_p2p"              RCN_HIP_DP_P2P              0 | 1 | 2 peer exchange over xGMI: never / when world > 1 / also at world 1 (tests)
+ *   "dp_fused"            RCN_HIP_DP_FUSED            0 | 1     the exchange may run inside a step kernel (1)
+ *   "dp_timeout_ticks"    RCN_HIP_DP_TIMEOUT_TICKS    >= 1      bound of a peer wait (100000000 = 1 s)
+ *   "dp_cached_buf"       RCN_HIP_DP_CACHED_BUF       0 | 1     exported buffers in cached device memory (A/B measurements; 0)
+ *   "dp_graph"            RCN_HIP_DP_GRAPH            0 | 1     the three-kernel data-parallel step replays as one hipGraph (1)
+ *   "feat_waves"          RCN_HIP_FEAT_WAVES          1 | 2     waves per picture in k_features_cpcp (measured neutral; 1)
+ *   "no_fragimg"          RCN_HIP_NO_FRAGIMG          0 | 1     k_p2_b gathers its tail parameters itself (0)
+ *   "exact_div_only"      RCN_HIP_EXACT_DIV_ONLY      0 | 1     the f32 standardisation always divides (0)
+ *   "pack_segment_bytes"  RCN_HIP_PACK_SEGMENT_BYTES  >= 1      one half of the epoch image (64 MiB) */
+int  rcn_hip_set_option(rcn_hip_ctx* ctx, const char* name, int64_t value);
+int  rcn_hip_get_option(const rcn_hip_ctx* ctx, const char* name, int64_t* value);
 /* Which kernel implements flatten_feature_set: 0 = automatic (the fused conv+pool kernel specialised for the default
  * stack conv(Same),pool(Max),conv(Same),pool(Max) on 28x28 input when the configuration is exactly that, the generic
  * layer-walking kernel otherwise), 1 = always the generic kernel.  Both are bit-identical (integer-valued arithmetic). */

@@ -33,7 +33,9 @@
 // agree with the two-kernel pipeline to f32 rounding of a different grouping (the oracle tolerances of tests/ hold for both).
 //
 // No hang by construction: every wait is bounded by the 100 MHz wall clock and raises a sticky error word that makes every
-// worker leave at its next wait; the parameters in memory are written only by a launch that ran to its end.
+// worker leave at its next wait.  The parameters in memory are written only by a launch ALL of whose workers finished its last step
+// (one closing flag round), and a launch that finds the word set leaves at once: after a failure the parameter vector is the state
+// after the last launch that reports itself in `done` -- what the host's replay on the two-kernel pipeline starts from.
 #pragma once
 
 #include "dense_p2.hpp"
@@ -57,6 +59,9 @@ struct XcdBufs {
     unsigned* flagB;   // [32 x stride]      step tag of the newest complete outputs of sample group w
     unsigned* flagT;   // [8 x stride]       step tag for which tail tile e's share of the fragment image is current
     unsigned* xcc;     // [32 x stride]      (launch tag << 4) | XCC_ID of worker w
+    unsigned* flagD;   // [32 x stride]      tag of the last step of the newest launch worker w finished computing (before any write-back)
+    unsigned* errd;    // [1]                device copy of the sticky error word
+    unsigned* done;    // pinned host word: id of the newest launch whose workers ALL finished (its parameters are in memory when it ends)
 };
 
 inline int xcd_na(const NetDesc& nd) { return (pipe_slices(nd) + kXcdSl - 1) / kXcdSl; }
@@ -64,21 +69,37 @@ inline int xcd_na(const NetDesc& nd) { return (pipe_slices(nd) + kXcdSl - 1) / k
 inline bool xcd_two_hidden(const NetDesc& nd) {
     return nd.L == 3 && nd.dims[1] <= kP2H && nd.dims[2] <= kP2C && nd.dims[3] <= kP2C && pipe_slices(nd) <= kP2MaxSlices;
 }
-inline bool xcd_supported(const NetDesc& nd, size_t B) {
-    return (p2_supported(nd, B) || xcd_two_hidden(nd)) && B == 256 && xcd_na(nd) + pipe_extra_wgs(nd) <= kXcdWorkers && pipe_extra_wgs(nd) <= 8;
+inline bool xcd_one_hidden(const NetDesc& nd) {
+    return nd.L == 2 && nd.dims[1] <= kP2H && nd.dims[2] <= kP2C && pipe_slices(nd) <= kP2MaxSlices;
 }
-inline size_t xcd_buf_bytes(const NetDesc& nd, size_t B) {
-    const size_t NS = B / kP2Ts, NA = (size_t)xcd_na(nd);
-    return (NS * NA * kP2Ts * kP2H + 2 * B * kP2H + 3 * B * kP2C + NS + (size_t)kP3BFrag * 64) * sizeof(float) +
-           (size_t)(3 * kXcdWorkers + 8) * kXcdFlagStride * sizeof(unsigned) + 512;
+// The batch the kernel is instantiated for: the reference trains at batch_size 10 (rcn/src/main.rs:36-37) and BASELINE's CPU case is
+// 32, the bench workload 256 -- any batch of 1..256 samples runs on the instantiation for the next of 32 / 64 / 128 / 256 (`BT`);
+// the samples between B and BT are rows of zeros whose deltas are masked to zero, so they add nothing to any sum, and the update
+// divides by the real batch.len() (rcn.rs:214).
+constexpr int kXcdMaxB = 256;
+inline int xcd_bt(size_t B) { return B <= 32 ? 32 : B <= 64 ? 64 : B <= 128 ? 128 : 256; }
+inline bool xcd_supported(const NetDesc& nd, size_t B) {
+    return (xcd_one_hidden(nd) || xcd_two_hidden(nd)) && B >= 1 && B <= (size_t)kXcdMaxB && xcd_na(nd) + pipe_extra_wgs(nd) <= kXcdWorkers &&
+           pipe_extra_wgs(nd) <= 8;
+}
+// workers of a launch: every feature worker and tail tile, and at least one worker per sample group of eight (BT / 8 <= 32)
+inline int xcd_workers(const NetDesc& nd, int BT) {
+    const int roles = xcd_na(nd) + pipe_extra_wgs(nd), groups = BT / kP2Ts;
+    return roles > groups ? roles : groups;
+}
+inline size_t xcd_buf_bytes(const NetDesc& nd, size_t BT) {
+    const size_t NS = BT / kP2Ts, NA = (size_t)xcd_na(nd);
+    return (NS * NA * kP2Ts * kP2H + 2 * BT * kP2H + 3 * BT * kP2C + NS + (size_t)kP3BFrag * 64) * sizeof(float) +
+           (size_t)(4 * kXcdWorkers + 8) * kXcdFlagStride * sizeof(unsigned) + 512;       // flagA, flagB, xcc, flagD, flagT, error word
 }
 // LDS (floats): two batch buffers of a slice pair, delta_1 of the whole batch (rows padded to 48: conflict-free MFMA operand reads),
-// the tail tiles' K-split partials, the second K-half's partial tiles of the slice gradient, the slice pair of W_0, and the sample
-// group's scratch (slab partial sums, a_1 / delta_2 tiles, target fragments): 151 KB of the CU's 160 -- one worker per CU
-constexpr size_t kXcdXs = (size_t)kXcdSl * 256 * 16;
+// the tail tiles' K-split partials, the slice pair of W_0, and the sample group's scratch (slab partial sums, a_1 / delta_2 tiles,
+// target fragments): 148 KB of the CU's 160 at BT = 256 -- one worker per CU -- 94 / 66 / 51 KB at BT = 128 / 64 / 32
 constexpr int kXcdD1Ld = 48;
-constexpr size_t kXcdLdsFloats = 2 * kXcdXs + (size_t)256 * kXcdD1Ld + (size_t)kDenseWaves * kMtp * kRedTile + (size_t)kXcdSl * kMtp * 256 +
-                                 (size_t)kXcdSl * 16 * kP2H + (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + 3 * kP2C * kLd + 4 * 64 + 64;
+constexpr size_t xcd_lds_floats(int BT) {
+    return 2 * (size_t)kXcdSl * BT * 16 + (size_t)BT * kXcdD1Ld + (size_t)kDenseWaves * kMtp * kRedTile + (size_t)kXcdSl * 16 * kP2H +
+           (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + 3 * kP2C * kLd + 4 * 64 + 64;
+}
 
 // diagnostic build only (-DRCN_STAMPS, tools/stamps_xcd.py): where each worker is at each point of the launch's last-but-one step
 #ifdef RCN_STAMPS
@@ -112,6 +133,13 @@ __device__ inline void xcd_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memo
 // write-through flat_store sc0 sc1 plus a wait.)
 __device__ inline void xcd_flag(unsigned* f, unsigned tag) { __hip_atomic_store(f, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void xcd_flag_wt(unsigned* f, unsigned v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The sticky error word lives twice: in pinned host memory (the host reads it after a synchronise without a copy in the stream) and in
+// device memory (what the waits of this and every later launch look at: a launch that finds it set leaves at once, writing nothing).
+__device__ inline void xcd_raise(unsigned* err_host, unsigned* err_dev, unsigned code) {
+    __hip_atomic_store(err_dev, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // a workgroup barrier for data exchanged through LDS only: outstanding global stores are not waited for
 __device__ inline void xcd_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -155,26 +183,34 @@ template <bool DP> using XcdDpArgs = typename XcdDpSel<DP>::type;
 // [W_2 | b_2] as well (from a_2 / delta_3); everything about the big first layer is unchanged.
 // GA = true: the gather form (rows fetched by the workers; opt-in, see below) -- its own instantiation, so that the default kernels do
 // not carry its registers and branches.
-template <bool DP, bool L3 = false, bool GA = false>
+// BT: the batch the kernel is built for (32 / 64 / 128 / 256); B <= BT is the real batch.len(): samples B .. BT-1 are rows of zeros in
+// LDS and their deltas are masked, `scale` / `loss_scale` are formed from B on the host (rcn.rs:214).
+template <int BT, bool DP, bool L3 = false, bool GA = false>
 __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     NetDesc nd, float* __restrict__ params, const float* __restrict__ xs_all, const float* __restrict__ ys_all, int B, int nb, int G, float scale,
     float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, XcdDpArgs<DP> dp,
-    int xsel, const int* __restrict__ gperm) {
+    int xsel, const int* __restrict__ gperm, unsigned launch_id) {
     constexpr bool gather = GA;
+    static_assert(BT == 32 || BT == 64 || BT == 128 || BT == 256, "k_xcd_epoch: batch instantiations");
+    static_assert(!GA || BT == 256, "the gather form exists for batch 256 only");
+    constexpr size_t kXs = (size_t)kXcdSl * BT * 16;              // one LDS batch buffer of a slice pair
+    constexpr int NS = BT / kP2Ts;                                  // sample groups of eight
     using T = float;
     using acc_t = Mfma16<T>::acc_t;
     using vec4 = Vec4<T>::type;
     if ((int)(blockIdx.x & 7) != xsel) return;                      // the other seven XCDs' blocks
     const int w = (int)(blockIdx.x >> 3);
-    if (w >= kXcdWorkers) return;
+    const int F = nd.dims[0], H = nd.dims[1], Cm = nd.dims[2], C = nd.dims[L3 ? 3 : 2];     // Cm: the units after W_1 (the classes, or h2)
+    const int NA = (G + kXcdSl - 1) / kXcdSl, NT = 1 + nd.tile_start[nd.L] - nd.tile_start[1];    // = pipe_extra_wgs(nd)
+    const int NW = NA + NT > NS ? NA + NT : NS;                     // workers of this launch (host: xcd_workers)
+    if (w >= NW) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     __shared__ int s_abort;
     T* smem = reinterpret_cast<T*>(smem_dyn);
     T* xbuf = smem;                                                 // [2][kXcdSl][B][16]
-    T* d1s = xbuf + 2 * kXcdXs;                                     // delta_1 of the batch [B][48] (32 used)
-    T* red = d1s + 256 * kXcdD1Ld;                                  // tail tiles: [wave][mt][16 x kLd]
-    T* hred = red + kDenseWaves * kMtp * kRedTile;                  // second K-half's partial tile of the slice gradient: [tile][lane][4]
-    T* wsl = hred + kXcdSl * kMtp * 256;                            // [slice][feature 0..15][32]
+    T* d1s = xbuf + 2 * kXs;                                        // delta_1 of the batch [BT][48] (32 used)
+    T* red = d1s + BT * kXcdD1Ld;                                   // tail tiles: [wave][mt][16 x kLd]
+    T* wsl = red + kDenseWaves * kMtp * kRedTile;                   // [slice][feature 0..15][32]
     vec4* zred = reinterpret_cast<vec4*>(wsl + kXcdSl * 16 * kP2H); // [8 waves][64 lanes]
     T* a1s = reinterpret_cast<T*>(zred) + kP2BWaves * 64 * 4;       // a_1 tile  [hidden 32][kLd]
     T* d2s = a1s + kP2H * kLd;                                      // delta_2   [class 16][kLd]
@@ -183,18 +219,15 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     T* d3s = a2s + kP2C * kLd;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
-    const int F = nd.dims[0], H = nd.dims[1], Cm = nd.dims[2], C = nd.dims[L3 ? 3 : 2];     // Cm: the units after W_1 (the classes, or h2)
-    const int NS = B / kP2Ts;                                       // 32 sample groups
-    const int NA = (G + kXcdSl - 1) / kXcdSl, NT = 1 + nd.tile_start[nd.L] - nd.tile_start[1];    // = pipe_extra_wgs(nd)
-    const bool is_a = w < NA, is_t = w >= NA && w < NA + NT;
+    const bool is_a = w < NA, is_t = w >= NA && w < NA + NT, is_s = w < NS;
     const int e = w - NA;                                           // tail tile index when is_t
     const int nsl = is_a ? (G - kXcdSl * w < kXcdSl ? G - kXcdSl * w : kXcdSl) : 0;
     const size_t xs_stride = (size_t)G * B * 16, ys_stride = (size_t)B * C;
     const auto r_slab = XCD_RSRC(bufs.slab, (size_t)NS * NA * kP2Ts * kP2H * 4);
-    const auto r_d1 = XCD_RSRC(bufs.d1, (size_t)B * kP2H * 4), r_a1 = XCD_RSRC(bufs.a1, (size_t)B * kP2H * 4);
-    const auto r_d2 = XCD_RSRC(bufs.d2, (size_t)B * kP2C * 4), r_loss = XCD_RSRC(bufs.loss, (size_t)NS * 4);
+    const auto r_d1 = XCD_RSRC(bufs.d1, (size_t)BT * kP2H * 4), r_a1 = XCD_RSRC(bufs.a1, (size_t)BT * kP2H * 4);
+    const auto r_d2 = XCD_RSRC(bufs.d2, (size_t)BT * kP2C * 4), r_loss = XCD_RSRC(bufs.loss, (size_t)NS * 4);
     const auto r_img = XCD_RSRC(bufs.fragimg, (size_t)(L3 ? kP3BFrag : kP2BFrag) * 64 * 4);
-    const auto r_a2 = XCD_RSRC(bufs.a2, (size_t)B * kP2C * 4), r_d3 = XCD_RSRC(bufs.d3, (size_t)B * kP2C * 4);
+    const auto r_a2 = XCD_RSRC(bufs.a2, (size_t)BT * kP2C * 4), r_d3 = XCD_RSRC(bufs.d3, (size_t)BT * kP2C * 4);
 
     if (tid == 0) s_abort = 0;
     __syncthreads();
@@ -208,25 +241,31 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         long long t0 = 0;
         bool ok = true;
         unsigned mine = 0, v = 0;
+        const bool stale = __hip_atomic_load(bufs.errd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;     // an earlier launch failed: the
+        if (stale && lane == 0) s_abort = 1;                          // parameters in memory are not this launch's starting point -> leave
+        if (!stale)
         for (unsigned it = 0;; ++it) {
-            v = lane < kXcdWorkers ? __hip_atomic_load(bufs.xcc + lane * kXcdFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag0 << 4);
+            v = lane < NW ? __hip_atomic_load(bufs.xcc + lane * kXcdFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag0 << 4);
             if (__all((v >> 4) == (tag0 & 0x0fffffffu))) break;
             if ((it & 255u) == 255u) {
                 const long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
-                else if (now - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                else if (now - t0 > timeout || __hip_atomic_load(bufs.errd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
             }
             __builtin_amdgcn_s_sleep(2);
         }
         mine = __shfl(v, w < 64 ? w : 0, 64) & 0xfu;
-        const bool same = __all(lane >= kXcdWorkers || (v & 0xfu) == mine);
-        if (lane == 0 && !(ok && same)) {
+        const bool same = __all(lane >= NW || (v & 0xfu) == mine);
+        if (lane == 0 && !stale && !(ok && same)) {
             s_abort = 1;
-            __hip_atomic_store(err, ok ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // 2: workers on different XCDs; 1: a wait expired
+            xcd_raise(err, bufs.errd, ok ? 2u : 1u);      // 2: workers on different XCDs; 1: a wait expired
         }
     }
     __syncthreads();
     if (s_abort) return;
+    // (test hook, option "xcd_fault_launch": bit 31 of the launch id makes worker 1 leave here, as a worker that never became resident
+    // would -- every wait for it expires and the launch fails without having written anything)
+    if ((launch_id >> 31) != 0u && w == 1) return;
 
     // ---- feature worker: its slice pair of W_0 into LDS and registers; the first two batches into the two LDS buffers.
     // The gradient of the slice pair is four 16 x 16 tiles (slice sl, hidden half mt); wave u owns tile u & 3 for the samples of K-half
@@ -264,14 +303,17 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             *reinterpret_cast<vec4*>(wsl + (usl * 16 + n) * kP2H + umt * 16 + 4 * g4) = vec4{wcur[0], wcur[1], wcur[2], wcur[3]};
         }
         // batches 0 and 1 of this launch: [slice pair][sample][16] is one contiguous run of nsl * B * 16 floats per batch
+        // (in LDS a slice holds BT rows: rows B .. BT-1, and a missing second slice, are zeros)
         for (int b = 0; b < 2 && b < nb; ++b) {
-            vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(b & 1) * kXcdXs);
-            if (gather) {
-                for (int i = tid; i < kXcdSl * B * 4; i += kXcdThreads) dst[i] = xrow4(b, i);
+            vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(b & 1) * kXs);
+            if constexpr (gather) {
+                for (int i = tid; i < kXcdSl * BT * 4; i += kXcdThreads) dst[i] = xrow4(b, i);
             } else {
                 const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)b * xs_stride + (size_t)(kXcdSl * w) * B * 16);
-                for (int i = tid; i < nsl * B * 4; i += kXcdThreads) dst[i] = src[i];
-                for (int i = nsl * B * 4 + tid; i < kXcdSl * B * 4; i += kXcdThreads) dst[i] = vec4{0, 0, 0, 0};
+                for (int i = tid; i < kXcdSl * BT * 4; i += kXcdThreads) {
+                    const int sl = i / (BT * 4), r = i % (BT * 4);
+                    dst[i] = (sl < nsl && (r >> 2) < B) ? src[sl * B * 4 + r] : vec4{0, 0, 0, 0};
+                }
             }
         }
     }
@@ -299,7 +341,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 
     // partial z_1 of batch `jn` (LDS buffer jn & 1) from the slice pair in LDS -> this worker's part of the slab
     auto forward = [&](int jn) {
-        const T* xb = xbuf + (size_t)(jn & 1) * kXcdXs;
+        const T* xb = xbuf + (size_t)(jn & 1) * kXs;
+        constexpr int NTILE = BT / 16, UT = NTILE > kDenseWaves ? NTILE / kDenseWaves : 1;      // sample tiles, and how many a wave takes
         T wf[kXcdSl][4][kMtp];
 #pragma unroll
         for (int sl = 0; sl < kXcdSl; ++sl)
@@ -307,12 +350,13 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int t = 0; t < kMtp; ++t) wf[sl][i][t] = wsl[(sl * 16 + 4 * g4 + i) * kP2H + t * 16 + n];
+        if (NTILE >= kDenseWaves || wave < NTILE)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                                // B = 256: 16 sample tiles, two per wave
+        for (int u = 0; u < UT; ++u) {                               // BT = 256: 16 sample tiles, two per wave; BT = 32: two tiles, waves 0 and 1
             const int s = 16 * (wave + 8 * u) + n;
             vec4 xv[kXcdSl];
 #pragma unroll
-            for (int sl = 0; sl < kXcdSl; ++sl) xv[sl] = *reinterpret_cast<const vec4*>(xb + ((size_t)sl * B + s) * 16 + 4 * g4);
+            for (int sl = 0; sl < kXcdSl; ++sl) xv[sl] = *reinterpret_cast<const vec4*>(xb + ((size_t)sl * BT + s) * 16 + 4 * g4);
             acc_t acc[kMtp];
 #pragma unroll
             for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
@@ -347,6 +391,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         if (tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag0);
     }
 
+    const bool live = n < kP2Ts && w * kP2Ts + n < B;                 // sample group: this lane's column of the 16-wide tiles is a sample of the batch
     unsigned yrow = 0;                                                // gather form: the row of this lane's sample (8 w + n % 8) in batch j
     if (gather) {
         const unsigned at = (unsigned)(w * kP2Ts + (n & 7));
@@ -358,39 +403,49 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         if (j == nb - 8) XCLOCK(1);
         const bool more = j + 1 < nb;
         // (1) the batch after next, a whole step ahead: into registers now, into the LDS buffer step j's gradient frees
-        vec4 xr[4];
+        constexpr int XR = (kXcdSl * BT * 4 + kXcdThreads - 1) / kXcdThreads;      // 16-byte pieces of a batch's slice pair per thread: 4 at BT = 256
+        vec4 xr[XR];
         const bool pre = is_a && j + 2 < nb;
         if (pre) {
-            if (gather) {
+            if constexpr (gather) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xr[r] = xrow4(j + 2, tid + r * kXcdThreads);
+                for (int r = 0; r < XR; ++r) xr[r] = xrow4(j + 2, tid + r * kXcdThreads);
             } else {
                 const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)(j + 2) * xs_stride + (size_t)(kXcdSl * w) * B * 16);
+                if (B == BT) {                                        // (uniform) the full batch: the image's slice pair is the LDS image
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = tid + r * kXcdThreads;
-                    xr[r] = i < nsl * B * 4 ? src[i] : vec4{0, 0, 0, 0};
+                    for (int r = 0; r < XR; ++r) {
+                        const int i = tid + r * kXcdThreads;
+                        xr[r] = i < nsl * BT * 4 ? src[i] : vec4{0, 0, 0, 0};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < XR; ++r) {
+                        const int i = tid + r * kXcdThreads, sl = i / (BT * 4), rr = i % (BT * 4);
+                        xr[r] = (sl < nsl && (rr >> 2) < B) ? src[sl * B * 4 + rr] : vec4{0, 0, 0, 0};
+                    }
                 }
             }
         }
 
         // =============================================================== sample group w: samples 8w .. 8w+7 of batch j
-        {
+        if (is_s) {
             const int s0 = w * kP2Ts;
+            const int srow = s0 + (n & 7) < B ? s0 + (n & 7) : B - 1;                             // (a padding sample reads a live row; its delta is masked)
             const T* Ys = gather ? ys_all + (size_t)yrow * C
-                                 : ys_all + (size_t)j * ys_stride + (size_t)(s0 + (n & 7)) * C;   // this lane's sample's targets
+                                 : ys_all + (size_t)j * ys_stride + (size_t)srow * C;             // this lane's sample's targets
             T fr[L3 ? kP3BFrag : kP2BFrag];
             if (wave == 0) {
                 XSTAMP(0);
                 // the tail tiles finish well before the feature workers: their flags first, the 24 parameter words of the image
                 // fetched under the wait for the slab
-                bool ok = xcd_wait(bufs.flagT, NT, nullptr, 0, tag, timeout, err);
+                bool ok = xcd_wait(bufs.flagT, NT, nullptr, 0, tag, timeout, bufs.errd);
 #pragma unroll
                 for (int q = 0; q < (L3 ? kP3BFrag : kP2BFrag); ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1(r_img, (q * 64 + lane) * 4);
-                ok = ok && xcd_wait(bufs.flagA, NA, nullptr, 0, tag, timeout, err);
+                ok = ok && xcd_wait(bufs.flagA, NA, nullptr, 0, tag, timeout, bufs.errd);
                 if (!ok && lane == 0) {
                     s_abort = 1;
-                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xcd_raise(err, bufs.errd, 1u);
                 }
                 XSTAMP(1);
             } else if (wave == 6) {                                   // targets per accumulator element: no flag to wait for
@@ -467,7 +522,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                         const int c = Mfma16<T>::row(lane, i);
                         const T a2 = sigmoid_fast(acc[i] + fr[16 + i]);
                         const T diff = a2 - fr[20 + i];
-                        const bool ok = c < C && n < kP2Ts;
+                        const bool ok = c < C && live;
                         dv[i] = ok ? diff * (a2 * ((T)1 - a2)) : (T)0;
                         lsum += ok ? diff * diff : (T)0;
                         d2s[c * kLd + n] = dv[i];
@@ -498,7 +553,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                         const int c = Mfma16<T>::row(lane, i);
                         const T a3 = sigmoid_fast(acc3[i] + fr[36 + i]);
                         const T diff = a3 - fr[20 + i];
-                        const bool ok = c < C && n < kP2Ts;
+                        const bool ok = c < C && live;
                         d3v[i] = ok ? diff * (a3 * ((T)1 - a3)) : (T)0;
                         lsum += ok ? diff * diff : (T)0;
                         d3s[c * kLd + n] = d3v[i];
@@ -552,9 +607,9 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 
         // =============================================================== second half of step j: needs every sample group's outputs
         if (is_a || is_t) {
-            if (wave == 1 && !xcd_wait(bufs.flagB, NS, nullptr, 0, tag, timeout, err) && lane == 0) {
+            if (wave == 1 && !xcd_wait(bufs.flagB, NS, nullptr, 0, tag, timeout, bufs.errd) && lane == 0) {
                 s_abort = 1;
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xcd_raise(err, bufs.errd, 1u);
             }
         }
         if (wave == 1) XSTAMP(6);
@@ -567,13 +622,14 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             // delta_1 of the whole batch into LDS first: 32 KB as 16-byte L1-bypassing loads, 4 per thread (as 4-byte loads straight
             // into MFMA operands it was 16 per lane and the slower part of this phase)
             {
-                vec4 dv[4];
+                constexpr int DR = (BT * 8 + kXcdThreads - 1) / kXcdThreads;
+                vec4 dv[DR];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dv[r] = xcd_ld4(r_d1, (tid + r * kXcdThreads) * 16);
+                for (int r = 0; r < DR; ++r) dv[r] = xcd_ld4(r_d1, (tid + r * kXcdThreads) * 16);       // (past the buffer: zeros, not stored)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = tid + r * kXcdThreads;                 // vec4 index in [B][8]
-                    *reinterpret_cast<vec4*>(d1s + (idx >> 3) * kXcdD1Ld + (idx & 7) * 4) = dv[r];
+                for (int r = 0; r < DR; ++r) {
+                    const int idx = tid + r * kXcdThreads;                 // vec4 index in [BT][8]
+                    if (BT * 8 >= kXcdThreads || idx < BT * 8) *reinterpret_cast<vec4*>(d1s + (idx >> 3) * kXcdD1Ld + (idx & 7) * 4) = dv[r];
                 }
             }
             __syncthreads();
@@ -583,7 +639,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             // in LDS, no second barrier -- on two interleaved accumulators (a single chain would be paced by the 40-cycle dependent
             // latency instead of the 32-cycle issue rate).  Waves 4..7 have no arithmetic here; they move the prefetched batch into LDS.
             if (kh == 0) {
-                const T* xb = xbuf + (size_t)(j & 1) * kXcdXs + (size_t)usl * B * 16;
+                const T* xb = xbuf + (size_t)(j & 1) * kXs + (size_t)usl * BT * 16;
+                constexpr int NQB = BT / 32;                               // blocks of eight k-steps (four samples each)
                 acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
                 // hand-pipelined: the operands of block qb + 1 are requested before the MFMAs of block qb issue, and fences keep the
                 // scheduler from folding that back into load-wait-MFMA triples (which ran at ~100 cycles per MFMA instead of 32)
@@ -593,8 +650,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { av[0][q] = ap[4 * q * kXcdD1Ld]; bv[0][q] = bp[4 * q * 16]; }
 #pragma unroll
-                for (int qb = 0; qb < 8; ++qb) {
-                    if (qb + 1 < 8) {
+                for (int qb = 0; qb < NQB; ++qb) {
+                    if (qb + 1 < NQB) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             av[(qb + 1) & 1][q] = ap[4 * (8 * (qb + 1) + q) * kXcdD1Ld];
@@ -629,7 +686,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     }
                     if (!ok) {
                         s_abort = 1;
-                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        xcd_raise(err, bufs.errd, 1u);
                     }
                 }
 #pragma unroll
@@ -648,9 +705,10 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             // the LDS buffer of batch j is free now (every wave is past its reads): the batch after next moves in; its first reader is
             // the forward of the NEXT iteration, several barriers away
             if (pre) {
-                vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(j & 1) * kXcdXs);
+                vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(j & 1) * kXs);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[tid + r * kXcdThreads] = xr[r];
+                for (int r = 0; r < XR; ++r)
+                    if (kXcdSl * BT * 4 >= kXcdThreads || tid + r * kXcdThreads < kXcdSl * BT * 4) dst[tid + r * kXcdThreads] = xr[r];
             }
             if (more) {
                 forward(j + 1);
@@ -678,7 +736,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     ll_store(mine, (size_t)nd.P, t, seq);
                     T g;
                     if (ll_gather_sum<T>(dp.pd, dp.pstride, (size_t)nd.P, seq, t, dp.ptimeout, g)) t = g;
-                    else { s_abort = 1; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    else { s_abort = 1; xcd_raise(err, bufs.errd, 1u); }
                 }
                 if (loss_dev) loss_dev[j] = t;
                 }
@@ -694,11 +752,12 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
             for (int t = 0; t < kMtp; ++t) acc[t] = acc_t{0, 0, 0, 0};
             {
-                const int kc = wave * (B >> 3);
+                constexpr int NQ = BT / 32;                                // k-steps of four samples per wave: the batch over eight waves
+                const int kc = wave * (BT >> 3);
                 const int cc_ld = (e != 0 && c < Kin) ? c : 0;
-                T bv[8], av[8][kMtp];
+                T bv[NQ], av[NQ][kMtp];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int s = kc + 4 * q + g4;
                     bv[q] = xcd_ld1(r_act, (int)(((size_t)s * ldA + cc_ld) * 4));
 #pragma unroll
@@ -709,7 +768,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const T b = (e != 0 && c < Kin) ? bv[q] : (c == Kin ? (T)1 : (T)0);     // bias column: activation 1 (rcn.rs:302,309)
 #pragma unroll
                     for (int t = 0; t < kMtp; ++t) acc[t] = Mfma16<T>::mfma(t * 16 + n < M ? av[q][t] : (T)0, b, acc[t]);
@@ -729,7 +788,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                         ll_store(mine, tpo, gsum, seq);
                         T g;
                         if (ll_gather_sum<T>(dp.pd, dp.pstride, tpo, seq, gsum, dp.ptimeout, g)) gsum = g;
-                        else { s_abort = 1; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        else { s_abort = 1; xcd_raise(err, bufs.errd, 1u); }
                     }
                     tcur -= scale * gsum;                                    // rcn.rs:214,221
                     int tmo = tm;                                            // opaque: the image addresses are recomputed per step, not
@@ -746,7 +805,21 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         }
     }
 
-    // ---- the slice pair of W_0 and the tail parameters go back to the parameter vector (only a launch that ran to its end gets here)
+    // ---- all or nothing: a worker writes its parameters back only after EVERY worker has finished the last step (one more flag
+    // round per launch) -- a wait that expires in the last step on one worker leaves the whole parameter vector as the launch found it
+    {
+        const unsigned tagD = tag0 + (unsigned)nb - 1u;
+        __syncthreads();
+        if (tid == 0) xcd_flag(bufs.flagD + w * kXcdFlagStride, tagD);
+        if (wave == 0 && !xcd_wait(bufs.flagD, NW, nullptr, 0, tagD, timeout, bufs.errd) && lane == 0) {
+            s_abort = 1;
+            xcd_raise(err, bufs.errd, 1u);
+        }
+        __syncthreads();
+        if (s_abort) return;
+        if (w == 0 && tid == 0) __hip_atomic_store(bufs.done, launch_id & 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // ---- the slice pair of W_0 and the tail parameters go back to the parameter vector
     if (is_a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)

@@ -67,9 +67,55 @@ struct EpochKey {
 
 }  // namespace
 
+// Per-context options (rcn_hip_set_option / rcn_hip_get_option).  The environment variable of the same meaning only SEEDS the default
+// when the context is created; two contexts of one process can differ, and nothing reads the environment afterwards.
+struct CtxOptions {
+    long long xcd = 1;                  // "xcd"               RCN_HIP_XCD            0: dense path 0 (auto) never selects the resident one-XCD kernel
+    long long xcd_select = 0;           // "xcd_select"        RCN_HIP_XCD_SELECT     which blocks are the workers: blockIdx.x % 8 == this (0..7)
+    long long xcd_gather = 0;           // "xcd_gather"        RCN_HIP_XCD_GATHER     1: rows fetched by the resident kernel itself (B = 256; measured slower)
+    long long xcd_timeout_ticks = 20000000;   // "xcd_timeout_ticks"            bound of every wait inside the resident kernel, 100 MHz ticks (0.2 s)
+    long long xcd_exact_lds = 0;        // "xcd_exact_lds"                            1: the resident kernel asks for exactly the LDS it uses (two workers may share a CU:
+                                        //                                            what lets two contexts' kernels be resident on ONE device); 0: at least half a CU's
+    long long xcd_fault_launch = 0;     // "xcd_fault_launch"                         test hook: the n-th resident launch of the context (1-based) loses a worker
+    long long xcd_auto_fallback = 1;    // "xcd_auto_fallback"                        1: an expired wait of the single-GPU resident kernel re-runs the segment on the two-kernel pipeline
+    long long dp_p2p = 1;               // "dp_p2p"            RCN_HIP_DP_P2P         0: no peer exchange (ncclAllReduce), 1: when world > 1, 2: also at world 1
+    long long dp_fused = 1;             // "dp_fused"          RCN_HIP_DP_FUSED       0: the exchange never runs inside a step kernel
+    long long dp_timeout_ticks = 100000000;   // "dp_timeout_ticks" RCN_HIP_DP_TIMEOUT_TICKS  bound of a peer wait, 100 MHz ticks (1 s)
+    long long dp_cached_buf = 0;        // "dp_cached_buf"     RCN_HIP_DP_CACHED_BUF  1: exported buffers in ordinary (cached) device memory (A/B measurements)
+    long long dp_graph = 1;             // "dp_graph"          RCN_HIP_DP_GRAPH       0: the three-kernel data-parallel step is enqueued eagerly
+    long long feat_waves = 1;           // "feat_waves"        RCN_HIP_FEAT_WAVES     2: two waves per picture in k_features_cpcp (measured neutral)
+    long long no_fragimg = 0;           // "no_fragimg"        RCN_HIP_NO_FRAGIMG     1: k_p2_b gathers its tail parameters itself
+    long long exact_div_only = 0;       // "exact_div_only"    RCN_HIP_EXACT_DIV_ONLY 1: the f32 standardisation always divides
+    long long pack_segment_bytes = (long long)64 << 20;   // "pack_segment_bytes" RCN_HIP_PACK_SEGMENT_BYTES  one half of the epoch image
+};
+
+namespace {
+struct OptDesc { const char* name; const char* env; long long CtxOptions::*field; long long lo, hi; };
+const OptDesc kOptTable[] = {
+    {"xcd", "RCN_HIP_XCD", &CtxOptions::xcd, 0, 1},
+    {"xcd_select", "RCN_HIP_XCD_SELECT", &CtxOptions::xcd_select, 0, 7},
+    {"xcd_gather", "RCN_HIP_XCD_GATHER", &CtxOptions::xcd_gather, 0, 1},
+    {"xcd_timeout_ticks", "RCN_HIP_XCD_TIMEOUT_TICKS", &CtxOptions::xcd_timeout_ticks, 1, 1LL << 40},
+    {"xcd_exact_lds", "RCN_HIP_XCD_EXACT_LDS", &CtxOptions::xcd_exact_lds, 0, 1},
+    {"xcd_auto_fallback", "RCN_HIP_XCD_AUTO_FALLBACK", &CtxOptions::xcd_auto_fallback, 0, 1},
+    {"xcd_fault_launch", "RCN_HIP_XCD_FAULT_LAUNCH", &CtxOptions::xcd_fault_launch, 0, 0x7fffffff},
+    {"dp_p2p", "RCN_HIP_DP_P2P", &CtxOptions::dp_p2p, 0, 2},
+    {"dp_fused", "RCN_HIP_DP_FUSED", &CtxOptions::dp_fused, 0, 1},
+    {"dp_timeout_ticks", "RCN_HIP_DP_TIMEOUT_TICKS", &CtxOptions::dp_timeout_ticks, 1, 1LL << 40},
+    {"dp_cached_buf", "RCN_HIP_DP_CACHED_BUF", &CtxOptions::dp_cached_buf, 0, 1},
+    {"dp_graph", "RCN_HIP_DP_GRAPH", &CtxOptions::dp_graph, 0, 1},
+    {"feat_waves", "RCN_HIP_FEAT_WAVES", &CtxOptions::feat_waves, 1, 2},
+    {"no_fragimg", "RCN_HIP_NO_FRAGIMG", &CtxOptions::no_fragimg, 0, 1},
+    {"exact_div_only", "RCN_HIP_EXACT_DIV_ONLY", &CtxOptions::exact_div_only, 0, 1},
+    {"pack_segment_bytes", "RCN_HIP_PACK_SEGMENT_BYTES", &CtxOptions::pack_segment_bytes, 1, 1LL << 40},
+};
+}  // namespace
+
 struct rcn_hip_ctx {
     int device = 0;
     int dtype = RCN_HIP_F32;
+    CtxOptions opt;
+    std::string dp_fault;                   // RCN_HIP_DP_FAULT as it was when the context was created (fault injection for the admission tests)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     FeatDesc fd{};
@@ -97,7 +143,6 @@ struct rcn_hip_ctx {
                                                        // (epoch_nb = 0: none; any other call that re-packs the image ends it)
     void* pin_host = nullptr;               // small pinned, device-mapped staging block for the serving path (classify)
     void* pin_dev = nullptr;
-    size_t pack_seg_bytes = (size_t)64 << 20;   // size of one half of the epoch image (env RCN_HIP_PACK_SEGMENT_BYTES, for tests)
     DevBuf params, acts, deltas, loss_part, grad, xstage, ystage, ostage, scratch0, scratch1, scratch2, redpart, misc;
     std::map<EpochKey, hipGraphExec_t> graphs, dp_graphs, img_graphs, step_graphs;
     ncclComm_t comm = nullptr;              // data-parallel group (rcn_hip_dp_init); one rank per context
@@ -123,6 +168,35 @@ struct rcn_hip_ctx {
     struct { const float* X = nullptr; const float* Y = nullptr; const int32_t* perm = nullptr; size_t B = 0, nb = 0; } xg;   // the last call the resident
                                             // kernel ran in its gather form (rcn_hip_time_kernels_dev times that form over the same rows)
     bool xcd_dp_used = false;               // the resident kernel ran data-parallel steps since dp_init: dp_finalize clears its timeout word
+    bool xcd_stepped_down = false;          // a wait of the resident kernel expired and the library stepped this context down to the two-kernel pipeline
+    unsigned xcd_launch_id = 0;             // id of the newest resident launch enqueued (the kernel reports the newest COMPLETE one in xerr_host[1])
+    int fallbacks_taken = 0;                // rcn_hip_fallbacks_taken
+    bool replaying = false;                 // the redo log is being replayed: nothing is logged
+    // Redo log of the training calls whose resident launches have not been seen complete yet (dense_xcd.hpp: parameters are written only
+    // by a launch ALL of whose workers finished, and a launch that finds the error word set leaves at once -- so after a failure the
+    // parameters are the state after launch xerr_host[1], and everything enqueued behind it can be re-run on the two-kernel pipeline).
+    struct PermSource {                      // how a call's index rows came to be: a device shuffle (re-drawn from its seed) or a host upload (kept)
+        int kind = 0;                        // 0 none (caller's buffer, taken as unchanged), 1 rcn_hip_shuffle_dev, 2 upload
+        int32_t* buf = nullptr; size_t n = 0, passes = 0; uint64_t seed = 0;
+        std::vector<int32_t> host;
+    };
+    struct XcdLaunchRec { unsigned id; size_t k0, n; };
+    struct BeginRec {                        // the arguments of the newest rcn_hip_epoch_begin*_dev (the epoch image can be laid out again from them)
+        const void* X = nullptr; const void* Y = nullptr; const int32_t* perm = nullptr; size_t B = 0, nb = 0; bool from_images = false; bool valid = false;
+        PermSource src;
+    };
+    struct RedoRec {
+        int kind = 0;                        // 0 train_epoch (X, Y, perm), 1 epoch_steps on the image of `begin`
+        const void* X = nullptr; const void* Y = nullptr; const int32_t* perm = nullptr;
+        size_t B = 0, nb = 0, j0 = 0; double eta = 0; void* loss_dev = nullptr; bool from_images = false;
+        PermSource src;
+        BeginRec begin;
+        std::vector<XcdLaunchRec> launches;
+    };
+    std::vector<RedoRec> redo;
+    std::vector<PermSource> perm_sources;    // newest source per index buffer
+    BeginRec last_begin;
+    unsigned* xerrd = nullptr;               // device copy of the resident kernel's sticky error word (outlives every workspace reset)
     int xcd_probe = 0;                      // 0 not probed, 1 the blocks with equal b % 8 share one XCD and the eight classes sit on eight XCDs, -1 not so
     struct ResidentSet {                     // rcn_hip_load_data: one of RCN::train's two data sets, kept in HBM (rcn.rs:134-137)
         DevBuf imgs, X, Y, perm, loss;
@@ -474,7 +548,7 @@ int launch_pipe_b(rcn_hip_ctx* c, const void* ys, size_t B) {
 // next to the source set however many batches one call covers (a 411 MB image made the per-step kernels ~15 % slower).
 size_t pack_segment(const rcn_hip_ctx* c, size_t B) {
     const size_t per_batch = (size_t)pipe_slices(c->nd) * B * 16 * c->esz();
-    const size_t seg = c->pack_seg_bytes / (per_batch ? per_batch : 1);
+    const size_t seg = (size_t)c->opt.pack_segment_bytes / (per_batch ? per_batch : 1);
     return seg ? seg : 1;
 }
 
@@ -521,8 +595,7 @@ static int resident_grid(rcn_hip_ctx* c, Kern kern, size_t work, int block = 64)
 // f32 standardisation in the specialised feature kernels: the reciprocal to use, or 0 when only a true division is
 // bit-exact for the scale in force (features.hpp: standardise_fast_is_exact, checked once per (mean, sd))
 static float fast_standardise_rcp(rcn_hip_ctx* c) {
-    static const bool off = getenv("RCN_HIP_EXACT_DIV_ONLY") && atoi(getenv("RCN_HIP_EXACT_DIV_ONLY")) != 0;
-    if (off) return 0.f;
+    if (c->opt.exact_div_only) return 0.f;
     const float m = (float)c->mean, sd = (float)c->sd;
     if (!c->fd_checked || std::memcmp(&m, &c->fd_mean, 4) != 0 || std::memcmp(&sd, &c->fd_sd, 4) != 0) {
         c->fd_mean = m; c->fd_sd = sd; c->fd_rcp = 0.f;
@@ -590,8 +663,7 @@ int enqueue_pipe_steps(rcn_hip_ctx* c, const void* X, const void* Y, const int32
     // parameter vector and kept current by k_p2_a's tail tiles for the rest of this call
     struct FragGuard { rcn_hip_ctx* c; ~FragGuard() { c->frag_on = false; } } frag_guard{c};
     if constexpr (std::is_same<T, float>::value) {
-        static const bool frag_off = getenv("RCN_HIP_NO_FRAGIMG") && atoi(getenv("RCN_HIP_NO_FRAGIMG")) != 0;
-        if (p2_supported(c->nd, B) && !p2_one_object() && !frag_off && c->fragimg.p) {
+        if (p2_supported(c->nd, B) && !p2_one_object() && !c->opt.no_fragimg && c->fragimg.p) {
             hipLaunchKernelGGL(k_p2_fragimg, dim3(1), dim3(512), 0, c->stream, c->nd, (const float*)c->params.p, (float*)c->fragimg.p);
             HIP_TRY(c, hipGetLastError());
             c->frag_on = true;
@@ -747,19 +819,15 @@ static bool use_persist(const rcn_hip_ctx*, size_t) { return false; }
 #endif
 
 // ---- the resident one-XCD epoch kernel (dense_xcd.hpp) ------------------------------------------------------------------
-constexpr long long kXcdTimeoutTicks = 20000000LL;          // 0.2 s of the 100 MHz wall clock per wait
+constexpr size_t kXcdProbeLds = xcd_lds_floats(256) * sizeof(float);
 
 // Are the 32 blocks with blockIdx.x % 8 == 0 of a 256-block launch with this LDS footprint on ONE XCD, and every other block
 // elsewhere?  Asked once per context, synchronously, before the resident kernel is ever selected (the kernel checks again itself).
 int xcd_probe(rcn_hip_ctx* c) {
     if (c->xcd_probe != 0) return RCN_HIP_OK;
     c->xcd_probe = -1;
-    const size_t lds = kXcdLdsFloats * sizeof(float);
+    const size_t lds = kXcdProbeLds;
     RCN_TRY(set_dyn_lds(c, k_xcd_probe, lds));
-    RCN_TRY(set_dyn_lds(c, k_xcd_epoch<false>, lds));
-    RCN_TRY(set_dyn_lds(c, k_xcd_epoch<true>, lds));
-    RCN_TRY(set_dyn_lds(c, (k_xcd_epoch<false, true>), lds));
-    RCN_TRY(set_dyn_lds(c, (k_xcd_epoch<false, false, true>), lds));
     DevBuf out;
     HIP_TRY(c, out.ensure(8 * kXcdWorkers * sizeof(unsigned)));
     std::vector<unsigned> host(8 * kXcdWorkers);
@@ -786,92 +854,125 @@ int xcd_probe(rcn_hip_ctx* c) {
 bool use_xcd(rcn_hip_ctx* c, size_t B) {
     if (c->dtype != RCN_HIP_F32 || !xcd_supported(c->nd, B)) return false;
     if (c->dense_path != 0 && c->dense_path != 5) return false;
-    static const int env = [] { const char* e = std::getenv("RCN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
-    if (c->dense_path == 0 && env == 0) return false;
+    if (c->xcd_stepped_down) return false;                              // (rcn_hip_set_dense_path(ctx, 5) arms it again)
+    if (c->dense_path == 0 && c->opt.xcd == 0) return false;
     if (c->xcd_probe == 0 && xcd_probe(c) != RCN_HIP_OK) return false;
     return c->xcd_probe == 1;
 }
 
+int xcd_heal(rcn_hip_ctx* c);
+
 int ensure_xcd_ws(rcn_hip_ctx* c, size_t B) {
     if (!c->xerr_host) {
         HIP_TRY(c, hipHostMalloc((void**)&c->xerr_host, 64, hipHostMallocMapped));
-        *c->xerr_host = 0;
+        c->xerr_host[0] = 0;                    // [0] the sticky error word, [1] id of the newest launch all of whose workers finished
+        c->xerr_host[1] = 0;
         HIP_TRY(c, hipHostGetDevicePointer((void**)&c->xerr_dev, c->xerr_host, 0));
+        HIP_TRY(c, hipMalloc((void**)&c->xerrd, 256));
+        HIP_TRY(c, hipMemsetAsync(c->xerrd, 0, 256, c->stream));
     }
     if (*c->xerr_host != 0)
         return fail(c, RCN_HIP_ERR_HIP, *c->xerr_host == 2 ? "train_epoch: the resident kernel's workgroups did not share one XCD in an earlier call; nothing was "
                                                              "updated by it.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline"
                                                            : "train_epoch: a bounded wait inside the resident kernel expired in an earlier call (is the device shared?); "
                                                              "that call's segment was not applied.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline");
-    const size_t bytes = xcd_buf_bytes(c->nd, B);
-    if (c->xcd_B != B || c->xcdbuf.cap < bytes) {
+    const size_t BT = (size_t)xcd_bt(B);
+    const size_t bytes = xcd_buf_bytes(c->nd, BT);
+    if (c->xcd_B != BT || c->xcdbuf.cap < bytes) {
         HIP_TRY(c, c->xcdbuf.ensure(bytes));
-        HIP_TRY(c, hipMemsetAsync(c->xcdbuf.p, 0, c->xcdbuf.cap, c->stream));      // flags 0: tags start at 1
-        c->xcd_B = B;
+        HIP_TRY(c, hipMemsetAsync(c->xcdbuf.p, 0, c->xcdbuf.cap, c->stream));      // flags 0: tags start at 1; error word 0
+        c->xcd_B = BT;
         c->xcd_tag = 0;
     }
     return RCN_HIP_OK;
 }
 
-// Which blocks of the 256 are the workers: blockIdx.x % 8 == xcd_select().  0 on a GPU of its own; the one-GPU test harness gives every
-// rank process its own XCD (RCN_HIP_XCD_SELECT) so that two resident kernels can be on the device at once.
-static int xcd_select() {
-    const char* e = std::getenv("RCN_HIP_XCD_SELECT");
-    const int v = e ? std::atoi(e) : 0;
-    return v >= 0 && v < 8 ? v : 0;
-}
-
 P2PDesc p2p_desc(const rcn_hip_ctx* c);
-long long p2p_timeout_ticks_fwd();
+static long long p2p_timeout_ticks(const rcn_hip_ctx* c);
 
-// nb consecutive steps over batches whose packed images are contiguous from xs / ys (one segment of the epoch image).
-// dp: the data-parallel step -- B is this rank's shard, the update uses the global batch length, gradients meet inside the kernel.
-// gather: xs / ys are the caller's X[rows][F] / Y[rows][C] as stored and gperm the order of their rows (NULL: stored order) -- the kernel
-// fetches every batch's rows itself, a step ahead; else they are the packed epoch image (k_pack_epoch) and gperm is unused.
-int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, double eta, float* loss_dev, bool dp = false,
-                      const int32_t* gperm = nullptr, bool gather = false) {
-    const NetDesc& nd = c->nd;
-    const size_t NS = B / kP2Ts, NA = (size_t)xcd_na(nd);
+// the workspace of one batch instantiation, carved out of c->xcdbuf
+static XcdBufs xcd_bufs(rcn_hip_ctx* c, size_t BT) {
+    const size_t NS = BT / kP2Ts, NA = (size_t)xcd_na(c->nd);
     XcdBufs xb;
     float* f = (float*)c->xcdbuf.p;
     xb.slab = f; f += NS * NA * kP2Ts * kP2H;
-    xb.d1 = f;   f += B * kP2H;
-    xb.a1 = f;   f += B * kP2H;
-    xb.d2 = f;   f += B * kP2C;
-    xb.a2 = f;   f += B * kP2C;
-    xb.d3 = f;   f += B * kP2C;
+    xb.d1 = f;   f += BT * kP2H;
+    xb.a1 = f;   f += BT * kP2H;
+    xb.d2 = f;   f += BT * kP2C;
+    xb.a2 = f;   f += BT * kP2C;
+    xb.d3 = f;   f += BT * kP2C;
     xb.loss = f; f += NS;
     xb.fragimg = f; f += (size_t)kP3BFrag * 64;
     unsigned* u = (unsigned*)(((uintptr_t)f + 127) & ~(uintptr_t)127);
     xb.flagA = u; u += kXcdWorkers * kXcdFlagStride;
     xb.flagB = u; u += kXcdWorkers * kXcdFlagStride;
     xb.xcc = u;   u += kXcdWorkers * kXcdFlagStride;
+    xb.flagD = u; u += kXcdWorkers * kXcdFlagStride;
     xb.flagT = u;
-    // (the tail parameters as the sample groups' operand fragments -- xb.fragimg -- are written by the kernel's own tail tiles: at its
-    // start from the parameter vector, then after every update; its pads are the zeros the buffer was created with)
-    const unsigned tag0 = c->xcd_tag + 1;
-    const double Bg = (double)B * (dp ? (double)c->dp_world : 1.0);          // the global batch.len() of rcn.rs:214
-    const float scale = (float)(eta / Bg), loss_scale = (float)(1.0 / (2.0 * Bg));
-    const size_t lds = kXcdLdsFloats * sizeof(float);
-    // instantiations: one hidden layer (single-GPU, data-parallel, gather form), two hidden layers (single-GPU)
-#define RCN_XCD_LAUNCH(KERN, DPARG)                                                                                                                  \
-    hipLaunchKernelGGL(KERN, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb, pipe_slices(nd), \
-                       scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, dp ? kXcdTimeoutTicks + 2 * p2p_timeout_ticks_fwd() : kXcdTimeoutTicks, DPARG,  \
-                       xcd_select(), (const int*)gperm)
+    xb.errd = c->xerrd;
+    xb.done = c->xerr_dev + 1;
+    return xb;
+}
+
+// One launch of the instantiation for batch BT.  The kernel asks for at least half a CU's LDS plus one byte so that no two of its
+// workers share a CU (option "xcd_exact_lds" = 1: exactly what it uses -- two contexts' resident kernels can then be on one device).
+template <int BT>
+int xcd_launch_bt(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, float scale, float loss_scale, float* loss_dev, bool dp,
+                  const int32_t* gperm, bool gather, const XcdBufs& xb, unsigned tag0, unsigned launch_id) {
+    const NetDesc& nd = c->nd;
+    size_t lds = xcd_lds_floats(BT) * sizeof(float);
+    if (!c->opt.xcd_exact_lds && lds < 81 * 1024) lds = 81 * 1024;
+    const long long to = c->opt.xcd_timeout_ticks;
+    const int xsel = (int)c->opt.xcd_select;
+#define RCN_XCD_LAUNCH(KERN, TO, DPARG)                                                                                                                   \
+    do {                                                                                                                                                  \
+        RCN_TRY(set_dyn_lds(c, KERN, lds));                                                                                                               \
+        hipLaunchKernelGGL(KERN, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,              \
+                           pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, TO, DPARG, xsel, (const int*)gperm, launch_id);           \
+    } while (0)
     if (dp) {
-        RCN_XCD_LAUNCH((k_xcd_epoch<true>), (XcdDpOn{p2p_desc(c), c->p2p.stride, c->p2p.seq + 1, p2p_timeout_ticks_fwd()}));
+        RCN_XCD_LAUNCH((k_xcd_epoch<BT, true>), to + 2 * p2p_timeout_ticks(c), (XcdDpOn{p2p_desc(c), c->p2p.stride, c->p2p.seq + 1, p2p_timeout_ticks(c)}));
         c->p2p.seq += (unsigned)nb;
         c->xcd_dp_used = true;
     } else if (nd.L == 3) {
-        RCN_XCD_LAUNCH((k_xcd_epoch<false, true>), XcdDpOff{});
+        RCN_XCD_LAUNCH((k_xcd_epoch<BT, false, true>), to, XcdDpOff{});
     } else if (gather) {
-        RCN_XCD_LAUNCH((k_xcd_epoch<false, false, true>), XcdDpOff{});
+        if constexpr (BT == 256) RCN_XCD_LAUNCH((k_xcd_epoch<256, false, false, true>), to, XcdDpOff{});
+        else return fail(c, RCN_HIP_ERR_UNSUPPORTED, "the gather form of the resident kernel exists for batch 256 only");
     } else {
-        RCN_XCD_LAUNCH((k_xcd_epoch<false>), XcdDpOff{});
+        RCN_XCD_LAUNCH((k_xcd_epoch<BT, false>), to, XcdDpOff{});
     }
 #undef RCN_XCD_LAUNCH
     HIP_TRY(c, hipGetLastError());
+    return RCN_HIP_OK;
+}
+
+// nb consecutive steps over batches whose packed images are contiguous from xs / ys (one segment of the epoch image).
+// dp: the data-parallel step -- B is this rank's shard, the update uses the global batch length, gradients meet inside the kernel.
+// gather: xs / ys are the caller's X[rows][F] / Y[rows][C] as stored and gperm the order of their rows (NULL: stored order) -- the kernel
+// fetches every batch's rows itself, a step ahead; else they are the packed epoch image (k_pack_epoch) and gperm is unused.
+// *id_out (nullable): the launch's id, which the kernel reports in `done` once all of its workers have finished.
+int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, double eta, float* loss_dev, bool dp = false,
+                      const int32_t* gperm = nullptr, bool gather = false, unsigned* id_out = nullptr) {
+    const int BT = xcd_bt(B);
+    const XcdBufs xb = xcd_bufs(c, (size_t)BT);
+    // (the tail parameters as the sample groups' operand fragments -- xb.fragimg -- are written by the kernel's own tail tiles: at its
+    // start from the parameter vector, then after every update; its pads are the zeros the buffer was created with)
+    const unsigned tag0 = c->xcd_tag + 1;
+    const unsigned id = ++c->xcd_launch_id & 0x7fffffffu;
+    const unsigned id_arg = id | ((c->opt.xcd_fault_launch != 0 && (long long)id == c->opt.xcd_fault_launch) ? 0x80000000u : 0u);
+    const double Bg = (double)B * (dp ? (double)c->dp_world : 1.0);          // the global batch.len() of rcn.rs:214
+    const float scale = (float)(eta / Bg), loss_scale = (float)(1.0 / (2.0 * Bg));
+    int st;
+    switch (BT) {
+    case 32:  st = xcd_launch_bt<32>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg); break;
+    case 64:  st = xcd_launch_bt<64>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg); break;
+    case 128: st = xcd_launch_bt<128>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg); break;
+    default:  st = xcd_launch_bt<256>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg); break;
+    }
+    RCN_TRY(st);
     c->xcd_tag += (unsigned)nb;
+    if (id_out) *id_out = id;
     return RCN_HIP_OK;
 }
 
@@ -882,22 +983,57 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
 // 0.39 us per step amortised: 7.39 vs 6.80 us per step in the bench's steady state.
 constexpr size_t kXcdMaxStepsPerLaunch = 1u << 20;
 static bool xcd_gather(const rcn_hip_ctx* c) {
-    static const int env = [] { const char* e = std::getenv("RCN_HIP_XCD_GATHER"); return e ? std::atoi(e) : 0; }();
-    return env != 0 && c->nd.dims[0] % 4 == 0 && c->nd.L == 2;
+    return c->opt.xcd_gather != 0 && c->nd.dims[0] % 4 == 0 && c->nd.L == 2;
+}
+
+// the newest source of the index rows `perm` points into (a shuffle or an upload the library performed), or none
+static rcn_hip_ctx::PermSource perm_source_of(const rcn_hip_ctx* c, const int32_t* perm) {
+    if (perm)
+        for (auto it = c->perm_sources.rbegin(); it != c->perm_sources.rend(); ++it)
+            if (perm >= it->buf && perm < it->buf + it->n * it->passes) return *it;
+    return rcn_hip_ctx::PermSource{};
+}
+static void note_perm_source(rcn_hip_ctx* c, rcn_hip_ctx::PermSource&& src) {
+    if (c->replaying) return;
+    for (auto& e : c->perm_sources)
+        if (e.buf == src.buf) { e = std::move(src); return; }
+    if (c->perm_sources.size() >= 8) c->perm_sources.erase(c->perm_sources.begin());
+    c->perm_sources.push_back(std::move(src));
 }
 
 // a whole call on the resident kernel: batches [j0, j0 + nb) of the call, packed segment by segment (or already packed)
 int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool from_images,
                       bool prepacked, size_t j0, size_t pre_seg, bool dp = false) {
     const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L];
+    // single-GPU calls are journalled until their launches have been seen complete (xcd_verify): what a failed launch did not apply is
+    // re-run from here on the two-kernel pipeline
+    rcn_hip_ctx::RedoRec* rec = nullptr;
+    if (!dp && !c->replaying && c->opt.xcd_auto_fallback) {
+        // (launches the kernel has already reported complete need no record any more: xerr_host[1] is pinned memory, read for free)
+        if (c->xerr_host && c->xerr_host[0] == 0) {
+            const unsigned done = c->xerr_host[1];
+            size_t keep = 0;
+            while (keep < c->redo.size() && (c->redo[keep].launches.empty() || (int)(c->redo[keep].launches.back().id - done) <= 0)) ++keep;
+            if (keep) c->redo.erase(c->redo.begin(), c->redo.begin() + keep);
+        }
+        c->redo.emplace_back();
+        rec = &c->redo.back();
+        rec->kind = prepacked ? 1 : 0;
+        rec->X = X; rec->Y = Y; rec->perm = perm; rec->B = B; rec->nb = nb; rec->j0 = j0; rec->eta = eta; rec->loss_dev = loss_dev; rec->from_images = from_images;
+        if (!prepacked) rec->src = perm_source_of(c, perm);
+        else rec->begin = c->last_begin;
+    }
+    auto note = [&](unsigned id, size_t k0, size_t n) { if (rec) rec->launches.push_back({id, k0, n}); };
     if (!prepacked && !from_images && !dp && xcd_gather(c)) {
         c->xg.X = (const float*)X; c->xg.Y = (const float*)Y; c->xg.perm = perm; c->xg.B = B; c->xg.nb = nb;
         // feature vectors as stored: no packed image at all -- ONE launch walks the whole call, every worker gathering its 128 bytes of
         // each row of the batch after next while it works on the current one (the bytes k_pack_epoch would read, write and hand back)
         for (size_t k = 0; k < nb;) {
             const size_t n = nb - k < kXcdMaxStepsPerLaunch ? nb - k : kXcdMaxStepsPerLaunch;
+            unsigned id = 0;
             RCN_TRY(enqueue_xcd_steps(c, (const float*)X, (const float*)Y, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr, dp,
-                                      perm ? perm + k * B : nullptr, true));
+                                      perm ? perm + k * B : nullptr, true, &id));
+            note(id, k, n);
             if (!perm) { X = (const float*)X + n * B * c->nd.dims[0]; Y = (const float*)Y + n * B * Cc; }
             k += n;
         }
@@ -913,7 +1049,9 @@ int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
         }
         const float* xs = (const float*)c->xpack.p + slot(j) * G * B * 16;
         const float* ys = (const float*)c->ypack.p + slot(j) * B * Cc;
-        RCN_TRY(enqueue_xcd_steps(c, xs, ys, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr, dp));
+        unsigned id = 0;
+        RCN_TRY(enqueue_xcd_steps(c, xs, ys, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr, dp, nullptr, false, &id));
+        note(id, k, n);
         j += n; k += n;
     }
     return RCN_HIP_OK;                      // (the sticky error word lives in pinned host memory: current once the stream has drained)
@@ -941,6 +1079,77 @@ int enqueue_train_step(rcn_hip_ctx* c, const void* x, const void* y, const int32
 
 int check_ctx(const rcn_hip_ctx* c) { return c ? RCN_HIP_OK : RCN_HIP_ERR_INVALID_ARG; }
 
+// the resident kernel's sticky error word, both copies (a recovery action of the caller, the heal below, the end of a data-parallel group)
+int xcd_clear_error(rcn_hip_ctx* c) {
+    if (c->xerr_host) c->xerr_host[0] = 0;
+    if (c->xerrd) HIP_TRY(c, hipMemsetAsync(c->xerrd, 0, 4, c->stream));
+    return RCN_HIP_OK;
+}
+
+// Self-healing step-down of the single-GPU resident kernel.  Precondition: the stream is drained and the sticky word is set (a bounded
+// wait expired -- typically a co-tenant holds CUs of the XCD, so the 32 workers were never resident together -- or the workers were
+// not on one XCD).  Nothing a failed launch computed reached memory and every launch enqueued behind it left at once, so the
+// parameter vector is the state after launch xerr_host[1]: the context steps down to the two-kernel pipeline for good, and every
+// step the journal holds beyond that launch is re-run there, from the arguments its call was given (index rows the library itself
+// shuffled or uploaded are re-created first; anything else the calls read is taken to be unchanged -- the contract of an
+// asynchronous call whose inputs must stay untouched until a synchronise).  Reported through rcn_hip_fallbacks_taken, not as an error.
+static int redo_perm(rcn_hip_ctx* c, const rcn_hip_ctx::PermSource& ps) {
+    if (ps.kind == 1) return rcn_hip_shuffle_dev(c, ps.buf, ps.n, ps.passes, ps.seed);
+    if (ps.kind == 2) {
+        HIP_TRY(c, hipMemcpyAsync(ps.buf, ps.host.data(), ps.host.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return RCN_HIP_OK;
+}
+static int redo_begin(rcn_hip_ctx* c, const rcn_hip_ctx::BeginRec& b) {
+    RCN_TRY(redo_perm(c, b.src));
+    return b.from_images ? rcn_hip_epoch_begin_images_dev(c, (const uint8_t*)b.X, b.Y, b.perm, b.B, b.nb) : rcn_hip_epoch_begin_dev(c, b.X, b.Y, b.perm, b.B, b.nb);
+}
+int xcd_heal(rcn_hip_ctx* c) {
+    const unsigned code = c->xerr_host[0], done = c->xerr_host[1];
+    RCN_TRY(xcd_clear_error(c));
+    c->xcd_stepped_down = true;
+    c->fallbacks_taken += 1;
+    std::vector<rcn_hip_ctx::RedoRec> redo;
+    redo.swap(c->redo);
+    c->replaying = true;
+    struct Guard { rcn_hip_ctx* c; ~Guard() { c->replaying = false; } } guard{c};
+    const size_t F = (size_t)c->nd.dims[0], Cc = (size_t)c->nd.dims[c->nd.L], es = c->esz(), HW = (size_t)c->fd.H * c->fd.W;
+    const bool image_was_live = c->epoch_nb != 0;
+    bool image_touched = false;
+    for (const auto& r : redo) {
+        size_t k0 = r.nb;                        // the first step of this call no complete launch covered
+        for (const auto& l : r.launches)
+            if ((int)(l.id - done) > 0) { k0 = l.k0; break; }
+        if (k0 >= r.nb) continue;
+        void* loss = r.loss_dev ? (char*)r.loss_dev + k0 * es : nullptr;
+        if (r.kind == 0) {
+            RCN_TRY(redo_perm(c, r.src));
+            const int32_t* pm = r.perm ? r.perm + k0 * r.B : nullptr;
+            const void* Y = r.perm ? r.Y : (const void*)((const char*)r.Y + k0 * r.B * Cc * es);
+            if (r.from_images) {
+                const uint8_t* X = r.perm ? (const uint8_t*)r.X : (const uint8_t*)r.X + k0 * r.B * HW;
+                RCN_TRY(rcn_hip_train_epoch_images_dev(c, X, Y, pm, r.B, r.nb - k0, r.eta, loss));
+            } else {
+                const void* X = r.perm ? r.X : (const void*)((const char*)r.X + k0 * r.B * F * es);
+                RCN_TRY(rcn_hip_train_epoch_dev(c, X, Y, pm, r.B, r.nb - k0, r.eta, loss));
+            }
+            image_touched = true;
+        } else {
+            if (!r.begin.valid) return fail(c, RCN_HIP_ERR_HIP, "the resident kernel failed and the epoch image its steps ran on cannot be laid out again; what it had not applied is lost");
+            RCN_TRY(redo_begin(c, r.begin));
+            RCN_TRY(rcn_hip_epoch_steps_dev(c, r.j0 + k0, r.nb - k0, r.eta, loss));
+            image_touched = true;
+        }
+    }
+    // the index buffers and the epoch image end as the caller's newest calls left them
+    for (const auto& ps : c->perm_sources) RCN_TRY(redo_perm(c, ps));
+    if (image_touched && image_was_live && c->last_begin.valid) RCN_TRY(redo_begin(c, c->last_begin));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)code;
+    return RCN_HIP_OK;
+}
+
 // The in-kernel waits (peer exchange, resident / one-launch step kernels) are bounded: a wait that expires sets a sticky
 // device word, every later kernel of that family drains, and the updates of the call are only partly applied.  The word is
 // copied back asynchronously at the end of each epoch call; after a stream synchronise it is current.  Every entry point
@@ -953,9 +1162,22 @@ int sticky_errors(rcn_hip_ctx* c) {
     }
     if (c->perr_host && *c->perr_host != 0)
         return fail(c, RCN_HIP_ERR_HIP, "a bounded wait inside the resident / one-launch step kernel expired; the last call's updates are incomplete");
-    if (c->xerr_host && *c->xerr_host != 0)
-        return fail(c, RCN_HIP_ERR_HIP, *c->xerr_host == 2 ? "the resident one-XCD kernel found its workgroups on different XCDs; the last call's segment was not applied"
-                                                           : "a bounded wait inside the resident one-XCD kernel expired; the last call's segment was not applied");
+    if (c->xerr_host && *c->xerr_host != 0) {
+        if (!c->xcd_dp_used && c->opt.xcd_auto_fallback && !c->replaying) return xcd_heal(c);
+        return fail(c, RCN_HIP_ERR_HIP, *c->xerr_host == 2 ? "the resident one-XCD kernel found its workgroups on different XCDs; what it had not applied is lost"
+                                                           : (c->xcd_dp_used ? "a bounded wait inside the resident one-XCD kernel expired in a data-parallel step; the replicas are no longer in step"
+                                                                             : "a bounded wait inside the resident one-XCD kernel expired; what it had not applied is lost"));
+    }
+    if (c->xerr_host) c->redo.clear();          // the stream is drained and nothing failed: every journalled launch is complete
+    return RCN_HIP_OK;
+}
+
+// a failure of the resident kernel the host can already see: healed (or reported) before anything else is enqueued behind it
+int xcd_entry_check(rcn_hip_ctx* c) {
+    if (c->xerr_host && c->xerr_host[0] != 0 && !c->replaying) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return sticky_errors(c);
+    }
     return RCN_HIP_OK;
 }
 
@@ -1007,8 +1229,7 @@ int p2p_export(rcn_hip_ctx* c, void* out) {
     // uses for its own low-latency buffers.  (Ordinary hipMalloc memory is only guaranteed visible to a peer at kernel
     // boundaries; two ranks sharing ONE GPU, the only multi-rank case the development box offers, share its L2 and cannot
     // tell the difference.)  RCN_HIP_DP_CACHED_BUF=1 restores hipMalloc for A/B measurements.
-    static const bool cached_buf = getenv("RCN_HIP_DP_CACHED_BUF") && atoi(getenv("RCN_HIP_DP_CACHED_BUF")) != 0;
-    if (cached_buf) HIP_TRY(c, hipMalloc(&q.local_buf, bytes));
+    if (c->opt.dp_cached_buf) HIP_TRY(c, hipMalloc(&q.local_buf, bytes));
     else HIP_TRY(c, hipExtMallocWithFlags(&q.local_buf, bytes, hipDeviceMallocUncached));
     HIP_TRY(c, hipExtMallocWithFlags((void**)&q.local_flags, 4096, hipDeviceMallocUncached));
     HIP_TRY(c, hipMalloc((void**)&q.err_dev, 256));
@@ -1051,13 +1272,8 @@ P2PDesc p2p_desc(const rcn_hip_ctx* c) {
     return d;
 }
 
-// 1 s of the 100 MHz wall clock; RCN_HIP_DP_TIMEOUT_TICKS overrides it (the tests force a tiny one to see the sticky error surface)
-static long long p2p_timeout_ticks() {
-    const char* e = std::getenv("RCN_HIP_DP_TIMEOUT_TICKS");
-    const long long t = e ? std::atoll(e) : 0;
-    return t > 0 ? t : 100000000LL;
-}
-long long p2p_timeout_ticks_fwd() { return p2p_timeout_ticks(); }
+// 1 s of the 100 MHz wall clock; option "dp_timeout_ticks" overrides it (the tests force a tiny one to see the sticky error surface)
+static long long p2p_timeout_ticks(const rcn_hip_ctx* c) { return c->opt.dp_timeout_ticks; }
 
 // one all-reduce step on the context's stream; mode 0 applies the update, mode 1 writes the raw sums to p2p.raw
 template <typename T>
@@ -1096,8 +1312,7 @@ int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const in
     // the in-kernel exchange form keeps k_p2_b's operand image current too (its tail tiles apply the summed gradient themselves)
     struct FragGuard { rcn_hip_ctx* c; ~FragGuard() { c->frag_on = false; } } frag_guard{c};
     if constexpr (std::is_same<T, float>::value) {
-        static const bool frag_off = getenv("RCN_HIP_NO_FRAGIMG") && atoi(getenv("RCN_HIP_NO_FRAGIMG")) != 0;
-        if (fused && !p2_one_object() && !frag_off && c->fragimg.p) {
+        if (fused && !p2_one_object() && !c->opt.no_fragimg && c->fragimg.p) {
             hipLaunchKernelGGL(k_p2_fragimg, dim3(1), dim3(512), 0, c->stream, c->nd, (const float*)c->params.p, (float*)c->fragimg.p);
             HIP_TRY(c, hipGetLastError());
             c->frag_on = true;
@@ -1115,7 +1330,7 @@ int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const in
             hipLaunchKernelGGL((k_p2_dp_fused<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)xb(j),
                                (const T*)(more ? xb(j + 1) : xb(j)), (int)B, (const T*)a1, (const T*)d1, (const T*)d2, (T)scale, (T*)c->slab.p, (int)G,
                                (const T*)c->loss_part.p, n_loss, (T)loss_scale, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev,
-                               p2p_timeout_ticks(), (T*)c->grad.p, c->frag_on ? (T*)c->fragimg.p : (T*)nullptr);
+                               p2p_timeout_ticks(c), (T*)c->grad.p, c->frag_on ? (T*)c->fragimg.p : (T*)nullptr);
             HIP_TRY(c, hipGetLastError());
             continue;
         }
@@ -1123,7 +1338,7 @@ int enqueue_pipe_steps_dp(rcn_hip_ctx* c, const void* X, const void* Y, const in
                            (const T*)d2, (T*)q.local_buf, q.stride, seq_base, seq, (int)G, (const T*)c->loss_part.p, n_loss, (T)loss_scale);
         HIP_TRY(c, hipGetLastError());
         hipLaunchKernelGGL((k_p2_dp_apply<T>), dim3(grid), dim3(kDenseThreads), lds, c->stream, nd, (T*)c->params.p, (const T*)(more ? xb(j + 1) : xb(j)),
-                           (int)B, (T)scale, (T*)c->slab.p, (int)G, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev, p2p_timeout_ticks());
+                           (int)B, (T)scale, (T*)c->slab.p, (int)G, lj, more ? 1 : 0, p2p_desc(c), seq_base, seq, q.stride, q.err_dev, p2p_timeout_ticks(c));
         HIP_TRY(c, hipGetLastError());
     }
     return RCN_HIP_OK;
@@ -1140,7 +1355,7 @@ int p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* err)
     for (int it = 0; it < iters; ++it) {
         const unsigned seq = q.seq + 1;
         char* slot = (char*)q.local_buf + (size_t)(seq & 1u) * q.stride * es;
-        const long long to = it == 0 ? 10 * p2p_timeout_ticks() : p2p_timeout_ticks();      // the first exchange absorbs start-up skew
+        const long long to = it == 0 ? 10 * p2p_timeout_ticks(c) : p2p_timeout_ticks(c);      // the first exchange absorbs start-up skew
         if (c->dtype == RCN_HIP_F64) {
             hipLaunchKernelGGL((k_p2p_fill<double>), dim3(48), dim3(256), 0, c->stream, (double*)slot, q.stride, c->dp_rank, seq);
             RCN_TRY(p2p_step<double>(c, 1, 0.0, nullptr, to));
@@ -1173,9 +1388,9 @@ int p2p_selftest_fused(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned
     for (int it = 0; it < iters; ++it) {
         const unsigned seq = ++q.seq;
         if (c->dtype == RCN_HIP_F64)
-            hipLaunchKernelGGL((k_p2p_ll_selftest<double>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, p2p_timeout_ticks(), (unsigned*)q.mism.p);
+            hipLaunchKernelGGL((k_p2p_ll_selftest<double>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, p2p_timeout_ticks(c), (unsigned*)q.mism.p);
         else
-            hipLaunchKernelGGL((k_p2p_ll_selftest<float>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, p2p_timeout_ticks(), (unsigned*)q.mism.p);
+            hipLaunchKernelGGL((k_p2p_ll_selftest<float>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, p2p_timeout_ticks(c), (unsigned*)q.mism.p);
         HIP_TRY(c, hipGetLastError());
     }
     unsigned host[2] = {0, 0};
@@ -1244,9 +1459,12 @@ int rcn_hip_create(const rcn_hip_cfg* cfg, rcn_hip_ctx** out) {
     *out = c;                                   // handed back even on failure so the caller can read last_error
     c->device = cfg->device;
     c->dtype = cfg->dtype;
-    if (const char* e = std::getenv("RCN_HIP_PACK_SEGMENT_BYTES")) {
+    if (const char* e = std::getenv("RCN_HIP_DP_FAULT")) c->dp_fault = e;
+    for (const OptDesc& od : kOptTable) {             // the environment seeds the defaults, once, here
+        const char* e = std::getenv(od.env);
+        if (!e || !*e) continue;
         const long long v = std::atoll(e);
-        if (v > 0) c->pack_seg_bytes = (size_t)v;
+        if (v >= od.lo && v <= od.hi) c->opt.*(od.field) = v;
     }
     RCN_TRY(build_feat_desc(c, cfg));
     // RCN::new itself never fails; a stack whose dense part cannot run in the reference is remembered and
@@ -1287,6 +1505,7 @@ void rcn_hip_destroy(rcn_hip_ctx* c) {
             b->release();
         c->xcdbuf.release();
         if (c->xerr_host) (void)hipHostFree(c->xerr_host);
+        if (c->xerrd) (void)hipFree(c->xerrd);
         for (auto& rs : c->sets) { rs.imgs.release(); rs.X.release(); rs.Y.release(); rs.perm.release(); rs.loss.release(); }
         if (c->pin_host) (void)hipHostFree(c->pin_host);
         c->pll.release();
@@ -1329,16 +1548,49 @@ int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
     if (mode == 5) {
         if (c->dtype != RCN_HIP_F32 || !xcd_supported(c->nd, 256))
             return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path(5): the resident one-XCD kernel covers the f32 context, one hidden layer <= 32 (or two: <= 32, <= 16), classes <= 16, "
-                                                      "at most 29 feature-slice pairs, batch 256");
+                                                      "at most 29 feature-slice pairs, batches of 1..256");
         RCN_TRY(xcd_probe(c));
         if (c->xcd_probe != 1)
             return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path(5): on this device the blocks with blockIdx.x % 8 == 0 do not share one XCD; the resident kernel "
                                                       "cannot be used");
     }
     drop_graphs(c);
+    if (mode != 0 && mode != 5 && c->xerr_host && c->xerr_host[0] != 0 && !c->xcd_dp_used && !c->opt.xcd_auto_fallback) {
+        // the recovery the error message names: leaving the resident kernel clears its sticky word (what it had not applied stays lost)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        RCN_TRY(xcd_clear_error(c));
+        c->redo.clear();
+    }
+    if (mode == 5) c->xcd_stepped_down = false;
     c->dense_path = mode;
     return RCN_HIP_OK;
 }
+
+int rcn_hip_set_option(rcn_hip_ctx* c, const char* name, int64_t value) {
+    RCN_TRY(check_ctx(c));
+    if (!name) return fail(c, RCN_HIP_ERR_INVALID_ARG, "set_option: NULL name");
+    for (const OptDesc& od : kOptTable)
+        if (std::strcmp(od.name, name) == 0) {
+            if (value < od.lo || value > od.hi)
+                return fail(c, RCN_HIP_ERR_INVALID_ARG, std::string("set_option: ") + name + " must be in " + std::to_string(od.lo) + ".." + std::to_string(od.hi));
+            if (c->opt.*(od.field) == (long long)value) return RCN_HIP_OK;
+            DevGuard g(c->device);
+            drop_graphs(c);                        // captured graphs bake in launch shapes, time-outs and the image's segment length
+            if (od.field == &CtxOptions::pack_segment_bytes) c->epoch_nb = 0;
+            c->opt.*(od.field) = (long long)value;
+            return RCN_HIP_OK;
+        }
+    return fail(c, RCN_HIP_ERR_INVALID_ARG, std::string("set_option: unknown option '") + name + "'");
+}
+
+int rcn_hip_get_option(const rcn_hip_ctx* c, const char* name, int64_t* value) {
+    if (!c || !name || !value) return RCN_HIP_ERR_INVALID_ARG;
+    for (const OptDesc& od : kOptTable)
+        if (std::strcmp(od.name, name) == 0) { *value = (int64_t)(c->opt.*(od.field)); return RCN_HIP_OK; }
+    return RCN_HIP_ERR_INVALID_ARG;
+}
+
+int rcn_hip_fallbacks_taken(const rcn_hip_ctx* c) { return c ? c->fallbacks_taken : 0; }
 
 int rcn_hip_synchronize(rcn_hip_ctx* c) {
     RCN_TRY(check_ctx(c));
@@ -1383,7 +1635,12 @@ int rcn_hip_set_params(rcn_hip_ctx* c, int layer, const double* W, const double*
         if (e != hipSuccess) st = fail(c, RCN_HIP_ERR_HIP, hipGetErrorString(e));
     }
     tmp.release();
-    if (st == RCN_HIP_OK) c->params_set = true;
+    if (st == RCN_HIP_OK) {
+        c->params_set = true;
+        // a recovery action: whatever an earlier resident launch failed to apply is moot now (the stream was drained above)
+        if (c->xerr_host && c->xerr_host[0] != 0 && !c->xcd_dp_used) { RCN_TRY(xcd_clear_error(c)); c->xcd_stepped_down = true; }
+        c->redo.clear();
+    }
     return st;
 }
 
@@ -1393,8 +1650,9 @@ int rcn_hip_get_params(rcn_hip_ctx* c, int layer, double* W, double* b) {
     DevGuard g(c->device);
     const size_t rows = c->nd.dims[layer + 1], cols = c->nd.dims[layer];
     std::vector<double> flat(rows * cols + rows);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    RCN_TRY(sticky_errors(c));                 // parameters of a timed-out call are not handed out as good (a single-GPU resident failure is healed here)
     RCN_TRY(download(c, (char*)c->params.p + (size_t)c->nd.w_off[layer] * c->esz(), flat.data(), flat.size()));
-    RCN_TRY(sticky_errors(c));                 // download synchronised the stream: parameters of a timed-out call are not handed out as good
     std::memcpy(W, flat.data(), rows * cols * 8);
     std::memcpy(b, flat.data() + rows * cols, rows * 8);
     return RCN_HIP_OK;
@@ -1548,7 +1806,7 @@ int rcn_hip_features_dev(rcn_hip_ctx* c, const uint8_t* imgs, size_t n, void* ou
         const float rcp = c->dtype == RCN_HIP_F32 && standardize ? fast_standardise_rcp(c) : 0.f;
         // RCN_HIP_FEAT_WAVES=2: two waves per picture (twice the waves per CU on the same LDS).  Measured neutral (144.8 vs 145.8 us per
         // 131 072 pictures): the kernel is not short of waves to hide latency behind, it is short of issue slots -- kept for the record.
-        static const int two_waves = [] { const char* e = std::getenv("RCN_HIP_FEAT_WAVES"); return e ? std::atoi(e) : 1; }();
+        const int two_waves = (int)c->opt.feat_waves;
 #define RCN_CPCP(TT, STD, FAST, RCPV)                                                                                              \
     do {                                                                                                                          \
         if (two_waves == 2) {                                                                                                     \
@@ -1739,6 +1997,7 @@ static int epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
     if (nb == 0) return RCN_HIP_OK;                 // chunks_exact yields nothing (rcn.rs:147)
     RCN_TRY(need_params(c));
     DevGuard g(c->device);
+    RCN_TRY(xcd_entry_check(c));
     RCN_TRY(ensure_dense_ws(c, B));
     if (use_pipe(c, B)) { RCN_TRY(ensure_pipe_ws(c, B)); RCN_TRY(ensure_pack_ws(c, B, nb)); }
     const bool step = use_pipe(c, B) && use_step(c, B);
@@ -1849,6 +2108,12 @@ static int epoch_begin_impl(rcn_hip_ctx* c, const void* X, const void* Y, const 
             RCN_TRY(c->dtype == RCN_HIP_F64 ? launch_pack<double>(c, X, Y, perm, B, j, n, half, seg) : launch_pack<float>(c, X, Y, perm, B, j, n, half, seg));
     }
     c->epoch_B = B; c->epoch_nb = nb; c->epoch_seg = seg;
+    if (!c->replaying) {
+        c->last_begin = rcn_hip_ctx::BeginRec{};
+        c->last_begin.X = X; c->last_begin.Y = Y; c->last_begin.perm = perm; c->last_begin.B = B; c->last_begin.nb = nb; c->last_begin.from_images = from_images;
+        c->last_begin.valid = true;
+        c->last_begin.src = perm_source_of(c, perm);
+    }
     return RCN_HIP_OK;
 }
 
@@ -1866,8 +2131,10 @@ static int epoch_steps_impl(rcn_hip_ctx* c, size_t j0, size_t n, double eta, voi
     if (j0 > c->epoch_nb || n > c->epoch_nb - j0) return fail(c, RCN_HIP_ERR_INVALID_ARG, "epoch_steps: batches beyond the begun epoch");
     if (n == 0) return RCN_HIP_OK;
     RCN_TRY(need_params(c));
-    const size_t B = c->epoch_B, nb_epoch = c->epoch_nb, seg = c->epoch_seg;
     DevGuard g(c->device);
+    RCN_TRY(xcd_entry_check(c));
+    if (c->epoch_nb == 0) return fail(c, RCN_HIP_ERR_STATE, "epoch_steps: the begun epoch did not survive the step-down from the resident kernel");
+    const size_t B = c->epoch_B, nb_epoch = c->epoch_nb, seg = c->epoch_seg;
     RCN_TRY(ensure_dense_ws(c, B));
     RCN_TRY(ensure_pipe_ws(c, B));
     if (use_xcd(c, B)) {
@@ -1915,6 +2182,11 @@ int rcn_hip_shuffle_dev(rcn_hip_ctx* c, int32_t* perm, size_t n, size_t passes, 
     hipLaunchKernelGGL(k_shuffle_indices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (int*)perm, (unsigned)n, (unsigned)passes,
                        (unsigned long long)seed, bits / 2);
     HIP_TRY(c, hipGetLastError());
+    {
+        rcn_hip_ctx::PermSource ps;
+        ps.kind = 1; ps.buf = perm; ps.n = n; ps.passes = passes; ps.seed = seed;
+        note_perm_source(c, std::move(ps));
+    }
     return RCN_HIP_OK;
 }
 
@@ -1990,10 +2262,9 @@ struct P2PTransport {
 };
 
 static bool p2p_fault(const rcn_hip_ctx* c, const char* stage) {
-    const char* e = std::getenv("RCN_HIP_DP_FAULT");
-    if (!e) return false;
+    if (c->dp_fault.empty()) return false;
     const std::string want = std::string(stage) + ":" + std::to_string(c->dp_rank);
-    std::string all(e);
+    const std::string& all = c->dp_fault;
     size_t pos = 0;
     while (pos <= all.size()) {
         const size_t end = all.find(',', pos);
@@ -2025,8 +2296,7 @@ static int p2p_admission(rcn_hip_ctx* c, const P2PTransport& t) {
         // second, independent question: may the exchange also run INSIDE the gradient kernel (tagged words, no flags)?  A failed
         // wait here leaves the sticky error word set, which would disable the kernel-boundary protocol too, so it is cleared
         // (after every rank has drained: the vote synchronises) when only this stage failed.
-        const char* fe = std::getenv("RCN_HIP_DP_FUSED");
-        int okf = (fe && fe[0] == '0') ? 0 : 1;
+        int okf = c->opt.dp_fused ? 1 : 0;
         if ((st = t.vote_min(okf)) != RCN_HIP_OK) break;         // every rank must want it (same environment everywhere, normally)
         if (!okf) break;
         if (p2p_fault(c, "llskip")) { c->p2p.seq += 16; okf = 0; }         // this rank stays silent: its peers' waits expire
@@ -2096,16 +2366,15 @@ int rcn_hip_dp_init(rcn_hip_ctx* c, const void* id_bytes, int rank, int world) {
     c->dp_rank = rank;
     c->dp_world = world;
     p2p_release(c);
-    const char* env = std::getenv("RCN_HIP_DP_P2P");
-    const bool force = env && env[0] == '2';          // "2": also at world size 1 (exercises the whole set-up path on one GPU)
-    if ((world > 1 || force) && world <= kP2PMaxWorld && !(env && env[0] == '0') && c->dense_err.empty()) RCN_TRY(p2p_bootstrap_over_rccl(c));
+    const bool force = c->opt.dp_p2p == 2;            // 2: also at world size 1 (exercises the whole set-up path on one GPU)
+    if ((world > 1 || force) && world <= kP2PMaxWorld && c->opt.dp_p2p != 0 && c->dense_err.empty()) RCN_TRY(p2p_bootstrap_over_rccl(c));
     return RCN_HIP_OK;
 }
 
 // A peer wait that expired inside the resident kernel's data-parallel form is a property of the group just torn down (a peer that
 // left), not of this context's single-GPU resident path: reported by dp_finalize, then cleared with the group.
 static void clear_xcd_dp_timeout(rcn_hip_ctx* c) {
-    if (c->xcd_dp_used && c->xerr_host && *c->xerr_host == 1u) *c->xerr_host = 0;
+    if (c->xcd_dp_used && c->xerr_host && *c->xerr_host == 1u) (void)xcd_clear_error(c);
     c->xcd_dp_used = false;
 }
 
@@ -2161,9 +2430,8 @@ int rcn_hip_dp_p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, uns
     RCN_TRY(p2p_selftest(c, iters, mismatches, timed_out));
     if (*mismatches || *timed_out) { c->p2p.on = false; return RCN_HIP_OK; }
     // the in-kernel form of the exchange, same verdict rule (the caller's ranks see the same result and decide alike)
-    const char* fe = std::getenv("RCN_HIP_DP_FUSED");
     unsigned bad2 = 0, to2 = 0;
-    if (!(fe && fe[0] == '0')) {
+    if (c->opt.dp_fused) {
         RCN_TRY(p2p_selftest_fused(c, iters, &bad2, &to2));
         c->p2p.fused = bad2 == 0 && to2 == 0;
     }
@@ -2279,8 +2547,7 @@ static int dp_epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int
         RCN_TRY(ensure_pack_ws(c, B, nb));
         // captured once per (pointers, B, n_batches, eta) and replayed: three launches per step would otherwise be bound by the
         // host's launch rate (~6 us each), not by the GPU.  Sequence numbers inside the graph are offsets from a device word.
-        const char* ge = std::getenv("RCN_HIP_DP_GRAPH");
-        if (ge && ge[0] == '0') {
+        if (!c->opt.dp_graph) {
             if (!launch) return RCN_HIP_OK;
             RCN_TRY(f64 ? enqueue_pipe_steps_dp<double>(c, X, Y, perm, B, nb, eta, loss_dev, false, c->p2p.fused)
                         : enqueue_pipe_steps_dp<float>(c, X, Y, perm, B, nb, eta, loss_dev, false, c->p2p.fused));
@@ -2324,11 +2591,11 @@ static int dp_epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int
             if (f64) {
                 RCN_TRY(launch_fwd<double>(c, true, xb, yb, ib, B, nullptr));
                 RCN_TRY(launch_wgrad<double>(c, false, xb, ib, B, 0.0, slot, slot + P * es, loss_scale));
-                RCN_TRY(p2p_step<double>(c, 0, scale, lj, p2p_timeout_ticks()));
+                RCN_TRY(p2p_step<double>(c, 0, scale, lj, p2p_timeout_ticks(c)));
             } else {
                 RCN_TRY(launch_fwd<float>(c, true, xb, yb, ib, B, nullptr));
                 RCN_TRY(launch_wgrad<float>(c, false, xb, ib, B, 0.0, slot, slot + P * es, loss_scale));
-                RCN_TRY(p2p_step<float>(c, 0, scale, lj, p2p_timeout_ticks()));
+                RCN_TRY(p2p_step<float>(c, 0, scale, lj, p2p_timeout_ticks(c)));
             }
         }
         HIP_TRY(c, hipMemcpyAsync(c->p2p.err_host, c->p2p.err_dev, 4, hipMemcpyDeviceToHost, c->stream));   // read at the next call
@@ -2408,13 +2675,23 @@ int rcn_hip_train_set_epoch(rcn_hip_ctx* c, int slot, const int32_t* perm, uint6
         for (size_t i = 0; i < nb * B; ++i)
             if (perm[i] < 0 || (size_t)perm[i] >= n) return fail(c, RCN_HIP_ERR_INVALID_ARG, "train_set_epoch: index out of range");
     DevGuard g(c->device);
-    if (perm) HIP_TRY(c, hipMemcpyAsync(rs.perm.p, perm, nb * B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (perm) {
+        rcn_hip_ctx::PermSource ps;
+        ps.kind = 2; ps.buf = (int32_t*)rs.perm.p; ps.n = nb * B; ps.passes = 1;
+        ps.host.assign(perm, perm + nb * B);
+        HIP_TRY(c, hipMemcpyAsync(rs.perm.p, perm, nb * B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        note_perm_source(c, std::move(ps));
+    }
     else RCN_TRY(rcn_hip_shuffle_dev(c, (int32_t*)rs.perm.p, n, 1, shuffle_seed ? shuffle_seed : ((uint64_t)std::random_device{}() << 32) ^ std::random_device{}()));   // rcn.rs:146
     if (nb == 0) return RCN_HIP_OK;
     void* loss_dev = nullptr;
     if (loss_out) { HIP_TRY(c, rs.loss.ensure(nb * c->esz())); loss_dev = rs.loss.p; }
     RCN_TRY(rcn_hip_train_epoch_dev(c, rs.X.p, rs.Y.p, (const int32_t*)rs.perm.p, B, nb, eta, loss_dev));
-    if (loss_out) return download(c, loss_dev, loss_out, nb);
+    if (loss_out) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        RCN_TRY(sticky_errors(c));                     // (a step-down from the resident kernel re-runs what was lost, costs included, before they are read)
+        return download(c, loss_dev, loss_out, nb);
+    }
     return RCN_HIP_OK;
 }
 
@@ -2489,6 +2766,12 @@ int rcn_hip_evaluate_dev(rcn_hip_ctx* c, const void* x, const void* y, size_t n,
     if (n == 0) return RCN_HIP_OK;
     DevGuard g(c->device);
     const int Cc = c->nd.dims[c->nd.L];
+    // the accuracy of rcn.rs:150-164 is read from the parameters the epoch left: if resident launches are still unverified, drain the
+    // stream first -- a failure is healed (or reported) before the forward pass runs, not after
+    if (c->xerr_host && (!c->redo.empty() || c->xerr_host[0] != 0 || c->xcd_dp_used)) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        RCN_TRY(sticky_errors(c));
+    }
     HIP_TRY(c, c->ostage.ensure(n * (size_t)Cc * c->esz()));
     RCN_TRY(rcn_hip_forward_dev(c, x, n, c->ostage.p));
     HIP_TRY(c, c->misc.ensure(64));

@@ -74,6 +74,15 @@ class DeviceRCN:
     def set_feature_kernel(self, mode: int):
         self.rcn.set_feature_kernel(mode)
 
+    def set_option(self, name: str, value: int):
+        self.rcn.set_option(name, value)
+
+    def get_option(self, name: str) -> int:
+        return self.rcn.get_option(name)
+
+    def fallbacks_taken(self) -> int:
+        return self.rcn.fallbacks_taken()
+
     # ---- feature pipeline --------------------------------------------------------------------------------------
     def features(self, imgs_u8: torch.Tensor, standardize: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert imgs_u8.dtype == torch.uint8 and imgs_u8.is_contiguous() and imgs_u8.device == self.device

@@ -138,6 +138,19 @@ class RCN:
         """0 auto, 1 sample-tile kernels, 2 feature-sliced pipeline, 3 resident epoch kernel, 4 one launch per step (include/rcn_hip.h)."""
         self._ck(self._lib.rcn_hip_set_dense_path(self._ctx, int(mode)))
 
+    def set_option(self, name: str, value: int):
+        """Per-context option (include/rcn_hip.h: rcn_hip_set_option); the environment only seeds the defaults at creation."""
+        self._ck(self._lib.rcn_hip_set_option(self._ctx, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64(0)
+        self._ck(self._lib.rcn_hip_get_option(self._ctx, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def fallbacks_taken(self) -> int:
+        """How often this context stepped down from the resident one-XCD kernel to the two-kernel pipeline by itself."""
+        return int(self._lib.rcn_hip_fallbacks_taken(self._ctx))
+
     def set_feature_kernel(self, mode: int):
         """0 auto (specialised fused kernel for the default stack on 28x28), 1 always the generic kernel."""
         self._ck(self._lib.rcn_hip_set_feature_kernel(self._ctx, int(mode)))

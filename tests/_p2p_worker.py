@@ -57,7 +57,7 @@ def main():
         said = {}
         if rank == 0:
             print(f"RESIDENT {int(resident)}", flush=True)
-            os.environ["RCN_HIP_DP_TIMEOUT_TICKS"] = "2000000"     # 20 ms of the 100 MHz clock, read when the next call is enqueued
+            d.set_option("dp_timeout_ticks", 2000000)              # 20 ms of the 100 MHz clock, from the next call on
             if resident:
                 d.dp_epoch_steps(0, 1, 3.0, None)                  # rank 1 never runs this step
             else:

@@ -741,7 +741,7 @@ def test_peer_allreduce_bootstrap_over_rccl_world1(amd, oracle, monkeypatch):
         costs.append(c)
     _check_params(gw + gb, rw + rb, 1)
     np.testing.assert_allclose(loss.cpu().numpy(), costs, rtol=1e-10)
-    monkeypatch.setenv("RCN_HIP_DP_P2P", "0")
+    d.set_option("dp_p2p", 0)                         # (the environment only seeds the option when the context is created)
     d.dp_init()
     assert not d.dp_p2p_active()
     d.dp_finalize()

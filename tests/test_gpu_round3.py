@@ -1,0 +1,246 @@
+"""GPU tests added in round 3 (run with -m gpu on an MI355X), all through the C ABI:
+
+* the resident one-XCD kernel at the reference's OWN operating points -- batch_size 10 (rcn/src/main.rs:36-37, rcn.rs:581), 32
+  (BASELINE configs[0]) -- and at every other batch of 1..256 samples, against the CPU restatement;
+* the 256-step loss curve at B = 32 and B = 10;
+* the self-healing step-down of the single-GPU resident kernel (a forced expiry; the epoch still equals the oracle);
+* per-context options (two contexts of one process on different forms).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle.rcn_oracle import DEFAULT_LAYERS, one_hot, synthetic_images, synthetic_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import mercer_research_amd as m
+    return m
+
+
+def _xcd_or_skip(d):
+    import mercer_research_amd as amd
+    try:
+        d.set_dense_path(5)
+    except amd.RcnHipError as e:
+        pytest.skip(f"the resident one-XCD kernel does not apply on this device: {e}")
+
+
+def _oracle_steps(oracle, ws, bs, X, Y, perm, B, nb, eta):
+    rw, rb, costs = ws, bs, []
+    for j in range(nb):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, X[sel], Y[sel], eta)
+        costs.append(c)
+    return rw, rb, np.array(costs)
+
+
+@pytest.mark.parametrize("hidden", [[30], [10, 10]], ids=["784-30-10", "reference-test-net-784-10-10-10"])
+@pytest.mark.parametrize("B", [10, 32, 1, 8, 33, 64, 100, 128, 200, 255])
+def test_resident_kernel_at_any_batch_of_1_to_256_is_the_reference_loop(amd, oracle, hidden, B):
+    """train_batch at batch.len() = B (rcn.rs:176-223; `eta / batch.len()` rcn.rs:214) on the resident kernel's instantiation for the
+    next of 32 / 64 / 128 / 256: the samples between B and that size are rows of zeros whose deltas are masked.  One step from
+    identical parameters at the one-step f32 tolerance of SURVEY 8(c) (1e-5 relative + 1e-6), six chained steps in a shuffled order
+    at the chained tolerance, and the sample-tile kernels (dense path 1, any B) on the same calls."""
+    from mercer_research_amd.device import DeviceRCN
+    dims = [784] + hidden + [10]
+    N, nb = 2048, 6
+    rng = np.random.default_rng(100 + B)
+    X = np.maximum(rng.standard_normal((N, 784)), 0.0).astype(np.float32).astype(np.float64)
+    Y = one_hot(rng.integers(0, 10, N))
+    ws, bs = synthetic_params(dims, seed=21)
+    ws = [w * 0.1 for w in ws]
+    perm = rng.permutation(N).astype(np.int32)
+    got = {}
+    for path in (5, 1):
+        d = DeviceRCN(dtype=0, feedforward_cfg=hidden)
+        if path == 5:
+            _xcd_or_skip(d)
+        else:
+            d.set_dense_path(1)
+        d.set_params(ws, bs)
+        Xd, Yd, pd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype), d.to_device(perm)
+        loss = d.empty(nb + 1)
+        d.train_epoch(Xd, Yd, None, B, 1, 3.0, loss)                   # one step, stored order
+        p1 = sum(d.get_params(), [])
+        d.train_epoch(Xd, Yd, pd, B, nb, 3.0, loss[1:])                 # six more, shuffled
+        d.synchronize()
+        got[path] = (p1, sum(d.get_params(), []), loss.cpu().numpy().astype(np.float64))
+        assert d.fallbacks_taken() == 0
+        d.rcn.close()
+    rw, rb, c0 = oracle.train_batch(ws, bs, X[:B], Y[:B], 3.0)
+    for path in (5, 1):
+        for a, b in zip(got[path][0], rw + rb):
+            assert np.all(np.abs(a - b) <= 1e-5 * np.abs(b) + 1e-6), (path, float(np.abs(a - b).max()))
+        assert abs(got[path][2][0] - c0) <= 1e-5 * c0
+    rw, rb, cs = _oracle_steps(oracle, rw, rb, X, Y, perm, B, nb, 3.0)
+    for path in (5, 1):
+        np.testing.assert_allclose(got[path][2][1:], cs, rtol=1e-4)
+        for a, b in zip(got[path][1], rw + rb):
+            assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5), (path, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("B", [32, 10], ids=["B32-baseline-config0", "B10-reference-default"])
+def test_loss_curve_256_steps_at_the_reference_batch_sizes(amd, oracle, B):
+    """256 consecutive steps at the reference's own batch sizes on the resident kernel against oracle/rcn_oracle.c on the identical
+    batches: the f32 cost within 1e-3 relative of the f64 restatement's at EVERY step and 1e-4 on the mean."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    N, steps, eta = 8192, 256, 3.0                                      # 256 batches of 32 out of ONE shuffled epoch
+    imgs, labels = synthetic_images(N, seed=77)
+    feats = oracle.features(imgs, DEFAULT_LAYERS)
+    m, s = oracle.gen_scales(feats)
+    X, Y = oracle.standardize(feats, m, s), one_hot(labels)
+    ws, bs = synthetic_params([784, 30, 10], seed=42)
+    d = DeviceRCN(dtype=0)
+    _xcd_or_skip(d)
+    d.set_params(ws, bs)
+    Xd, Yd = d.load_data(d.to_device(imgs), d.to_device(labels))
+    perm = torch.empty(N, dtype=torch.int32, device=d.device)
+    loss = d.empty(steps)
+    d.shuffle(perm, N, 1, seed=0xABCD)
+    d.synchronize()
+    p = perm.cpu().numpy().astype(np.int64)
+    d.epoch_begin(Xd, Yd, perm, B, steps)
+    d.epoch_steps(0, 100, eta, loss)
+    d.epoch_steps(100, steps - 100, eta, loss[100:])
+    gw, gb = d.get_params()
+    gpu = loss.double().cpu().numpy()
+    assert d.fallbacks_taken() == 0
+    d.rcn.close()
+    h = oracle.net(ws, bs)
+    cpu = np.zeros(steps)
+    for j in range(steps):
+        idx = p[j * B:(j + 1) * B]
+        xb, yb = np.ascontiguousarray(X[idx]), np.ascontiguousarray(Y[idx])
+        cpu[j] = oracle.lib.rcn_o_train_batch(C.byref(h.net), xb.ctypes.data_as(C.POINTER(C.c_double)), yb.ctypes.data_as(C.POINTER(C.c_double)), B, eta)
+    rel = np.abs(gpu - cpu) / np.abs(cpu)
+    assert rel.max() <= 1e-3, (rel.max(), int(rel.argmax()))
+    assert abs(gpu.mean() - cpu.mean()) <= 1e-4 * cpu.mean()
+    for a, b in zip(gw + gb, h.weights() + h.biases()):
+        assert np.all(np.abs(a - b) <= 2e-3 * np.abs(b) + 2e-4), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("fail_launch", [1, 2, 3])
+def test_resident_kernel_steps_down_by_itself_and_the_epochs_still_equal_the_oracle(amd, oracle, fail_launch):
+    """A resident launch that loses a worker (test hook "xcd_fault_launch": what a co-tenant holding a CU of the XCD does) fails on a
+    bounded wait without writing anything, and every launch queued behind it leaves at once.  At the next synchronise the library
+    -- not the caller -- clears the error, steps the context down to the two-kernel pipeline and re-runs exactly the steps that were
+    not applied, from the arguments the calls were given (the shuffles it drew itself are drawn again): three epochs enqueued back
+    to back, with a shuffle between them, still equal the oracle's loop, the counter reads 1, and the context keeps training."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 256, 4, 1024
+    imgs, labels = synthetic_images(N, seed=9)
+    ws, bs = synthetic_params([784, 30, 10], seed=3)
+    ws = [w * 0.1 for w in ws]
+    d = DeviceRCN(dtype=0)
+    _xcd_or_skip(d)
+    d.set_dense_path(0)
+    d.set_option("xcd_timeout_ticks", 300000)                          # 3 ms per expired wait instead of 0.2 s
+    d.set_option("xcd_fault_launch", fail_launch)
+    d.set_params(ws, bs)
+    Xd, Yd = d.load_data(d.to_device(imgs), d.to_device(labels))
+    Xh, Yh = Xd.double().cpu().numpy(), one_hot(labels)
+    perm = torch.empty(N, dtype=torch.int32, device=d.device)
+    loss = d.empty(3 * nb)
+    perms = []
+    ref = DeviceRCN(dtype=0)                                            # the same shuffles, drawn on a second context, for the oracle
+    pr = torch.empty(N, dtype=torch.int32, device=ref.device)
+    for e in range(3):
+        ref.shuffle(pr, N, 1, seed=500 + e)
+        ref.synchronize()
+        perms.append(pr.cpu().numpy().astype(np.int64))
+    ref.rcn.close()
+    for e in range(3):                                                  # nothing synchronises in here
+        d.shuffle(perm, N, 1, seed=500 + e)
+        if e == 1:
+            d.epoch_begin(Xd, Yd, perm, B, nb)
+            d.epoch_steps(0, nb, 3.0, loss[e * nb:])
+        else:
+            d.train_epoch(Xd, Yd, perm, B, nb, 3.0, loss[e * nb:])
+    d.synchronize()                                                     # heals
+    assert d.fallbacks_taken() == 1
+    got = sum(d.get_params(), [])
+    costs = loss.double().cpu().numpy()
+    assert np.array_equal(perm.cpu().numpy(), perms[2])                 # the index buffer ends as the caller's last shuffle left it
+    rw, rb, cs = ws, bs, []
+    for e in range(3):
+        rw, rb, c = _oracle_steps(oracle, rw, rb, Xh, Yh, perms[e], B, nb, 3.0)
+        cs.extend(c)
+    np.testing.assert_allclose(costs, cs, rtol=2e-3)
+    for a, b in zip(got, rw + rb):
+        assert np.all(np.abs(a - b) <= 5e-4 * np.abs(b) + 5e-5), float(np.abs(a - b).max())
+    # the context keeps working (on the two-kernel pipeline now) and does not step down again
+    d.shuffle(perm, N, 1, seed=777)
+    d.train_epoch(Xd, Yd, perm, B, nb, 3.0, loss)
+    d.synchronize()
+    assert d.fallbacks_taken() == 1
+    d.rcn.close()
+
+
+def test_without_auto_fallback_the_error_is_sticky_and_a_recovery_action_clears_it(amd):
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 256, 2, 512
+    rng = np.random.default_rng(0)
+    X, Y = np.maximum(rng.standard_normal((N, 784)), 0.0), one_hot(rng.integers(0, 10, N))
+    ws, bs = synthetic_params([784, 30, 10], seed=3)
+    d = DeviceRCN(dtype=0)
+    _xcd_or_skip(d)
+    d.set_option("xcd_auto_fallback", 0)
+    d.set_option("xcd_timeout_ticks", 300000)
+    d.set_option("xcd_fault_launch", 1)
+    d.set_params(ws, bs)
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    d.train_epoch(Xd, Yd, None, B, nb, 3.0, None)
+    with pytest.raises(amd.RcnHipError):
+        d.synchronize()
+    with pytest.raises(amd.RcnHipError):
+        d.get_params()
+    assert d.fallbacks_taken() == 0
+    d.set_dense_path(2)                                                 # the recovery the message names
+    d.synchronize()
+    got = sum(d.get_params(), [])
+    for a, b in zip(got, ws + bs):
+        assert np.allclose(a, b.astype(np.float32))                     # the failed launch wrote nothing
+    d.train_epoch(Xd, Yd, None, B, nb, 3.0, None)
+    d.synchronize()
+    d.rcn.close()
+
+
+def test_options_are_per_context(amd, oracle):
+    """rcn_hip_set_option: two contexts of ONE process on different forms (environment knobs read into function-local statics
+    made that impossible); unknown names and values out of range are refused; the environment only seeds the defaults."""
+    from mercer_research_amd.device import DeviceRCN
+    B, N = 256, 512
+    rng = np.random.default_rng(1)
+    X, Y = np.maximum(rng.standard_normal((N, 784)), 0.0), one_hot(rng.integers(0, 10, N))
+    ws, bs = synthetic_params([784, 30, 10], seed=5)
+    ws = [w * 0.1 for w in ws]
+    a, b = DeviceRCN(dtype=0), DeviceRCN(dtype=0)
+    _xcd_or_skip(a)
+    a.set_dense_path(0)
+    b.set_option("xcd", 0)
+    assert a.get_option("xcd") == 1 and b.get_option("xcd") == 0
+    with pytest.raises(amd.RcnHipError):
+        a.set_option("no_such_option", 1)
+    with pytest.raises(amd.RcnHipError):
+        a.set_option("xcd_select", 8)
+    out = []
+    for d in (a, b):
+        d.set_params(ws, bs)
+        Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+        d.train_epoch(Xd, Yd, None, B, 2, 3.0, None)
+        d.synchronize()
+        us_first, _, _ = d.time_kernels(Xd[:B], Yd[:B], reps=8)
+        out.append((us_first == 0.0, sum(d.get_params(), [])))
+    assert out[0][0] and not out[1][0]                                  # a ran the resident kernel, b the two-kernel pipeline
+    for x, y in zip(out[0][1], out[1][1]):
+        assert np.all(np.abs(x - y) <= 1e-4 * np.abs(y) + 1e-5)
+    a.rcn.close(); b.rcn.close()
