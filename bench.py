@@ -277,8 +277,9 @@ def main():
             return bool(flag.item())
 
         def dp_kind():
-            if d.dp_p2p_mode() == 2 and d.dp_resident(B):
-                return "xgmi peer reads inside the resident one-XCD step kernel (csrc/dense_xcd.hpp, DP form: one launch per 64-step segment)"
+            if d.dp_p2p_mode() != 0 and d.dp_resident(B):
+                return ("xgmi reduce-scatter + all-gather on pushed self-validating words inside the resident one-XCD step kernel "
+                        "(csrc/dense_xcd.hpp DP form, csrc/dp_push.hpp: one launch per 64-step segment)")
             return {0: "ncclAllReduce (RCCL)", 1: "xgmi peer reads between kernels, fused with the update (csrc/dense_p2_dp.hpp, 3 kernels/step)",
                     2: "xgmi peer reads inside the gradient kernel (csrc/dense_p2_dp.hpp, 2 kernels/step)"}[d.dp_p2p_mode()]
 
@@ -337,11 +338,35 @@ def main():
             same = replicas_check() if flag.item() else False
             return bool(flag.item()) and same
 
-        # Rehearse before anything is timed, and step down together if the rehearsal fails: xGMI exchange inside the resident
-        # step kernel -> the same exchange inside the two-kernel pipeline's gradient kernel -> ncclAllReduce inside the library -> torch.distributed all_reduce.  Every rank takes the same branch (votes above).
+        def voted(fn):
+            """fn() on every rank, then ONE vote: (every rank succeeded, fn's value here).  Every rank executes the same collectives
+            whatever happened locally, so a failure on one rank never leaves its peers inside a different collective."""
+            ok, val = 1, None
+            try:
+                val = fn()
+            except Exception as e:
+                print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item()), val
+
+        def reset_session():
+            d.set_params(ws, bs)
+            step_no[0] = 0
+            epoch_no[0] = 0
+
+        # The default at N > 1 is the form that has run between real peers before: the two-kernel pipeline with the exchange inside
+        # its gradient kernel (tests/: two and four processes), not the resident kernel's data-parallel form, which no run on more
+        # than one GPU has been recorded for yet (ADVICE r2).  Rehearse it before anything is timed, and step down together if the
+        # rehearsal fails: -> ncclAllReduce inside the library -> torch.distributed all_reduce.  Every rank takes the same branch.
         rehearsal = max(8, min(args.warmup, 64))
+        resident_offered = False
         while True:
             if args.dp_impl == "native":
+                if d.dp_p2p_mode() != 0 and d.dp_resident(B):
+                    resident_offered = True
+                    d.set_dense_path(2)                     # same group, the exchange between the halves of the two-kernel pipeline
                 d.dp_broadcast_params(0)
                 allreduce_kind = dp_kind()
             else:
@@ -354,79 +379,72 @@ def main():
             if args.dp_impl != "native":
                 raise SystemExit("[bench] the torch.distributed data-parallel loop failed its rehearsal too")
             was_p2p = d.dp_p2p_mode() != 0
-            was_resident = was_p2p and d.dp_p2p_mode() == 2 and d.dp_resident(B)
+            resident_offered = False
             try:
                 d.dp_finalize()
             except Exception as e:
                 print(f"[bench] rank {rank}: dp_finalize after a failed rehearsal: {e}", file=sys.stderr, flush=True)
-            d.set_params(ws, bs)
-            step_no[0] = 0
-            epoch_no[0] = 0
-            if was_resident:
-                d.set_dense_path(2)                         # same exchange between the halves of the two-kernel pipeline
-                if not dp_native_setup():
-                    args.dp_impl = "torch"
-            elif was_p2p:
-                os.environ["RCN_HIP_DP_P2P"] = "0"          # same library loop on ncclAllReduce
+            reset_session()
+            if was_p2p:
+                d.set_option("dp_p2p", 0)                   # same library loop on ncclAllReduce
                 if not dp_native_setup():
                     args.dp_impl = "torch"
             else:
                 args.dp_impl = "torch"
 
-        # Two forms carry the same in-kernel exchange: the resident one-XCD kernel and the two-kernel pipeline.  Which is faster over
-        # real xGMI links has never been measured on the dev box (one GPU), so the bench tries both for a short, untimed stretch and
-        # keeps the faster -- the maximum over the ranks decides, identically on every rank -- before anything is timed.
-        if args.dp_impl == "native" and d.dp_p2p_mode() == 2 and d.dp_resident(B):
-            def trial(k: int) -> float:
+        # The resident one-XCD kernel carries the same step with the exchange inside it (reduce-scatter + all-gather on pushed words,
+        # csrc/dp_push.hpp).  It is tried for a short, untimed stretch -- rehearsal, replica check and timing all inside votes -- and
+        # kept only if it is healthy on every rank AND faster (the maximum over the ranks decides, identically everywhere).
+        if args.dp_impl == "native" and resident_offered:
+            def stretch(k: int) -> float:
                 prime(k)
                 d.synchronize(); dist.barrier(); torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 run(k)
-                d.synchronize(); dist.barrier()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=d.device)
+                d.synchronize()
+                return time.perf_counter() - t0
+
+            def timed_trial(k: int):
+                ok, el = voted(lambda: stretch(k))
+                t = torch.tensor([el if ok and el is not None else float("inf")], dtype=torch.float64, device=d.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return float(t.item()) * 1e6 / k
-            try:
-                trial_steps = 2 * nb_epoch
-                t_res = trial(trial_steps)
-                d.set_dense_path(2)
-                ok2 = healthy(rehearsal)
-                t_two = trial(trial_steps) if ok2 else float("inf")
-                dp_form_trial = {"resident_us_per_step": round(t_res, 3), "two_kernel_us_per_step": round(t_two, 3) if ok2 else None, "steps": trial_steps}
-                if not ok2:
-                    # the other form failed its own rehearsal (its sticky time-out word stays set): a fresh group, resident form again
+                return ok, float(t.item()) * 1e6 / k
+
+            trial_steps = 2 * nb_epoch
+            ok_two, t_two = timed_trial(trial_steps)                      # (the two-kernel form is warm from its rehearsal)
+            reset_session()
+            ok_sw, _ = voted(lambda: d.set_dense_path(0))
+            if ok_sw:
+                d.dp_broadcast_params(0)
+            ok_res = ok_sw and healthy(rehearsal)
+            t_res = float("inf")
+            if ok_res:
+                ok_res, t_res = timed_trial(trial_steps)
+            ok_res = ok_res and (replicas_check() if ok_res else False)
+            dp_form_trial = {"two_kernel_us_per_step": round(t_two, 3) if ok_two else None, "resident_us_per_step": round(t_res, 3) if ok_res else None,
+                             "resident_healthy": bool(ok_res), "steps": trial_steps}
+            keep_resident = ok_res and t_res < t_two
+            if not keep_resident:
+                if not ok_res:
+                    # the resident form failed on some rank (its sticky words stay set, replicas may be out of step): a fresh group
+                    fallbacks.append("xgmi exchange inside the resident one-XCD step kernel (untimed trial)")
                     try:
                         d.dp_finalize()
                     except Exception as e:
-                        print(f"[bench] rank {rank}: dp_finalize after the two-kernel trial: {e}", file=sys.stderr, flush=True)
-                    d.set_dense_path(0)
+                        print(f"[bench] rank {rank}: dp_finalize after the resident trial: {e}", file=sys.stderr, flush=True)
+                    d.set_dense_path(2)
                     if not dp_native_setup():
-                        raise RuntimeError("the data-parallel group could not be set up again after the two-kernel trial")
-                elif not t_two < t_res:
-                    d.set_dense_path(0)
-                dp_form_trial["kept"] = "two-kernel pipeline" if (ok2 and t_two < t_res) else "resident kernel"
-                allreduce_kind = dp_kind()
-            except Exception as e:                   # a failed trial must not cost the run: a fresh group on the default form, or the torch loop
-                print(f"[bench] rank {rank}: exchange-form trial: {e}", file=sys.stderr, flush=True)
-                dp_form_trial = {"error": str(e)[:200]}
-                try:
-                    d.dp_finalize()
-                except Exception:
-                    pass
-                d.set_dense_path(0)
-                if dp_native_setup():
-                    allreduce_kind = dp_kind()
+                        raise SystemExit("[bench] the data-parallel group could not be set up again after the resident trial")
                 else:
-                    args.dp_impl = "torch"
-                    allreduce_kind = "torch.distributed all_reduce (RCCL)"
-                    dp = DataParallelStep(d)
-            d.set_params(ws, bs)                     # the timed session starts from the common initial state again
-            if args.dp_impl == "native":
-                d.dp_broadcast_params(0)
-            else:
-                dp.broadcast_params(0)
-            step_no[0] = 0
-            epoch_no[0] = 0
+                    d.set_dense_path(2)
+            dp_form_trial["kept"] = "resident kernel" if keep_resident else "two-kernel pipeline"
+            reset_session()
+            d.dp_broadcast_params(0)
+            if not healthy(rehearsal):
+                raise SystemExit("[bench] the selected data-parallel form failed its final rehearsal")
+            reset_session()
+            d.dp_broadcast_params(0)
+            allreduce_kind = dp_kind()
 
     def sync():
         d.synchronize()

@@ -249,7 +249,7 @@ int  rcn_hip_dp_p2p_selftest(rcn_hip_ctx* ctx, int iters, unsigned* mismatches, 
  * `vote_min` must replace *v by the minimum of *v over the ranks; both return 0 on success and are called the same number of
  * times on every rank.  Afterwards rcn_hip_dp_p2p_active tells which form was admitted (identical on every rank); with 0 the
  * context has no exchange of its own and the caller combines rcn_hip_batch_gradient_dev / rcn_hip_apply_gradient_dev itself.
- * RCN_HIP_DP_FAULT="<stage>:<rank>,..." (stages export, attach, kat, ll, llskip) makes a rank fail a stage on purpose (tests). */
+ * RCN_HIP_DP_FAULT="<stage>:<rank>,..." (stages export, attach, kat, ll, llskip, push, pushskip) makes a rank fail a stage on purpose (tests). */
 typedef int (*rcn_hip_allgather_fn)(void* user, const void* mine, void* all, size_t bytes);
 typedef int (*rcn_hip_vote_min_fn)(void* user, int* v);
 int  rcn_hip_dp_p2p_admit(rcn_hip_ctx* ctx, int rank, int world, rcn_hip_allgather_fn allgather, rcn_hip_vote_min_fn vote_min, void* user);
@@ -259,7 +259,10 @@ int  rcn_hip_dp_p2p_admit(rcn_hip_ctx* ctx, int rank, int world, rcn_hip_allgath
  * like rcn_hip_dp_train_epoch_dev; available where rcn_hip_dp_resident says 1, RCN_HIP_ERR_UNSUPPORTED elsewhere. */
 int  rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* ctx, size_t first_batch, size_t n_batches, double eta, void* loss_dev);
 /* 1 when rcn_hip_dp_train_epoch_dev at this shard size runs the data-parallel step on the resident one-XCD kernel with the exchange
- * inside it (csrc/dense_xcd.hpp, DP form: the in-kernel exchange was admitted and the single-GPU resident kernel applies), else 0 */
+ * inside it (csrc/dense_xcd.hpp, DP form; csrc/dp_push.hpp: the shards' partial sums are PUSHED to one owner rank per slice pair of
+ * W_0, added there in rank order and pushed back -- a reduce-scatter and an all-gather on self-validating words, 1.75 P words per
+ * step and rank at eight ranks instead of the 7 P of an all-to-all read).  Needs: the pushed exchange admitted by its own
+ * known-answer vote, an f32 context, one hidden layer, a shard of exactly 32, 64, 128 or 256 samples.  Else 0. */
 int  rcn_hip_dp_resident(rcn_hip_ctx* ctx, size_t B_shard);
 int  rcn_hip_dp_p2p_active(const rcn_hip_ctx* ctx);   /* 0 ncclAllReduce, 1 peer exchange at kernel boundaries, 2 also inside the gradient kernel */
 /* ---- RCN::train's data flow with both data sets RESIDENT in HBM (rcn.rs:126-167): what a host-language `RCN::train` calls.

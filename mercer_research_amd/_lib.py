@@ -116,6 +116,7 @@ SIGNATURES = {
     "rcn_hip_time_kernels_dev": (_i, [_vp, _vp, _vp, _sz, _i, _dp, _dp, _dp]),
 }
 
+FALLBACKS_SEEN = 0          # step-downs from the resident kernel counted over every context this process has closed (rcn.py: RCN.close)
 _lib = None
 _lib_exp = None
 _hip_preloaded = False

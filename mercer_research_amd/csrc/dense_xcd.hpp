@@ -40,6 +40,7 @@
 
 #include "dense_p2.hpp"
 #include "dense_p2_dp.hpp"
+#include "dp_push.hpp"
 
 namespace rcn {
 
@@ -165,14 +166,14 @@ __device__ inline bool xcd_wait(const unsigned* f0, int n0, const unsigned* f1, 
 // nb consecutive train_batch steps (rcn.rs:176-223) over the packed batches xs[j] (slice-major, k_pack_epoch), ys[j].
 //
 // DP = true: the data-parallel step (one rank per GPU, this rank's shard of every global batch in xs / ys).  Between the gradient
-// MFMAs and the update every owner of a parameter -- the feature workers' waves 0..3 for their slice pair of W_0, the tail tiles'
-// threads for theirs -- publishes its shard's partial gradient as a self-validating {value, step} word in this rank's exported
-// buffer and polls the same word of every peer over xGMI (dense_p2_dp.hpp: ll_store / ll_gather_sum, the exchange k_p2_dp_fused
-// runs between the two-kernel pipeline's halves); sums are in rank order, so every rank applies the bit-identical update with the
-// GLOBAL batch length (`scale` = eta / (B * world)).  The cost travels the same way as element P.  xsel: which blocks are the
-// workers (blockIdx.x % 8 == xsel) -- 0 on a GPU of its own; the one-GPU test harness gives each rank another XCD.
+// MFMAs and the update the shards' partial gradients meet (dp_push.hpp): the feature workers' waves 0..3 push the four sums of a lane
+// to the slice pair's owner rank (worker w -> rank w % world), which adds the ranks' rows in rank order and pushes the totals back --
+// a reduce-scatter and an all-gather on self-validating {value, step} words, every poll local; the tail tiles' threads and the cost
+// (element P) go all-to-all the same way.  Every rank applies the bit-identical update with the GLOBAL batch length (`scale` =
+// eta / (B * world)).  xsel: which blocks are the workers (blockIdx.x % 8 == xsel) -- 0 on a GPU of its own; the one-GPU test
+// harness gives each rank another XCD.
 // the data-parallel form's arguments; the single-GPU instantiations carry an empty struct instead (no kernel-argument registers)
-struct XcdDpOn { P2PDesc pd; size_t pstride; unsigned seq0; long long ptimeout; };
+struct XcdDpOn { PushDesc pd; unsigned seq0; long long ptimeout; };
 struct XcdDpOff {};
 template <bool DP> struct XcdDpSel { using type = XcdDpOff; };
 template <> struct XcdDpSel<true> { using type = XcdDpOn; };
@@ -185,12 +186,16 @@ template <bool DP> using XcdDpArgs = typename XcdDpSel<DP>::type;
 // not carry its registers and branches.
 // BT: the batch the kernel is built for (32 / 64 / 128 / 256); B <= BT is the real batch.len(): samples B .. BT-1 are rows of zeros in
 // LDS and their deltas are masked, `scale` / `loss_scale` are formed from B on the host (rcn.rs:214).
-template <int BT, bool DP, bool L3 = false, bool GA = false>
+// FULL: B == BT, known at compile time (measured: with the batch length a run-time value the BT = 256 step is 0.2 us slower -- the
+// address arithmetic of the prefetch and of the targets, and the padding masks, sit on the step's critical waves).
+template <int BT, bool FULL, bool DP, bool L3 = false, bool GA = false>
 __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
-    NetDesc nd, float* __restrict__ params, const float* __restrict__ xs_all, const float* __restrict__ ys_all, int B, int nb, int G, float scale,
+    NetDesc nd, float* __restrict__ params, const float* __restrict__ xs_all, const float* __restrict__ ys_all, int B_arg, int nb, int G, float scale,
     float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, XcdDpArgs<DP> dp,
     int xsel, const int* __restrict__ gperm, unsigned launch_id) {
     constexpr bool gather = GA;
+    const int B = FULL ? BT : B_arg;
+    static_assert(!GA || FULL, "the gather form exists for the full batch only");
     static_assert(BT == 32 || BT == 64 || BT == 128 || BT == 256, "k_xcd_epoch: batch instantiations");
     static_assert(!GA || BT == 256, "the gather form exists for batch 256 only");
     constexpr size_t kXs = (size_t)kXcdSl * BT * 16;              // one LDS batch buffer of a slice pair
@@ -231,11 +236,22 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 
     if (tid == 0) s_abort = 0;
     __syncthreads();
-    // ---- placement: every worker says where it runs; nobody trusts a plain store before it has seen 32 equal answers
+    // ---- placement: every worker says where it runs; nobody trusts a plain store before it has seen the answers of all workers.
+    // Before it answers, a worker sets the flags it owns to "one before this launch's first tag": the protocol then does not depend on
+    // what the workspace held (zeros from its creation, the tags of an earlier launch -- or, seen once in round 3 right after another
+    // context had been destroyed, flag words of that context's workspace at the same address, which let sample groups of the new
+    // context's first step run ahead of their slab).  The answer carries the launch's process-wide id, so an answer left by any
+    // earlier launch of any context never counts.
+    const unsigned vtag = launch_id & 0x0fffffffu;
     if (tid == 0) {
         unsigned id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        xcd_flag_wt(bufs.xcc + w * kXcdFlagStride, (tag0 << 4) | (id & 0xfu));
+        xcd_flag(bufs.flagA + w * kXcdFlagStride, tag0 - 1u);
+        xcd_flag(bufs.flagB + w * kXcdFlagStride, tag0 - 1u);
+        xcd_flag(bufs.flagD + w * kXcdFlagStride, tag0 - 1u);
+        if (w < 8) xcd_flag(bufs.flagT + w * kXcdFlagStride, tag0 - 1u);
+        xcd_drain();
+        xcd_flag_wt(bufs.xcc + w * kXcdFlagStride, (vtag << 4) | (id & 0xfu));
     }
     if (wave == 0) {
         long long t0 = 0;
@@ -245,8 +261,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         if (stale && lane == 0) s_abort = 1;                          // parameters in memory are not this launch's starting point -> leave
         if (!stale)
         for (unsigned it = 0;; ++it) {
-            v = lane < NW ? __hip_atomic_load(bufs.xcc + lane * kXcdFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag0 << 4);
-            if (__all((v >> 4) == (tag0 & 0x0fffffffu))) break;
+            v = lane < NW ? __hip_atomic_load(bufs.xcc + lane * kXcdFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (vtag << 4);
+            if (__all((v >> 4) == vtag)) break;
             if ((it & 255u) == 255u) {
                 const long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         if (tid == 0) xcd_flag(bufs.flagT + e * kXcdFlagStride, tag0);
     }
 
-    const bool live = n < kP2Ts && w * kP2Ts + n < B;                 // sample group: this lane's column of the 16-wide tiles is a sample of the batch
+    const bool live = n < kP2Ts && (FULL || w * kP2Ts + n < B);                 // sample group: this lane's column of the 16-wide tiles is a sample of the batch
     unsigned yrow = 0;                                                // gather form: the row of this lane's sample (8 w + n % 8) in batch j
     if (gather) {
         const unsigned at = (unsigned)(w * kP2Ts + (n & 7));
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 for (int r = 0; r < XR; ++r) xr[r] = xrow4(j + 2, tid + r * kXcdThreads);
             } else {
                 const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)(j + 2) * xs_stride + (size_t)(kXcdSl * w) * B * 16);
-                if (B == BT) {                                        // (uniform) the full batch: the image's slice pair is the LDS image
+                if (FULL) {                                           // the full batch: the image's slice pair is the LDS image
 #pragma unroll
                     for (int r = 0; r < XR; ++r) {
                         const int i = tid + r * kXcdThreads;
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         // =============================================================== sample group w: samples 8w .. 8w+7 of batch j
         if (is_s) {
             const int s0 = w * kP2Ts;
-            const int srow = s0 + (n & 7) < B ? s0 + (n & 7) : B - 1;                             // (a padding sample reads a live row; its delta is masked)
+            const int srow = (FULL || s0 + (n & 7) < B) ? s0 + (n & 7) : B - 1;                             // (a padding sample reads a live row; its delta is masked)
             const T* Ys = gather ? ys_all + (size_t)yrow * C
                                  : ys_all + (size_t)j * ys_stride + (size_t)srow * C;             // this lane's sample's targets
             T fr[L3 ? kP3BFrag : kP2BFrag];
@@ -670,20 +686,14 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gsum[i] = acc0[i] + acc1[i];
                 if constexpr (DP) {
-                    // publish this shard's four sums, then collect the peers' of the same parameters (rank order)
+                    // this shard's four sums per lane meet the other ranks' at the slice pair's owner rank, the totals come back
+                    // (dp_push.hpp: reduce-scatter + all-gather on pushed, self-validating words; rank-order sums)
                     const unsigned seq = dp.seq0 + (unsigned)j;
-                    u64* mine = ll_region<T>(dp.pd.buf[dp.pd.rank], dp.pstride) + (size_t)(seq & 1u) * dp.pstride * LLWords<T>::n;
-                    bool ok = true;
-                    unsigned wo = woff0;                                     // opaque: the eight peers' addresses of these words are formed
-                    asm volatile("" : "+v"(wo));                             // here, per step, instead of living in 16 registers all loop long
+                    unsigned wo = woff0;                                     // opaque: the peers' addresses of these words are formed
+                    asm volatile("" : "+v"(wo));                             // here, per step, instead of living in registers all loop long
                     const size_t i0 = (size_t)nd.w_off[0] + wo;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (wvalid[i]) ll_store(mine, i0 + i, gsum[i], seq);
-                    {
-                        const bool gw[4] = {wvalid[0], wvalid[1], wvalid[2], wvalid[3]};
-                        ok = ll_gather_sum4(dp.pd, dp.pstride, i0, gw, seq, gsum, dp.ptimeout);   // the lane's four values in one round trip
-                    }
+                    const bool gw[4] = {wvalid[0], wvalid[1], wvalid[2], wvalid[3]};
+                    const bool ok = push_reduce4(dp.pd, w, seq, i0, gw, gsum, dp.ptimeout);
                     if (!ok) {
                         s_abort = 1;
                         xcd_raise(err, bufs.errd, 1u);
@@ -732,10 +742,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 if (lane == 0) {
                 if constexpr (DP) {                                          // the global cost: every shard's share, element P of the exchange
                     const unsigned seq = dp.seq0 + (unsigned)j;
-                    u64* mine = ll_region<T>(dp.pd.buf[dp.pd.rank], dp.pstride) + (size_t)(seq & 1u) * dp.pstride * LLWords<T>::n;
-                    ll_store(mine, (size_t)nd.P, t, seq);
-                    T g;
-                    if (ll_gather_sum<T>(dp.pd, dp.pstride, (size_t)nd.P, seq, t, dp.ptimeout, g)) t = g;
+                    T g = t;
+                    if (dp.pd.pd.world == 1 || push_all1(dp.pd, seq, (size_t)nd.P, t, dp.ptimeout, g)) t = g;
                     else { s_abort = 1; xcd_raise(err, bufs.errd, 1u); }
                 }
                 if (loss_dev) loss_dev[j] = t;
@@ -782,12 +790,10 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     T gsum = sum_partials<T>(red, mt, tcl, tml);
                     if constexpr (DP) {
                         const unsigned seq = dp.seq0 + (unsigned)j;
-                        u64* mine = ll_region<T>(dp.pd.buf[dp.pd.rank], dp.pstride) + (size_t)(seq & 1u) * dp.pstride * LLWords<T>::n;
                         size_t tpo = tp;                                     // (opaque, as in the feature workers' exchange)
                         asm volatile("" : "+v"(tpo));
-                        ll_store(mine, tpo, gsum, seq);
-                        T g;
-                        if (ll_gather_sum<T>(dp.pd, dp.pstride, tpo, seq, gsum, dp.ptimeout, g)) gsum = g;
+                        T g = gsum;
+                        if (dp.pd.pd.world == 1 || push_all1(dp.pd, seq, tpo, gsum, dp.ptimeout, g)) gsum = g;
                         else { s_abort = 1; xcd_raise(err, bufs.errd, 1u); }
                     }
                     tcur -= scale * gsum;                                    // rcn.rs:214,221

@@ -38,6 +38,7 @@
 #include "dense_p2_persist.hpp"
 #include "dense_p2_step.hpp"
 #endif
+#include <atomic>
 #include <chrono>
 
 using namespace rcn;
@@ -150,7 +151,11 @@ struct rcn_hip_ctx {
     struct P2P {                            // peer-read all-reduce over xGMI (dp_p2p.hpp)
         bool exported = false, attached = false, on = false;
         bool fused = false;                 // the exchange may run inside the gradient kernel (passed its own known-answer vote)
-        void* local_buf = nullptr;          // [2][stride] values + [2][stride] tagged words, ordinary device memory
+        bool push = false;                  // the pushed reduce-scatter + all-gather of the resident kernel passed its vote (dp_push.hpp)
+        size_t push_off = 0;                // byte offset of its region in every rank's exported buffer
+        void* local_buf = nullptr;          // [2][stride] values + [2][stride] tagged words + the pushed exchange's rows, uncached device memory
+        size_t local_bytes = 0;
+        bool local_uncached = false;
         unsigned* local_flags = nullptr;    // [kP2PMaxWorld], uncached device memory
         void* peer_buf[rcn::kP2PMaxWorld] = {};
         unsigned* peer_flags[rcn::kP2PMaxWorld] = {};
@@ -170,6 +175,7 @@ struct rcn_hip_ctx {
     bool xcd_dp_used = false;               // the resident kernel ran data-parallel steps since dp_init: dp_finalize clears its timeout word
     bool xcd_stepped_down = false;          // a wait of the resident kernel expired and the library stepped this context down to the two-kernel pipeline
     unsigned xcd_launch_id = 0;             // id of the newest resident launch enqueued (the kernel reports the newest COMPLETE one in xerr_host[1])
+    unsigned long long xcd_launches = 0;    // resident launches of this context so far (option "xcd_fault_launch" counts them)
     int fallbacks_taken = 0;                // rcn_hip_fallbacks_taken
     bool replaying = false;                 // the redo log is being replayed: nothing is logged
     // Redo log of the training calls whose resident launches have not been seen complete yet (dense_xcd.hpp: parameters are written only
@@ -862,6 +868,11 @@ bool use_xcd(rcn_hip_ctx* c, size_t B) {
 
 int xcd_heal(rcn_hip_ctx* c);
 
+// the data-parallel step runs on the resident kernel: the in-kernel exchange was admitted, one hidden layer, a shard of 32 / 64 / 128 / 256
+bool dp_on_xcd(rcn_hip_ctx* c, size_t B) {
+    return c->p2p.on && c->p2p.push && c->dtype == RCN_HIP_F32 && c->nd.L == 2 && (size_t)xcd_bt(B) == B && use_xcd(c, B);
+}
+
 int ensure_xcd_ws(rcn_hip_ctx* c, size_t B) {
     if (!c->xerr_host) {
         HIP_TRY(c, hipHostMalloc((void**)&c->xerr_host, 64, hipHostMallocMapped));
@@ -916,7 +927,7 @@ static XcdBufs xcd_bufs(rcn_hip_ctx* c, size_t BT) {
 
 // One launch of the instantiation for batch BT.  The kernel asks for at least half a CU's LDS plus one byte so that no two of its
 // workers share a CU (option "xcd_exact_lds" = 1: exactly what it uses -- two contexts' resident kernels can then be on one device).
-template <int BT>
+template <int BT, bool FULL>
 int xcd_launch_bt(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, float scale, float loss_scale, float* loss_dev, bool dp,
                   const int32_t* gperm, bool gather, const XcdBufs& xb, unsigned tag0, unsigned launch_id) {
     const NetDesc& nd = c->nd;
@@ -931,16 +942,20 @@ int xcd_launch_bt(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, si
                            pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, TO, DPARG, xsel, (const int*)gperm, launch_id);           \
     } while (0)
     if (dp) {
-        RCN_XCD_LAUNCH((k_xcd_epoch<BT, true>), to + 2 * p2p_timeout_ticks(c), (XcdDpOn{p2p_desc(c), c->p2p.stride, c->p2p.seq + 1, p2p_timeout_ticks(c)}));
-        c->p2p.seq += (unsigned)nb;
-        c->xcd_dp_used = true;
+        // (the data-parallel form exists for whole instantiation sizes: a shard of 32 / 64 / 128 / 256 samples per rank)
+        if constexpr (FULL) {
+            RCN_XCD_LAUNCH((k_xcd_epoch<BT, true, true>), to + 2 * p2p_timeout_ticks(c),
+                           (XcdDpOn{PushDesc{p2p_desc(c), c->p2p.stride, c->p2p.push_off}, c->p2p.seq + 1, p2p_timeout_ticks(c)}));
+            c->p2p.seq += (unsigned)nb;
+            c->xcd_dp_used = true;
+        } else return fail(c, RCN_HIP_ERR_UNSUPPORTED, "the resident kernel's data-parallel form needs a shard of 32, 64, 128 or 256 samples");
     } else if (nd.L == 3) {
-        RCN_XCD_LAUNCH((k_xcd_epoch<BT, false, true>), to, XcdDpOff{});
+        RCN_XCD_LAUNCH((k_xcd_epoch<BT, FULL, false, true>), to, XcdDpOff{});
     } else if (gather) {
-        if constexpr (BT == 256) RCN_XCD_LAUNCH((k_xcd_epoch<256, false, false, true>), to, XcdDpOff{});
+        if constexpr (BT == 256 && FULL) RCN_XCD_LAUNCH((k_xcd_epoch<256, true, false, false, true>), to, XcdDpOff{});
         else return fail(c, RCN_HIP_ERR_UNSUPPORTED, "the gather form of the resident kernel exists for batch 256 only");
     } else {
-        RCN_XCD_LAUNCH((k_xcd_epoch<BT, false>), to, XcdDpOff{});
+        RCN_XCD_LAUNCH((k_xcd_epoch<BT, FULL, false>), to, XcdDpOff{});
     }
 #undef RCN_XCD_LAUNCH
     HIP_TRY(c, hipGetLastError());
@@ -959,17 +974,29 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
     // (the tail parameters as the sample groups' operand fragments -- xb.fragimg -- are written by the kernel's own tail tiles: at its
     // start from the parameter vector, then after every update; its pads are the zeros the buffer was created with)
     const unsigned tag0 = c->xcd_tag + 1;
-    const unsigned id = ++c->xcd_launch_id & 0x7fffffffu;
-    const unsigned id_arg = id | ((c->opt.xcd_fault_launch != 0 && (long long)id == c->opt.xcd_fault_launch) ? 0x80000000u : 0u);
+    // launch ids are unique in the process (the placement vote of a launch accepts only answers that carry its id: dense_xcd.hpp) and
+    // increase along a context's stream (the redo journal compares them with the id the kernel reports complete)
+    static std::atomic<unsigned> g_launch{0};
+    unsigned id = (g_launch.fetch_add(1) + 1u) & 0x7fffffffu;
+    if (id == 0) id = (g_launch.fetch_add(1) + 1u) & 0x7fffffffu;
+    c->xcd_launch_id = id;
+    c->xcd_launches += 1;
+    const bool faulty = c->opt.xcd_fault_launch != 0 && (long long)c->xcd_launches == c->opt.xcd_fault_launch;
+    const unsigned id_arg = id | (faulty ? 0x80000000u : 0u);
     const double Bg = (double)B * (dp ? (double)c->dp_world : 1.0);          // the global batch.len() of rcn.rs:214
     const float scale = (float)(eta / Bg), loss_scale = (float)(1.0 / (2.0 * Bg));
     int st;
+    const bool full = (size_t)BT == B;
+#define RCN_XCD_BT(N)                                                                                                                        \
+    st = full ? xcd_launch_bt<N, true>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg)                  \
+              : xcd_launch_bt<N, false>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg)
     switch (BT) {
-    case 32:  st = xcd_launch_bt<32>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg); break;
-    case 64:  st = xcd_launch_bt<64>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg); break;
-    case 128: st = xcd_launch_bt<128>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg); break;
-    default:  st = xcd_launch_bt<256>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg); break;
+    case 32:  RCN_XCD_BT(32); break;
+    case 64:  RCN_XCD_BT(64); break;
+    case 128: RCN_XCD_BT(128); break;
+    default:  RCN_XCD_BT(256); break;
     }
+#undef RCN_XCD_BT
     RCN_TRY(st);
     c->xcd_tag += (unsigned)nb;
     if (id_out) *id_out = id;
@@ -1193,6 +1220,34 @@ int need_params(rcn_hip_ctx* c) {
 }
 
 // ---- peer-read all-reduce plumbing (dp_p2p.hpp) ------------------------------------------------------------------
+// Uncached (fine-grained) device memory is never handed back to the runtime while the process lives: it is parked here and reused by the
+// next data-parallel group.  Measured in round 3: after a 3.9 MB hipDeviceMallocUncached block had been hipFree'd, the next context's
+// ORDINARY hipMalloc allocations came back on that memory still behaving uncached -- plain stores no longer stayed in the XCD's L2 and
+// the resident kernel's hand-offs (payload, drain, flag: dense_xcd.hpp) were read stale: deterministic wrong costs in the first step
+// of a context created right after a data-parallel one, gone with RCN_HIP_DP_CACHED_BUF=1 and gone with this cache.
+struct UncachedCache {
+    std::mutex mu;
+    std::vector<std::tuple<int, size_t, void*>> free_list;        // (device, bytes, pointer)
+    hipError_t alloc(int device, size_t bytes, void** out) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_list.size(); ++i)
+                if (std::get<0>(free_list[i]) == device && std::get<1>(free_list[i]) == bytes) {
+                    *out = std::get<2>(free_list[i]);
+                    free_list.erase(free_list.begin() + i);
+                    return hipSuccess;
+                }
+        }
+        return hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
+    }
+    void park(int device, size_t bytes, void* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        free_list.emplace_back(device, bytes, p);
+    }
+};
+UncachedCache& uncached_cache() { static UncachedCache* u = new UncachedCache(); return *u; }      // (never destroyed: no hipFree at exit)
+constexpr size_t kP2PFlagBytes = 4096;
+
 void p2p_release(rcn_hip_ctx* c) {
     auto& q = c->p2p;
     if (!c->dp_graphs.empty() && c->stream) (void)hipStreamSynchronize(c->stream);     // a replay may still be in flight
@@ -1206,8 +1261,8 @@ void p2p_release(rcn_hip_ctx* c) {
         q.peer_buf[r] = nullptr;
         q.peer_flags[r] = nullptr;
     }
-    if (q.local_buf) (void)hipFree(q.local_buf);
-    if (q.local_flags) (void)hipFree(q.local_flags);
+    if (q.local_buf) { if (q.local_uncached) uncached_cache().park(c->device, q.local_bytes, q.local_buf); else (void)hipFree(q.local_buf); }
+    if (q.local_flags) uncached_cache().park(c->device, kP2PFlagBytes, q.local_flags);
     if (q.err_dev) (void)hipFree(q.err_dev);
     if (q.err_host) (void)hipHostFree(q.err_host);
     q.raw.release();
@@ -1222,21 +1277,24 @@ int p2p_export(rcn_hip_ctx* c, void* out) {
     auto& q = c->p2p;
     if (q.exported) p2p_release(c);
     q.stride = (((size_t)c->nd.P + 1) + 3) & ~(size_t)3;
-    // [2 plain slots | 2 slots of self-validating words, 2 * esz bytes per value]  (dp_p2p.hpp / dense_p2_dp.hpp)
-    const size_t bytes = 6 * q.stride * c->esz();
+    // [2 plain slots | 2 slots of self-validating words, 2 * esz bytes per value | the pushed exchange's rows]  (dp_p2p.hpp / dense_p2_dp.hpp / dp_push.hpp)
+    q.push_off = 6 * q.stride * c->esz();
+    const size_t bytes = q.push_off + push_region_bytes(q.stride);
     // Uncached (fine-grained) device memory for everything a peer reads while a kernel of ours is still running: the words of
     // the in-kernel exchange must leave this GPU's L2 when they are stored, not when the kernel ends -- the allocation type RCCL
     // uses for its own low-latency buffers.  (Ordinary hipMalloc memory is only guaranteed visible to a peer at kernel
     // boundaries; two ranks sharing ONE GPU, the only multi-rank case the development box offers, share its L2 and cannot
     // tell the difference.)  RCN_HIP_DP_CACHED_BUF=1 restores hipMalloc for A/B measurements.
+    q.local_bytes = bytes;
+    q.local_uncached = !c->opt.dp_cached_buf;
     if (c->opt.dp_cached_buf) HIP_TRY(c, hipMalloc(&q.local_buf, bytes));
-    else HIP_TRY(c, hipExtMallocWithFlags(&q.local_buf, bytes, hipDeviceMallocUncached));
-    HIP_TRY(c, hipExtMallocWithFlags((void**)&q.local_flags, 4096, hipDeviceMallocUncached));
+    else HIP_TRY(c, uncached_cache().alloc(c->device, bytes, &q.local_buf));
+    HIP_TRY(c, uncached_cache().alloc(c->device, kP2PFlagBytes, (void**)&q.local_flags));
     HIP_TRY(c, hipMalloc((void**)&q.err_dev, 256));
     HIP_TRY(c, hipHostMalloc((void**)&q.err_host, 64, hipHostMallocDefault));
     *q.err_host = 0;
     HIP_TRY(c, hipMemset(q.local_buf, 0, bytes));
-    HIP_TRY(c, hipMemset(q.local_flags, 0, 4096));
+    HIP_TRY(c, hipMemset(q.local_flags, 0, kP2PFlagBytes));
     HIP_TRY(c, hipMemset(q.err_dev, 0, 256));
     HIP_TRY(c, hipDeviceSynchronize());
     hipIpcMemHandle_t h[2];
@@ -1391,6 +1449,28 @@ int p2p_selftest_fused(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned
             hipLaunchKernelGGL((k_p2p_ll_selftest<double>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, p2p_timeout_ticks(c), (unsigned*)q.mism.p);
         else
             hipLaunchKernelGGL((k_p2p_ll_selftest<float>), dim3(wgs), dim3(256), 0, c->stream, p2p_desc(c), seq, q.stride, q.err_dev, p2p_timeout_ticks(c), (unsigned*)q.mism.p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    unsigned host[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&host[0], q.mism.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&host[1], q.err_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *mismatches = host[0];
+    *err = host[1];
+    return RCN_HIP_OK;
+}
+
+// the same for the pushed reduce-scatter + all-gather of the resident kernel's data-parallel form (dp_push.hpp; f32).  Collective.
+int p2p_selftest_push(rcn_hip_ctx* c, int iters, unsigned* mismatches, unsigned* err) {
+    auto& q = c->p2p;
+    if (!q.attached) return fail(c, RCN_HIP_ERR_STATE, "p2p_selftest: not attached");
+    HIP_TRY(c, q.mism.ensure(64));
+    HIP_TRY(c, hipMemsetAsync(q.mism.p, 0, 64, c->stream));
+    const int wgs = (int)((q.stride + 255) / 256);
+    for (int it = 0; it < iters; ++it) {
+        const unsigned seq = ++q.seq;
+        hipLaunchKernelGGL(k_push_selftest, dim3(wgs), dim3(256), 0, c->stream, PushDesc{p2p_desc(c), q.stride, q.push_off}, seq, q.err_dev,
+                           it == 0 ? 10 * p2p_timeout_ticks(c) : p2p_timeout_ticks(c), (unsigned*)q.mism.p);
         HIP_TRY(c, hipGetLastError());
     }
     unsigned host[2] = {0, 0};
@@ -2302,12 +2382,24 @@ static int p2p_admission(rcn_hip_ctx* c, const P2PTransport& t) {
         if (p2p_fault(c, "llskip")) { c->p2p.seq += 16; okf = 0; }         // this rank stays silent: its peers' waits expire
         else okf = (p2p_selftest_fused(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "ll")) ? 1 : 0;
         if ((st = t.vote_min(okf)) != RCN_HIP_OK) break;
-        if (okf) c->p2p.fused = true;
-        else {
+        auto clear_sticky = [&]() {
             // every rank has drained (the vote synchronised them); clear the sticky word and the pinned mirror of it
             if (hipMemsetAsync(c->p2p.err_dev, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) c->p2p.on = false;
             if (c->p2p.err_host) *c->p2p.err_host = 0;
-        }
+        };
+        if (okf) c->p2p.fused = true;
+        else clear_sticky();
+        if (!c->p2p.on) break;
+        // third, independent question: the pushed reduce-scatter + all-gather the resident kernel's data-parallel form runs (f32 contexts;
+        // remote STORES into the peers' memory and local polls, where the two forms above only ever read a peer's memory)
+        int okp = (c->opt.dp_fused && c->dtype == RCN_HIP_F32) ? 1 : 0;
+        if ((st = t.vote_min(okp)) != RCN_HIP_OK) break;
+        if (!okp) break;
+        if (p2p_fault(c, "pushskip")) { c->p2p.seq += 16; okp = 0; }
+        else okp = (p2p_selftest_push(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "push")) ? 1 : 0;
+        if ((st = t.vote_min(okp)) != RCN_HIP_OK) break;
+        if (okp) c->p2p.push = true;
+        else clear_sticky();
     } while (0);
     if (!c->p2p.on) { const int rk = c->dp_rank, w = c->dp_world; p2p_release(c); c->dp_rank = rk; c->dp_world = w; }
     c->err.clear();                                              // a failed attempt is not an error: the loop runs on the previous form
@@ -2437,6 +2529,13 @@ int rcn_hip_dp_p2p_selftest(rcn_hip_ctx* c, int iters, unsigned* mismatches, uns
     }
     *mismatches += bad2;
     *timed_out |= to2;
+    if (c->opt.dp_fused && c->dtype == RCN_HIP_F32 && bad2 == 0 && to2 == 0) {
+        unsigned bad3 = 0, to3 = 0;
+        RCN_TRY(p2p_selftest_push(c, iters, &bad3, &to3));
+        c->p2p.push = bad3 == 0 && to3 == 0;
+        *mismatches += bad3;
+        *timed_out |= to3;
+    }
     return RCN_HIP_OK;
 }
 
@@ -2471,7 +2570,7 @@ int rcn_hip_train_epoch_gathers(rcn_hip_ctx* c, size_t B) {
 int rcn_hip_dp_resident(rcn_hip_ctx* c, size_t B_shard) {
     if (!c) return 0;
     DevGuard g(c->device);
-    return c->p2p.on && c->p2p.fused && c->dtype == RCN_HIP_F32 && c->nd.L == 2 && use_xcd(c, B_shard) ? 1 : 0;
+    return dp_on_xcd(c, B_shard) ? 1 : 0;
 }
 
 int rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* c, size_t first_batch, size_t n_batches, double eta, void* loss_dev) {
@@ -2485,7 +2584,7 @@ int rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* c, size_t first_batch, size_t n_batc
     RCN_TRY(need_params(c));
     const size_t B = c->epoch_B, seg = c->epoch_seg;
     DevGuard g(c->device);
-    if (!(c->p2p.on && c->p2p.fused && c->dtype == RCN_HIP_F32 && c->nd.L == 2 && use_xcd(c, B)))
+    if (!(dp_on_xcd(c, B)))
         return fail(c, RCN_HIP_ERR_UNSUPPORTED, "dp_epoch_steps: only where the data-parallel step runs on the resident kernel (rcn_hip_dp_resident); "
                                                 "rcn_hip_dp_train_epoch_dev packs and runs its batches itself on every form");
     RCN_TRY(ensure_dense_ws(c, B));
@@ -2530,7 +2629,7 @@ static int dp_epoch_impl(rcn_hip_ctx* c, const void* X, const void* Y, const int
     char* gbuf = (char*)c->grad.p;
     void* lslot = gbuf + P * es;
     const bool f64 = c->dtype == RCN_HIP_F64;
-    if (c->p2p.on && c->p2p.fused && !f64 && c->nd.L == 2 && use_xcd(c, B)) {
+    if (dp_on_xcd(c, B)) {
         // the resident one-XCD kernel with the exchange between its gradient MFMAs and its update (dense_xcd.hpp, DP = true): one
         // launch per segment of the epoch image, nothing to capture
         RCN_TRY(ensure_pipe_ws(c, B));

@@ -122,6 +122,7 @@ class RCN:
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            _lib.FALLBACKS_SEEN += int(self._lib.rcn_hip_fallbacks_taken(self._ctx))     # (the tests assert that none goes unnoticed)
             self._lib.rcn_hip_destroy(self._ctx)
             self._ctx = C.c_void_p()
 

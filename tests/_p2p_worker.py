@@ -40,6 +40,11 @@ def main():
     ws, bs = synthetic_params(dims, seed=int(case["seed"]))
     ws = [w * 0.1 for w in ws]
     d = DeviceRCN(feedforward_cfg=dims[1:-1], classes=dims[-1], dtype=dtype)
+    # Ranks that SHARE this box's one GPU: every rank's resident workers on an XCD of their own, and the kernel asking for exactly the
+    # LDS it uses -- at a shard of <= 64 samples that is under half a CU's, so a rank's idle blocks (same launch, same LDS request)
+    # fit beside a peer's workers instead of queueing behind them.  With a GPU per rank neither option is needed.
+    d.set_option("xcd_select", rank % 8)
+    d.set_option("xcd_exact_lds", 1)
     d.set_params(ws, bs)
     X, Y = d.to_device(case[f"X{rank}"], d.tdtype), d.to_device(case[f"Y{rank}"], d.tdtype)
     loss = d.empty(nb)

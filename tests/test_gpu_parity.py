@@ -643,7 +643,7 @@ def test_native_rccl_epoch_world1_matches_oracle(amd, oracle, dtype):
 
 @pytest.mark.parametrize("dtype,Bs,nb,fused,world", [(1, 16, 4, 1, 2), (0, 16, 4, 1, 2), (1, 256, 3, 0, 2), (0, 256, 3, 0, 2), (1, 256, 3, 1, 2),
                                                       (0, 256, 3, 1, 2), (1, 256, 2, 1, 4), (0, 16, 3, 1, 4), (1, 256, 2, 0, 4), (1, 256, 2, 1, -2), (1, 256, 2, 0, -2),
-                                                      (0, 256, 5, 2, 2), (0, 256, 3, 2, -2)],
+                                                      (0, 64, 5, 2, 2), (0, 64, 3, 2, -2)],
                          ids=["f64-sample-tile", "f32-sample-tile", "f64-pipeline-3-kernels", "f32-pipeline-3-kernels",
                               "f64-pipeline-exchange-in-kernel", "f32-pipeline-exchange-in-kernel", "f64-4-ranks-exchange-in-kernel",
                               "f32-4-ranks-sample-tile", "f64-4-ranks-3-kernels", "f64-784-12-7-exchange-in-kernel", "f64-784-12-7-3-kernels",
@@ -669,16 +669,13 @@ def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused,
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_p2p_worker.py")
-    # fused == 2: the resident one-XCD kernel with the exchange inside it (dense_xcd.hpp, DP form; every rank on an XCD of its own,
-    # tests/_p2p_worker.py); the other cases keep the kernels they were written for.  Opt-in: every block of a resident launch --
-    # also the 224 idle ones -- asks for a whole CU's LDS, so a rank's idle blocks bound for the XCD its peer already fills wait for
-    # the peer, which waits for this rank's workers queued behind them: two ranks got through when their launches interleaved
-    # (parameters equal to the oracle, replicas bit-identical), four never did.  An artefact of sharing ONE device.
+    # fused == 2: the resident one-XCD kernel with the exchange inside it (dense_xcd.hpp, DP form: reduce-scatter + all-gather on pushed
+    # words, dp_push.hpp), every rank on an XCD of its own (tests/_p2p_worker.py).  At a shard of 64 samples: a resident launch's
+    # blocks -- also the 224 idle ones -- all ask for the kernel's LDS, 66 KB at this size, so a rank's idle blocks fit beside the
+    # workers of the peer whose XCD they land on.  At a shard of 256 (148 KB, a whole CU) they cannot: they queue behind the peer's
+    # workers, which wait for this rank's workers queued behind them -- by construction, on ONE shared device only; a GPU per rank
+    # has no peer workers on it (round 2 ran that case opt-in and saw it pass once and time out otherwise).
     resident = fused == 2
-    if resident and os.environ.get("RCN_TEST_SHARED_GPU_RESIDENT", "0") != "1":
-        # measured: green when the two launches interleave, a bounded timeout on both ranks when one rank's idle blocks find the
-        # peer's XCD already full -- placement luck of two resident kernels on ONE device, which a GPU per rank does not have
-        pytest.skip("two resident kernels on one shared GPU depend on launch interleaving; set RCN_TEST_SHARED_GPU_RESIDENT=1 to try")
     fused = 1 if resident else fused
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RCN_HIP_DP_FUSED=str(fused), RCN_HIP_XCD="1" if resident else "0")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(dtype), str(tmp_path)], env=env,

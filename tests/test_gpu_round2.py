@@ -637,9 +637,9 @@ def test_resident_kernel_data_parallel_form_at_world_one_is_the_single_gpu_kerne
         if form == "dp":
             d.dp_finalize()
         d.rcn.close()
+    assert np.array_equal(got["dp"][1], got["single"][1]) and np.array_equal(got["dp"][2], got["single"][2]), (got["dp"][1] - got["single"][1], got["dp"][2] - got["single"][2])
     for a, b in zip(got["dp"][0], got["single"][0]):
-        assert np.array_equal(a, b)
-    assert np.array_equal(got["dp"][1], got["single"][1]) and np.array_equal(got["dp"][2], got["single"][2])
+        assert np.array_equal(a, b), float(np.abs(a - b).max())
 
 
 _GATHER_SCRIPT = r"""

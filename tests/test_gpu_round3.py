@@ -127,6 +127,7 @@ def test_loss_curve_256_steps_at_the_reference_batch_sizes(amd, oracle, B):
         assert np.all(np.abs(a - b) <= 2e-3 * np.abs(b) + 2e-4), float(np.abs(a - b).max())
 
 
+@pytest.mark.steps_down
 @pytest.mark.parametrize("fail_launch", [1, 2, 3])
 def test_resident_kernel_steps_down_by_itself_and_the_epochs_still_equal_the_oracle(amd, oracle, fail_launch):
     """A resident launch that loses a worker (test hook "xcd_fault_launch": what a co-tenant holding a CU of the XCD does) fails on a
@@ -244,3 +245,92 @@ def test_options_are_per_context(amd, oracle):
     for x, y in zip(out[0][1], out[1][1]):
         assert np.all(np.abs(x - y) <= 1e-4 * np.abs(y) + 1e-5)
     a.rcn.close(); b.rcn.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the data-parallel form of the resident kernel between PROCESSES (default on)
+
+def _spawn_ranks(tmp_path, world, dtype, case_name, env_extra, dims=(784, 30, 10), Bs=64, nb=3, seed=17):
+    import socket
+    import subprocess
+    import sys
+    rng = np.random.default_rng(31)
+    dims = list(dims)
+    Xs = [np.maximum(rng.standard_normal((Bs * nb, dims[0])), 0.0) for _ in range(world)]
+    Ys = [one_hot(rng.integers(0, dims[-1], Bs * nb), dims[-1]) for _ in range(world)]
+    np.savez(tmp_path / "case.npz", dims=dims, Bs=Bs, nb=nb, seed=seed, **{f"X{r}": Xs[r] for r in range(world)}, **{f"Y{r}": Ys[r] for r in range(world)})
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    worker = os.path.join(ROOT, "tests", "_p2p_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(dtype), str(tmp_path), case_name], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, _ = pr.communicate()
+        logs.append(out.decode(errors="replace")[-3000:])
+    assert all(pr.returncode == 0 for pr in procs), "\n----\n".join(logs)
+    return Xs, Ys, logs
+
+
+def _oracle_global_epochs(oracle, dims, Xs, Ys, Bs, nb, seed=17):
+    ws, bs = synthetic_params(dims, seed=seed)
+    rw, rb, costs = [w * 0.1 for w in ws], bs, []
+    for ep in range(2):
+        for j in range(nb):
+            xb = np.concatenate([X[j * Bs:(j + 1) * Bs] for X in Xs])
+            yb = np.concatenate([Y[j * Bs:(j + 1) * Bs] for Y in Ys])
+            rw, rb, c = oracle.train_batch(rw, rb, xb, yb, 3.0)
+            if ep == 0:
+                costs.append(c)
+    return rw, rb, costs
+
+
+@pytest.mark.parametrize("world,Bs,dims", [(2, 64, (784, 30, 10)), (2, 32, (784, 12, 7)), (4, 32, (784, 30, 10)), (3, 64, (784, 30, 10))],
+                         ids=["2-ranks-shard-64", "2-ranks-784-12-7-shard-32", "4-ranks-shard-32", "3-ranks-shard-64"])
+def test_resident_kernel_data_parallel_form_between_processes(amd, oracle, tmp_path, world, Bs, dims):
+    """k_xcd_epoch<DP> between 2, 3 and 4 PROCESSES on this box's GPU, the form bench.py selects first at N > 1: the shards' partial
+    gradients meet inside the resident kernel by a reduce-scatter + all-gather on pushed self-validating words (csrc/dp_push.hpp; a
+    slice pair's owner is rank worker % world, so with 3 ranks the ownership is uneven), the tail parameters and the cost all-to-all.
+    Replicas bit-identical; two epochs equal the oracle's train_batch on the concatenated global batches at the f32 tolerances;
+    the admitted form reports itself resident on every rank."""
+    nb = 3
+    Xs, Ys, logs = _spawn_ranks(tmp_path, world, 0, "default", {}, dims=dims, Bs=Bs, nb=nb)
+    outs = [np.load(tmp_path / f"out{r}.npz") for r in range(world)]
+    for o in outs:
+        assert int(o["bad"]) == 0 and int(o["timed_out"]) == 0 and int(o["active"]) == 2, logs
+        assert int(o["resident"]) == 1, "the data-parallel epoch did not run on the resident kernel"
+    for r in range(1, world):
+        for k in ("w0", "w1", "b0", "b1", "loss"):
+            assert np.array_equal(outs[0][k], outs[r][k]), (r, k)
+    rw, rb, costs = _oracle_global_epochs(oracle, list(dims), Xs, Ys, Bs, nb)
+    for a, b in zip([outs[0]["w0"], outs[0]["w1"], outs[0]["b0"], outs[0]["b1"]], [rw[0], rw[1], rb[0], rb[1]]):
+        assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5), float(np.abs(a - b).max())     # six chained f32 steps
+    np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-4)
+
+
+@pytest.mark.parametrize("fault,resident", [("", 1), ("push:1", 0), ("pushskip:0", 0)], ids=["no-fault", "pushed-selftest-mismatch-on-rank1", "pushed-selftest-timeout"])
+def test_admission_of_the_pushed_exchange_is_voted_like_the_others(amd, oracle, tmp_path, fault, resident):
+    """The third vote of p2p_admission (csrc/rcn_hip_api.hip): a rank whose known-answer exchange on the pushed primitives is wrong, or
+    that stays silent in it so that its peer's waits really expire, keeps EVERY rank off the resident kernel's data-parallel form --
+    the in-kernel exchange of the two-kernel pipeline (form 2) stays admitted, the sticky word is cleared -- and the epochs on the
+    form the ranks landed on equal the oracle."""
+    env = {"RCN_HIP_DP_FAULT": fault} if fault else {}
+    if "skip" in fault:
+        env["RCN_HIP_DP_TIMEOUT_TICKS"] = "5000000"
+    world, Bs, nb, dims = 2, 256 if not resident else 64, 2, [784, 30, 10]
+    Xs, Ys, logs = _spawn_ranks(tmp_path, world, 0, "admit", env, dims=dims, Bs=Bs, nb=nb)
+    outs = [np.load(tmp_path / f"out{r}.npz") for r in range(world)]
+    assert [int(o["active"]) for o in outs] == [2] * world, logs
+    assert [int(o["resident"]) for o in outs] == [resident] * world, logs
+    for k in ("w0", "w1", "b0", "b1", "loss"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    rw, rb, costs = _oracle_global_epochs(oracle, dims, Xs, Ys, Bs, nb)
+    for a, b in zip([outs[0]["w0"], outs[0]["w1"], outs[0]["b0"], outs[0]["b1"]], [rw[0], rw[1], rb[0], rb[1]]):
+        assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5), float(np.abs(a - b).max())
+    np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-4)
