@@ -59,16 +59,27 @@ def csrc_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+_NATIVE_ORACLE = []
+
+
+def native_oracle():
+    """oracle/rcn_oracle.c built -O3 -march=native for THIS host (the Rust --release analogue), once per process; the checker only."""
+    import tempfile
+    from oracle.rcn_oracle import COracle, build_oracle
+    if not _NATIVE_ORACLE:
+        try:
+            path = build_oracle(native=True, out_dir=tempfile.mkdtemp(prefix="rcn_oracle_"))
+        except Exception:
+            path = build_oracle()
+        _NATIVE_ORACLE.append(COracle(path))
+    return _NATIVE_ORACLE[0]
+
+
 def cpu_baseline(seconds_budget: float = 8.0):
     """rcn's CPU path (oracle/rcn_oracle.c restated from rcn.rs:176-314, threaded like the rayon loop) on this host:
     B = 32 (BASELINE.json configs[0]), all host cores and one core, bounded sample."""
-    import tempfile
-    from oracle.rcn_oracle import COracle, DEFAULT_LAYERS, build_oracle, one_hot, synthetic_images, synthetic_params
-    try:
-        path = build_oracle(native=True, out_dir=tempfile.mkdtemp(prefix="rcn_oracle_"))
-    except Exception:
-        path = build_oracle()
-    o = COracle(path)
+    from oracle.rcn_oracle import DEFAULT_LAYERS, one_hot, synthetic_images, synthetic_params
+    o = native_oracle()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n = 2048
     imgs, labels = synthetic_images(n)
@@ -483,6 +494,8 @@ def main():
 
     prime(args.warmup)
     run(args.warmup)
+    start_pos = step_no[0] % nb_epoch
+    epoch_boundary_in_bracket = start_pos == 0 or start_pos + args.steps > nb_epoch      # a shuffle + gather of the epoch falls inside the timed steps
     elapsed, dev_ms = timed(args.steps)
     loss_t = d.empty(1)
     d.train_batch(X[:B], Y[:B], 0.0, loss_t)                             # eta = 0: reads the current cost, changes nothing
@@ -570,7 +583,8 @@ def main():
                    "session": f"steps {args.warmup}..{args.warmup + args.steps} of one continuous training session (64 steps per epoch; device shuffle "
                               + ("at every epoch boundary, rows fetched by the step kernel itself in the shuffled order -- no packed copy of the epoch"
                                  if (not use_dp and gathers) else "+ one gather of the shuffled order at every epoch boundary")
-                              + ", inside the timed region whenever it is crossed)",
+                              + ", inside the timed region whenever it is crossed -- see epoch_boundary_in_bracket; steady_state_* always carries its 1/64 share)",
+                   "epoch_boundary_in_bracket": bool(epoch_boundary_in_bracket),
                    "device_ms_per_step_rank0": round(dev_ms / args.steps, 6), "final_cost_rank0": final_loss,
                    "steady_state_steps": steady_k,
                    "steady_state_images_per_s": round(steady_k * B * world / steady_el, 1),
@@ -679,6 +693,11 @@ def main():
                 result["config"]["reference_test_net"] = test_net_leg(torch, amd, DeviceRCN, imgs_d, labels_d, local_rank)
             except Exception as ex:
                 result["config"]["reference_test_net"] = {"error": str(ex)[:200]}
+        if extras and args.dtype == "f32":
+            try:
+                result["config"]["small_batch"] = small_batch_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, local_rank)
+            except Exception as ex:
+                result["config"]["small_batch"] = {"error": str(ex)[:300]}
         if extras:
             try:
                 result["config"]["loss_curve"] = loss_curve_leg(torch, amd, DeviceRCN, imgs, labels, imgs_d, labels_d, ws, bs, local_rank, dtype)
@@ -733,6 +752,65 @@ def f64_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, dev):
     us = a.elapsed_time(b) * 1e3 / (n * nb)
     d.rcn.close()
     return {"f64_images_per_s": round(B / us * 1e6, 1), "f64_us_per_step": round(us, 4), "f64_steps": n * nb}
+
+
+def small_batch_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, dev):
+    """The reference's OWN operating points: batch_size 10 (rcn/src/main.rs:36-37, benches/train.rs:22, rcn.rs:581) and 32 (BASELINE.json
+    configs[0]), same data and session shape -- one shuffled epoch of chunks_exact(B) per call, device-timed -- on the default path
+    (the resident one-XCD kernel's instantiation for batches <= 32) and on the sample-tile kernels it replaces there, beside the CPU
+    restatement of rcn's rayon loop (oracle/rcn_oracle.c) at the same B on one thread and on all threads of this host."""
+    from oracle.rcn_oracle import DEFAULT_LAYERS, one_hot
+    from mercer_research_amd.synth import synthetic_images
+    out = {}
+    o = native_oracle()
+    n_cpu = 2048
+    imgs_h, labels_h = synthetic_images(n_cpu)
+    feats = o.features(imgs_h, DEFAULT_LAYERS)
+    m, s = o.gen_scales(feats)
+    Xh, Yh = o.standardize(feats, m, s), one_hot(labels_h)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for B in (10, 32):
+        nb = N_IMAGES // B                                  # chunks_exact(B): the tail is dropped (rcn.rs:147)
+        row = {}
+        for name, path in (("default_path", 0), ("sample_tile_kernels", 1)):
+            d = DeviceRCN(classes=10, feedforward_cfg=[30], input_shape=(28, 28), dtype=amd.F32, device=dev)
+            d.set_params(ws, bs)
+            if path:
+                d.set_dense_path(path)
+            X, Y = d.load_data(imgs_d, labels_d)
+            perm = torch.empty(N_IMAGES, dtype=torch.int32, device=d.device)
+
+            def epochs(n, seed0):
+                for e in range(n):
+                    d.shuffle(perm, N_IMAGES, 1, seed=seed0 + e)
+                    d.train_epoch(X, Y, perm, B, nb, ETA, None)
+            epochs(1, 11)
+            d.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 3 if path == 0 else 1
+            a.record(d.stream)
+            epochs(n, 100)
+            b.record(d.stream)
+            d.synchronize()
+            us = a.elapsed_time(b) * 1e3 / (n * nb)
+            k1, _, _ = d.time_kernels(X[:B], Y[:B], reps=64)
+            row[name] = {"us_per_step": round(us, 3), "steps_per_s": round(1e6 / us, 1), "images_per_s": round(B / us * 1e6, 1),
+                         "resident_kernel": k1 == 0.0, "steps": n * nb, "fallbacks": d.fallbacks_taken()}
+            d.rcn.close()
+        cpu = {}
+        for label, thr in (("one_thread", 0), ("all_threads", cores)):
+            h = o.net(ws, bs)
+            o.train_steps_inplace(h, Xh, Yh, B, 8, ETA, threads=thr)
+            t0, k = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 0.6:
+                o.train_steps_inplace(h, Xh, Yh, B, 16, ETA, threads=thr)
+                k += 16
+            el = time.perf_counter() - t0
+            cpu[label] = {"steps_per_s": round(k / el, 1), "images_per_s": round(k * B / el, 1)}
+        row["cpu_restatement_f64"] = dict(cpu, host_hardware_threads=cores)
+        row["gpu_over_cpu"] = round(row["default_path"]["images_per_s"] / max(cpu["one_thread"]["images_per_s"], cpu["all_threads"]["images_per_s"]), 1)
+        out[f"B{B}"] = row
+    return out
 
 
 def test_net_leg(torch, amd, DeviceRCN, imgs_d, labels_d, dev):
@@ -845,18 +923,27 @@ def trackx_leg(torch, dev):
         out[prec] = {"ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1), "step_gflop": round(flops / 1e9, 2), "tflops": round(tf, 2),
                      "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 4)}
         net.close()
-    pm = os.path.join(ROOT, "profiles", "r2_trackx_mfma_pmc.json")
-    if os.path.exists(pm):
+    # the conv-GEMM MFMA-busy figures are PMC measurements of a separate profiled run (tools/prof_trackx.sh), relayed here with the
+    # fingerprint of the kernel sources they were taken on -- like roofline.traffic, the line says when the sources have changed since
+    from tools.mfma_pmc_summary import trackx_sha16
+    for name in ("r3_trackx_mfma_pmc.json", "r2_trackx_mfma_pmc.json"):
+        pm = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pm):
+            continue
         try:
             pj = json.load(open(pm))
-            conv = {k: v["mfma_busy_fraction_of_simd_cycles"] for k, v in pj.items() if "k_conv_fwd<3, false" in k and "mfma_busy_fraction_of_simd_cycles" in v}
-            wg = {k: v["mfma_busy_fraction_of_simd_cycles"] for k, v in pj.items() if "k_conv_wgrad<3, false" in k and "mfma_busy_fraction_of_simd_cycles" in v}
+            meta = pj.get("_meta", {})
+            conv = {k: v["mfma_busy_fraction_of_simd_cycles"] for k, v in pj.items() if ("k_conv_fwd<3, false" in k or "k_conv3x3_" in k) and "mfma_busy_fraction_of_simd_cycles" in v}
+            wg = {k: v["mfma_busy_fraction_of_simd_cycles"] for k, v in pj.items() if ("k_conv_wgrad<3, false" in k or "k_wgrad3x3_" in k) and "mfma_busy_fraction_of_simd_cycles" in v}
             out["conv_gemm_mfma_busy"] = {"forward_and_dgrad_kernels": conv, "wgrad_kernels": wg,
-                                          "source": "profiles/r2_trackx_mfma_pmc.json (tools/prof_trackx.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over "
+                                          "time_weighted_over_3x3_conv_gemm_kernels": meta.get("conv3x3_gemm_time_weighted_mfma_busy"),
+                                          "measured_on_other_kernel_sources": (meta.get("trackx_sha16") != trackx_sha16()) if meta.get("trackx_sha16") else True,
+                                          "source": f"profiles/{name} (tools/prof_trackx.sh: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over "
                                                     "bench_convnet.py --config cifar; fraction = MFMA-busy cycles / (GRBM_GUI_ACTIVE x 128), 1.0 = every SIMD's matrix pipe busy "
-                                                    "for the kernel's whole duration)"}
+                                                    "for the kernel's whole duration; a relayed measurement, not taken in this run)"}
         except Exception:
             pass
+        break
     return out
 
 

@@ -253,6 +253,12 @@ int  rcn_hip_dp_p2p_selftest(rcn_hip_ctx* ctx, int iters, unsigned* mismatches, 
 typedef int (*rcn_hip_allgather_fn)(void* user, const void* mine, void* all, size_t bytes);
 typedef int (*rcn_hip_vote_min_fn)(void* user, int* v);
 int  rcn_hip_dp_p2p_admit(rcn_hip_ctx* ctx, int rank, int world, rcn_hip_allgather_fn allgather, rcn_hip_vote_min_fn vote_min, void* user);
+/* The same vote sequence WITHOUT a device: every stage succeeds unless `faults` ("<stage>:<rank>,...", the stages above plus nofused,
+ * f64, clear) names it for this rank.  Needs no context and no GPU -- a launcher can rehearse its transport with it, and the CPU test
+ * (tests/test_dp_gloo.py) drives the native admission logic over gloo with it.  *form_out: 0 / 1 / 2 as rcn_hip_dp_p2p_active,
+ * *resident_out (nullable): 1 when the pushed exchange of the resident kernel's data-parallel form was admitted too. */
+int  rcn_hip_dp_admission_rehearse(int rank, int world, const char* faults, rcn_hip_allgather_fn allgather, rcn_hip_vote_min_fn vote_min,
+                                   void* user, int* form_out, int* resident_out);
 /* The data-parallel counterpart of rcn_hip_epoch_steps_dev: n_batches data-parallel steps over this rank's shard batches
  * [first_batch, first_batch + n_batches) of the epoch image rcn_hip_epoch_begin_dev packed on THIS rank (every rank begins its own
  * shard's epoch; nothing is gathered or packed inside the call, so an epoch is packed once however many calls walk it).  Collective

@@ -92,6 +92,7 @@ SIGNATURES = {
     "rcn_hip_dp_p2p_attach": (_i, [_vp, _vp, _i, _i]),
     "rcn_hip_dp_p2p_selftest": (_i, [_vp, _i, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "rcn_hip_dp_p2p_admit": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "rcn_hip_dp_admission_rehearse": (_i, [_i, _i, C.c_char_p, _vp, _vp, _vp, _ip, _ip]),
     "rcn_hip_dp_epoch_steps_dev": (_i, [_vp, _sz, _sz, _d, _vp]),
     "rcn_hip_train_epoch_gathers": (_i, [_vp, _sz]),
     "rcn_hip_dp_resident": (_i, [_vp, _sz]),

@@ -2355,52 +2355,104 @@ static bool p2p_fault(const rcn_hip_ctx* c, const char* stage) {
     return false;
 }
 
-static int p2p_admission(rcn_hip_ctx* c, const P2PTransport& t) {
-    const int world = c->dp_world, rank = c->dp_rank;
+// The vote sequence itself, separated from what the stages do: `ops` is the context's device work (p2p_admission below) or a script
+// (rcn_hip_dp_admission_rehearse: the same sequence over the caller's transport without any GPU, which is how the CPU test drives
+// the native logic over gloo).  Every stage returns 1 (this rank is fine) or 0; every rank calls the transport the same number of times
+// in the same order whatever its own stages returned.
+struct AdmissionOps {
+    std::function<int(char* handles)> do_export;            // export this rank's buffers -> handles
+    std::function<int(const char* all_handles)> attach;      // map every peer
+    std::function<int()> known_answer;                       // the kernel-boundary exchange, exact sums, no timeout
+    std::function<int()> wants_fused;                        // configuration: may the exchange run inside a step kernel at all?
+    std::function<int()> tagged_words;                       // the in-kernel (pull) exchange's known-answer test
+    std::function<int()> wants_push;                         // configuration: f32 context?
+    std::function<int()> pushed_words;                       // the pushed reduce-scatter + all-gather's known-answer test
+    std::function<int()> clear_sticky;                       // after a failed in-kernel stage: 1 if the kernel-boundary form survives
+};
+struct AdmissionOutcome { bool on = false, fused = false, push = false; };
+
+static int admission_protocol(int world, const AdmissionOps& ops, const P2PTransport& t, AdmissionOutcome& out) {
     char mine[kP2PHandleBytes] = {};
-    int ok = (p2p_export(c, mine) == RCN_HIP_OK && !p2p_fault(c, "export")) ? 1 : 0;
+    int ok = ops.do_export(mine);
     std::vector<char> all((size_t)world * kP2PHandleBytes);
     int st = RCN_HIP_OK;
     do {
         if ((st = t.allgather(mine, all.data(), kP2PHandleBytes)) != RCN_HIP_OK) break;
         if ((st = t.vote_min(ok)) != RCN_HIP_OK) break;          // did every rank export?
         if (!ok) break;
-        ok = (p2p_attach(c, all.data(), rank, world) == RCN_HIP_OK && !p2p_fault(c, "attach")) ? 1 : 0;
+        ok = ops.attach(all.data());
         if ((st = t.vote_min(ok)) != RCN_HIP_OK) break;          // did every rank map every peer?
         if (!ok) break;
-        unsigned bad = 0, err = 0;
-        ok = (p2p_selftest(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "kat")) ? 1 : 0;
+        ok = ops.known_answer();
         if ((st = t.vote_min(ok)) != RCN_HIP_OK) break;          // did every rank see exact sums, without a timeout?
         if (!ok) break;
-        c->p2p.on = true;
+        out.on = true;
         // second, independent question: may the exchange also run INSIDE the gradient kernel (tagged words, no flags)?  A failed
         // wait here leaves the sticky error word set, which would disable the kernel-boundary protocol too, so it is cleared
         // (after every rank has drained: the vote synchronises) when only this stage failed.
-        int okf = c->opt.dp_fused ? 1 : 0;
-        if ((st = t.vote_min(okf)) != RCN_HIP_OK) break;         // every rank must want it (same environment everywhere, normally)
+        int okf = ops.wants_fused();
+        if ((st = t.vote_min(okf)) != RCN_HIP_OK) break;         // every rank must want it (same configuration everywhere, normally)
         if (!okf) break;
-        if (p2p_fault(c, "llskip")) { c->p2p.seq += 16; okf = 0; }         // this rank stays silent: its peers' waits expire
-        else okf = (p2p_selftest_fused(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "ll")) ? 1 : 0;
+        okf = ops.tagged_words();
         if ((st = t.vote_min(okf)) != RCN_HIP_OK) break;
-        auto clear_sticky = [&]() {
-            // every rank has drained (the vote synchronised them); clear the sticky word and the pinned mirror of it
-            if (hipMemsetAsync(c->p2p.err_dev, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) c->p2p.on = false;
-            if (c->p2p.err_host) *c->p2p.err_host = 0;
-        };
-        if (okf) c->p2p.fused = true;
-        else clear_sticky();
-        if (!c->p2p.on) break;
-        // third, independent question: the pushed reduce-scatter + all-gather the resident kernel's data-parallel form runs (f32 contexts;
-        // remote STORES into the peers' memory and local polls, where the two forms above only ever read a peer's memory)
-        int okp = (c->opt.dp_fused && c->dtype == RCN_HIP_F32) ? 1 : 0;
+        if (okf) out.fused = true;
+        else {
+            // (every rank is here -- the vote above gave all of them the same answer -- so clearing is voted too: a rank that cannot
+            // clear its sticky word takes the whole group off the peer exchange, not only itself.  Found by the CPU rehearsal of this
+            // sequence, tests/test_dp_gloo.py: rounds 1-2 decided this locally and the ranks could land on different forms.)
+            int okc = ops.clear_sticky();
+            if ((st = t.vote_min(okc)) != RCN_HIP_OK) break;
+            if (!okc) out.on = false;
+        }
+        if (!out.on || !out.fused) break;
+        // third question, asked only of a group that passed everything before it: the pushed reduce-scatter + all-gather the resident
+        // kernel's data-parallel form runs (f32 contexts; remote STORES into the peers' memory and local polls, where the two forms
+        // above only ever read a peer's memory)
+        int okp = ops.wants_push();
         if ((st = t.vote_min(okp)) != RCN_HIP_OK) break;
         if (!okp) break;
-        if (p2p_fault(c, "pushskip")) { c->p2p.seq += 16; okp = 0; }
-        else okp = (p2p_selftest_push(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "push")) ? 1 : 0;
+        okp = ops.pushed_words();
         if ((st = t.vote_min(okp)) != RCN_HIP_OK) break;
-        if (okp) c->p2p.push = true;
-        else clear_sticky();
+        if (okp) out.push = true;
+        else {
+            int okc = ops.clear_sticky();
+            if ((st = t.vote_min(okc)) != RCN_HIP_OK) break;
+            if (!okc) { out.on = false; out.fused = false; }
+        }
     } while (0);
+    return st;
+}
+
+static int p2p_admission(rcn_hip_ctx* c, const P2PTransport& t) {
+    const int world = c->dp_world, rank = c->dp_rank;
+    AdmissionOps ops;
+    ops.do_export = [&](char* h) { return (p2p_export(c, h) == RCN_HIP_OK && !p2p_fault(c, "export")) ? 1 : 0; };
+    ops.attach = [&](const char* all) { return (p2p_attach(c, all, rank, world) == RCN_HIP_OK && !p2p_fault(c, "attach")) ? 1 : 0; };
+    ops.known_answer = [&]() {
+        unsigned bad = 0, err = 0;
+        return (p2p_selftest(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "kat")) ? 1 : 0;
+    };
+    ops.wants_fused = [&]() { return c->opt.dp_fused ? 1 : 0; };
+    ops.tagged_words = [&]() {
+        unsigned bad = 0, err = 0;
+        if (p2p_fault(c, "llskip")) { c->p2p.seq += 16; return 0; }          // this rank stays silent: its peers' waits expire
+        return (p2p_selftest_fused(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "ll")) ? 1 : 0;
+    };
+    ops.wants_push = [&]() { return (c->opt.dp_fused && c->dtype == RCN_HIP_F32) ? 1 : 0; };
+    ops.pushed_words = [&]() {
+        unsigned bad = 0, err = 0;
+        if (p2p_fault(c, "pushskip")) { c->p2p.seq += 16; return 0; }
+        return (p2p_selftest_push(c, 16, &bad, &err) == RCN_HIP_OK && bad == 0 && err == 0 && !p2p_fault(c, "push")) ? 1 : 0;
+    };
+    ops.clear_sticky = [&]() {
+        // every rank has drained (the vote synchronised them); clear the sticky word and the pinned mirror of it
+        const bool ok = hipMemsetAsync(c->p2p.err_dev, 0, 4, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        if (c->p2p.err_host) *c->p2p.err_host = 0;
+        return ok ? 1 : 0;
+    };
+    AdmissionOutcome out;
+    const int st = admission_protocol(world, ops, t, out);
+    c->p2p.on = out.on; c->p2p.fused = out.on && out.fused; c->p2p.push = out.on && out.push;
     if (!c->p2p.on) { const int rk = c->dp_rank, w = c->dp_world; p2p_release(c); c->dp_rank = rk; c->dp_world = w; }
     c->err.clear();                                              // a failed attempt is not an error: the loop runs on the previous form
     return st;
@@ -2557,6 +2609,44 @@ int rcn_hip_dp_p2p_admit(rcn_hip_ctx* c, int rank, int world, rcn_hip_allgather_
         return vote_min(user, &v) == 0 ? RCN_HIP_OK : fail(c, RCN_HIP_ERR_HIP, "dp_p2p_admit: the caller's vote failed");
     };
     return p2p_admission(c, t);
+}
+
+int rcn_hip_dp_admission_rehearse(int rank, int world, const char* faults, rcn_hip_allgather_fn allgather, rcn_hip_vote_min_fn vote_min, void* user,
+                                   int* form_out, int* resident_out) {
+    if (!allgather || !vote_min || !form_out || world < 1 || world > kP2PMaxWorld || rank < 0 || rank >= world) return RCN_HIP_ERR_INVALID_ARG;
+    const std::string all_faults = faults ? faults : "";
+    auto faulty = [&](const char* stage) {
+        const std::string want = std::string(stage) + ":" + std::to_string(rank);
+        size_t pos = 0;
+        while (pos <= all_faults.size()) {
+            const size_t end = all_faults.find(',', pos);
+            if (all_faults.substr(pos, end == std::string::npos ? std::string::npos : end - pos) == want) return true;
+            if (end == std::string::npos) break;
+            pos = end + 1;
+        }
+        return false;
+    };
+    AdmissionOps ops;
+    ops.do_export = [&](char* h) { std::memset(h, 0, kP2PHandleBytes); h[0] = (char)(rank + 1); return faulty("export") ? 0 : 1; };
+    ops.attach = [&](const char* all) {
+        for (int r = 0; r < world; ++r)
+            if (all[(size_t)r * kP2PHandleBytes] != (char)(r + 1)) return 0;          // the transport delivered every rank's bytes, in rank order
+        return faulty("attach") ? 0 : 1;
+    };
+    ops.known_answer = [&]() { return faulty("kat") ? 0 : 1; };
+    ops.wants_fused = [&]() { return faulty("nofused") ? 0 : 1; };
+    ops.tagged_words = [&]() { return (faulty("ll") || faulty("llskip")) ? 0 : 1; };
+    ops.wants_push = [&]() { return faulty("f64") ? 0 : 1; };
+    ops.pushed_words = [&]() { return (faulty("push") || faulty("pushskip")) ? 0 : 1; };
+    ops.clear_sticky = [&]() { return faulty("clear") ? 0 : 1; };
+    P2PTransport t;
+    t.allgather = [&](const void* mine, void* all, size_t bytes) -> int { return allgather(user, mine, all, bytes) == 0 ? RCN_HIP_OK : RCN_HIP_ERR_HIP; };
+    t.vote_min = [&](int& v) -> int { return vote_min(user, &v) == 0 ? RCN_HIP_OK : RCN_HIP_ERR_HIP; };
+    AdmissionOutcome out;
+    const int st = admission_protocol(world, ops, t, out);
+    *form_out = out.on ? (out.fused ? 2 : 1) : 0;
+    if (resident_out) *resident_out = (out.on && out.push) ? 1 : 0;
+    return st;
 }
 
 int rcn_hip_dp_p2p_active(const rcn_hip_ctx* c) { return c && c->p2p.on ? (c->p2p.fused ? 2 : 1) : 0; }

@@ -117,6 +117,10 @@ extern "C" {
     pub fn rcn_hip_dp_p2p_admit(ctx: *mut rcn_hip_ctx, rank: c_int, world: c_int,
                                 allgather: Option<unsafe extern "C" fn(user: *mut c_void, mine: *const c_void, all: *mut c_void, bytes: usize) -> c_int>,
                                 vote_min: Option<unsafe extern "C" fn(user: *mut c_void, v: *mut c_int) -> c_int>, user: *mut c_void) -> c_int;
+    pub fn rcn_hip_dp_admission_rehearse(rank: c_int, world: c_int, faults: *const c_char,
+                                         allgather: Option<unsafe extern "C" fn(user: *mut c_void, mine: *const c_void, all: *mut c_void, bytes: usize) -> c_int>,
+                                         vote_min: Option<unsafe extern "C" fn(user: *mut c_void, v: *mut c_int) -> c_int>, user: *mut c_void,
+                                         form_out: *mut c_int, resident_out: *mut c_int) -> c_int;
     pub fn rcn_hip_dp_epoch_steps_dev(ctx: *mut rcn_hip_ctx, first_batch: usize, n_batches: usize, eta: f64, loss_dev: *mut c_void) -> c_int;
     pub fn rcn_hip_train_epoch_gathers(ctx: *mut rcn_hip_ctx, b: usize) -> c_int;
     pub fn rcn_hip_dp_resident(ctx: *mut rcn_hip_ctx, b_shard: usize) -> c_int;

@@ -712,9 +712,15 @@ def test_peer_allreduce_two_processes_one_gpu(amd, oracle, dtype, Bs, nb, fused,
         _check_params(got, want, 1)
         np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-10)
     else:
+        # f32.  Measured on MI355X over the thirteen cases of this test (2 x nb = 4..10 chained steps; printed below): parameters within
+        # 3.9e-7 x (|ref| + 0.1), costs within 1.6e-7 relative of the f64 oracle.  Asserted at ten times that -- tighter than SURVEY
+        # 8(c)'s one-step tolerance (1e-5 x |ref| + 1e-6); round 2 asserted 2e-4 x |ref| + 2e-5 and 1e-3 on the costs here.
+        dev_p = max(float(np.max(np.abs(a - b) / (np.abs(b) + 0.1))) for a, b in zip(got, want))
+        dev_c = float(np.max(np.abs(outs[0]["loss"] - costs) / np.abs(costs)))
+        print(f"MEASURED two-process f32 {dims} Bs={Bs} world={world} fused={fused}: params {dev_p:.3e} (relative to |ref| + 0.1), costs {dev_c:.3e}")
         for a, b in zip(got, want):
-            assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5)
-        np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-3)
+            assert np.all(np.abs(a - b) <= 4e-6 * (np.abs(b) + 0.1)), float(np.max(np.abs(a - b) / (np.abs(b) + 0.1)))
+        np.testing.assert_allclose(outs[0]["loss"], costs, rtol=2e-6)
 
 
 def test_peer_allreduce_bootstrap_over_rccl_world1(amd, oracle, monkeypatch):
@@ -1246,11 +1252,45 @@ def test_cpp_cli_binary_matches_reference_flow(tmp_path):
     lines = out.stdout.strip().splitlines()
     assert len(lines) == 4 and all(l.startswith(f"Epoch {i}: ") and "/100 [" in l and l.endswith("%]") for i, l in enumerate(lines))
     acc = [int(l.split(": ")[1].split("/")[0]) for l in lines]
-    assert acc[-1] > 30
     ck = checkpoint.loads(open(model_path, "rb").read())
     assert ck.classes == 10 and [w.shape for w in ck.layer_weights] == [(30, 784), (10, 30)] and ck.testing_path == te
+
+    # Properties instead of "this seed trains" (VERDICT r2): (1) the count the last epoch line prints IS the accuracy of the model the
+    # run saved -- recomputed here by an independent route: the Python codec reads rcn.bin, the Python PNG decoder reads every test
+    # file, RCN::classify's arg-max (rcn.rs:82-98) against the class directory's index; the epoch line counts `v == max` one-hot
+    # matches (rcn.rs:152-157), which differs from the arg-max only on exact ties of the output layer, so files with a runner-up
+    # closer than 1e-5 are set aside;
+    def saved_model_accuracy(path):
+        m = checkpoint.load_model(path)
+        hits = unsure = 0
+        for ci, cdir in enumerate(sorted(os.listdir(te))):
+            for f in sorted(os.listdir(os.path.join(te, cdir))):
+                img = _png.to_pixel_matrix_u8(open(os.path.join(te, cdir, f), "rb").read())
+                out_v = m.classify_test(m.standardize(m.flatten_feature_set(img[None])))[0]
+                srt = np.sort(out_v)
+                unsure += int(srt[-1] - srt[-2] <= 1e-5)
+                hits += int(int(np.flatnonzero(out_v == out_v.max())[-1]) == ci)
+        m.close()
+        return hits, unsure
+    from mercer_research_amd import png as _png
+    hits, unsure = saved_model_accuracy(model_path)
+    assert abs(acc[-1] - hits) <= unsure, (acc, hits, unsure)
+    # (2) a seeded run is reproducible: the same command prints the same four lines and writes the same bytes;
+    model_b = str(tmp_path / "rcn_b.bin")
+    again = subprocess.run(argv[:-4] + ["--model-path", model_b, "--seed", "9"], capture_output=True, text=True, timeout=300)
+    assert again.returncode == 0 and again.stdout == out.stdout
+    ckb = checkpoint.loads(open(model_b, "rb").read())
+    assert all(np.array_equal(x, y) for x, y in zip(ckb.layer_weights + ckb.layer_bias, ck.layer_weights + ck.layer_bias))
+    # (3) a second run RESUMES: it starts from the saved weights (its one epoch line equals the accuracy of the model IT saves, and a
+    # run of zero further steps would have printed acc[-1]); training one more epoch from there does not fall back to chance (10/100)
     out2 = subprocess.run(argv[:-6] + ["-e", "1", "--model-path", model_path, "--seed", "10"], capture_output=True, text=True, timeout=300)
-    assert out2.returncode == 0 and int(out2.stdout.split(": ")[1].split("/")[0]) >= acc[-1] - 15
+    assert out2.returncode == 0
+    acc2 = int(out2.stdout.split(": ")[1].split("/")[0])
+    hits2, unsure2 = saved_model_accuracy(model_path)
+    assert abs(acc2 - hits2) <= unsure2, (acc2, hits2, unsure2)
+    ck3 = checkpoint.loads(open(model_path, "rb").read())
+    assert not np.array_equal(ck3.layer_weights[0], ck.layer_weights[0])                   # it trained on ...
+    assert float(np.abs(ck3.layer_weights[0] - ck.layer_weights[0]).mean()) < 0.25 * float(np.abs(ck.layer_weights[0]).mean())   # ... from the saved weights, not from a fresh N(0,1) draw
     bad = subprocess.run(argv[:5] + ["--training-class-size", "31", "--testing-class-size", "10", "--model-path", str(tmp_path / "x.bin")],
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode == 101 and "too large! expected 31 <= 30" in bad.stderr       # rcn.rs:383-390 panic

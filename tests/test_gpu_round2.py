@@ -51,13 +51,12 @@ def _oracle_curve(oracle, X, Y, ws, bs, perms, nb, B, eta):
     return np.array(costs), h.weights(), h.biases()
 
 
-# f32 envelope of the curve (measured on MI355X, stated here because the tolerance belongs in the test): eta = 3 on un-scaled
-# N(0,1) parameters saturates the sigmoids (|z_1| ~ sqrt(784) |x|), every step is a large move and f32 rounding differences
-# are amplified along the trajectory.  Per-step parity from identical parameters is tight (test_gpu_parity: 1e-5); along 256
-# chained steps the f32 cost stays within F32_CURVE_RTOL of the f64 restatement's at every step and within F32_MEAN_RTOL on
-# the mean over the curve.  SURVEY §8(c)'s 1e-3 is the bar for the first F32_TIGHT_STEPS steps.
-F32_TIGHT_STEPS, F32_TIGHT_RTOL = 32, 1e-3
-F32_CURVE_RTOL, F32_MEAN_RTOL = 5e-2, 5e-3
+# f32 envelope of the curve.  Measured on MI355X (printed by the test): bench net 784-30-10 -- 4.1e-7 over the first 32 steps, 2.3e-5
+# worst over all 256, 1.4e-7 on the mean; the reference's test net 784-10-10-10 -- 8.0e-8 / 8.0e-8 / 8.3e-10.  eta = 3 on un-scaled
+# N(0,1) parameters saturates the sigmoids, so f32 rounding differences do grow along the trajectory.  Asserted: 1e-5 over the first
+# 32 steps, ten times the measurement (2.5e-4 <= SURVEY 8(c)'s 1e-3) at every step, 1e-5 on the mean (round 2: 1e-3 / 5e-2 / 5e-3).
+F32_TIGHT_STEPS, F32_TIGHT_RTOL = 32, 1e-5
+F32_CURVE_RTOL, F32_MEAN_RTOL = 2.5e-4, 1e-5
 
 
 @pytest.mark.parametrize("dtype", [1, 0], ids=["f64", "f32"])
@@ -110,6 +109,7 @@ def _loss_curve_case(amd, oracle, bench_workload, dtype, dims):
         for a, b in zip(gw + gb, rw + rb):
             assert np.all(np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-10)
     else:
+        print(f"MEASURED f32 loss curve {dims}: first {F32_TIGHT_STEPS} steps {rel[:F32_TIGHT_STEPS].max():.3e}, whole curve {rel.max():.3e}, mean {abs(gpu.mean() - cpu.mean()) / cpu.mean():.3e}")
         assert rel[:F32_TIGHT_STEPS].max() <= F32_TIGHT_RTOL, (rel[:F32_TIGHT_STEPS].max(), int(rel[:F32_TIGHT_STEPS].argmax()))
         assert rel.max() <= F32_CURVE_RTOL, (rel.max(), int(rel.argmax()))
         assert abs(gpu.mean() - cpu.mean()) <= F32_MEAN_RTOL * cpu.mean()
