@@ -630,12 +630,13 @@ def main():
         us = us_second if resident else us_pair * (us_first, us_second)[k] / (us_first + us_second)
         flops_step = 2 * B * ((F * H + H * C) * 2 + H * C)
         traffic, traffic_src, traffic_stale = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
+        pmc_name = next((f for f in ("r3_pmc_summary.json", "r2_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+        pmc = os.path.join(ROOT, "profiles", pmc_name or "none")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get(names[k], {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/r2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/prof_bench.sh)"
+                traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/prof_r3.sh)"
                 traffic_stale = pj.get("csrc_sha16") != csrc_sha16()     # True: kernels changed since the counters were collected
             except Exception:
                 traffic = None
