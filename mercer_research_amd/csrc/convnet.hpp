@@ -570,3 +570,28 @@ __global__ void k_sum_small(const float* __restrict__ part, int n, float scale, 
 }
 
 }  // namespace rcnx
+
+namespace rcnx {
+
+// A gradient tensor that exists only at pooled resolution.  dZ of a conv layer followed by a 2x2 max-pool is
+//     dZ[n, y, x, c] = (arg-max of its window == (y & 1, x & 1) && pooled value > 0) ? dP[n, y/2, x/2, c] : 0
+// (k_pool_bwd); the LDS-tiled kernels can rebuild it while staging instead of reading a full-resolution copy that another
+// kernel wrote: three reads at quarter resolution (4 + 4 + 1 bytes per channel) replace one write and one read of 4 x 4.
+struct PooledGrad {
+    const float* dP;          // [N][H/2][W/2][C] gradient wrt the pooled map; nullptr: the tensor is materialised, read it directly
+    const float* P;           // pooled activations (the ReLU gate)
+    const uint8_t* idx;       // arg-max position 0..3 = dy * 2 + dx
+};
+
+__device__ inline f32x4 pooled_grad4(const PooledGrad& g, int img, int y, int x, int c, int H, int W, int C) {
+    const long long o = ((((long long)img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C) + c;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(g.dP + o), pv = *reinterpret_cast<const f32x4*>(g.P + o);
+    const unsigned ii = *reinterpret_cast<const unsigned*>(g.idx + o);
+    const unsigned pos = (unsigned)(((y & 1) << 1) | (x & 1));
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (((ii >> (8 * i)) & 3u) == pos && pv[i] > 0.f) ? d[i] : 0.f;
+    return v;
+}
+
+}  // namespace rcnx

@@ -1,0 +1,455 @@
+// convnet_halo.hpp -- Track X, fp32 MFMA path: LDS-tiled 3x3 convolution kernels (round 3; north_star: "coalesced HBM loads of
+// image / filter tiles into LDS", configs[2] "LDS-tiled filters").  No reference counterpart; parity is against
+// oracle/convnet_oracle.py like the rest of Track X.
+//
+// The implicit-GEMM kernels of convnet.hpp re-gather every input pixel once per filter tap: nine shifted 128 x 32 A tiles out of L2
+// per K-sweep (PMC, round 2: 7.4 VALU instructions per MFMA, 48 % of the wave cycles waiting, ~21 TB/s of L2 traffic over the chip).
+// Here a workgroup owns a block of 128 output pixels -- 8 x 16 of one image, or, for narrow maps, 8 x 8 of TWO images side by side
+// (HaloGeom<8>) -- and stages the input HALO of one 32-channel block ONCE; all nine taps read their operands out of that image.
+//
+//   k_conv3x3_halo_f32    forward, and the input gradient (on dZ with the tap-flipped transposed weights)
+//   k_wgrad3x3_halo_f32   weight gradient: one staged halo + dZ block serves all nine taps of a 32 x 32 (ci, co) tile
+//   k_conv1_fwd_f32 / k_conv1_wgrad_f32   the first layer (9 * Cin <= 32: the whole patch is ONE k-block), organised around its
+//                         activations: the weights live in registers, the input halo of a block is a few hundred floats
+#pragma once
+
+#include "convnet.hpp"
+
+namespace rcnx {
+
+template <int TW> struct HaloGeom {
+    static constexpr int NIMG = 16 / TW;                  // images per block (TW = 16: one, TW = 8: two side by side)
+    static constexpr int TH = 8, HH = TH + 2, HWD = TW + 2, IMG_PIX = HH * HWD;
+    // LDS pixel stride between the two images of a TW = 8 block: 104 = 8 (mod 16), so that the 16 lanes of one ds_read_b128 pass
+    // (8 pixels of image 0, 8 of image 1, 36-float rows) fall into 16 different 4-bank groups
+    static constexpr int IS = TW == 16 ? IMG_PIX : 104;
+    static constexpr int NPIX = NIMG * IMG_PIX;            // staged pixels
+    static constexpr int LPIX = (NIMG - 1) * IS + IMG_PIX; // LDS pixel slots
+    __device__ static int lds_pix(int pix) { return TW == 16 ? pix : pix + (pix >= IMG_PIX ? IS - IMG_PIX : 0); }
+};
+
+// The four full-resolution values of one pooled gradient chunk: position pos = dy * 2 + dx of the window gets the pooled gradient
+// where it was the arg-max and the pooled activation is positive (k_pool_bwd's rule), zero elsewhere.
+__device__ inline f32x4 unpool4(const f32x4& d, const f32x4& p, unsigned idx4, unsigned pos) {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (((idx4 >> (8 * i)) & 3u) == pos && p[i] > 0.f) ? d[i] : 0.f;
+    return v;
+}
+
+// The staging lambdas decode "which pixel / row is chunk q of this thread" from the thread index.  Those values are loop-invariant and
+// the compiler hoists all of them out of the phase loop -- dozens of registers held across the MFMAs, which then spill (and a
+// scratch reload shares the vector-memory counter with the prefetch loads: its wait serialises the pipeline).  Reading the thread
+// index through an empty asm makes it opaque, so the few integer instructions are redone where they are used.
+__device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv3x3_halo_f32
+//
+// LDS images.  Halo: [pixel][32 channels], 36-float rows (16-byte stores, and a lane's FOUR k-steps are ONE ds_read_b128: the
+// contraction order inside a channel block is free, so lane (r, h) of the 32x32x2 MFMA takes channels 8j + 4h .. 8j + 4h + 3 of its
+// pixel for k-steps 4j .. 4j + 3; the weights are read in the matching order).  Weights of one filter row: [kw * 32 + ci][BN],
+// unpadded, 16-byte stores, bank-swizzled so that the two half-waves of a ds_read_b32 (weight rows 4 apart) hit different halves of
+// the 64 banks: BN = 64 -> column ^ 32 on rows with bit 2 set; BN = 32 -> bits 0 and 2 of the row index swapped.
+// Work items = (pixel block, BN-wide column block); a workgroup takes items blockIdx.x, + gridDim.x, ... (the host launches at most
+// as many workgroups as the chip holds at once: a grid of 1024 one-item workgroups on 768 slots ran as two full-length rounds,
+// measured), as ONE software pipeline of phases (item, channel block, filter row): the global loads of the next phase's weights --
+// and halo, when the channel block or the item changes -- are issued before the 96 / 48 MFMAs of the current phase and stored to LDS
+// after them, so an item's epilogue stores and the next item's first loads overlap too.
+// Wave w computes output rows 2w, 2w + 1 of the block (32 pixels) x BN channels.  Epilogues as k_conv_fwd, plus EPI 4: bias +
+// ReLU + the 2 x 2 max-pool that follows, fused (a lane's sixteen accumulator rows are four complete pooling windows), writing
+// the pooled map and the arg-max image exactly as k_pool_fwd would.  PIN: the input is a gradient that exists only at pooled
+// resolution (PooledGrad): a thread loads (dP, P, arg-max) of ONE pooled pixel's four channels and expands it into the up to four
+// halo pixels of that window -- no k_pool_bwd, no full-size dZ, a quarter of the loads.
+template <int TW, int BN, int EPI, bool PIN = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_conv3x3_halo_f32(
+    const float* __restrict__ X, const float* __restrict__ Wk, const float* __restrict__ bias, float* __restrict__ Y, ConvShape s, int tiles_w,
+    int tiles_h, int n_items, uint8_t* __restrict__ pool_idx, PooledGrad pin) {
+    using Gm = HaloGeom<TW>;
+    constexpr int CB = 32, NT = BN / 32, LDC = 36;
+    constexpr int HCH = Gm::NPIX * (CB / 4);                          // f32x4 chunks of one channel block of the halo
+    constexpr int PPW = TW / 2 + 2, PPI = 6 * PPW;                    // pooled pixels under one image's halo: 6 rows x (TW/2 + 2)
+    constexpr int PCH = Gm::NIMG * PPI * (CB / 4);                    // PIN: chunks of the pooled pixels under the halo
+    constexpr int NH = ((PIN ? PCH : HCH) + kThreads - 1) / kThreads;
+    constexpr int NB = 3 * CB * (BN / 4) / kThreads;                  // f32x4 chunks per thread of one filter row's weights
+    static_assert(3 * CB * (BN / 4) % kThreads == 0, "weight chunks divide over the threads");
+    __shared__ __attribute__((aligned(16))) float Hs[Gm::LPIX * LDC];
+    __shared__ __attribute__((aligned(16))) float Bs[3 * CB * BN];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Cin = s.Cin, nblk = s.Cout / BN;
+
+    const int r = lane & 31, h = lane >> 5;
+    // this lane's A row = output pixel r of the wave's 32: block row 2 wave + (r >> 4), block column r & 15 -> image (column / TW)
+    const int py = 2 * wave + (r >> 4), pxb = r & 15;
+    const float* arow = Hs + ((pxb / TW) * Gm::IS + py * Gm::HWD + pxb % TW) * LDC + 4 * h;
+    const float* bt[NT];
+    if (BN == 64) { bt[0] = Bs + 256 * h + r + 32 * h; bt[NT - 1] = Bs + 256 * h + r + 32 * (1 - h); }
+    else bt[0] = Bs + 32 * h + r;
+
+    struct Item { int img0, oh0, ow0, n0; };
+    auto decode = [&](int item) {
+        Item it;
+        it.n0 = (item % nblk) * BN;
+        int tile = item / nblk;
+        it.ow0 = (tile % tiles_w) * TW; tile /= tiles_w;
+        it.oh0 = (tile % tiles_h) * Gm::TH;
+        it.img0 = (tile / tiles_h) * Gm::NIMG;
+        return it;
+    };
+
+    // ---- staging: registers first (loads fly under the MFMAs), LDS after the barrier
+    f32x4 hv[NH], hp[PIN ? NH : 1];
+    unsigned hi[PIN ? NH : 1];
+    unsigned okm = 0;
+    auto halo_load = [&](const Item& it, int cb) {
+        okm = 0;
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int e = to + kThreads * q;
+            if (PIN) {
+                if (NH * kThreads == PCH || e < PCH) {
+                    const int pp = e >> 3, c4 = (e & 7) * 4;
+                    const int i = pp / PPI, pr_ = pp - i * PPI;
+                    const int pr = pr_ / PPW, pc = pr_ - pr * PPW;
+                    const int poh = (it.oh0 >> 1) - 1 + pr, pow_ = (it.ow0 >> 1) - 1 + pc, img = it.img0 + i;
+                    const bool ok = img < s.N && (unsigned)poh < (unsigned)(s.H >> 1) && (unsigned)pow_ < (unsigned)(s.W >> 1);
+                    okm |= (ok ? 1u : 0u) << q;
+                    const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * Cin + cb + c4 : 0;
+                    hv[q] = *reinterpret_cast<const f32x4*>(pin.dP + o);
+                    hp[q] = *reinterpret_cast<const f32x4*>(pin.P + o);
+                    hi[q] = *reinterpret_cast<const unsigned*>(pin.idx + o);
+                }
+            } else if (NH * kThreads == HCH || e < HCH) {
+                const int pix = e >> 3, c4 = (e & 7) * 4;
+                const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
+                const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
+                const int ih = it.oh0 - 1 + hy, iw = it.ow0 - 1 + hx, img = it.img0 + i;
+                const bool ok = img < s.N && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+                okm |= (ok ? 1u : 0u) << q;
+                hv[q] = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
+            }
+        }
+    };
+    auto halo_store = [&]() {
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int e = to + kThreads * q;
+            const bool ok = (okm >> q) & 1u;
+            if (PIN) {
+                if (NH * kThreads == PCH || e < PCH) {
+                    const int pp = e >> 3, c4 = (e & 7) * 4;
+                    const int i = pp / PPI, pr_ = pp - i * PPI;
+                    const int pr = pr_ / PPW, pc = pr_ - pr * PPW;
+#pragma unroll
+                    for (int pos = 0; pos < 4; ++pos) {
+                        const int hy = 2 * pr - 1 + (pos >> 1), hx = 2 * pc - 1 + (pos & 1);      // halo pixel of window position pos
+                        if ((unsigned)hy < (unsigned)Gm::HH && (unsigned)hx < (unsigned)Gm::HWD)
+                            *reinterpret_cast<f32x4*>(&Hs[(i * Gm::IS + hy * Gm::HWD + hx) * LDC + c4]) = ok ? unpool4(hv[q], hp[q], hi[q], (unsigned)pos) : f32x4{0, 0, 0, 0};
+                    }
+                }
+            } else if (NH * kThreads == HCH || e < HCH) {
+                *reinterpret_cast<f32x4*>(&Hs[Gm::lds_pix(e >> 3) * LDC + (e & 7) * 4]) = ok ? hv[q] : f32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    f32x4 bv[NB];
+    auto b_load = [&](const Item& it, int cb, int kh) {
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int e = to + kThreads * q;
+            const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;          // row = kw * 32 + ci
+            bv[q] = *reinterpret_cast<const f32x4*>(Wk + ((long long)(kh * 3 + (row >> 5)) * Cin + cb + (row & 31)) * s.Cout + it.n0 + c4);
+        }
+    };
+    auto b_store = [&]() {
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int e = to + kThreads * q;
+            const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;
+            if (BN == 64) *reinterpret_cast<f32x4*>(&Bs[row * 64 + (c4 ^ (((row >> 2) & 1) << 5))]) = bv[q];
+            else *reinterpret_cast<f32x4*>(&Bs[((row & ~5) | ((row & 1) << 2) | ((row >> 2) & 1)) * 32 + c4]) = bv[q];
+        }
+    };
+
+    const int nph = (Cin / CB) * 3;                                   // phases of one item: (channel block, filter row)
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    Item cur = decode(item);
+    halo_load(cur, 0);
+    b_load(cur, 0, 0);
+    bool first = true;
+#pragma unroll 1
+    for (; item < n_items; item += gridDim.x) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        const int nitem = item + gridDim.x;
+        const Item nxt = decode(nitem < n_items ? nitem : item);
+        int cb = 0, kh = 0;
+#pragma unroll 1
+        for (int ph = 0; ph < nph; ++ph) {
+            if (!first) __syncthreads();                              // the previous phase's operands have been consumed
+            first = false;
+            if (kh == 0) halo_store();
+            b_store();
+            __syncthreads();
+            const int nkh = kh == 2 ? 0 : kh + 1, ncb = kh == 2 ? cb + CB : cb;
+            if (ph + 1 < nph) {
+                b_load(cur, ncb, nkh);
+                if (nkh == 0) halo_load(cur, ncb);
+            } else if (nitem < n_items) {                             // the next item's first phase
+                b_load(nxt, 0, 0);
+                halo_load(nxt, 0);
+            }
+            const float* ak = arow + kh * Gm::HWD * LDC;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ak + kw * LDC + 8 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const float b = BN == 64 ? bt[t][(kw * 32 + 8 * j + i) * 64] : bt[0][(kw * 32 + 8 * j + 4 * (i & 1) + (i & 2)) * 32];
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], b, acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            kh = nkh; cb = ncb;
+        }
+        // ---- epilogue: accumulator row i of lane = block pixel mfma32_row(lane, i) of this wave's 32
+        const int img0 = cur.img0, oh0 = cur.oh0, ow0 = cur.ow0, n0 = cur.n0;
+        if (EPI == 4) {
+            // bias + ReLU + the 2x2 max-pool that follows: a lane's sixteen rows are block columns 4h..4h+3 and 8+4h..8+4h+3 of BOTH
+            // pixel rows of its wave -- four complete pooling windows (TW = 8: columns 0..7 are image 0, 8..15 image 1: still whole
+            // windows).  First maximum in the order 00, 01, 10, 11, as k_pool_fwd.
+            const int OH = s.H / 2, OW = s.W / 2;
+            const int poh = oh0 / 2 + wave;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = n0 + 32 * t + (lane & 31);
+                const float bb = bias[co];
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const int i0 = 4 * gq + 2 * pp;
+                        float v[4] = {acc[t][i0] + bb, acc[t][i0 + 1] + bb, acc[t][8 + i0] + bb, acc[t][8 + i0 + 1] + bb};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                        float best = v[0];
+                        int bk = 0;
+#pragma unroll
+                        for (int k = 1; k < 4; ++k)
+                            if (v[k] > best) { best = v[k]; bk = k; }
+                        const int colb = 4 * h + 8 * gq + 2 * pp;                   // block column of the window's left pixel
+                        const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
+                        if (img < s.N && poh < OH && pow_ < OW) {
+                            const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
+                            Y[o] = best;
+                            pool_idx[o] = (uint8_t)bk;
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = n0 + 32 * t + (lane & 31);
+                const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int pr = mfma32_row(lane, i);
+                    const int colb = pr & 15;
+                    const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+                    if (img < s.N && oh < s.H && ow < s.W) {
+                        const long long m = ((long long)img * s.H + oh) * s.W + ow;
+                        float v = acc[t][i] + bb;
+                        if (EPI == 2) v = v > 0.f ? v : 0.f;
+                        if (EPI == 3) v = bias[m * s.Cout + co] > 0.f ? v : 0.f;
+                        Y[m * s.Cout + co] = v;
+                    }
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_wgrad3x3_halo_f32 -- dW of a 3x3 layer, LDS-tiled.
+//
+// k_conv_wgrad gives every 32-row k-block (one filter tap of 32 channels) its own staged X tile: the input is read nine times and
+// dZ once per k-block.  Here workgroup (ci block, co block, chunk) stages, per block of 128 output pixels, the input halo of its 32
+// input channels and the block's dZ for its 32 output channels ONCE; each of its four waves takes two of the block's eight pixel
+// rows and contracts them into ALL NINE taps' 32 x 32 tiles (144 accumulator registers): per pair of pixels one dZ fragment is
+// read and used by nine MFMAs.  The contraction index is the pixel = the row of both LDS images, so lane (r, h) reads element r of
+// pixel p + h: 32-float rows put the two half-waves on different halves of the banks with no padding, and every offset except the
+// lane's own is an immediate.  The four waves' tiles are summed in wave order through LDS at the end; the partial goes to
+// slab[chunk][K + 1][Cout] exactly as k_conv_wgrad's (row K = bias partial from the ci block 0 workgroups), so k_reduce_update[_wide]
+// finishes either.  PDZ: dZ exists only at pooled resolution (PooledGrad): a block has 32 pooled pixels x 8 channel chunks = one
+// chunk per thread, expanded into its window's four pixels while staging.
+template <int TW, bool PDZ = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad3x3_halo_f32(
+    const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ slab, ConvShape s, int tiles_w, int tiles_h, int blocks_per_chunk,
+    PooledGrad pdz) {
+    using Gm = HaloGeom<TW>;
+    constexpr int CB = 32, BN = 32, NPX = 128;
+    constexpr int HCH = Gm::NPIX * (CB / 4), NH = (HCH + kThreads - 1) / kThreads;
+    constexpr int ND = PDZ ? 1 : NPX * (BN / 4) / kThreads;           // 4 (full resolution) or 1 (pooled)
+    constexpr int kHalo = Gm::LPIX * CB, kLds = kHalo + NPX * BN;
+    static_assert(kLds >= 4 * 16 * 64, "the wave partials of one tap must fit the staging memory");
+    __shared__ __attribute__((aligned(16))) float smem[kLds];
+    float* Hs = smem;                                                 // [halo pixel][ci]
+    float* Ds = smem + kHalo;                                         // [block pixel][co]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cb = blockIdx.x * CB, n0 = blockIdx.y * BN, chunk = blockIdx.z;
+    const int Cin = s.Cin, K = 9 * Cin;
+    const int total_blocks = tiles_w * tiles_h * ((s.N + Gm::NIMG - 1) / Gm::NIMG);
+    const int b0 = chunk * blocks_per_chunk, b1 = b0 + blocks_per_chunk < total_blocks ? b0 + blocks_per_chunk : total_blocks;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 hv[NH], dv[ND], dp[PDZ ? 1 : 1];
+    unsigned di = 0;
+    unsigned okm = 0;
+    auto gload = [&](int blk) {
+        int q0 = blk;
+        const int tw = q0 % tiles_w; q0 /= tiles_w;
+        const int th = q0 % tiles_h;
+        const int img0 = (q0 / tiles_h) * Gm::NIMG;
+        const int oh0 = th * Gm::TH, ow0 = tw * TW;
+        okm = 0;
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int e = to + kThreads * q;
+            if (NH * kThreads == HCH || e < HCH) {
+                const int pix = e >> 3, c4 = (e & 7) * 4;
+                const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
+                const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
+                const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx, img = img0 + i;
+                const bool ok = img < s.N && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+                okm |= (ok ? 1u : 0u) << q;
+                hv[q] = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
+            }
+        }
+        if (PDZ) {
+            // pooled pixel tid >> 3 of the block (4 rows x 8 columns; TW = 8: columns 0..3 image 0, 4..7 image 1), channels 4 (tid & 7)
+            const int pp = to >> 3, c4 = (to & 7) * 4;
+            const int colb = 2 * (pp & 7);
+            const int img = img0 + colb / TW, poh = (oh0 >> 1) + (pp >> 3), pow_ = (ow0 + colb % TW) >> 1;
+            const bool ok = img < s.N && poh < (s.H >> 1) && pow_ < (s.W >> 1);
+            okm |= (ok ? 1u : 0u) << 16;
+            const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
+            dv[0] = *reinterpret_cast<const f32x4*>(pdz.dP + o);
+            dp[0] = *reinterpret_cast<const f32x4*>(pdz.P + o);
+            di = *reinterpret_cast<const unsigned*>(pdz.idx + o);
+        } else {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                const int e = to + kThreads * q;
+                const int pix = e >> 3, c4 = (e & 7) * 4;             // block pixel (row pix >> 4, block column pix & 15)
+                const int colb = pix & 15;
+                const int img = img0 + colb / TW, oh = oh0 + (pix >> 4), ow = ow0 + colb % TW;
+                const bool ok = img < s.N && oh < s.H && ow < s.W;
+                okm |= (ok ? 1u : 0u) << (16 + q);
+                dv[q] = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+            }
+        }
+    };
+    auto lstore = [&]() {
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int e = to + kThreads * q;
+            if (NH * kThreads == HCH || e < HCH)
+                *reinterpret_cast<f32x4*>(&Hs[Gm::lds_pix(e >> 3) * CB + (e & 7) * 4]) = ((okm >> q) & 1u) ? hv[q] : f32x4{0, 0, 0, 0};
+        }
+        if (PDZ) {
+            const int pp = to >> 3, c4 = (to & 7) * 4;
+            const bool ok = (okm >> 16) & 1u;
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const f32x4 v = ok ? unpool4(dv[0], dp[0], di, (unsigned)pos) : f32x4{0, 0, 0, 0};
+                *reinterpret_cast<f32x4*>(&Ds[((2 * (pp >> 3) + (pos >> 1)) * 16 + 2 * (pp & 7) + (pos & 1)) * BN + c4]) = v;
+                colsum += v;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                const int e = to + kThreads * q;
+                const f32x4 v = ((okm >> (16 + q)) & 1u) ? dv[q] : f32x4{0, 0, 0, 0};
+                *reinterpret_cast<f32x4*>(&Ds[e * 4]) = v;
+                colsum += v;                                          // the thread's four columns are the same for every q (256 % 8 == 0)
+            }
+        }
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    const float* al = Hs + 32 * h + r;
+    const float* dl = Ds + 32 * h + r;
+    if (b0 < b1) gload(b0);
+#pragma unroll 1
+    for (int blk = b0; blk < b1; ++blk) {
+        if (blk != b0) __syncthreads();                               // the previous block's images have been consumed
+        lstore();
+        __syncthreads();
+        if (blk + 1 < b1) gload(blk + 1);                             // the next block's loads fly under this block's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            // pixels (y, xb) and (y, xb + 1) of the block, y = 2 wave + (ks >> 3); lane half h takes xb + h
+            const int xb = 2 * (ks & 7);
+            const float b = dl[((ks >> 3) * 16 + xb) * 32 + wave * (2 * 16 * 32)];
+            const int hp0 = (xb / TW) * Gm::IS + (xb % TW);           // halo pixel of (row 0, xb), tap (0, 0), before the row term
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float a = al[(hp0 + ((ks >> 3) + kh) * Gm::HWD + kw) * 32 + wave * (2 * Gm::HWD * 32)];
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kh * 3 + kw], 0, 0, 0);
+                }
+        }
+    }
+    // ---- the four waves' tiles, summed in wave order, tap by tap
+    float* out = slab + (long long)chunk * (K + 1) * s.Cout;
+    float* Red = smem;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Red[(wave * 16 + i) * 64 + lane] = acc[tap][i];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + kThreads * u, i = e >> 6, ln = e & 63;
+            const float v = (Red[(0 * 16 + i) * 64 + ln] + Red[(1 * 16 + i) * 64 + ln]) + (Red[(2 * 16 + i) * 64 + ln] + Red[(3 * 16 + i) * 64 + ln]);
+            out[(long long)(tap * Cin + cb + mfma32_row(ln, i)) * s.Cout + n0 + (ln & 31)] = v;
+        }
+    }
+    if (blockIdx.x == 0) {                                            // bias row: thread's four columns are 4 (tid % 8); fixed-order sum
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&Red[tid * 4]) = colsum;
+        __syncthreads();
+        if (tid < BN) {
+            const int grp = tid >> 2, comp = tid & 3;
+            float t = 0.f;
+            for (int u = grp; u < kThreads; u += BN / 4) t += Red[u * 4 + comp];
+            out[(long long)K * s.Cout + n0 + tid] = t;
+        }
+    }
+}
+
+}  // namespace rcnx

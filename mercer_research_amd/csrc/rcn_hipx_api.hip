@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <random>
 #include <string>
@@ -15,6 +16,7 @@
 
 #include "convnet.hpp"
 #include "convnet_bf16.hpp"
+#include "convnet_halo.hpp"
 
 using namespace rcnx;
 
@@ -88,18 +90,61 @@ int grid1d(long long total, int block) { long long g = (total + block - 1) / blo
 // epi 4 (bias + ReLU + the following 2x2 max-pool, written to Y = pooled map and pool_idx) exists only in the LDS-tiled bf16 kernel:
 // callers ask conv_pool_fusable() first
 static bool halo_enabled() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO"); return e ? std::atoi(e) : 1; }(); return v != 0; }
+static bool halo_f32_enabled() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO_F32"); return e ? std::atoi(e) : 1; }(); return v != 0; }
+
+// workgroups of `kernel` (256 threads, static LDS only) the device holds at once: the grid of a kernel whose workgroups loop over
+// work items.  Asked from the runtime once per kernel.
+long long resident_slots(rcn_hipx_net* n, const void* kernel) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, long long> cache;
+    const std::lock_guard<std::mutex> lock(mu);
+    const std::pair<int, const void*> key{n->device, kernel};
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, n->device) != hipSuccess || cus < 1) cus = 256;
+    static const int forced = [] { const char* e = std::getenv("RCN_HIPX_HALO_F32_SLOTS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
+    const long long v = forced ? forced : (long long)per_cu * cus;
+    cache.emplace(key, v);
+    return v;
+}
+
+// split-K factor of the implicit-GEMM kernels: few output tiles and a long contraction
+int splitk_z(long long M, int Cout, int bn, int nkt) {
+    const long long tiles = ((M + kBM - 1) / kBM) * (Cout / bn);
+    int Z = 1;
+    if (tiles < 256 && nkt >= 8) { Z = (int)(512 / tiles); if (Z > nkt / 4) Z = nkt / 4; if (Z < 1) Z = 1; }
+    return Z;
+}
+
+// Pixel-block geometry of the fp32 LDS-tiled kernels for an H x W map: 8 x 16 blocks of one image, or 8 x 8 blocks of two images
+// side by side where that wastes fewer MFMA rows (8-, 24-, 56-pixel-wide maps).  Not used when less than 70 % of a block's rows
+// are real pixels (the implicit-GEMM kernels have no such waste).
+struct HaloPlan { bool ok; int tw; };
+HaloPlan halo_plan(const ConvShape& s) {
+    const double uh = (double)s.H / ((s.H + 7) / 8 * 8);
+    const double u16 = (double)s.W / ((s.W + 15) / 16 * 16);
+    const double u8 = (double)s.W / ((s.W + 7) / 8 * 8) * ((double)s.N / ((s.N + 1) / 2 * 2));
+    const int tw = u8 > u16 ? 8 : 16;
+    return HaloPlan{uh * (tw == 8 ? u8 : u16) >= 0.7, tw};
+}
+bool conv_halo_f32_shape(const ConvShape& s) { return halo_f32_enabled() && s.Cin % 32 == 0 && s.Cout % 32 == 0 && halo_plan(s).ok; }
+
+// does the 2x2 max-pool that follows this 3x3 convolution run in the convolution kernel's epilogue (EPI 4: LDS-tiled kernels only)?
 bool conv_pool_fusable(const rcn_hipx_net* n, const ConvShape& s) {
-    return n->precision == RCN_HIPX_BF16 && halo_enabled() && (s.Cin == 32 || s.Cin % 64 == 0) && s.H % 2 == 0 && s.W % 2 == 0;
+    if (s.H % 2 || s.W % 2) return false;
+    if (n->precision == RCN_HIPX_BF16) return halo_enabled() && (s.Cin == 32 || s.Cin % 64 == 0);
+    return conv_halo_f32_shape(s);
 }
 
 // can the LDS-tiled kernel run this 3x3 convolution (as launch_conv would decide)?  Mirrors launch_conv's split-K rule.
 bool conv_halo_runs(const rcn_hipx_net* n, const ConvShape& s) {
-    if (n->precision != RCN_HIPX_BF16 || !halo_enabled() || !(s.Cin == 32 || s.Cin % 64 == 0) || s.Cout % 32) return false;
     const long long M = (long long)s.N * s.H * s.W;
+    if (n->precision != RCN_HIPX_BF16) return conv_halo_f32_shape(s) && splitk_z(M, s.Cout, s.Cout % 64 == 0 ? 64 : 32, 9 * s.Cin / 32) == 1;
+    if (!halo_enabled() || !(s.Cin == 32 || s.Cin % 64 == 0) || s.Cout % 32) return false;
     const int bn = s.Cout % 128 == 0 ? 128 : s.Cout % 64 == 0 ? 64 : 32;
-    const long long tiles = ((M + kBM - 1) / kBM) * (s.Cout / bn);
-    const int nkt = 9 * s.Cin / 32;
-    return !(tiles < 256 && nkt >= 8 && 512 / tiles > 1 && nkt / 4 > 1);
+    return splitk_z(M, s.Cout, bn, 9 * s.Cin / 32) == 1;
 }
 
 int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi, uint8_t* pool_idx = nullptr,
@@ -110,10 +155,8 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     if (s.Cout % 32) return fail(n, -3, "output channels must be a multiple of 32");
     const bool bf16 = n->precision == RCN_HIPX_BF16;
     const int bn = (bf16 && s.Cout % 128 == 0) ? 128 : (s.Cout % 64 == 0) ? 64 : 32;
-    const long long tiles = ((M + kBM - 1) / kBM) * (s.Cout / bn);
     const int nkt = smallc ? 1 : ks * ks * s.Cin / 32;
-    int Z = 1;
-    if (tiles < 256 && nkt >= 8 && epi != 4) { Z = (int)(512 / tiles); if (Z > nkt / 4) Z = nkt / 4; if (Z < 1) Z = 1; }
+    const int Z = epi == 4 ? 1 : splitk_z(M, s.Cout, bn, nkt);
     float* out = Y;
     int kepi = epi;
     if (Z > 1) {
@@ -154,6 +197,30 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #undef CONVB_EPI
 #undef CONVB_CASE
     } else {
+        if (epi == 4 && !(ks == 3 && conv_pool_fusable(n, s))) return fail(n, -3, "internal: fused conv+pool epilogue requested for a layer the LDS-tiled kernel does not cover");
+        if (ks == 3 && !smallc && Z == 1 && conv_halo_f32_shape(s)) {
+            // LDS-tiled (convnet_halo.hpp): one staged halo per block of 128 output pixels serves all nine taps
+            const int tw = halo_plan(s).tw, nimg = 16 / tw;
+            const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
+            // work items = (pixel block, bn-wide column block); at most as many workgroups as the chip holds at once (three per CU), each
+            // taking items blockIdx.x, + gridDim.x, ...
+            const long long items = (long long)tiles_w * tiles_h * ((s.N + nimg - 1) / nimg) * (s.Cout / bn);
+            if (items > 0x7fffffffLL) return fail(n, -3, "too many pixel blocks in one layer");
+            const PooledGrad pg = pin ? *pin : PooledGrad{nullptr, nullptr, nullptr};
+#define HF_LAUNCH(TW_, BN_, EPI_, PIN_) do { const long long slots = resident_slots(n, (const void*)k_conv3x3_halo_f32<TW_, BN_, EPI_, PIN_>); \
+            hipLaunchKernelGGL((k_conv3x3_halo_f32<TW_, BN_, EPI_, PIN_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, Wk, bias, out, s, tiles_w, tiles_h, (int)items, pool_idx, pg); } while (0)
+            // a pooled-resolution input only occurs in the input-gradient pass (EPI 0 / 3)
+#define HF_EPI(TW_, BN_) do { if (pin) { if (kepi == 3) HF_LAUNCH(TW_, BN_, 3, true); else if (kepi == 0) HF_LAUNCH(TW_, BN_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
+                              else if (kepi == 0) HF_LAUNCH(TW_, BN_, 0, false); else if (kepi == 1) HF_LAUNCH(TW_, BN_, 1, false); else if (kepi == 2) HF_LAUNCH(TW_, BN_, 2, false); \
+                              else if (kepi == 3) HF_LAUNCH(TW_, BN_, 3, false); else HF_LAUNCH(TW_, BN_, 4, false); } while (0)
+            if (tw == 16) { if (bn == 64) HF_EPI(16, 64); else HF_EPI(16, 32); }
+            else { if (bn == 64) HF_EPI(8, 64); else HF_EPI(8, 32); }
+#undef HF_EPI
+#undef HF_LAUNCH
+            XTRY(n, hipGetLastError());
+            return 0;
+        }
+        if (pin) return fail(n, -3, "internal: pooled-resolution input requested for a layer the LDS-tiled kernel does not cover");
 #define CONV_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, Wk, bias, out, s)
 #define CONV_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONV_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONV_CASE(KS_, SM_, BN_, 1); else if (kepi == 2) CONV_CASE(KS_, SM_, BN_, 2); else CONV_CASE(KS_, SM_, BN_, 3); } while (0)
 #define CONV_BN(KS_, SM_) do { if (bn == 64) CONV_EPI(KS_, SM_, 64); else CONV_EPI(KS_, SM_, 32); } while (0)
@@ -188,7 +255,9 @@ static int pix_per_chunk(long long M, long long tiles) {
 #define kPixPerChunk (pix_per_chunk(M, (long long)(smallc ? 1 : K / 32) * (s.Cout / bn)))
 
 static bool wgrad_halo_on() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO_WGRAD"); return e ? std::atoi(e) : 1; }(); return v != 0; }
+bool wgrad_halo_f32_runs(const ConvShape& s, int ks) { return ks == 3 && ks * ks * s.Cin > 32 && conv_halo_f32_shape(s); }
 bool wgrad_halo_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) {
+    if (n->precision != RCN_HIPX_BF16) return wgrad_halo_on() && wgrad_halo_f32_runs(s, ks);
     return n->precision == RCN_HIPX_BF16 && wgrad_halo_on() && ks == 3 && ks * ks * s.Cin > 32 && (s.Cin == 32 || s.Cin % 64 == 0) && s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2;
 }
 
@@ -201,6 +270,31 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
     XTRY(n, scratch_ensure(n, n->slab, (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
     if (pdz && !wgrad_halo_runs(n, s, ks)) return fail(n, -3, "internal: pooled-resolution dZ requested for a layer the LDS-tiled weight-gradient kernel does not cover");
+    if (n->precision != RCN_HIPX_BF16 && wgrad_halo_runs(n, s, ks)) {
+        // fp32 LDS-tiled (convnet_halo.hpp): workgroup = (32 input channels, 32 output channels, chunk of pixel blocks), all nine taps.
+        // Every chunk costs one (K+1) x Cout partial written and read back by the reduce whatever the number of (ci, co) workgroups
+        // that share it, so: as few chunks as fill the chip twice over.
+        const int tw = halo_plan(s).tw, nimg = 16 / tw;
+        const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
+        const long long blocks = (long long)tiles_w * tiles_h * ((s.N + nimg - 1) / nimg);
+        static const int target = [] { const char* e = std::getenv("RCN_HIPX_WGH_F32_TARGET"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 512; }();
+        const long long combos = (long long)(s.Cin / 32) * (s.Cout / 32);
+        long long want = (target + combos - 1) / combos;
+        if (want > blocks) want = blocks;
+        if (want > 32768) want = 32768;
+        const int bpc = (int)((blocks + want - 1) / want);
+        const int hchunks = (int)((blocks + bpc - 1) / bpc);
+        XTRY(n, scratch_ensure(n, n->slab, (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
+        const dim3 hgrid((unsigned)(s.Cin / 32), (unsigned)(s.Cout / 32), (unsigned)hchunks);
+        const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
+#define WGF_CASE(TW_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_f32<TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tiles_w, tiles_h, bpc, pg); \
+                           else hipLaunchKernelGGL((k_wgrad3x3_halo_f32<TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tiles_w, tiles_h, bpc, pg); } while (0)
+        if (tw == 16) WGF_CASE(16); else WGF_CASE(8);
+#undef WGF_CASE
+        XTRY(n, hipGetLastError());
+        *chunks_out = hchunks;
+        return 0;
+    }
     if (wgrad_halo_runs(n, s, ks)) {
         // LDS-tiled: input halo + dZ block staged once per 8x16 pixel block, nine waves = nine filter taps (convnet_bf16.hpp)
         const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
