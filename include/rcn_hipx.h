@@ -49,6 +49,12 @@ int  rcn_hipx_classes(const rcn_hipx_net* net);
 enum { RCN_HIPX_FP32 = 0, RCN_HIPX_BF16 = 1 };
 int  rcn_hipx_set_precision(rcn_hipx_net* net, int mode);
 /* logical layout, host memory, all layers back to back: W_0[K][Cout], b_0[Cout], W_1 ... */
+/* Which fp32 3x3 convolution kernels run (bf16 mode has its own rule).  GEMM: the implicit-GEMM kernels only.  AUTO (default): the
+ * LDS-tiled kernels where at least 70 % of a 128-pixel block's rows are real pixels and the layer is not a split-K case, the first
+ * layer's own kernels for 1 / 3 input channels.  LDS: the LDS-tiled kernels wherever their shape constraints hold (tests).
+ * The environment variable RCN_HIPX_HALO_F32 (0 / 1 / 2) only seeds a new net's mode. */
+enum { RCN_HIPX_TILING_GEMM = 0, RCN_HIPX_TILING_AUTO = 1, RCN_HIPX_TILING_LDS = 2 };
+int  rcn_hipx_set_tiling(rcn_hipx_net* net, int mode);
 int  rcn_hipx_set_params(rcn_hipx_net* net, const float* flat);
 int  rcn_hipx_get_params(rcn_hipx_net* net, float* flat);
 int  rcn_hipx_init_params(rcn_hipx_net* net, uint64_t seed);            /* He-normal weights, zero biases */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "rcn_hipx_apply_dev": (_i, [_vp, _vp, C.c_float]),
     "rcn_hipx_unpad_host": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "rcn_hipx_set_precision": (_i, [_vp, _i]),
+    "rcn_hipx_set_tiling": (_i, [_vp, _i]),
     "rcn_hipx_step_flops": (_i, [_vp, _i, C.POINTER(C.c_double)]),
 }
 _libx = None
@@ -109,6 +110,10 @@ class ConvNet:
     def set_precision(self, mode: str):
         """"fp32" (fp32 MFMA, default) or "bf16" (bf16 MFMA operands, fp32 accumulate / storage / update)."""
         self._ck(self.lib.rcn_hipx_set_precision(self.net, {"fp32": 0, "bf16": 1}[mode]))
+
+    def set_tiling(self, mode: str):
+        """fp32 3x3 kernels: "gemm" (implicit GEMM only), "auto" (by shape, the default) or "lds" (LDS-tiled wherever they apply)."""
+        self._ck(self.lib.rcn_hipx_set_tiling(self.net, {"gemm": 0, "auto": 1, "lds": 2}[mode]))
 
     def set_params(self, flat: np.ndarray):
         f = np.ascontiguousarray(flat, dtype=np.float32)

@@ -427,33 +427,52 @@ __global__ void k_splitk_epilogue(const float* __restrict__ part, const float* _
     }
 }
 
-// slab reduction for many chunks and few elements: 8 chunk-groups x 32 elements per workgroup, groups combined in order
+// The input-gradient pass wants the weights tap-flipped and transposed (k_flip_weights).  Instead of re-making that copy every
+// step, the kernels that UPDATE a weight also store it at its flipped position: the copy is always current (the host refreshes it
+// with k_flip_weights after every other kind of parameter write).
+struct FlipSpec {
+    float* wt;                // nullptr: no copy (first layer: no input gradient)
+    int taps, Cin, Cout;      // element i < taps * Cin * Cout of [W | b] is W[(tap, ci)][co]; the rest is the bias row
+};
+__device__ inline void store_flipped(const FlipSpec& f, long long i, float v) {
+    if (!f.wt || i >= (long long)f.taps * f.Cin * f.Cout) return;
+    const int co = (int)(i % f.Cout), k = (int)(i / f.Cout);
+    const int tap = k / f.Cin, ci = k - tap * f.Cin;
+    f.wt[((long long)(f.taps - 1 - tap) * f.Cout + co) * f.Cin + ci] = v;
+}
+
+// slab reduction for many chunks and few elements: 8 chunk-groups x 32 elements per workgroup, groups combined in order.
+// gridDim.y > 1: FIRST STAGE of a two-stage reduction -- slice y sums chunks [y * cpg, (y + 1) * cpg) into grad_out + y * n (no
+// update), and a second launch over the gridDim.y partial rows finishes (a layer with a thousand chunks of a 28 x 32 tile left 28
+// workgroups walking 128 chunks each: 30 us for 3.7 MB).
 __global__ __launch_bounds__(256) void k_reduce_update_wide(float* __restrict__ p, float* __restrict__ grad_out, const float* __restrict__ slab, long long n,
-                                                            int chunks, float lr, int apply) {
+                                                            int chunks, float lr, int apply, FlipSpec flip, int cpg) {
     __shared__ float red[8][33];
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const long long i = (long long)blockIdx.x * 32 + el;
+    int c0 = 0, c1 = chunks;
+    if (gridDim.y > 1) { c0 = blockIdx.y * cpg; c1 = c0 + cpg < chunks ? c0 + cpg : chunks; grad_out += (long long)blockIdx.y * n; }
     float g = 0.f;
     if (i < n)
-        for (int c = grp; c < chunks; c += 8) g += slab[(long long)c * n + i];
+        for (int c = c0 + grp; c < c1; c += 8) g += slab[(long long)c * n + i];
     red[grp][el] = g;
     __syncthreads();
     if (threadIdx.x < 32 && i < n) {
         float t = 0.f;
         for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
         if (grad_out) grad_out[i] = t;
-        if (apply) p[i] = p[i] - lr * t;
+        if (apply) { const float v = p[i] - lr * t; p[i] = v; store_flipped(flip, i, v); }
     }
 }
 
 // p <- p - lr * sum_chunks slab[c][i]   (or grad out when apply == 0); fixed chunk order
 __global__ void k_reduce_update(float* __restrict__ p, float* __restrict__ grad_out, const float* __restrict__ slab, long long n, int chunks,
-                                float lr, int apply) {
+                                float lr, int apply, FlipSpec flip) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float g = 0.f;
         for (int c = 0; c < chunks; ++c) g += slab[(long long)c * n + i];
         if (grad_out) grad_out[i] = g;
-        if (apply) p[i] = p[i] - lr * g;
+        if (apply) { const float v = p[i] - lr * g; p[i] = v; store_flipped(flip, i, v); }
     }
 }
 
@@ -535,37 +554,58 @@ __global__ void k_relu_bwd(const float* __restrict__ dY, const float* __restrict
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) dZ[e] = Y[e] > 0.f ? dY[e] : 0.f;
 }
 
-// fused softmax + cross-entropy: one thread per sample (C small); loss_part[block] = sum of -log p[label] over the block
+// fused softmax + cross-entropy: 32 lanes per sample (lane c takes classes c, c + 32, ...; the padded logits row is ldl wide), eight
+// samples per 256-thread workgroup.  loss_part[block] = sum of -log p[label] over the block's samples in order; the workgroup that
+// finishes LAST (a counter behind the partials, which it leaves at zero for the next launch) adds the partials in block order and
+// writes the mean loss -- no second launch, and the sum does not depend on which workgroup that was.
+// (One thread per sample -- three serial passes over the classes on two CUs -- took 11 us for 512 samples, plus 5 us for the
+// one-thread k_sum_small behind it.)
 __global__ __launch_bounds__(256) void k_softmax_ce(const float* __restrict__ logits, const int* __restrict__ labels, int B, int C, int ldl,
-                                                    float* __restrict__ dlogits, float* __restrict__ loss_part, float inv_b) {
-    __shared__ float red[4];
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+                                                    float* __restrict__ dlogits, float* loss_part, unsigned* counter, float inv_b, float* __restrict__ loss_out) {
+    __shared__ float red[256];
+    __shared__ int last;
+    const int grp = threadIdx.x >> 5, ln = threadIdx.x & 31;
+    const int s = blockIdx.x * 8 + grp;
     float loss = 0.f;
     if (s < B) {
         const float* z = logits + (long long)s * ldl;
-        float mx = z[0];
-        for (int c = 1; c < C; ++c) mx = z[c] > mx ? z[c] : mx;
-        float sum = 0.f;
-        for (int c = 0; c < C; ++c) sum += expf(z[c] - mx);
         const int y = labels[s];
+        float mx = -3.0e38f;
+        for (int c = ln; c < C; c += 32) mx = z[c] > mx ? z[c] : mx;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) { const float o = __shfl_xor(mx, off, 32); mx = o > mx ? o : mx; }
+        float sum = 0.f;
+        for (int c = ln; c < C; c += 32) sum += expf(z[c] - mx);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 32);
         loss = -(z[y] - mx - logf(sum));
         if (dlogits) {
             float* d = dlogits + (long long)s * ldl;
-            for (int c = 0; c < ldl; ++c) d[c] = c < C ? (expf(z[c] - mx) / sum - (c == y ? 1.f : 0.f)) * inv_b : 0.f;
+            for (int c = ln; c < ldl; c += 32) d[c] = c < C ? (expf(z[c] - mx) / sum - (c == y ? 1.f : 0.f)) * inv_b : 0.f;
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) loss += __shfl_down(loss, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loss;
+    if (ln == 0) red[grp] = loss;
     __syncthreads();
-    if (threadIdx.x == 0 && loss_part) loss_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-__global__ void k_sum_small(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (threadIdx.x == 0) {
         float t = 0.f;
-        for (int i = 0; i < n; ++i) t += part[i];
-        *out = t * scale;
+        for (int g = 0; g < 8; ++g) t += red[g];
+        __hip_atomic_store(&loss_part[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last || !loss_out) {
+        if (last && threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    float t = 0.f;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) t += __hip_atomic_load(&loss_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 256; ++i) tot += red[i];
+        *loss_out = tot * inv_b;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -452,4 +452,298 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// First layer (CIN = 1 or 3 input channels: the whole 3 x 3 x CIN patch is one k-block of 9 / 27 <= 32).
+//
+// The implicit-GEMM kernels gather this layer's A tile with one guarded scalar load per element (and the layer is pure traffic:
+// 1.8 of the CIFAR step's 32 GFLOP, 67 MB of activations).  Here the input halo of a block of 128 output pixels is a few hundred
+// floats in LDS ([pixel][CIN], rows of the image stay contiguous, so the loads are coalesced dwords), element k = (kh, kw, ci) of
+// pixel p sits at p * CIN + koff(k) with koff a compile-time table, and the weights never leave registers.
+
+template <int CIN, int HWD> __host__ __device__ constexpr int conv1_koff(int k) {
+    const int kk = k < 9 * CIN ? k : 9 * CIN - 1;           // padding columns read a real element (their weight / their output row is dropped)
+    const int tap = kk / CIN, ci = kk % CIN;
+    return ((tap / 3) * HWD + tap % 3) * CIN + ci;
+}
+
+// k_conv1_fwd_f32: Y = relu(conv3x3(X) + b), EPI 2, or the same followed by the 2 x 2 max-pool, EPI 4 (as k_conv3x3_halo_f32).
+// 14 (CIN = 3) / 5 (CIN = 1) MFMAs per wave and block; work items = (32-channel column block, pixel block), persistent workgroups,
+// the next block's halo in flight under the MFMAs and the stores of this one.
+template <int CIN, int TW, int EPI>
+__global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restrict__ X, const float* __restrict__ Wk, const float* __restrict__ bias,
+                                                            float* __restrict__ Y, ConvShape s, int tiles_w, int tiles_h, int n_items,
+                                                            uint8_t* __restrict__ pool_idx) {
+    using Gm = HaloGeom<TW>;
+    constexpr int K = 9 * CIN, KS2 = (K + 1) / 2;
+    constexpr int HF = Gm::NPIX * CIN, NL = (HF + kThreads - 1) / kThreads;
+    __shared__ float Hs[Gm::LPIX * CIN];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int py = 2 * wave + (r >> 4), pxb = r & 15;
+    const float* hb = Hs + ((pxb / TW) * Gm::IS + py * Gm::HWD + pxb % TW) * CIN;
+    const int n_tiles = tiles_w * tiles_h * ((s.N + Gm::NIMG - 1) / Gm::NIMG);
+
+    struct Item { int img0, oh0, ow0, n0; };
+    auto decode = [&](int item) {
+        Item it;
+        it.n0 = (item / n_tiles) * 32;
+        int tile = item % n_tiles;
+        it.ow0 = (tile % tiles_w) * TW; tile /= tiles_w;
+        it.oh0 = (tile % tiles_h) * Gm::TH;
+        it.img0 = (tile / tiles_h) * Gm::NIMG;
+        return it;
+    };
+    float hv[NL];
+    unsigned okm = 0;
+    auto halo_load = [&](const Item& it) {
+        okm = 0;
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = to + kThreads * q;
+            if (NL * kThreads == HF || e < HF) {
+                const int pix = e / CIN, ci = e - pix * CIN;
+                const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
+                const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
+                const int ih = it.oh0 - 1 + hy, iw = it.ow0 - 1 + hx, img = it.img0 + i;
+                const bool ok = img < s.N && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+                okm |= (ok ? 1u : 0u) << q;
+                hv[q] = X[ok ? (((long long)img * s.H + ih) * s.W + iw) * CIN + ci : 0];
+            }
+        }
+    };
+    auto halo_store = [&]() {
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = to + kThreads * q;
+            if (NL * kThreads == HF || e < HF) {
+                const int pix = e / CIN, ci = e - pix * CIN;
+                Hs[Gm::lds_pix(pix) * CIN + ci] = ((okm >> q) & 1u) ? hv[q] : 0.f;
+            }
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    Item cur = decode(item);
+    halo_load(cur);
+    float wreg[KS2];
+    int wn0 = -1;
+    bool first = true;
+#pragma unroll 1
+    for (; item < n_items; item += gridDim.x) {
+        if (cur.n0 != wn0) {                                          // this lane's B operands: W[k = 2 ks + h][n0 + r]
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const int k = 2 * ks + h;
+                wreg[ks] = k < K ? Wk[(long long)k * s.Cout + cur.n0 + r] : 0.f;
+            }
+            wn0 = cur.n0;
+        }
+        const int nitem = item + gridDim.x;
+        const Item nxt = decode(nitem < n_items ? nitem : item);
+        if (!first) __syncthreads();                                  // the previous block's halo has been consumed
+        first = false;
+        halo_store();
+        __syncthreads();
+        if (nitem < n_items) halo_load(nxt);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+            const float a = hb[h ? conv1_koff<CIN, Gm::HWD>(2 * ks + 1) : conv1_koff<CIN, Gm::HWD>(2 * ks)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[ks], acc, 0, 0, 0);
+        }
+        const int img0 = cur.img0, oh0 = cur.oh0, ow0 = cur.ow0;
+        const int co = cur.n0 + r;
+        const float bb = bias[co];
+        if (EPI == 4) {
+            const int OH = s.H / 2, OW = s.W / 2;
+            const int poh = oh0 / 2 + wave;
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int i0 = 4 * gq + 2 * pp;
+                    float v[4] = {acc[i0] + bb, acc[i0 + 1] + bb, acc[8 + i0] + bb, acc[8 + i0 + 1] + bb};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                    float best = v[0];
+                    int bk = 0;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+                        if (v[k] > best) { best = v[k]; bk = k; }
+                    const int colb = 4 * h + 8 * gq + 2 * pp;
+                    const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
+                    if (img < s.N && poh < OH && pow_ < OW) {
+                        const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
+                        Y[o] = best;
+                        pool_idx[o] = (uint8_t)bk;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pr = mfma32_row(lane, i);
+                const int colb = pr & 15;
+                const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+                if (img < s.N && oh < s.H && ow < s.W) {
+                    const float v = acc[i] + bb;
+                    Y[(((long long)img * s.H + oh) * s.W + ow) * s.Cout + co] = v > 0.f ? v : 0.f;
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// k_conv1_wgrad_f32: dW[k][co] = sum over pixels of patch element k times dZ[pixel][co], one 32 x 32 tile (rows k < 9 CIN real) per
+// workgroup (co block, chunk of pixel blocks); the MFMA's row index is k -- lane r reads element koff(r) of pixel p + h, a lane
+// constant plus an immediate -- and its contraction index the pixel, as in k_wgrad3x3_halo_f32.  Same slab layout.
+template <int CIN, int TW, bool PDZ>
+__global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ slab, ConvShape s,
+                                                              int tiles_w, int tiles_h, int blocks_per_chunk, PooledGrad pdz) {
+    using Gm = HaloGeom<TW>;
+    constexpr int K = 9 * CIN, BN = 32, NPX = 128;
+    constexpr int HF = Gm::NPIX * CIN, NL = (HF + kThreads - 1) / kThreads;
+    constexpr int ND = PDZ ? 1 : NPX * (BN / 4) / kThreads;
+    constexpr int kHalo = (Gm::LPIX * CIN + 2 * CIN + 3) / 4 * 4;     // + one pixel pair of slack for the padding rows' reads, 16-byte aligned
+    __shared__ __attribute__((aligned(16))) float smem[kHalo + NPX * BN];
+    float* Hs = smem;
+    float* Ds = smem + kHalo;
+    static_assert(NPX * BN >= 4 * 16 * 64, "the wave partials fit the dZ image");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = blockIdx.x * BN, chunk = blockIdx.y;
+    const int total_blocks = tiles_w * tiles_h * ((s.N + Gm::NIMG - 1) / Gm::NIMG);
+    const int b0 = chunk * blocks_per_chunk, b1 = b0 + blocks_per_chunk < total_blocks ? b0 + blocks_per_chunk : total_blocks;
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+    float hv[NL];
+    f32x4 dv[ND], dp[1];
+    unsigned di = 0, okm = 0;
+    auto gload = [&](int blk) {
+        int q0 = blk;
+        const int tw = q0 % tiles_w; q0 /= tiles_w;
+        const int th = q0 % tiles_h;
+        const int img0 = (q0 / tiles_h) * Gm::NIMG;
+        const int oh0 = th * Gm::TH, ow0 = tw * TW;
+        okm = 0;
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = to + kThreads * q;
+            if (NL * kThreads == HF || e < HF) {
+                const int pix = e / CIN, ci = e - pix * CIN;
+                const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
+                const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
+                const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx, img = img0 + i;
+                const bool ok = img < s.N && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+                okm |= (ok ? 1u : 0u) << q;
+                hv[q] = X[ok ? (((long long)img * s.H + ih) * s.W + iw) * CIN + ci : 0];
+            }
+        }
+        if (PDZ) {
+            const int pp = to >> 3, c4 = (to & 7) * 4;
+            const int colb = 2 * (pp & 7);
+            const int img = img0 + colb / TW, poh = (oh0 >> 1) + (pp >> 3), pow_ = (ow0 + colb % TW) >> 1;
+            const bool ok = img < s.N && poh < (s.H >> 1) && pow_ < (s.W >> 1);
+            okm |= (ok ? 1u : 0u) << 16;
+            const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
+            dv[0] = *reinterpret_cast<const f32x4*>(pdz.dP + o);
+            dp[0] = *reinterpret_cast<const f32x4*>(pdz.P + o);
+            di = *reinterpret_cast<const unsigned*>(pdz.idx + o);
+        } else {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                const int e = to + kThreads * q;
+                const int pix = e >> 3, c4 = (e & 7) * 4;
+                const int colb = pix & 15;
+                const int img = img0 + colb / TW, oh = oh0 + (pix >> 4), ow = ow0 + colb % TW;
+                const bool ok = img < s.N && oh < s.H && ow < s.W;
+                okm |= (ok ? 1u : 0u) << (16 + q);
+                dv[q] = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+            }
+        }
+    };
+    auto lstore = [&]() {
+        const int to = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = to + kThreads * q;
+            if (NL * kThreads == HF || e < HF) {
+                const int pix = e / CIN, ci = e - pix * CIN;
+                Hs[Gm::lds_pix(pix) * CIN + ci] = ((okm >> q) & 1u) ? hv[q] : 0.f;
+            }
+        }
+        if (PDZ) {
+            const int pp = to >> 3, c4 = (to & 7) * 4;
+            const bool ok = (okm >> 16) & 1u;
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const f32x4 v = ok ? unpool4(dv[0], dp[0], di, (unsigned)pos) : f32x4{0, 0, 0, 0};
+                *reinterpret_cast<f32x4*>(&Ds[((2 * (pp >> 3) + (pos >> 1)) * 16 + 2 * (pp & 7) + (pos & 1)) * BN + c4]) = v;
+                colsum += v;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                const int e = to + kThreads * q;
+                const f32x4 v = ((okm >> (16 + q)) & 1u) ? dv[q] : f32x4{0, 0, 0, 0};
+                *reinterpret_cast<f32x4*>(&Ds[e * 4]) = v;
+                colsum += v;
+            }
+        }
+    };
+    if (tid < kHalo - Gm::LPIX * CIN) Hs[Gm::LPIX * CIN + tid] = 0.f;    // the slack is read (by rows that are dropped) but never staged
+    const int r = lane & 31, h = lane >> 5;
+    // lane's A element: patch entry r (clamped for the padding rows 9 CIN .. 31, which are not written back) of pixel p + h
+    int ko = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) ko = r == k ? conv1_koff<CIN, Gm::HWD>(k) : ko;
+    const float* al = Hs + ko + h * CIN;
+    const float* dl = Ds + 32 * h + r;
+    if (b0 < b1) gload(b0);
+#pragma unroll 1
+    for (int blk = b0; blk < b1; ++blk) {
+        if (blk != b0) __syncthreads();
+        lstore();
+        __syncthreads();
+        if (blk + 1 < b1) gload(blk + 1);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int xb = 2 * (ks & 7);
+            const float b = dl[((ks >> 3) * 16 + xb) * 32 + wave * (2 * 16 * 32)];
+            const float a = al[((xb / TW) * Gm::IS + (xb % TW) + (ks >> 3) * Gm::HWD) * CIN + wave * (2 * Gm::HWD * CIN)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    float* out = slab + (long long)chunk * (K + 1) * s.Cout;
+    float* Red = Ds;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Red[(wave * 16 + i) * 64 + lane] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + kThreads * u, i = e >> 6, ln = e & 63;
+        const int k = mfma32_row(ln, i);
+        const float v = (Red[(0 * 16 + i) * 64 + ln] + Red[(1 * 16 + i) * 64 + ln]) + (Red[(2 * 16 + i) * 64 + ln] + Red[(3 * 16 + i) * 64 + ln]);
+        if (k < K) out[(long long)k * s.Cout + n0 + (ln & 31)] = v;
+    }
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&Red[tid * 4]) = colsum;
+    __syncthreads();
+    if (tid < BN) {
+        const int grp = tid >> 2, comp = tid & 3;
+        float t = 0.f;
+        for (int u = grp; u < kThreads; u += BN / 4) t += Red[u * 4 + comp];
+        out[(long long)K * s.Cout + n0 + tid] = t;
+    }
+}
+
 }  // namespace rcnx

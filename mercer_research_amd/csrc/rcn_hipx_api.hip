@@ -58,8 +58,9 @@ struct rcn_hipx_net {
     hipStream_t stream = nullptr; bool own_stream = false;
     std::vector<Layer> L;
     long long n_pad = 0, n_log = 0;
-    Buf params, wt, slab, dz, loss_part, grad_tmp, dlogits, skbuf, wb;
+    Buf params, wt, slab, slab2, dz, loss_part, grad_tmp, dlogits, skbuf, wb;      // wt: tap-flipped transposed weights, laid out like params (w_off)
     int precision = RCN_HIPX_FP32;          // GEMM operand precision of forward / dgrad (rcn_hipx_set_precision)
+    int tiling = RCN_HIPX_TILING_AUTO;      // fp32 3x3 kernels: implicit GEMM only / by shape / LDS-tiled wherever they apply (rcn_hipx_set_tiling)
     std::map<Key, hipGraphExec_t> graphs;
     std::string err;
 };
@@ -90,7 +91,8 @@ int grid1d(long long total, int block) { long long g = (total + block - 1) / blo
 // epi 4 (bias + ReLU + the following 2x2 max-pool, written to Y = pooled map and pool_idx) exists only in the LDS-tiled bf16 kernel:
 // callers ask conv_pool_fusable() first
 static bool halo_enabled() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO"); return e ? std::atoi(e) : 1; }(); return v != 0; }
-static bool halo_f32_enabled() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO_F32"); return e ? std::atoi(e) : 1; }(); return v != 0; }
+// RCN_HIPX_HALO_F32 only seeds a new net's tiling mode (rcn_hipx_create); rcn_hipx_set_tiling changes it per net
+static int halo_f32_default() { const char* e = std::getenv("RCN_HIPX_HALO_F32"); const int v = e ? std::atoi(e) : 1; return v < 0 || v > 2 ? 1 : v; }
 
 // workgroups of `kernel` (256 threads, static LDS only) the device holds at once: the grid of a kernel whose workgroups loop over
 // work items.  Asked from the runtime once per kernel.
@@ -122,26 +124,33 @@ int splitk_z(long long M, int Cout, int bn, int nkt) {
 // side by side where that wastes fewer MFMA rows (8-, 24-, 56-pixel-wide maps).  Not used when less than 70 % of a block's rows
 // are real pixels (the implicit-GEMM kernels have no such waste).
 struct HaloPlan { bool ok; int tw; };
-HaloPlan halo_plan(const ConvShape& s) {
+HaloPlan halo_plan(const rcn_hipx_net* n, const ConvShape& s) {
     const double uh = (double)s.H / ((s.H + 7) / 8 * 8);
     const double u16 = (double)s.W / ((s.W + 15) / 16 * 16);
     const double u8 = (double)s.W / ((s.W + 7) / 8 * 8) * ((double)s.N / ((s.N + 1) / 2 * 2));
     const int tw = u8 > u16 ? 8 : 16;
-    return HaloPlan{uh * (tw == 8 ? u8 : u16) >= 0.7, tw};
+    return HaloPlan{n->tiling == RCN_HIPX_TILING_LDS || uh * (tw == 8 ? u8 : u16) >= 0.7, tw};
 }
-bool conv_halo_f32_shape(const ConvShape& s) { return halo_f32_enabled() && s.Cin % 32 == 0 && s.Cout % 32 == 0 && halo_plan(s).ok; }
+// the first layer's own kernels (k_conv1_*_f32): 1 or 3 input channels
+bool conv1_f32_shape(const rcn_hipx_net* n, const ConvShape& s) { return n->tiling != RCN_HIPX_TILING_GEMM && (s.Cin == 1 || s.Cin == 3) && s.Cout % 32 == 0 && halo_plan(n, s).ok; }
+bool conv_halo_f32_shape(const rcn_hipx_net* n, const ConvShape& s) { return n->tiling != RCN_HIPX_TILING_GEMM && s.Cin % 32 == 0 && s.Cout % 32 == 0 && halo_plan(n, s).ok; }
+// split-K factor of a fp32 3x3 layer as launch_conv decides it (the LDS-tiled kernels have no split-K form)
+int conv3_f32_z(const rcn_hipx_net* n, const ConvShape& s) {
+    if (n->tiling == RCN_HIPX_TILING_LDS && conv_halo_f32_shape(n, s)) return 1;
+    return splitk_z((long long)s.N * s.H * s.W, s.Cout, s.Cout % 64 == 0 ? 64 : 32, 9 * s.Cin / 32);
+}
 
 // does the 2x2 max-pool that follows this 3x3 convolution run in the convolution kernel's epilogue (EPI 4: LDS-tiled kernels only)?
 bool conv_pool_fusable(const rcn_hipx_net* n, const ConvShape& s) {
     if (s.H % 2 || s.W % 2) return false;
     if (n->precision == RCN_HIPX_BF16) return halo_enabled() && (s.Cin == 32 || s.Cin % 64 == 0);
-    return conv_halo_f32_shape(s);
+    return conv_halo_f32_shape(n, s) || conv1_f32_shape(n, s);
 }
 
 // can the LDS-tiled kernel run this 3x3 convolution (as launch_conv would decide)?  Mirrors launch_conv's split-K rule.
 bool conv_halo_runs(const rcn_hipx_net* n, const ConvShape& s) {
     const long long M = (long long)s.N * s.H * s.W;
-    if (n->precision != RCN_HIPX_BF16) return conv_halo_f32_shape(s) && splitk_z(M, s.Cout, s.Cout % 64 == 0 ? 64 : 32, 9 * s.Cin / 32) == 1;
+    if (n->precision != RCN_HIPX_BF16) return conv_halo_f32_shape(n, s) && conv3_f32_z(n, s) == 1;
     if (!halo_enabled() || !(s.Cin == 32 || s.Cin % 64 == 0) || s.Cout % 32) return false;
     const int bn = s.Cout % 128 == 0 ? 128 : s.Cout % 64 == 0 ? 64 : 32;
     return splitk_z(M, s.Cout, bn, 9 * s.Cin / 32) == 1;
@@ -156,7 +165,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     const bool bf16 = n->precision == RCN_HIPX_BF16;
     const int bn = (bf16 && s.Cout % 128 == 0) ? 128 : (s.Cout % 64 == 0) ? 64 : 32;
     const int nkt = smallc ? 1 : ks * ks * s.Cin / 32;
-    const int Z = epi == 4 ? 1 : splitk_z(M, s.Cout, bn, nkt);
+    const int Z = epi == 4 ? 1 : (!bf16 && ks == 3 && !smallc) ? conv3_f32_z(n, s) : splitk_z(M, s.Cout, bn, nkt);
     float* out = Y;
     int kepi = epi;
     if (Z > 1) {
@@ -198,9 +207,25 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #undef CONVB_CASE
     } else {
         if (epi == 4 && !(ks == 3 && conv_pool_fusable(n, s))) return fail(n, -3, "internal: fused conv+pool epilogue requested for a layer the LDS-tiled kernel does not cover");
-        if (ks == 3 && !smallc && Z == 1 && conv_halo_f32_shape(s)) {
+        if (ks == 3 && smallc && (epi == 2 || epi == 4) && conv1_f32_shape(n, s)) {
+            // first layer (convnet_halo.hpp): weights in registers, the block's input halo in LDS
+            const int tw = halo_plan(n, s).tw, nimg = 16 / tw;
+            const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
+            const long long items = (long long)tiles_w * tiles_h * ((s.N + nimg - 1) / nimg) * (s.Cout / 32);
+            if (items > 0x7fffffffLL) return fail(n, -3, "too many pixel blocks in one layer");
+#define C1_LAUNCH(CIN_, TW_, EPI_) do { const long long slots = resident_slots(n, (const void*)k_conv1_fwd_f32<CIN_, TW_, EPI_>); \
+            hipLaunchKernelGGL((k_conv1_fwd_f32<CIN_, TW_, EPI_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, Wk, bias, Y, s, tiles_w, tiles_h, (int)items, pool_idx); } while (0)
+#define C1_EPI(CIN_, TW_) do { if (epi == 4) C1_LAUNCH(CIN_, TW_, 4); else C1_LAUNCH(CIN_, TW_, 2); } while (0)
+            if (s.Cin == 3) { if (tw == 16) C1_EPI(3, 16); else C1_EPI(3, 8); }
+            else { if (tw == 16) C1_EPI(1, 16); else C1_EPI(1, 8); }
+#undef C1_EPI
+#undef C1_LAUNCH
+            XTRY(n, hipGetLastError());
+            return 0;
+        }
+        if (ks == 3 && !smallc && Z == 1 && conv_halo_f32_shape(n, s)) {
             // LDS-tiled (convnet_halo.hpp): one staged halo per block of 128 output pixels serves all nine taps
-            const int tw = halo_plan(s).tw, nimg = 16 / tw;
+            const int tw = halo_plan(n, s).tw, nimg = 16 / tw;
             const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
             // work items = (pixel block, bn-wide column block); at most as many workgroups as the chip holds at once (three per CU), each
             // taking items blockIdx.x, + gridDim.x, ...
@@ -255,9 +280,9 @@ static int pix_per_chunk(long long M, long long tiles) {
 #define kPixPerChunk (pix_per_chunk(M, (long long)(smallc ? 1 : K / 32) * (s.Cout / bn)))
 
 static bool wgrad_halo_on() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO_WGRAD"); return e ? std::atoi(e) : 1; }(); return v != 0; }
-bool wgrad_halo_f32_runs(const ConvShape& s, int ks) { return ks == 3 && ks * ks * s.Cin > 32 && conv_halo_f32_shape(s); }
+bool wgrad_halo_f32_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) { return ks == 3 && ((ks * ks * s.Cin > 32 && conv_halo_f32_shape(n, s)) || conv1_f32_shape(n, s)); }
 bool wgrad_halo_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) {
-    if (n->precision != RCN_HIPX_BF16) return wgrad_halo_on() && wgrad_halo_f32_runs(s, ks);
+    if (n->precision != RCN_HIPX_BF16) return wgrad_halo_on() && wgrad_halo_f32_runs(n, s, ks);
     return n->precision == RCN_HIPX_BF16 && wgrad_halo_on() && ks == 3 && ks * ks * s.Cin > 32 && (s.Cin == 32 || s.Cin % 64 == 0) && s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2;
 }
 
@@ -270,11 +295,32 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
     XTRY(n, scratch_ensure(n, n->slab, (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
     if (pdz && !wgrad_halo_runs(n, s, ks)) return fail(n, -3, "internal: pooled-resolution dZ requested for a layer the LDS-tiled weight-gradient kernel does not cover");
+    if (n->precision != RCN_HIPX_BF16 && wgrad_halo_runs(n, s, ks) && smallc) {
+        // first layer (convnet_halo.hpp): one 32 x 32 tile (rows = patch entries) per (co block, chunk of pixel blocks)
+        const int tw = halo_plan(n, s).tw, nimg = 16 / tw;
+        const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
+        const long long blocks = (long long)tiles_w * tiles_h * ((s.N + nimg - 1) / nimg);
+        long long want = (1024 + s.Cout / 32 - 1) / (s.Cout / 32);
+        if (want > blocks) want = blocks;
+        const int bpc = (int)((blocks + want - 1) / want);
+        const int hchunks = (int)((blocks + bpc - 1) / bpc);
+        XTRY(n, scratch_ensure(n, n->slab, (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
+        const dim3 hgrid((unsigned)(s.Cout / 32), (unsigned)hchunks);
+        const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
+#define W1_CASE(CIN_, TW_) do { if (pdz) hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tiles_w, tiles_h, bpc, pg); \
+                                else hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tiles_w, tiles_h, bpc, pg); } while (0)
+        if (s.Cin == 3) { if (tw == 16) W1_CASE(3, 16); else W1_CASE(3, 8); }
+        else { if (tw == 16) W1_CASE(1, 16); else W1_CASE(1, 8); }
+#undef W1_CASE
+        XTRY(n, hipGetLastError());
+        *chunks_out = hchunks;
+        return 0;
+    }
     if (n->precision != RCN_HIPX_BF16 && wgrad_halo_runs(n, s, ks)) {
         // fp32 LDS-tiled (convnet_halo.hpp): workgroup = (32 input channels, 32 output channels, chunk of pixel blocks), all nine taps.
         // Every chunk costs one (K+1) x Cout partial written and read back by the reduce whatever the number of (ci, co) workgroups
         // that share it, so: as few chunks as fill the chip twice over.
-        const int tw = halo_plan(s).tw, nimg = 16 / tw;
+        const int tw = halo_plan(n, s).tw, nimg = 16 / tw;
         const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
         const long long blocks = (long long)tiles_w * tiles_h * ((s.N + nimg - 1) / nimg);
         static const int target = [] { const char* e = std::getenv("RCN_HIPX_WGH_F32_TARGET"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 512; }();
@@ -424,15 +470,13 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         }
         // dgrad first (needs the weights BEFORE this step's update): dX = conv(dZ, flip(W)^T)
         if (din) {
-            const long long wn = (long long)ks * ks * s.Cin * s.Cout;
-            XTRY(n, scratch_ensure(n, n->wt, (size_t)wn * sizeof(float)));
-            hipLaunchKernelGGL(k_flip_weights, dim3(grid1d(wn, 256)), dim3(256), 0, n->stream, (const float*)P(n, l.w_off), (float*)n->wt.p, ks, s.Cin, s.Cout);
-            XTRY(n, hipGetLastError());
+            // the tap-flipped transposed weights are kept current by every kernel that writes a weight (FlipSpec, refresh_flipped)
+            const float* wt = (const float*)n->wt.p + l.w_off;
             // the layer below is a ReLU layer feeding this one directly (no pool in between): gate the gradient with its output in
             // this kernel's epilogue, so that layer finds its dZ ready instead of running a k_relu_bwd pass over the tensor
             const Layer& below = n->L[i - 1];
             const bool gate = below.kind == RCN_HIPX_CONV3X3_RELU || below.kind == RCN_HIPX_DENSE_RELU;
-            RTRY(launch_conv(n, dZ, (const float*)n->wt.p, gate ? (const float*)below.out.p : nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, gate ? 3 : 0,
+            RTRY(launch_conv(n, dZ, wt, gate ? (const float*)below.out.p : nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, gate ? 3 : 0,
                              nullptr, pooled[i].dP ? &pooled[i] : nullptr));
             gated[i - 1] = gate;
         }
@@ -440,12 +484,22 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks, pooled[i].dP ? &pooled[i] : nullptr));
         // [W | b] is contiguous (b_off == w_off + K * CoutP): one pass reduces the slab (incl. its bias row) and updates both
         const long long wcount = ((long long)s.Cin * ks * ks + 1) * s.Cout;
-        if (chunks >= 8)
-            hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32)), dim3(256), 0, n->stream, P(n, l.w_off), grad ? grad + l.w_off : (float*)nullptr,
-                               (const float*)n->slab.p, wcount, chunks, lr, apply ? 1 : 0);
+        const FlipSpec flip{(apply && i > 0) ? (float*)n->wt.p + l.w_off : (float*)nullptr, ks * ks, s.Cin, s.Cout};
+        float* gout = grad ? grad + l.w_off : (float*)nullptr;
+        int rchunks = chunks;
+        const float* rslab = (const float*)n->slab.p;
+        if (chunks > 64) {
+            // two stages: 32 chunks per slice into slab2, then the slices
+            const int cpg = 32, slices = (chunks + cpg - 1) / cpg;
+            XTRY(n, scratch_ensure(n, n->slab2, (size_t)slices * wcount * sizeof(float)));
+            hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32), (unsigned)slices), dim3(256), 0, n->stream, (float*)nullptr, (float*)n->slab2.p,
+                               rslab, wcount, chunks, 0.f, 0, FlipSpec{nullptr, 0, 0, 0}, cpg);
+            rslab = (const float*)n->slab2.p; rchunks = slices;
+        }
+        if (rchunks >= 8)
+            hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32)), dim3(256), 0, n->stream, P(n, l.w_off), gout, rslab, wcount, rchunks, lr, apply ? 1 : 0, flip, 0);
         else
-            hipLaunchKernelGGL(k_reduce_update, dim3(grid1d(wcount, 256)), dim3(256), 0, n->stream, P(n, l.w_off), grad ? grad + l.w_off : (float*)nullptr,
-                               (const float*)n->slab.p, wcount, chunks, lr, apply ? 1 : 0);
+            hipLaunchKernelGGL(k_reduce_update, dim3(grid1d(wcount, 256)), dim3(256), 0, n->stream, P(n, l.w_off), gout, rslab, wcount, rchunks, lr, apply ? 1 : 0, flip);
         XTRY(n, hipGetLastError());
     }
     return 0;
@@ -453,11 +507,28 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
 
 int loss_and_dlogits(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, bool want_grad) {
     Layer& l = n->L.back();
-    const int blocks = (B + 255) / 256;
-    XTRY(n, scratch_ensure(n, n->loss_part, blocks * sizeof(float)));
+    const int blocks = (B + 7) / 8;                       // eight samples per workgroup
+    // [blocks partial sums][counter of finished workgroups: zero between launches]
+    const void* before = n->loss_part.p;
+    XTRY(n, scratch_ensure(n, n->loss_part, ((size_t)n->max_batch / 8 + 2) * sizeof(float)));
+    unsigned* counter = (unsigned*)n->loss_part.p + (n->max_batch / 8 + 1);
+    if (n->loss_part.p != before) XTRY(n, hipMemsetAsync(n->loss_part.p, 0, n->loss_part.cap, n->stream));
     hipLaunchKernelGGL(k_softmax_ce, dim3(blocks), dim3(256), 0, n->stream, (const float*)l.out.p, labels, B, n->classes, l.CoutP, want_grad ? (float*)l.dout.p : (float*)nullptr,
-                       (float*)n->loss_part.p, 1.0f / (float)B);
-    if (loss_dev) hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, n->stream, (const float*)n->loss_part.p, blocks, 1.0f / (float)B, loss_dev);
+                       (float*)n->loss_part.p, counter, 1.0f / (float)B, loss_dev);
+    XTRY(n, hipGetLastError());
+    return 0;
+}
+
+// the tap-flipped transposed copy of every layer's weights that has an input gradient, from the current parameters
+int refresh_flipped(rcn_hipx_net* n) {
+    for (size_t i = 1; i < n->L.size(); ++i) {
+        const Layer& l = n->L[i];
+        if (l.kind == RCN_HIPX_MAXPOOL2) continue;
+        const int ks = l.kind == RCN_HIPX_CONV3X3_RELU ? 3 : 1;
+        const int cin = l.kind == RCN_HIPX_CONV3X3_RELU ? l.Cin : l.K;
+        const long long wn = (long long)l.K * l.CoutP;
+        hipLaunchKernelGGL(k_flip_weights, dim3(grid1d(wn, 256)), dim3(256), 0, n->stream, (const float*)P(n, l.w_off), (float*)n->wt.p + l.w_off, ks, cin, l.CoutP);
+    }
     XTRY(n, hipGetLastError());
     return 0;
 }
@@ -477,6 +548,7 @@ int rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_lay
     if (!n) return -7;
     *out = n;
     n->device = device; n->in_h = in_h; n->in_w = in_w; n->in_c = in_c; n->max_batch = max_batch;
+    n->tiling = halo_f32_default();
     int H = in_h, W = in_w, C = in_c;
     bool flat = false;
     for (int i = 0; i < n_layers; ++i) {
@@ -515,6 +587,8 @@ int rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_lay
     if (stream) { n->stream = (hipStream_t)stream; } else { XTRY(n, hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking)); n->own_stream = true; }
     XTRY(n, n->params.ensure((size_t)n->n_pad * sizeof(float)));
     XTRY(n, hipMemsetAsync(n->params.p, 0, (size_t)n->n_pad * sizeof(float), n->stream));
+    XTRY(n, n->wt.ensure((size_t)n->n_pad * sizeof(float)));
+    XTRY(n, hipMemsetAsync(n->wt.p, 0, (size_t)n->n_pad * sizeof(float), n->stream));
     for (Layer& l : n->L) {
         const size_t elems = (size_t)max_batch * l.oH * l.oW * l.CoutP;
         XTRY(n, l.out.ensure(elems * sizeof(float)));
@@ -532,7 +606,7 @@ void rcn_hipx_destroy(rcn_hipx_net* n) {
         if (n->stream) (void)hipStreamSynchronize(n->stream);
         drop_graphs(n);
         for (Layer& l : n->L) { l.out.release(); l.idx.release(); l.dout.release(); }
-        for (Buf* b : {&n->params, &n->wt, &n->slab, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf, &n->wb}) b->release();
+        for (Buf* b : {&n->params, &n->wt, &n->slab, &n->slab2, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf, &n->wb}) b->release();
         if (n->own_stream && n->stream) (void)hipStreamDestroy(n->stream);
     }
     delete n;
@@ -552,6 +626,15 @@ int rcn_hipx_set_precision(rcn_hipx_net* n, int mode) {
     return 0;
 }
 
+int rcn_hipx_set_tiling(rcn_hipx_net* n, int mode) {
+    if (!n) return -1;
+    if (mode != RCN_HIPX_TILING_GEMM && mode != RCN_HIPX_TILING_AUTO && mode != RCN_HIPX_TILING_LDS) return fail(n, -1, "set_tiling: unknown mode");
+    Dev g(n->device);
+    if (mode != n->tiling) { XTRY(n, hipStreamSynchronize(n->stream)); drop_graphs(n); }
+    n->tiling = mode;
+    return 0;
+}
+
 int rcn_hipx_set_params(rcn_hipx_net* n, const float* flat) {
     if (!n || !flat) return -1;
     Dev g(n->device);
@@ -562,6 +645,7 @@ int rcn_hipx_set_params(rcn_hipx_net* n, const float* flat) {
         std::memcpy(&pad[l.b_off], &flat[l.lb_off], sizeof(float) * l.Cout);
     }
     XTRY(n, hipMemcpyAsync(n->params.p, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice, n->stream));
+    RTRY(refresh_flipped(n));
     XTRY(n, hipStreamSynchronize(n->stream));
     return 0;
 }
@@ -654,7 +738,7 @@ int rcn_hipx_apply_dev(rcn_hipx_net* n, const float* grad, float scale) {
     Dev g(n->device);
     hipLaunchKernelGGL(k_axpy, dim3(grid1d(n->n_pad, 256)), dim3(256), 0, n->stream, (float*)n->params.p, grad, scale, n->n_pad);
     XTRY(n, hipGetLastError());
-    return 0;
+    return refresh_flipped(n);
 }
 
 int rcn_hipx_step_flops(const rcn_hipx_net* n, int B, double* flops) {
