@@ -394,11 +394,10 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __r
                     for (int k = 1; k < 4; ++k)
                         if (v[k] > best) { best = v[k]; bk = k; }
                     const int pow_ = ow0 / 2 + 2 * h + 4 * gq + pp;
-                    if (poh < OH && pow_ < OW) {
-                        const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
-                        Y[o] = best;
-                        pool_idx[o] = (uint8_t)bk;
-                    }
+                    const bool ok = poh < OH && pow_ < OW;
+                    const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
+                    if (ok) Y[o] = best;
+                    store_idx_quad(pool_idx, o, bk, ok, lane);
                 }
         }
         return;

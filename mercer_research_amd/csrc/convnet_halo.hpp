@@ -15,6 +15,19 @@
 
 #include "convnet.hpp"
 
+// Timeline instrumentation for tools/halo_stamps.hip (never defined in the library build): thread 0 of a workgroup records the
+// 100 MHz wall clock at a few points of its life.
+#ifdef RCNX_STAMPS
+__device__ unsigned long long* g_rcnx_stamps = nullptr;      // [workgroup][32]: 30 stamps, [30] = XCC id, [31] = HW_ID
+#define RCNX_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); if (g_rcnx_stamps && threadIdx.x == 0 && (slot) < 30) { unsigned long long t_; \
+    asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_rcnx_stamps[(size_t)blockIdx.x * 32 + (slot)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RCNX_STAMP_HW() do { if (g_rcnx_stamps && threadIdx.x == 0) { unsigned x_, h_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x_)); \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h_)); g_rcnx_stamps[(size_t)blockIdx.x * 32 + 30] = x_ & 0xf; g_rcnx_stamps[(size_t)blockIdx.x * 32 + 31] = h_; } } while (0)
+#else
+#define RCNX_STAMP(slot) do { } while (0)
+#define RCNX_STAMP_HW() do { } while (0)
+#endif
+
 namespace rcnx {
 
 template <int TW> struct HaloGeom {
@@ -37,11 +50,36 @@ __device__ inline f32x4 unpool4(const f32x4& d, const f32x4& p, unsigned idx4, u
     return v;
 }
 
-// The staging lambdas decode "which pixel / row is chunk q of this thread" from the thread index.  Those values are loop-invariant and
-// the compiler hoists all of them out of the phase loop -- dozens of registers held across the MFMAs, which then spill (and a
-// scratch reload shares the vector-memory counter with the prefetch loads: its wait serialises the pipeline).  Reading the thread
-// index through an empty asm makes it opaque, so the few integer instructions are redone where they are used.
+// Reading the thread index through an empty asm makes it opaque: what is computed from it is redone where it is used instead of
+// being hoisted out of the loops into registers that then spill (first-layer kernels: a handful of integer instructions).
 __device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// One thread's share of a staged pixel grid (ROWS x COLS pixels of each of NIMG images, 32 channels): chunk q is channels
+// 4 (tid & 7) .. + 3 of grid pixel (tid >> 3) + 32 q.  Decoded ONCE per kernel into one register per chunk -- the pixel's
+// (row, column, image), packed -- so that staging a grid costs a few integer instructions per chunk and no division: every VALU instruction issued between the MFMAs takes an issue slot from them (timeline + PMC, round 3:
+// four VALU instructions per MFMA held these kernels at 60-65 % of the MFMA rate).
+template <int NQ> struct StageMap {
+    int pk[NQ];               // row | column << 8 | image << 16 of the chunk's pixel; negative: no such pixel
+};
+template <int NQ, int ROWS, int COLS, int NIMG>
+__device__ inline void stage_map_init(StageMap<NQ>& m, int tid) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pix = (tid >> 3) + 32 * q;
+        const int i = pix / (ROWS * COLS), pr = pix - i * (ROWS * COLS);
+        const int y = pr / COLS, x = pr - y * COLS;
+        m.pk[q] = pix < NIMG * ROWS * COLS ? (y | (x << 8) | (i << 16)) : -1;
+    }
+}
+// Element offset of a packed pixel relative to the grid's origin, and whether it lies inside the image, for a grid whose origin is
+// pixel (y0, x0) of image img0.  Callers pass pk through opaque(): otherwise these few instructions are hoisted out of the loops
+// too, into registers the kernels do not have.
+__device__ inline int stage_rel(int pk, int tid, int Himg, int Wimg, int C) {
+    return (((pk >> 16) * Himg + (pk & 255)) * Wimg + ((pk >> 8) & 255)) * C + (tid & 7) * 4;
+}
+__device__ inline bool stage_ok(int pk, int y0, int x0, int img0, int Himg, int Wimg, int N) {
+    return pk >= 0 && (unsigned)(y0 + (pk & 255)) < (unsigned)Himg && (unsigned)(x0 + ((pk >> 8) & 255)) < (unsigned)Wimg && img0 + (pk >> 16) < N;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_conv3x3_halo_f32
@@ -67,16 +105,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     int tiles_h, int n_items, uint8_t* __restrict__ pool_idx, PooledGrad pin) {
     using Gm = HaloGeom<TW>;
     constexpr int CB = 32, NT = BN / 32, LDC = 36;
-    constexpr int HCH = Gm::NPIX * (CB / 4);                          // f32x4 chunks of one channel block of the halo
-    constexpr int PPW = TW / 2 + 2, PPI = 6 * PPW;                    // pooled pixels under one image's halo: 6 rows x (TW/2 + 2)
-    constexpr int PCH = Gm::NIMG * PPI * (CB / 4);                    // PIN: chunks of the pooled pixels under the halo
-    constexpr int NH = ((PIN ? PCH : HCH) + kThreads - 1) / kThreads;
+    constexpr int PPW = TW / 2 + 2;                                   // PIN: pooled pixels under one image's halo: 6 rows x (TW/2 + 2)
+    constexpr int GR = PIN ? 6 : Gm::HH, GC = PIN ? PPW : Gm::HWD;    // the grid that is loaded: pooled pixels, or the halo itself
+    constexpr int NH = (Gm::NIMG * GR * GC * (CB / 4) + kThreads - 1) / kThreads;
     constexpr int NB = 3 * CB * (BN / 4) / kThreads;                  // f32x4 chunks per thread of one filter row's weights
     static_assert(3 * CB * (BN / 4) % kThreads == 0, "weight chunks divide over the threads");
     __shared__ __attribute__((aligned(16))) float Hs[Gm::LPIX * LDC];
     __shared__ __attribute__((aligned(16))) float Bs[3 * CB * BN];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Cin = s.Cin, nblk = s.Cout / BN;
+    const int GH = PIN ? s.H >> 1 : s.H, GW = PIN ? s.W >> 1 : s.W;   // image size of the loaded grid
 
     const int r = lane & 31, h = lane >> 5;
     // this lane's A row = output pixel r of the wave's 32: block row 2 wave + (r >> 4), block column r & 15 -> image (column / TW)
@@ -86,62 +124,57 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     if (BN == 64) { bt[0] = Bs + 256 * h + r + 32 * h; bt[NT - 1] = Bs + 256 * h + r + 32 * (1 - h); }
     else bt[0] = Bs + 32 * h + r;
 
+    // Work item = (column block nb fastest, block column tw, block row th, image group g): kept as a mixed-radix counter that is
+    // advanced by the (decomposed) grid size -- scalar adds and compares per item instead of three integer divisions (which
+    // compile to dozens of VALU instructions each, even for uniform operands).
     struct Item { int img0, oh0, ow0, n0; };
-    auto decode = [&](int item) {
-        Item it;
-        it.n0 = (item % nblk) * BN;
-        int tile = item / nblk;
-        it.ow0 = (tile % tiles_w) * TW; tile /= tiles_w;
-        it.oh0 = (tile % tiles_h) * Gm::TH;
-        it.img0 = (tile / tiles_h) * Gm::NIMG;
-        return it;
+    struct Pos { int nb, tw, th, g; };
+    auto split = [&](int item) { Pos p; p.nb = item % nblk; item /= nblk; p.tw = item % tiles_w; item /= tiles_w; p.th = item % tiles_h; p.g = item / tiles_h; return p; };
+    const Pos stride = split((int)gridDim.x);
+    auto advance = [&](Pos p) {
+        p.nb += stride.nb; if (p.nb >= nblk) { p.nb -= nblk; ++p.tw; }
+        p.tw += stride.tw; if (p.tw >= tiles_w) { p.tw -= tiles_w; ++p.th; }
+        p.th += stride.th; if (p.th >= tiles_h) { p.th -= tiles_h; ++p.g; }
+        p.g += stride.g;
+        return p;
     };
+    auto item_of = [&](const Pos& p) { return Item{p.g * Gm::NIMG, p.th * Gm::TH, p.tw * TW, p.nb * BN}; };
 
     // ---- staging: registers first (loads fly under the MFMAs), LDS after the barrier
+    StageMap<NH> hm;
+    stage_map_init<NH, GR, GC, Gm::NIMG>(hm, tid);
     f32x4 hv[NH], hp[PIN ? NH : 1];
     unsigned hi[PIN ? NH : 1];
     unsigned okm = 0;
     auto halo_load = [&](const Item& it, int cb) {
+        // grid origin: halo pixel (oh0 - 1, ow0 - 1), or the pooled pixel under it
+        const int y0 = PIN ? (it.oh0 >> 1) - 1 : it.oh0 - 1, x0 = PIN ? (it.ow0 >> 1) - 1 : it.ow0 - 1;
+        const int base = ((it.img0 * GH + y0) * GW + x0) * Cin + cb;          // element offset of the origin (may be negative: masked below)
         okm = 0;
-        const int to = opaque(tid);
 #pragma unroll
         for (int q = 0; q < NH; ++q) {
-            const int e = to + kThreads * q;
+            const int pk = opaque(hm.pk[q]);
+            const bool ok = stage_ok(pk, y0, x0, it.img0, GH, GW, s.N);
+            okm |= (ok ? 1u : 0u) << q;
+            const unsigned off = ok ? (unsigned)(base + stage_rel(pk, tid, GH, GW, Cin)) : 0u;
             if (PIN) {
-                if (NH * kThreads == PCH || e < PCH) {
-                    const int pp = e >> 3, c4 = (e & 7) * 4;
-                    const int i = pp / PPI, pr_ = pp - i * PPI;
-                    const int pr = pr_ / PPW, pc = pr_ - pr * PPW;
-                    const int poh = (it.oh0 >> 1) - 1 + pr, pow_ = (it.ow0 >> 1) - 1 + pc, img = it.img0 + i;
-                    const bool ok = img < s.N && (unsigned)poh < (unsigned)(s.H >> 1) && (unsigned)pow_ < (unsigned)(s.W >> 1);
-                    okm |= (ok ? 1u : 0u) << q;
-                    const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * Cin + cb + c4 : 0;
-                    hv[q] = *reinterpret_cast<const f32x4*>(pin.dP + o);
-                    hp[q] = *reinterpret_cast<const f32x4*>(pin.P + o);
-                    hi[q] = *reinterpret_cast<const unsigned*>(pin.idx + o);
-                }
-            } else if (NH * kThreads == HCH || e < HCH) {
-                const int pix = e >> 3, c4 = (e & 7) * 4;
-                const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
-                const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
-                const int ih = it.oh0 - 1 + hy, iw = it.ow0 - 1 + hx, img = it.img0 + i;
-                const bool ok = img < s.N && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-                okm |= (ok ? 1u : 0u) << q;
-                hv[q] = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
+                hv[q] = *reinterpret_cast<const f32x4*>(pin.dP + off);
+                hp[q] = *reinterpret_cast<const f32x4*>(pin.P + off);
+                hi[q] = *reinterpret_cast<const unsigned*>(pin.idx + off);
+            } else {
+                hv[q] = *reinterpret_cast<const f32x4*>(X + off);
             }
         }
     };
     auto halo_store = [&]() {
-        const int to = opaque(tid);
+        const int c4 = (tid & 7) * 4;
 #pragma unroll
         for (int q = 0; q < NH; ++q) {
-            const int e = to + kThreads * q;
             const bool ok = (okm >> q) & 1u;
+            const int pk = hm.pk[q];
             if (PIN) {
-                if (NH * kThreads == PCH || e < PCH) {
-                    const int pp = e >> 3, c4 = (e & 7) * 4;
-                    const int i = pp / PPI, pr_ = pp - i * PPI;
-                    const int pr = pr_ / PPW, pc = pr_ - pr * PPW;
+                if (pk >= 0) {
+                    const int pr = pk & 255, pc = (pk >> 8) & 255, i = pk >> 16;
 #pragma unroll
                     for (int pos = 0; pos < 4; ++pos) {
                         const int hy = 2 * pr - 1 + (pos >> 1), hx = 2 * pc - 1 + (pos & 1);      // halo pixel of window position pos
@@ -149,36 +182,39 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
                             *reinterpret_cast<f32x4*>(&Hs[(i * Gm::IS + hy * Gm::HWD + hx) * LDC + c4]) = ok ? unpool4(hv[q], hp[q], hi[q], (unsigned)pos) : f32x4{0, 0, 0, 0};
                     }
                 }
-            } else if (NH * kThreads == HCH || e < HCH) {
-                *reinterpret_cast<f32x4*>(&Hs[Gm::lds_pix(e >> 3) * LDC + (e & 7) * 4]) = ok ? hv[q] : f32x4{0, 0, 0, 0};
+            } else if (pk >= 0) {
+                *reinterpret_cast<f32x4*>(&Hs[Gm::lds_pix((tid >> 3) + 32 * q) * LDC + c4]) = ok ? hv[q] : f32x4{0, 0, 0, 0};
             }
         }
     };
+    // weights of one filter row: chunk q of the thread is row (tid / (BN/4)) + (1024 / BN) q of the [kw * 32 + ci][BN] tile, i.e. a
+    // thread offset plus offsets that are uniform over the workgroup; likewise in LDS (the swizzles only involve the thread's part)
     f32x4 bv[NB];
+    constexpr int RQ = kThreads / (BN / 4);                           // rows per q step: 16 (BN = 64) / 32 (BN = 32)
+    const int br0 = tid / (BN / 4), bc4 = (tid % (BN / 4)) * 4;
+    const unsigned b_goff = (unsigned)(br0 * s.Cout + bc4);
+    float* const b_lds = BN == 64 ? &Bs[br0 * 64 + (bc4 ^ (((br0 >> 2) & 1) << 5))] : &Bs[((br0 & ~5) | ((br0 & 1) << 2) | ((br0 >> 2) & 1)) * 32 + bc4];
     auto b_load = [&](const Item& it, int cb, int kh) {
-        const int to = opaque(tid);
+        const float* wp = Wk + ((long long)(kh * 3) * Cin + cb) * s.Cout + it.n0;
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-            const int e = to + kThreads * q;
-            const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;          // row = kw * 32 + ci
-            bv[q] = *reinterpret_cast<const f32x4*>(Wk + ((long long)(kh * 3 + (row >> 5)) * Cin + cb + (row & 31)) * s.Cout + it.n0 + c4);
+            const int row = RQ * q;                                    // + br0: kw = row >> 5 and ci = row & 31 (+ br0 < RQ <= 32) are compile-time
+            bv[q] = *reinterpret_cast<const f32x4*>(wp + ((long long)(row >> 5) * Cin + (row & 31)) * s.Cout + b_goff);
         }
     };
     auto b_store = [&]() {
-        const int to = opaque(tid);
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int e = to + kThreads * q;
-            const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;
-            if (BN == 64) *reinterpret_cast<f32x4*>(&Bs[row * 64 + (c4 ^ (((row >> 2) & 1) << 5))]) = bv[q];
-            else *reinterpret_cast<f32x4*>(&Bs[((row & ~5) | ((row & 1) << 2) | ((row >> 2) & 1)) * 32 + c4]) = bv[q];
-        }
+        for (int q = 0; q < NB; ++q) *reinterpret_cast<f32x4*>(b_lds + RQ * q * BN) = bv[q];
     };
 
     const int nph = (Cin / CB) * 3;                                   // phases of one item: (channel block, filter row)
     int item = blockIdx.x;
     if (item >= n_items) return;
-    Item cur = decode(item);
+    RCNX_STAMP(0);
+    RCNX_STAMP_HW();
+    int stamp_slot = 1;
+    Pos pos = split(item);
+    Item cur = item_of(pos);
     halo_load(cur, 0);
     b_load(cur, 0, 0);
     bool first = true;
@@ -190,7 +226,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
         const int nitem = item + gridDim.x;
-        const Item nxt = decode(nitem < n_items ? nitem : item);
+        pos = advance(pos);
+        const Item nxt = item_of(pos);
         int cb = 0, kh = 0;
 #pragma unroll 1
         for (int ph = 0; ph < nph; ++ph) {
@@ -199,6 +236,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
             if (kh == 0) halo_store();
             b_store();
             __syncthreads();
+            RCNX_STAMP(stamp_slot); ++stamp_slot;                     // operands staged (slot 1: end of the prologue)
             const int nkh = kh == 2 ? 0 : kh + 1, ncb = kh == 2 ? cb + CB : cb;
             if (ph + 1 < nph) {
                 b_load(cur, ncb, nkh);
@@ -207,6 +245,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
                 b_load(nxt, 0, 0);
                 halo_load(nxt, 0);
             }
+            RCNX_STAMP(stamp_slot); ++stamp_slot;                     // the next phase's loads issued
             const float* ak = arow + kh * Gm::HWD * LDC;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
@@ -225,6 +264,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
             }
             kh = nkh; cb = ncb;
         }
+        RCNX_STAMP(stamp_slot); ++stamp_slot;                         // the item's MFMAs issued
         // ---- epilogue: accumulator row i of lane = block pixel mfma32_row(lane, i) of this wave's 32
         const int img0 = cur.img0, oh0 = cur.oh0, ow0 = cur.ow0, n0 = cur.n0;
         if (EPI == 4) {
@@ -252,11 +292,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
                             if (v[k] > best) { best = v[k]; bk = k; }
                         const int colb = 4 * h + 8 * gq + 2 * pp;                   // block column of the window's left pixel
                         const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
-                        if (img < s.N && poh < OH && pow_ < OW) {
-                            const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
-                            Y[o] = best;
-                            pool_idx[o] = (uint8_t)bk;
-                        }
+                        const bool ok = img < s.N && poh < OH && pow_ < OW;         // the same for the 32 lanes of a half-wave
+                        const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
+                        if (ok) Y[o] = best;
+                        store_idx_quad(pool_idx, o, bk, ok, lane);
                     }
             }
         } else {
@@ -279,8 +318,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
                 }
             }
         }
+        RCNX_STAMP(stamp_slot); ++stamp_slot;                         // epilogue stores issued
         cur = nxt;
     }
+    RCNX_STAMP(29);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -322,7 +363,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 hv[NH], dv[ND], dp[PDZ ? 1 : 1];
+    // this thread's chunks of the two staged grids, decoded once (StageMap): halo pixels of X, and the block's dZ pixels -- full
+    // resolution [8][16] (column = block column: TW = 8 puts image 1 at columns 8..15), or, PDZ, its 4 x 8 pooled pixels
+    // (144 accumulator registers leave no room for the table: it lives in LDS, whose reads do not share a counter with the global
+    // loads as a scratch reload would)
+    __shared__ int Pk[NH * kThreads];
+    {
+        StageMap<NH> hm;
+        stage_map_init<NH, Gm::HH, Gm::HWD, Gm::NIMG>(hm, tid);
+#pragma unroll
+        for (int q = 0; q < NH; ++q) Pk[q * kThreads + tid] = hm.pk[q];          // read back by the same thread only: no barrier needed
+    }
+    int drel0;                                                     // dZ chunk q: block pixel (tid >> 3) + 32 q = (row (tid >> 7) + 2 q, block column (tid >> 3) & 15)
+    const int dcolb = PDZ ? 2 * ((tid >> 3) & 7) : (tid >> 3) & 15;   // block column of the chunk's (window's left) pixel
+    const int drow0 = PDZ ? tid >> 6 : tid >> 7;                      // its (pooled) row for q = 0
+    const int DH = PDZ ? s.H >> 1 : s.H, DW = PDZ ? s.W >> 1 : s.W;
+    const int dximg = dcolb / TW, dxcol = PDZ ? (dcolb % TW) >> 1 : dcolb % TW;
+    drel0 = ((dximg * DH + drow0) * DW + dxcol) * s.Cout + (tid & 7) * 4;
+    f32x4 hv[NH], dv[ND], dp[1];
     unsigned di = 0;
     unsigned okm = 0;
     auto gload = [&](int blk) {
@@ -331,68 +389,49 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
         const int th = q0 % tiles_h;
         const int img0 = (q0 / tiles_h) * Gm::NIMG;
         const int oh0 = th * Gm::TH, ow0 = tw * TW;
+        const int hbase = ((img0 * s.H + oh0 - 1) * s.W + ow0 - 1) * Cin + cb;
         okm = 0;
-        const int to = opaque(tid);
 #pragma unroll
         for (int q = 0; q < NH; ++q) {
-            const int e = to + kThreads * q;
-            if (NH * kThreads == HCH || e < HCH) {
-                const int pix = e >> 3, c4 = (e & 7) * 4;
-                const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
-                const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
-                const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx, img = img0 + i;
-                const bool ok = img < s.N && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-                okm |= (ok ? 1u : 0u) << q;
-                hv[q] = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
-            }
+            const int pk = opaque(Pk[q * kThreads + tid]);            // opaque: or the offsets below are hoisted out of the block loop into registers
+            const bool ok = stage_ok(pk, oh0 - 1, ow0 - 1, img0, s.H, s.W, s.N);
+            okm |= (ok ? 1u : 0u) << q;
+            hv[q] = *reinterpret_cast<const f32x4*>(X + (ok ? (unsigned)(hbase + stage_rel(pk, tid, s.H, s.W, Cin)) : 0u));
         }
-        if (PDZ) {
-            // pooled pixel tid >> 3 of the block (4 rows x 8 columns; TW = 8: columns 0..3 image 0, 4..7 image 1), channels 4 (tid & 7)
-            const int pp = to >> 3, c4 = (to & 7) * 4;
-            const int colb = 2 * (pp & 7);
-            const int img = img0 + colb / TW, poh = (oh0 >> 1) + (pp >> 3), pow_ = (ow0 + colb % TW) >> 1;
-            const bool ok = img < s.N && poh < (s.H >> 1) && pow_ < (s.W >> 1);
-            okm |= (ok ? 1u : 0u) << 16;
-            const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
-            dv[0] = *reinterpret_cast<const f32x4*>(pdz.dP + o);
-            dp[0] = *reinterpret_cast<const f32x4*>(pdz.P + o);
-            di = *reinterpret_cast<const unsigned*>(pdz.idx + o);
-        } else {
+        const int dy0 = PDZ ? oh0 >> 1 : oh0, dx0 = PDZ ? ow0 >> 1 : ow0;
+        const int dbase = ((img0 * DH + dy0) * DW + dx0) * s.Cout + n0;
 #pragma unroll
-            for (int q = 0; q < ND; ++q) {
-                const int e = to + kThreads * q;
-                const int pix = e >> 3, c4 = (e & 7) * 4;             // block pixel (row pix >> 4, block column pix & 15)
-                const int colb = pix & 15;
-                const int img = img0 + colb / TW, oh = oh0 + (pix >> 4), ow = ow0 + colb % TW;
-                const bool ok = img < s.N && oh < s.H && ow < s.W;
-                okm |= (ok ? 1u : 0u) << (16 + q);
-                dv[q] = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+        for (int q = 0; q < ND; ++q) {
+            const bool ok = img0 + dximg < s.N && dy0 + drow0 + 2 * q < DH && dx0 + dxcol < DW;
+            okm |= (ok ? 1u : 0u) << (16 + q);
+            const unsigned off = ok ? (unsigned)(dbase + drel0 + 2 * q * DW * s.Cout) : 0u;
+            if (PDZ) {
+                dv[q] = *reinterpret_cast<const f32x4*>(pdz.dP + off);
+                dp[q] = *reinterpret_cast<const f32x4*>(pdz.P + off);
+                di = *reinterpret_cast<const unsigned*>(pdz.idx + off);
+            } else {
+                dv[q] = *reinterpret_cast<const f32x4*>(dZ + off);
             }
         }
     };
     auto lstore = [&]() {
-        const int to = opaque(tid);
+        const int c4 = (tid & 7) * 4;
 #pragma unroll
-        for (int q = 0; q < NH; ++q) {
-            const int e = to + kThreads * q;
-            if (NH * kThreads == HCH || e < HCH)
-                *reinterpret_cast<f32x4*>(&Hs[Gm::lds_pix(e >> 3) * CB + (e & 7) * 4]) = ((okm >> q) & 1u) ? hv[q] : f32x4{0, 0, 0, 0};
-        }
+        for (int q = 0; q < NH; ++q)
+            if ((NH * kThreads == HCH) || (tid >> 3) + 32 * q < Gm::NPIX) *reinterpret_cast<f32x4*>(&Hs[Gm::lds_pix((tid >> 3) + 32 * q) * CB + c4]) = ((okm >> q) & 1u) ? hv[q] : f32x4{0, 0, 0, 0};
         if (PDZ) {
-            const int pp = to >> 3, c4 = (to & 7) * 4;
             const bool ok = (okm >> 16) & 1u;
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos) {
                 const f32x4 v = ok ? unpool4(dv[0], dp[0], di, (unsigned)pos) : f32x4{0, 0, 0, 0};
-                *reinterpret_cast<f32x4*>(&Ds[((2 * (pp >> 3) + (pos >> 1)) * 16 + 2 * (pp & 7) + (pos & 1)) * BN + c4]) = v;
+                *reinterpret_cast<f32x4*>(&Ds[((2 * drow0 + (pos >> 1)) * 16 + dcolb + (pos & 1)) * BN + c4]) = v;
                 colsum += v;
             }
         } else {
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
-                const int e = to + kThreads * q;
                 const f32x4 v = ((okm >> (16 + q)) & 1u) ? dv[q] : f32x4{0, 0, 0, 0};
-                *reinterpret_cast<f32x4*>(&Ds[e * 4]) = v;
+                *reinterpret_cast<f32x4*>(&Ds[(tid + kThreads * q) * 4]) = v;
                 colsum += v;                                          // the thread's four columns are the same for every q (256 % 8 == 0)
             }
         }
@@ -577,11 +616,10 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
                         if (v[k] > best) { best = v[k]; bk = k; }
                     const int colb = 4 * h + 8 * gq + 2 * pp;
                     const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
-                    if (img < s.N && poh < OH && pow_ < OW) {
-                        const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
-                        Y[o] = best;
-                        pool_idx[o] = (uint8_t)bk;
-                    }
+                    const bool ok = img < s.N && poh < OH && pow_ < OW;
+                    const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
+                    if (ok) Y[o] = best;
+                    store_idx_quad(pool_idx, o, bk, ok, lane);
                 }
         } else {
 #pragma unroll
