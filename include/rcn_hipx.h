@@ -55,6 +55,10 @@ int  rcn_hipx_set_precision(rcn_hipx_net* net, int mode);
  * The environment variable RCN_HIPX_HALO_F32 (0 / 1 / 2) only seeds a new net's mode. */
 enum { RCN_HIPX_TILING_GEMM = 0, RCN_HIPX_TILING_AUTO = 1, RCN_HIPX_TILING_LDS = 2 };
 int  rcn_hipx_set_tiling(rcn_hipx_net* net, int mode);
+/* Backward pass: run every layer's weight gradient (+ its slab reduction and update) on a second stream beside the input-gradient
+ * chain.  Default OFF (measured slower on MI355X: the kernels fill the chip on their own); RCN_HIPX_OVERLAP=1 seeds a new net with it
+ * on.  Same kernels, same sums, same results either way. */
+int  rcn_hipx_set_overlap(rcn_hipx_net* net, int on);
 int  rcn_hipx_set_params(rcn_hipx_net* net, const float* flat);
 int  rcn_hipx_get_params(rcn_hipx_net* net, float* flat);
 int  rcn_hipx_init_params(rcn_hipx_net* net, uint64_t seed);            /* He-normal weights, zero biases */

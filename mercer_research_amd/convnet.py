@@ -37,6 +37,7 @@ SIGNATURES = {
     "rcn_hipx_unpad_host": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "rcn_hipx_set_precision": (_i, [_vp, _i]),
     "rcn_hipx_set_tiling": (_i, [_vp, _i]),
+    "rcn_hipx_set_overlap": (_i, [_vp, _i]),
     "rcn_hipx_step_flops": (_i, [_vp, _i, C.POINTER(C.c_double)]),
 }
 _libx = None
@@ -114,6 +115,10 @@ class ConvNet:
     def set_tiling(self, mode: str):
         """fp32 3x3 kernels: "gemm" (implicit GEMM only), "auto" (by shape, the default) or "lds" (LDS-tiled wherever they apply)."""
         self._ck(self.lib.rcn_hipx_set_tiling(self.net, {"gemm": 0, "auto": 1, "lds": 2}[mode]))
+
+    def set_overlap(self, on: bool):
+        """Backward pass: weight gradients on a second stream beside the input-gradient chain (default off: measured slower)."""
+        self._ck(self.lib.rcn_hipx_set_overlap(self.net, 1 if on else 0))
 
     def set_params(self, flat: np.ndarray):
         f = np.ascontiguousarray(flat, dtype=np.float32)

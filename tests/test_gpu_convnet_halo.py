@@ -107,3 +107,23 @@ def test_set_tiling_rejects_unknown_modes():
     net = ConvNet((8, 8, 3), (("conv", 32), ("pool",), ("dense", 10)), 2)
     with pytest.raises(ConvNetError):
         net._ck(net.lib.rcn_hipx_set_tiling(net.net, 7))
+
+
+@pytest.mark.parametrize("in_shape,layers,B", [NETS[0], NETS[2]])
+def test_backward_overlap_changes_nothing_but_the_schedule(in_shape, layers, B):
+    """The weight gradients of the backward pass run on a second stream beside the input-gradient chain (rcn_hipx_set_overlap):
+    same kernels, same summation orders -- parameters after three steps (one eager, two replayed graphs) are bit-identical."""
+    out = []
+    for on in (True, False):
+        torch, net, flat, x, y, _, _ = _setup(in_shape, layers, B, "lds")
+        net.set_overlap(on)
+        xd, yd = net.to_device(x), net.to_device(y)
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        with torch.cuda.stream(net.stream):
+            for _ in range(3):
+                net.train_step(xd, yd, 0.05, loss)
+        net.synchronize()
+        out.append((net.get_params(), loss.item()))
+        net.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
