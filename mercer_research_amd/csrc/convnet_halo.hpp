@@ -784,4 +784,142 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_head_f32 -- the classifier head in one launch: logits = H W + b, softmax + cross-entropy, d logits, the gradient into the hidden
+// layer (gated by its ReLU) and the per-workgroup partial of the logits layer's weight gradient.
+//
+// With a few hundred samples these are five tiny GEMMs and a reduction -- 512 x 256 x 32, 512 x 32 x 256, 256 x 512 x 32 on the
+// CIFAR net -- each of which ran as its own launch on a handful of workgroups (forward 9.6 + split-K epilogue 5.4, loss 5.5, input
+// gradient 14.8, weight gradient 10.6 us: latency, not arithmetic).  Here a workgroup owns 32 samples: their hidden activations,
+// the weights in both orientations (the flipped copy is kept current by the update kernels) and d logits stay in LDS between the
+// steps.  F = hidden width (multiple of 32, <= 256: LDS), classes <= 32 (one padded column block).  The weight-gradient partials go
+// to slab[workgroup][F + 1][32] like k_conv_wgrad's, so k_reduce_update[_wide] finishes; the loss like k_softmax_ce (last workgroup
+// adds the partials in order).
+template <bool GATE>
+__global__ __launch_bounds__(kThreads) void k_head_f32(const float* __restrict__ Hin, const float* __restrict__ Wk, const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias, const int* __restrict__ labels, int B, int F, int C,
+                                                       float* __restrict__ logits, float* __restrict__ dH, float* __restrict__ slab, float* loss_part,
+                                                       unsigned* counter, float inv_b, float* __restrict__ loss_out) {
+    extern __shared__ __attribute__((aligned(16))) float head_smem[];
+    const int LDH = F + 1, LDT = F + 32;
+    float* Hs = head_smem;                       // [32 samples][F + 1]: odd rows, read along samples (logits) and along features (weight gradient)
+    float* Ws = Hs + 32 * LDH;                   // [F][32]
+    float* WTs = Ws + F * 32;                    // [32 classes][F + 32]: the two half-waves' rows on different halves of the banks
+    float* Ls = WTs + 32 * LDT;                  // [4 waves][32][32] partial logits
+    float* Ds = Ls + 4 * 1024;                   // [32 samples][32]: d logits, B operand of the weight gradient
+    float* DsA = Ds + 1024;                      // [32][33]: the same, A operand of the input gradient
+    __shared__ float red[kThreads];
+    __shared__ int last;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int s0 = blockIdx.x * 32, F4 = F >> 2;
+    for (int e = tid; e < 32 * F4; e += kThreads) {
+        const int row = e / F4, c4 = (e - row * F4) * 4;
+        const f32x4 v = s0 + row < B ? *reinterpret_cast<const f32x4*>(Hin + (long long)(s0 + row) * F + c4) : f32x4{0, 0, 0, 0};
+        float* d = &Hs[row * LDH + c4];
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        *reinterpret_cast<f32x4*>(&WTs[row * LDT + c4]) = *reinterpret_cast<const f32x4*>(Wt + (long long)row * F + c4);
+    }
+    for (int e = tid; e < F * 8; e += kThreads) *reinterpret_cast<f32x4*>(&Ws[e * 4]) = *reinterpret_cast<const f32x4*>(Wk + e * 4);
+    __syncthreads();
+    // ---- logits: wave w contracts features [w F/4, (w + 1) F/4)
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const int k0 = wave * (F >> 2);
+        for (int ks = 0; ks < (F >> 3); ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hs[r * LDH + k0 + 2 * ks + h], Ws[(k0 + 2 * ks + h) * 32 + r], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Ls[wave * 1024 + mfma32_row(lane, i) * 32 + r] = acc[i];
+    }
+    __syncthreads();
+    // ---- softmax + cross-entropy: 8 lanes per sample, 4 classes each
+    {
+        const int sm = tid >> 3, cg = (tid & 7) * 4, s = s0 + sm;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((Ls[sm * 32 + cg + j] + Ls[1024 + sm * 32 + cg + j]) + (Ls[2048 + sm * 32 + cg + j] + Ls[3072 + sm * 32 + cg + j])) + bias[cg + j];
+        if (logits && s < B) *reinterpret_cast<f32x4*>(logits + (long long)s * 32 + cg) = f32x4{v[0], v[1], v[2], v[3]};
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = (cg + j < C && v[j] > mx) ? v[j] : mx;
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) { const float o = __shfl_xor(mx, off, 8); mx = o > mx ? o : mx; }
+        float ex[4], sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ex[j] = cg + j < C ? expf(v[j] - mx) : 0.f; sum += ex[j]; }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 8);
+        const int y = s < B ? labels[s] : 0;
+        float zy = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zy += cg + j == y ? v[j] : 0.f;
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) zy += __shfl_xor(zy, off, 8);
+        if ((tid & 7) == 0) red[sm] = s < B ? -(zy - mx - logf(sum)) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = (s < B && cg + j < C) ? (ex[j] / sum - (cg + j == y ? 1.f : 0.f)) * inv_b : 0.f;
+            Ds[sm * 32 + cg + j] = d;
+            DsA[sm * 33 + cg + j] = d;
+        }
+    }
+    __syncthreads();
+    // ---- gradient into the hidden layer: dH[32][F] = D[32][32] W^T, feature blocks of 32 over the waves
+    if (dH) {
+        for (int blk = wave; blk < (F >> 5); blk += 4) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(DsA[r * 33 + 2 * ks + h], WTs[(2 * ks + h) * LDT + blk * 32 + r], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int sr = mfma32_row(lane, i);
+                if (s0 + sr < B) {
+                    float v = acc[i];
+                    if (GATE) v = Hs[sr * LDH + blk * 32 + r] > 0.f ? v : 0.f;
+                    dH[(long long)(s0 + sr) * F + blk * 32 + r] = v;
+                }
+            }
+        }
+    }
+    // ---- weight-gradient partial: dW[F][32] = H^T D over this workgroup's samples; bias row = column sums of D
+    float* out = slab + (long long)blockIdx.x * (F + 1) * 32;
+    for (int blk = wave; blk < (F >> 5); blk += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hs[(2 * ks + h) * LDH + blk * 32 + r], Ds[(2 * ks + h) * 32 + r], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[(long long)(blk * 32 + mfma32_row(lane, i)) * 32 + r] = acc[i];
+    }
+    if (tid < 32) {
+        float t = 0.f;
+        for (int sm = 0; sm < 32; ++sm) t += Ds[sm * 32 + tid];
+        out[(long long)F * 32 + tid] = t;
+    }
+    // ---- loss: this workgroup's samples in order, then (last workgroup) the workgroups in order
+    if (tid == 0) {
+        float t = 0.f;
+        for (int g = 0; g < 32; ++g) t += red[g];
+        __hip_atomic_store(&loss_part[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    float t = 0.f;
+    if (loss_out)
+        for (int b = tid; b < (int)gridDim.x; b += kThreads) t += __hip_atomic_load(&loss_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    red[tid] = t;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < kThreads; ++i) tot += red[i];
+        if (loss_out) *loss_out = tot * inv_b;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace rcnx

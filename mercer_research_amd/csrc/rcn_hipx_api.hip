@@ -424,9 +424,10 @@ int stream_after(rcn_hipx_net* n, hipStream_t from, hipStream_t to) {
 }
 
 // forward for batch B; returns pointer to logits (padded rows of CoutP)
-int forward(rcn_hipx_net* n, const float* x, int B) {
+int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1) {
     const float* cur = x;
-    for (size_t i = 0; i < n->L.size(); ++i) {
+    if (n_layers > n->L.size()) n_layers = n->L.size();
+    for (size_t i = 0; i < n_layers; ++i) {
         Layer& l = n->L[i];
         if (l.kind == RCN_HIPX_MAXPOOL2) {
             const long long tot = (long long)B * l.oH * l.oW * (l.Cin / 4);
@@ -451,16 +452,43 @@ int forward(rcn_hipx_net* n, const float* x, int B) {
     return 0;
 }
 
+// The slab of partial [W | b] tiles of layer i (chunks x (K + 1) x Cout, as the weight-gradient kernels leave it) summed in chunk
+// order, and either applied (p <- p - lr g, the flipped copy of the weights kept current) or written to grad.
+// [W | b] is contiguous (b_off == w_off + K * CoutP): one pass finishes both.
+int reduce_slab(rcn_hipx_net* n, size_t i, int chunks, int ks, const ConvShape& s, float lr, float* grad, bool apply) {
+    Layer& l = n->L[i];
+    const long long wcount = ((long long)s.Cin * ks * ks + 1) * s.Cout;
+    const FlipSpec flip{(apply && i > 0) ? (float*)n->wt.p + l.w_off : (float*)nullptr, ks * ks, s.Cin, s.Cout};
+    float* gout = grad ? grad + l.w_off : (float*)nullptr;
+    int rchunks = chunks;
+    const float* rslab = (const float*)n->slab.p;
+    if (chunks > 64) {
+        // two stages: 32 chunks per slice into slab2, then the slices
+        const int cpg = 32, slices = (chunks + cpg - 1) / cpg;
+        XTRY(n, scratch_ensure(n, n->slab2, (size_t)slices * wcount * sizeof(float)));
+        hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32), (unsigned)slices), dim3(256), 0, n->stream, (float*)nullptr, (float*)n->slab2.p,
+                           rslab, wcount, chunks, 0.f, 0, FlipSpec{nullptr, 0, 0, 0}, cpg);
+        rslab = (const float*)n->slab2.p; rchunks = slices;
+    }
+    if (rchunks >= 8)
+        hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32)), dim3(256), 0, n->stream, P(n, l.w_off), gout, rslab, wcount, rchunks, lr, apply ? 1 : 0, flip, 0);
+    else
+        hipLaunchKernelGGL(k_reduce_update, dim3(grid1d(wcount, 256)), dim3(256), 0, n->stream, P(n, l.w_off), gout, rslab, wcount, rchunks, lr, apply ? 1 : 0, flip);
+    XTRY(n, hipGetLastError());
+    return 0;
+}
+
 // backward from dlogits (already in L.back().dout); apply: update parameters with lr, else write gradients to grad (padded layout)
-int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply) {
+int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply, int first = -1, bool first_gated = false) {
     std::vector<char> gated(n->L.size(), 0);       // layer's dout already holds dZ (ReLU gate applied by the producer)
+    if (first >= 0 && first_gated) gated[first] = 1;
     std::vector<PooledGrad> pooled(n->L.size(), PooledGrad{nullptr, nullptr, nullptr});   // layer's dZ exists only at pooled resolution
     hipStream_t const main_s = n->stream;
     struct Restore { rcn_hipx_net* n; hipStream_t s; ~Restore() { n->stream = s; } } restore{n, main_s};   // launch_* enqueue on n->stream: it is switched below
     const bool ov = n->overlap && n->side;
     bool side_busy = false;
     n->ev_next = 0;
-    for (int i = (int)n->L.size() - 1; i >= 0; --i) {
+    for (int i = first >= 0 ? first : (int)n->L.size() - 1; i >= 0; --i) {
         Layer& l = n->L[i];
         const float* in = i == 0 ? x : (const float*)n->L[i - 1].out.p;
         float* din = i == 0 ? nullptr : (float*)n->L[i - 1].dout.p;
@@ -515,42 +543,60 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks, pooled[i].dP ? &pooled[i] : nullptr));
         // the update below writes the weights (and their flipped copy) that the input-gradient kernel on the main stream reads
         if (on_side && din && apply) RTRY(stream_after(n, main_s, n->side));
-        // [W | b] is contiguous (b_off == w_off + K * CoutP): one pass reduces the slab (incl. its bias row) and updates both
-        const long long wcount = ((long long)s.Cin * ks * ks + 1) * s.Cout;
-        const FlipSpec flip{(apply && i > 0) ? (float*)n->wt.p + l.w_off : (float*)nullptr, ks * ks, s.Cin, s.Cout};
-        float* gout = grad ? grad + l.w_off : (float*)nullptr;
-        int rchunks = chunks;
-        const float* rslab = (const float*)n->slab.p;
-        if (chunks > 64) {
-            // two stages: 32 chunks per slice into slab2, then the slices
-            const int cpg = 32, slices = (chunks + cpg - 1) / cpg;
-            XTRY(n, scratch_ensure(n, n->slab2, (size_t)slices * wcount * sizeof(float)));
-            hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32), (unsigned)slices), dim3(256), 0, n->stream, (float*)nullptr, (float*)n->slab2.p,
-                               rslab, wcount, chunks, 0.f, 0, FlipSpec{nullptr, 0, 0, 0}, cpg);
-            rslab = (const float*)n->slab2.p; rchunks = slices;
-        }
-        if (rchunks >= 8)
-            hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32)), dim3(256), 0, n->stream, P(n, l.w_off), gout, rslab, wcount, rchunks, lr, apply ? 1 : 0, flip, 0);
-        else
-            hipLaunchKernelGGL(k_reduce_update, dim3(grid1d(wcount, 256)), dim3(256), 0, n->stream, P(n, l.w_off), gout, rslab, wcount, rchunks, lr, apply ? 1 : 0, flip);
-        XTRY(n, hipGetLastError());
+        RTRY(reduce_slab(n, (size_t)i, chunks, ks, s, lr, grad, apply));
         n->stream = main_s;
     }
     if (side_busy) RTRY(stream_after(n, n->side, main_s));            // join: the step's next kernels (and an end of capture) find everything on the main stream
     return 0;
 }
 
+// [partial sums of the loss, one per workgroup][counter of finished workgroups: zero between launches]
+int ensure_loss_buf(rcn_hipx_net* n, unsigned** counter) {
+    const void* before = n->loss_part.p;
+    XTRY(n, scratch_ensure(n, n->loss_part, ((size_t)n->max_batch / 8 + 2) * sizeof(float)));
+    *counter = (unsigned*)n->loss_part.p + (n->max_batch / 8 + 1);
+    if (n->loss_part.p != before) XTRY(n, hipMemsetAsync(n->loss_part.p, 0, n->loss_part.cap, n->stream));
+    return 0;
+}
+
 int loss_and_dlogits(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, bool want_grad) {
     Layer& l = n->L.back();
     const int blocks = (B + 7) / 8;                       // eight samples per workgroup
-    // [blocks partial sums][counter of finished workgroups: zero between launches]
-    const void* before = n->loss_part.p;
-    XTRY(n, scratch_ensure(n, n->loss_part, ((size_t)n->max_batch / 8 + 2) * sizeof(float)));
-    unsigned* counter = (unsigned*)n->loss_part.p + (n->max_batch / 8 + 1);
-    if (n->loss_part.p != before) XTRY(n, hipMemsetAsync(n->loss_part.p, 0, n->loss_part.cap, n->stream));
+    unsigned* counter = nullptr;
+    RTRY(ensure_loss_buf(n, &counter));
     hipLaunchKernelGGL(k_softmax_ce, dim3(blocks), dim3(256), 0, n->stream, (const float*)l.out.p, labels, B, n->classes, l.CoutP, want_grad ? (float*)l.dout.p : (float*)nullptr,
                        (float*)n->loss_part.p, counter, 1.0f / (float)B, loss_dev);
     XTRY(n, hipGetLastError());
+    return 0;
+}
+
+// Does the classifier head run as one launch (k_head_f32)?  fp32 mode; logits layer of at most 32 classes on a ReLU dense layer of
+// at most 256 units.
+bool head_fusable(const rcn_hipx_net* n) {
+    static const int on = [] { const char* e = std::getenv("RCN_HIPX_HEAD"); return e ? std::atoi(e) : 1; }();
+    if (!on || n->precision != RCN_HIPX_FP32 || n->tiling == RCN_HIPX_TILING_GEMM || n->L.size() < 2) return false;
+    const Layer& l = n->L.back();
+    const Layer& b = n->L[n->L.size() - 2];
+    return l.kind == RCN_HIPX_DENSE && l.CoutP == 32 && l.K % 32 == 0 && l.K <= 256 && b.kind == RCN_HIPX_DENSE_RELU && b.CoutP == l.K;
+}
+
+// logits, loss, d logits, gradient into the hidden layer below (gated by its ReLU) and the logits layer's weight-gradient partials
+int launch_head(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, int* chunks_out) {
+    Layer& l = n->L.back();
+    Layer& b = n->L[n->L.size() - 2];
+    const int F = l.K, blocks = (B + 31) / 32;
+    XTRY(n, scratch_ensure(n, n->slab, (size_t)blocks * (F + 1) * 32 * sizeof(float)));
+    unsigned* counter = nullptr;
+    RTRY(ensure_loss_buf(n, &counter));
+    const size_t lds = ((size_t)32 * (F + 1) + (size_t)F * 32 + (size_t)32 * (F + 32) + 4 * 1024 + 1024 + 32 * 33) * sizeof(float);
+    // more than 64 KB of dynamic LDS has to be asked for (at most 127 KB here: F <= 256)
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k_head_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    XTRY(n, attr);
+    hipLaunchKernelGGL((k_head_f32<true>), dim3(blocks), dim3(kThreads), lds, n->stream, (const float*)b.out.p, (const float*)P(n, l.w_off), (const float*)n->wt.p + l.w_off,
+                       (const float*)P(n, l.b_off), labels, B, F, n->classes, (float*)l.out.p, (float*)b.dout.p, (float*)n->slab.p, (float*)n->loss_part.p, counter,
+                       1.0f / (float)B, loss_dev);
+    XTRY(n, hipGetLastError());
+    *chunks_out = blocks;
     return 0;
 }
 
@@ -566,6 +612,24 @@ int refresh_flipped(rcn_hipx_net* n) {
     }
     XTRY(n, hipGetLastError());
     return 0;
+}
+
+int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply, int first, bool first_gated);
+int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers);
+
+// forward + loss + backward of one batch: parameters updated in place (apply) or gradients written to grad (padded layout)
+int step_core(rcn_hipx_net* n, const float* x, const int32_t* labels, int B, float lr, float* grad, bool apply, float* loss_dev) {
+    if (head_fusable(n)) {
+        const int last = (int)n->L.size() - 1;
+        RTRY(forward(n, x, B, (size_t)last));
+        int chunks = 0;
+        RTRY(launch_head(n, labels, B, loss_dev, &chunks));
+        RTRY(reduce_slab(n, (size_t)last, chunks, 1, ConvShape{B, 1, 1, n->L[last].K, n->L[last].CoutP}, lr, grad, apply));
+        return backward(n, x, B, lr, grad, apply, last - 1, true);
+    }
+    RTRY(forward(n, x, B, (size_t)-1));
+    RTRY(loss_and_dlogits(n, labels, B, loss_dev, true));
+    return backward(n, x, B, lr, grad, apply, -1, false);
 }
 
 void drop_graphs(rcn_hipx_net* n) { for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second); n->graphs.clear(); }
@@ -743,14 +807,10 @@ int rcn_hipx_train_step_dev(rcn_hipx_net* n, const float* x, const int32_t* labe
     auto it = n->graphs.find(key);
     if (it == n->graphs.end()) {
         // one eager step first: sizes every scratch buffer outside capture (hipMalloc is illegal while capturing)
-        RTRY(forward(n, x, B));
-        RTRY(loss_and_dlogits(n, labels, B, loss_dev, true));
-        RTRY(backward(n, x, B, lr, nullptr, true));
+        RTRY(step_core(n, x, labels, B, lr, nullptr, true, loss_dev));
         hipGraph_t graph = nullptr;
         XTRY(n, hipStreamBeginCapture(n->stream, hipStreamCaptureModeThreadLocal));
-        int st = forward(n, x, B);
-        if (st == 0) st = loss_and_dlogits(n, labels, B, loss_dev, true);
-        if (st == 0) st = backward(n, x, B, lr, nullptr, true);
+        const int st = step_core(n, x, labels, B, lr, nullptr, true, loss_dev);
         hipError_t e = hipStreamEndCapture(n->stream, &graph);
         if (st != 0) { if (graph) (void)hipGraphDestroy(graph); return st; }
         XTRY(n, e);
@@ -771,9 +831,7 @@ int rcn_hipx_gradients_dev(rcn_hipx_net* n, const float* x, const int32_t* label
     RTRY(ensure_batch(n, B));
     Dev g(n->device);
     XTRY(n, hipMemsetAsync(grad, 0, (size_t)n->n_pad * sizeof(float), n->stream));
-    RTRY(forward(n, x, B));
-    RTRY(loss_and_dlogits(n, labels, B, loss_dev, true));
-    return backward(n, x, B, 0.f, grad, false);
+    return step_core(n, x, labels, B, 0.f, grad, false, loss_dev);
 }
 
 __global__ void k_axpy(float* __restrict__ p, const float* __restrict__ g, float scale, long long n) {
