@@ -96,7 +96,8 @@ __device__ inline bool stage_ok(int pk, int y0, int x0, int img0, int Himg, int 
 // after them, so an item's epilogue stores and the next item's first loads overlap too.
 // Wave w computes output rows 2w, 2w + 1 of the block (32 pixels) x BN channels.  Epilogues as k_conv_fwd, plus EPI 4: bias +
 // ReLU + the 2 x 2 max-pool that follows, fused (a lane's sixteen accumulator rows are four complete pooling windows), writing
-// the pooled map and the arg-max image exactly as k_pool_fwd would.  PIN: the input is a gradient that exists only at pooled
+// the pooled map and the arg-max image as k_pool_fwd would (the arg-max is taken on the raw sums: it can differ from k_pool_fwd's
+// only in windows whose pooled value is zero, where the ReLU gate of every consumer ignores it).  PIN: the input is a gradient that exists only at pooled
 // resolution (PooledGrad): a thread loads (dP, P, arg-max) of ONE pooled pixel's four channels and expands it into the up to four
 // halo pixels of that window -- no k_pool_bwd, no full-size dZ, a quarter of the loads.
 template <int TW, int BN, int EPI, bool PIN = false>
@@ -281,19 +282,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
                 for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp) {
+                        // max-pool of relu(x + b) = relu(max(x) + b): the maximum (first of equals) is taken on the raw sums
                         const int i0 = 4 * gq + 2 * pp;
-                        float v[4] = {acc[t][i0] + bb, acc[t][i0 + 1] + bb, acc[t][8 + i0] + bb, acc[t][8 + i0 + 1] + bb};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                        const float v[4] = {acc[t][i0], acc[t][i0 + 1], acc[t][8 + i0], acc[t][8 + i0 + 1]};
                         float best = v[0];
                         int bk = 0;
 #pragma unroll
                         for (int k = 1; k < 4; ++k)
                             if (v[k] > best) { best = v[k]; bk = k; }
+                        best += bb;
+                        best = best > 0.f ? best : 0.f;
                         const int colb = 4 * h + 8 * gq + 2 * pp;                   // block column of the window's left pixel
                         const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
                         const bool ok = img < s.N && poh < OH && pow_ < OW;         // the same for the 32 lanes of a half-wave
-                        const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
+                        const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co);
                         if (ok) Y[o] = best;
                         store_idx_quad(pool_idx, o, bk, ok, lane);
                     }
@@ -309,11 +311,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
                     const int colb = pr & 15;
                     const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
                     if (img < s.N && oh < s.H && ow < s.W) {
-                        const long long m = ((long long)img * s.H + oh) * s.W + ow;
+                        const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co);      // the host keeps tensors below 2^31 elements
                         float v = acc[t][i] + bb;
                         if (EPI == 2) v = v > 0.f ? v : 0.f;
-                        if (EPI == 3) v = bias[m * s.Cout + co] > 0.f ? v : 0.f;
-                        Y[m * s.Cout + co] = v;
+                        if (EPI == 3) v = bias[o] > 0.f ? v : 0.f;
+                        Y[o] = v;
                     }
                 }
             }
@@ -508,6 +510,28 @@ template <int CIN, int HWD> __host__ __device__ constexpr int conv1_koff(int k) 
 // k_conv1_fwd_f32: Y = relu(conv3x3(X) + b), EPI 2, or the same followed by the 2 x 2 max-pool, EPI 4 (as k_conv3x3_halo_f32).
 // 14 (CIN = 3) / 5 (CIN = 1) MFMAs per wave and block; work items = (32-channel column block, pixel block), persistent workgroups,
 // the next block's halo in flight under the MFMAs and the stores of this one.
+// One thread's elements of a staged first-layer halo: element q is float (tid + 256 q) of the [pixel][CIN] image.  Decoded once.
+template <int NL> struct Stage1Map {
+    int pk[NL];               // halo row | column << 8 | image << 16; negative: past the end
+    int rel[NL];              // ((image * H + row) * W + column) * CIN + channel
+    int lds[NL];              // float index in the LDS image
+};
+template <int NL, int CIN, int TW>
+__device__ inline void stage1_init(Stage1Map<NL>& m, int tid, int Himg, int Wimg) {
+    using Gm = HaloGeom<TW>;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+        const int e = tid + kThreads * q;
+        const int pix = e / CIN, ci = e - pix * CIN;
+        const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
+        const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
+        const bool valid = e < Gm::NPIX * CIN;
+        m.pk[q] = valid ? (hy | (hx << 8) | (i << 16)) : -1;
+        m.rel[q] = valid ? ((i * Himg + hy) * Wimg + hx) * CIN + ci : 0;
+        m.lds[q] = valid ? Gm::lds_pix(pix) * CIN + ci : 0;
+    }
+}
+
 template <int CIN, int TW, int EPI>
 __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restrict__ X, const float* __restrict__ Wk, const float* __restrict__ bias,
                                                             float* __restrict__ Y, ConvShape s, int tiles_w, int tiles_h, int n_items,
@@ -520,52 +544,47 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
     const int r = lane & 31, h = lane >> 5;
     const int py = 2 * wave + (r >> 4), pxb = r & 15;
     const float* hb = Hs + ((pxb / TW) * Gm::IS + py * Gm::HWD + pxb % TW) * CIN;
-    const int n_tiles = tiles_w * tiles_h * ((s.N + Gm::NIMG - 1) / Gm::NIMG);
+    const int n_groups = (s.N + Gm::NIMG - 1) / Gm::NIMG;
 
+    // work item = (block column tw fastest, block row th, image group g, column block nb): a mixed-radix counter advanced by the
+    // decomposed grid size, as in k_conv3x3_halo_f32
     struct Item { int img0, oh0, ow0, n0; };
-    auto decode = [&](int item) {
-        Item it;
-        it.n0 = (item / n_tiles) * 32;
-        int tile = item % n_tiles;
-        it.ow0 = (tile % tiles_w) * TW; tile /= tiles_w;
-        it.oh0 = (tile % tiles_h) * Gm::TH;
-        it.img0 = (tile / tiles_h) * Gm::NIMG;
-        return it;
+    struct Pos { int tw, th, g, nb; };
+    auto split = [&](int item) { Pos p; p.tw = item % tiles_w; item /= tiles_w; p.th = item % tiles_h; item /= tiles_h; p.g = item % n_groups; p.nb = item / n_groups; return p; };
+    const Pos stride = split((int)gridDim.x);
+    auto advance = [&](Pos p) {
+        p.tw += stride.tw; if (p.tw >= tiles_w) { p.tw -= tiles_w; ++p.th; }
+        p.th += stride.th; if (p.th >= tiles_h) { p.th -= tiles_h; ++p.g; }
+        p.g += stride.g; if (p.g >= n_groups) { p.g -= n_groups; ++p.nb; }
+        p.nb += stride.nb;
+        return p;
     };
+    auto item_of = [&](const Pos& p) { return Item{p.g * Gm::NIMG, p.th * Gm::TH, p.tw * TW, p.nb * 32}; };
+
+    Stage1Map<NL> hm;
+    stage1_init<NL, CIN, TW>(hm, tid, s.H, s.W);
     float hv[NL];
     unsigned okm = 0;
     auto halo_load = [&](const Item& it) {
+        const int base = ((it.img0 * s.H + it.oh0 - 1) * s.W + it.ow0 - 1) * CIN;
         okm = 0;
-        const int to = opaque(tid);
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
-            const int e = to + kThreads * q;
-            if (NL * kThreads == HF || e < HF) {
-                const int pix = e / CIN, ci = e - pix * CIN;
-                const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
-                const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
-                const int ih = it.oh0 - 1 + hy, iw = it.ow0 - 1 + hx, img = it.img0 + i;
-                const bool ok = img < s.N && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-                okm |= (ok ? 1u : 0u) << q;
-                hv[q] = X[ok ? (((long long)img * s.H + ih) * s.W + iw) * CIN + ci : 0];
-            }
+            const bool ok = stage_ok(hm.pk[q], it.oh0 - 1, it.ow0 - 1, it.img0, s.H, s.W, s.N);
+            okm |= (ok ? 1u : 0u) << q;
+            hv[q] = X[ok ? (unsigned)(base + hm.rel[q]) : 0u];
         }
     };
     auto halo_store = [&]() {
-        const int to = opaque(tid);
 #pragma unroll
-        for (int q = 0; q < NL; ++q) {
-            const int e = to + kThreads * q;
-            if (NL * kThreads == HF || e < HF) {
-                const int pix = e / CIN, ci = e - pix * CIN;
-                Hs[Gm::lds_pix(pix) * CIN + ci] = ((okm >> q) & 1u) ? hv[q] : 0.f;
-            }
-        }
+        for (int q = 0; q < NL; ++q)
+            if (hm.pk[q] >= 0) Hs[hm.lds[q]] = ((okm >> q) & 1u) ? hv[q] : 0.f;
     };
 
     int item = blockIdx.x;
     if (item >= n_items) return;
-    Item cur = decode(item);
+    Pos pos = split(item);
+    Item cur = item_of(pos);
     halo_load(cur);
     float wreg[KS2];
     int wn0 = -1;
@@ -581,7 +600,8 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
             wn0 = cur.n0;
         }
         const int nitem = item + gridDim.x;
-        const Item nxt = decode(nitem < n_items ? nitem : item);
+        pos = advance(pos);
+        const Item nxt = item_of(pos);
         if (!first) __syncthreads();                                  // the previous block's halo has been consumed
         first = false;
         halo_store();
@@ -599,6 +619,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
         const int co = cur.n0 + r;
         const float bb = bias[co];
         if (EPI == 4) {
+            // max-pool of relu(x + b) = relu(max(x) + b): the maximum (first of equals, order 00 01 10 11) is taken on the raw sums
             const int OH = s.H / 2, OW = s.W / 2;
             const int poh = oh0 / 2 + wave;
 #pragma unroll
@@ -606,18 +627,18 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
                     const int i0 = 4 * gq + 2 * pp;
-                    float v[4] = {acc[i0] + bb, acc[i0 + 1] + bb, acc[8 + i0] + bb, acc[8 + i0 + 1] + bb};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                    const float v[4] = {acc[i0], acc[i0 + 1], acc[8 + i0], acc[8 + i0 + 1]};
                     float best = v[0];
                     int bk = 0;
 #pragma unroll
                     for (int k = 1; k < 4; ++k)
                         if (v[k] > best) { best = v[k]; bk = k; }
+                    best += bb;
+                    best = best > 0.f ? best : 0.f;
                     const int colb = 4 * h + 8 * gq + 2 * pp;
                     const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
                     const bool ok = img < s.N && poh < OH && pow_ < OW;
-                    const long long o = (((long long)img * OH + poh) * OW + pow_) * s.Cout + co;
+                    const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co);
                     if (ok) Y[o] = best;
                     store_idx_quad(pool_idx, o, bk, ok, lane);
                 }
@@ -629,7 +650,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
                 const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
                 if (img < s.N && oh < s.H && ow < s.W) {
                     const float v = acc[i] + bb;
-                    Y[(((long long)img * s.H + oh) * s.W + ow) * s.Cout + co] = v > 0.f ? v : 0.f;
+                    Y[(unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co)] = v > 0.f ? v : 0.f;
                 }
             }
         }
@@ -661,6 +682,14 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+    Stage1Map<NL> hm;
+    stage1_init<NL, CIN, TW>(hm, tid, s.H, s.W);
+    // dZ chunk q of the thread: block pixel (tid >> 3) + 32 q = (row (tid >> 7) + 2 q, block column (tid >> 3) & 15); PDZ: pooled pixel
+    const int dcolb = PDZ ? 2 * ((tid >> 3) & 7) : (tid >> 3) & 15;
+    const int drow0 = PDZ ? tid >> 6 : tid >> 7;
+    const int DH = PDZ ? s.H >> 1 : s.H, DW = PDZ ? s.W >> 1 : s.W;
+    const int dximg = dcolb / TW, dxcol = PDZ ? (dcolb % TW) >> 1 : dcolb % TW;
+    const int drel0 = ((dximg * DH + drow0) * DW + dxcol) * s.Cout + (tid & 7) * 4;
     float hv[NL];
     f32x4 dv[ND], dp[1];
     unsigned di = 0, okm = 0;
@@ -670,69 +699,48 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
         const int th = q0 % tiles_h;
         const int img0 = (q0 / tiles_h) * Gm::NIMG;
         const int oh0 = th * Gm::TH, ow0 = tw * TW;
+        const int hbase = ((img0 * s.H + oh0 - 1) * s.W + ow0 - 1) * CIN;
         okm = 0;
-        const int to = opaque(tid);
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
-            const int e = to + kThreads * q;
-            if (NL * kThreads == HF || e < HF) {
-                const int pix = e / CIN, ci = e - pix * CIN;
-                const int i = pix / Gm::IMG_PIX, pr = pix - i * Gm::IMG_PIX;
-                const int hy = pr / Gm::HWD, hx = pr - hy * Gm::HWD;
-                const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx, img = img0 + i;
-                const bool ok = img < s.N && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-                okm |= (ok ? 1u : 0u) << q;
-                hv[q] = X[ok ? (((long long)img * s.H + ih) * s.W + iw) * CIN + ci : 0];
-            }
+            const bool ok = stage_ok(hm.pk[q], oh0 - 1, ow0 - 1, img0, s.H, s.W, s.N);
+            okm |= (ok ? 1u : 0u) << q;
+            hv[q] = X[ok ? (unsigned)(hbase + hm.rel[q]) : 0u];
         }
-        if (PDZ) {
-            const int pp = to >> 3, c4 = (to & 7) * 4;
-            const int colb = 2 * (pp & 7);
-            const int img = img0 + colb / TW, poh = (oh0 >> 1) + (pp >> 3), pow_ = (ow0 + colb % TW) >> 1;
-            const bool ok = img < s.N && poh < (s.H >> 1) && pow_ < (s.W >> 1);
-            okm |= (ok ? 1u : 0u) << 16;
-            const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
-            dv[0] = *reinterpret_cast<const f32x4*>(pdz.dP + o);
-            dp[0] = *reinterpret_cast<const f32x4*>(pdz.P + o);
-            di = *reinterpret_cast<const unsigned*>(pdz.idx + o);
-        } else {
+        const int dy0 = PDZ ? oh0 >> 1 : oh0, dx0 = PDZ ? ow0 >> 1 : ow0;
+        const int dbase = ((img0 * DH + dy0) * DW + dx0) * s.Cout + n0;
 #pragma unroll
-            for (int q = 0; q < ND; ++q) {
-                const int e = to + kThreads * q;
-                const int pix = e >> 3, c4 = (e & 7) * 4;
-                const int colb = pix & 15;
-                const int img = img0 + colb / TW, oh = oh0 + (pix >> 4), ow = ow0 + colb % TW;
-                const bool ok = img < s.N && oh < s.H && ow < s.W;
-                okm |= (ok ? 1u : 0u) << (16 + q);
-                dv[q] = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+        for (int q = 0; q < ND; ++q) {
+            const bool ok = img0 + dximg < s.N && dy0 + drow0 + 2 * q < DH && dx0 + dxcol < DW;
+            okm |= (ok ? 1u : 0u) << (16 + q);
+            const unsigned off = ok ? (unsigned)(dbase + drel0 + 2 * q * DW * s.Cout) : 0u;
+            if (PDZ) {
+                dv[q] = *reinterpret_cast<const f32x4*>(pdz.dP + off);
+                dp[q] = *reinterpret_cast<const f32x4*>(pdz.P + off);
+                di = *reinterpret_cast<const unsigned*>(pdz.idx + off);
+            } else {
+                dv[q] = *reinterpret_cast<const f32x4*>(dZ + off);
             }
         }
     };
     auto lstore = [&]() {
-        const int to = opaque(tid);
+        const int c4 = (tid & 7) * 4;
 #pragma unroll
-        for (int q = 0; q < NL; ++q) {
-            const int e = to + kThreads * q;
-            if (NL * kThreads == HF || e < HF) {
-                const int pix = e / CIN, ci = e - pix * CIN;
-                Hs[Gm::lds_pix(pix) * CIN + ci] = ((okm >> q) & 1u) ? hv[q] : 0.f;
-            }
-        }
+        for (int q = 0; q < NL; ++q)
+            if (hm.pk[q] >= 0) Hs[hm.lds[q]] = ((okm >> q) & 1u) ? hv[q] : 0.f;
         if (PDZ) {
-            const int pp = to >> 3, c4 = (to & 7) * 4;
             const bool ok = (okm >> 16) & 1u;
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos) {
                 const f32x4 v = ok ? unpool4(dv[0], dp[0], di, (unsigned)pos) : f32x4{0, 0, 0, 0};
-                *reinterpret_cast<f32x4*>(&Ds[((2 * (pp >> 3) + (pos >> 1)) * 16 + 2 * (pp & 7) + (pos & 1)) * BN + c4]) = v;
+                *reinterpret_cast<f32x4*>(&Ds[((2 * drow0 + (pos >> 1)) * 16 + dcolb + (pos & 1)) * BN + c4]) = v;
                 colsum += v;
             }
         } else {
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
-                const int e = to + kThreads * q;
                 const f32x4 v = ((okm >> (16 + q)) & 1u) ? dv[q] : f32x4{0, 0, 0, 0};
-                *reinterpret_cast<f32x4*>(&Ds[e * 4]) = v;
+                *reinterpret_cast<f32x4*>(&Ds[(tid + kThreads * q) * 4]) = v;
                 colsum += v;
             }
         }

@@ -136,7 +136,9 @@ HaloPlan halo_plan(const rcn_hipx_net* n, const ConvShape& s) {
     const double u16 = (double)s.W / ((s.W + 15) / 16 * 16);
     const double u8 = (double)s.W / ((s.W + 7) / 8 * 8) * ((double)s.N / ((s.N + 1) / 2 * 2));
     const int tw = u8 > u16 ? 8 : 16;
-    return HaloPlan{n->tiling == RCN_HIPX_TILING_LDS || uh * (tw == 8 ? u8 : u16) >= 0.7, tw};
+    // the LDS-tiled kernels address with 32-bit element offsets
+    const bool fits = (long long)(s.N + 1) * s.H * s.W * (s.Cin > s.Cout ? s.Cin : s.Cout) < 0x7fffffffLL;
+    return HaloPlan{fits && (n->tiling == RCN_HIPX_TILING_LDS || uh * (tw == 8 ? u8 : u16) >= 0.7), tw};
 }
 // the first layer's own kernels (k_conv1_*_f32): 1 or 3 input channels
 bool conv1_f32_shape(const rcn_hipx_net* n, const ConvShape& s) { return n->tiling != RCN_HIPX_TILING_GEMM && (s.Cin == 1 || s.Cin == 3) && s.Cout % 32 == 0 && halo_plan(n, s).ok; }

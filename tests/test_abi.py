@@ -148,3 +148,20 @@ def test_parked_experiments_are_not_in_the_shipping_library(lib):
                 assert "load_experiments" not in open(os.path.join(root, f)).read(), f
     for f in ("bench.py", "bench_convnet.py", "__graft_entry__.py"):
         assert "experiments" not in open(os.path.join(ROOT, f)).read(), f
+
+
+def test_trackx_library_exports_its_header_and_binding_table():
+    """include/rcn_hipx.h (Track X: the trainable convolution net, no reference counterpart) against librcn_hipx.so and the ctypes
+    table of mercer_research_amd/convnet.py; the header compiles as plain C; the library does not link the oracle or torch."""
+    from mercer_research_amd import build as hipbuild, convnet
+    hipbuild.build_x()
+    text = open(os.path.join(ROOT, "include", "rcn_hipx.h")).read()
+    declared = sorted(set(re.findall(r"\b(rcn_hipx_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S))))
+    assert len(declared) >= 18
+    raw = C.CDLL(convnet.LIBX_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/rcn_hipx.h but not exported"
+    assert sorted(convnet.SIGNATURES) == declared, "python binding table and header disagree"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "rcn_hipx.h")], check=True)
+    out = subprocess.run(["ldd", convnet.LIBX_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "torch" not in out
