@@ -48,14 +48,14 @@ WORKLOAD = ("MNIST-shape 28x28x1, rcn default net conv(Same)-pool-conv(Same)-poo
 
 
 def csrc_sha16() -> str:
-    """Fingerprint of the kernel sources: profiles/r2_pmc_summary.json records the one it was measured on."""
+    """Fingerprint of the kernel sources librcn_hip.so is built from (mercer_research_amd.build SOURCES + DEPS): profiles/r3_pmc_summary.json
+    records the one it was measured on.  (Track X's sources -- convnet*.hpp, rcn_hipx_api.hip -- have their own fingerprint, tools/mfma_pmc_summary.py.)"""
+    from mercer_research_amd import build as hipbuild
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mercer_research_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        p = os.path.join(d, f)
-        if os.path.isfile(p):
-            h.update(f.encode())
-            h.update(open(p, "rb").read())
+    for f in sorted(set(hipbuild.SOURCES + [x for x in hipbuild.DEPS if os.sep not in x and "/" not in x])):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -300,8 +300,9 @@ def test_resident_kernel_data_parallel_form_between_processes(amd, oracle, tmp_p
     Replicas bit-identical; two epochs equal the oracle's train_batch on the concatenated global batches at the f32 tolerances;
     the admitted form reports itself resident on every rank."""
     nb = 3
-    # (four processes time-share one device: every hand-off may cost a scheduling quantum, so the bounded waits get seconds, not 0.2 s)
-    env = {"RCN_HIP_XCD_TIMEOUT_TICKS": "400000000", "RCN_HIP_DP_TIMEOUT_TICKS": "400000000"} if world > 3 else {}
+    # (the processes time-share ONE device here, which is not the product's configuration of a GPU per rank: every hand-off may cost a
+    # scheduling quantum, so the bounded waits get seconds, not 0.2 s -- at three ranks with the default 0.2 s one run in a few expired)
+    env = {"RCN_HIP_XCD_TIMEOUT_TICKS": "400000000", "RCN_HIP_DP_TIMEOUT_TICKS": "400000000"}
     Xs, Ys, logs = _spawn_ranks(tmp_path, world, 0, "default", env, dims=dims, Bs=Bs, nb=nb)
     outs = [np.load(tmp_path / f"out{r}.npz") for r in range(world)]
     for o in outs:

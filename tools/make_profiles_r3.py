@@ -8,14 +8,8 @@ def one(pat):
     m = glob.glob(pat, recursive=True)
     assert m, pat
     return max(m, key=os.path.getmtime)          # gpurun merges every call's files into the same directory: the newest run counts
-def csrc_sha16():
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "mercer_research_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        p = os.path.join(d, f)
-        if os.path.isfile(p):
-            h.update(f.encode()); h.update(open(p, "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from bench import csrc_sha16          # the fingerprint bench.py compares with: the sources librcn_hip.so is built from
 shutil.copy(one(f"{G}/prof3_stats/**/*kernel_stats.csv"), "profiles/r3_bench_kernel_stats.csv")
 for f in ("r3_bench_n1.json", "r3_bench_n1_steps20.json", "r3_bench_under_rocprof.json"):
     shutil.copy(f"{G}/{f}", f"profiles/{f}")
