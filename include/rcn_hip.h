@@ -166,7 +166,7 @@ int  rcn_hip_train_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_
  * pass into perm_dev (each pass is rcn.rs:146-149 once). */
 int  rcn_hip_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* Y_dev, const int32_t* perm_dev,
                                size_t B, size_t n_batches, double eta, void* loss_dev);
-/* (Opt-in form, option "xcd_gather" = 1; measured slower than the packed image on MI355X -- csrc/rcn_hip_api.hip.)
+/* (Opt-in form, option "xcd_gather" = 1; measured slower than the packed image on MI355X -- csrc/rcn_hip_api_xcd.ipp.)
  * 1 when rcn_hip_train_epoch_dev at this batch size runs on the resident one-XCD kernel in its GATHER form: no packed epoch image is
  * written -- one launch walks the whole call and every worker fetches its 128 bytes of each row of the batch after next while it
  * works on the current one (csrc/dense_xcd.hpp).  The feature matrix is then read from memory exactly once per step and

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librcn_hip.so")
 SOURCES = ["rcn_hip_api.hip"]
-DEPS = ["common.hpp", "dense.hpp", "dense_pipe.hpp", "dense_p2.hpp", "features.hpp", "ops.hpp", "dp_rccl.hpp", "serve.hpp", "dp_p2p.hpp", "dense_p2_dp.hpp", "dense_xcd.hpp", "dense_wide.hpp", "dense_p2_persist.hpp", "dense_p2_step.hpp", os.path.join("..", "..", "include", "rcn_hip.h")]
+DEPS = ["rcn_hip_api_shapes.ipp", "rcn_hip_api_dense_launch.ipp", "rcn_hip_api_xcd.ipp", "rcn_hip_api_p2p.ipp", "rcn_hip_api_params.ipp", "rcn_hip_api_operators.ipp", "rcn_hip_api_features.ipp", "rcn_hip_api_dense.ipp", "rcn_hip_api_dp.ipp", "rcn_hip_api_sets.ipp", "common.hpp", "dense.hpp", "dense_pipe.hpp", "dense_p2.hpp", "features.hpp", "ops.hpp", "dp_rccl.hpp", "serve.hpp", "dp_p2p.hpp", "dense_p2_dp.hpp", "dense_xcd.hpp", "dense_wide.hpp", "dense_p2_persist.hpp", "dense_p2_step.hpp", os.path.join("..", "..", "include", "rcn_hip.h")]
 # -ffp-contract=off: the reference (rustc) never fuses a*b+c; the operator kernels reproduce its f64 rounding.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-result",
          "-Wno-pass-failed"]

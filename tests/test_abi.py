@@ -49,7 +49,7 @@ def test_library_does_not_link_the_oracle():
     assert "rcn_oracle" not in out and "torch" not in out
     for root, _, files in os.walk(os.path.join(ROOT, "mercer_research_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".ipp", ".cpp", ".h")):
                 assert "rcn_oracle" not in open(os.path.join(root, f)).read(), f"{f} references the oracle"
 
 

@@ -288,7 +288,7 @@ def test_sticky_timeout_of_the_peer_exchange_surfaces_from_synchronize_and_get_p
                          ids=["no-fault", "export-fails-on-rank1", "peer-map-fails-on-rank0", "known-answer-mismatch-on-rank1",
                               "tagged-word-selftest-mismatch-on-rank1", "tagged-word-selftest-timeout", "two-faults"])
 def test_admission_votes_land_every_rank_on_the_same_form_and_the_epoch_equals_the_oracle(amd, oracle, tmp_path, fault, expect):
-    """The admission logic of rcn_hip_dp_init (one procedure, p2p_admission in csrc/rcn_hip_api.hip, run here over gloo by
+    """The admission logic of rcn_hip_dp_init (one procedure, p2p_admission in csrc/rcn_hip_api_dp.ipp, run here over gloo by
     rcn_hip_dp_p2p_admit) under injected faults: every rank executes the same votes, lands on the same form, and two epochs of the
     sharded loop on that form equal the oracle's train_batch on the concatenated global batches (f64, 1e-11)."""
     env = {"RCN_HIP_DP_FAULT": fault} if fault else {}
@@ -670,7 +670,7 @@ np.savez(sys.argv[3], skipped=0, gathers=int(d.train_epoch_gathers(B)), loss=los
 
 
 def test_resident_kernel_gather_form_equals_the_packed_image_bit_for_bit(amd, tmp_path):
-    """RCN_HIP_XCD_GATHER=1 (opt-in; measured slower, csrc/rcn_hip_api.hip): the resident kernel fetches every batch's rows itself --
+    """RCN_HIP_XCD_GATHER=1 (opt-in; measured slower, csrc/rcn_hip_api_xcd.ipp): the resident kernel fetches every batch's rows itself --
     no k_pack_epoch, one launch per call.  Same loads, same arithmetic: parameters and per-step costs must equal the default
     (packed image) form bit for bit, in shuffled and stored order and for a one-step call.  The form is chosen per process
     (environment), hence two child processes."""

@@ -319,7 +319,7 @@ def test_resident_kernel_data_parallel_form_between_processes(amd, oracle, tmp_p
 
 @pytest.mark.parametrize("fault,resident", [("", 1), ("push:1", 0), ("pushskip:0", 0)], ids=["no-fault", "pushed-selftest-mismatch-on-rank1", "pushed-selftest-timeout"])
 def test_admission_of_the_pushed_exchange_is_voted_like_the_others(amd, oracle, tmp_path, fault, resident):
-    """The third vote of p2p_admission (csrc/rcn_hip_api.hip): a rank whose known-answer exchange on the pushed primitives is wrong, or
+    """The third vote of p2p_admission (csrc/rcn_hip_api_dp.ipp): a rank whose known-answer exchange on the pushed primitives is wrong, or
     that stays silent in it so that its peer's waits really expire, keeps EVERY rank off the resident kernel's data-parallel form --
     the in-kernel exchange of the two-kernel pipeline (form 2) stays admitted, the sticky word is cleared -- and the epochs on the
     form the ranks landed on equal the oracle."""
