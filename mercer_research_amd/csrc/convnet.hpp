@@ -12,7 +12,7 @@
 //                  register-staged double buffering, bias + ReLU epilogue.
 //   dgrad          the same kernel on dZ with the tap-flipped, transposed weights Wt[(kh',kw',co)][ci] (k_flip_weights).
 //   k_conv_wgrad   dW[k][co] = sum_m A[m][k] dZ[m][co]: contraction over the output pixels, split over workgroups in
-//                  chunks whose partial tiles go to a slab; k_reduce_update sums the slab in chunk order (bit-
+//                  chunks whose partial tiles go to a slab; k_reduce_all sums every layer's slab in chunk order (bit-
 //                  reproducible) and applies the SGD step.
 //   k_pool_fwd/bwd 2x2/2 max-pool with a 2-bit arg-max image; backward also applies the ReLU mask.
 //   k_softmax_ce   fused softmax + cross-entropy forward and (p - onehot)/B backward.
@@ -261,7 +261,7 @@ struct WgradGrid {
 // dW partial tiles: workgroup (kb, nb, chunk) computes rows [32 kb, +32) x cols [BN nb, +BN) of dW over the pixels of
 // its chunk and writes them to slab[chunk][K + 1][Cout]; row K is the chunk's partial bias gradient (column sums of dZ,
 // taken by the kb == 0 workgroups from the dZ tiles they stage anyway).  [W | b] is contiguous in the parameter buffer,
-// so ONE k_reduce_update over (K + 1) * Cout elements finishes both.
+// so ONE k_reduce_all job over (K + 1) * Cout elements finishes both.
 template <int KS, bool SMALLC, int BN>
 __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ X, const float* __restrict__ dZ,
                                                          float* __restrict__ slab, ConvShape s, int pix_per_chunk, WgradGrid gd) {
@@ -441,38 +441,53 @@ __device__ inline void store_flipped(const FlipSpec& f, long long i, float v) {
     f.wt[((long long)(f.taps - 1 - tap) * f.Cout + co) * f.Cin + ci] = v;
 }
 
-// slab reduction for many chunks and few elements: 8 chunk-groups x 32 elements per workgroup, groups combined in order.
-// gridDim.y > 1: FIRST STAGE of a two-stage reduction -- slice y sums chunks [y * cpg, (y + 1) * cpg) into grad_out + y * n (no
-// update), and a second launch over the gridDim.y partial rows finishes (a layer with a thousand chunks of a 28 x 32 tile left 28
-// workgroups walking 128 chunks each: 30 us for 3.7 MB).
-__global__ __launch_bounds__(256) void k_reduce_update_wide(float* __restrict__ p, float* __restrict__ grad_out, const float* __restrict__ slab, long long n,
-                                                            int chunks, float lr, int apply, FlipSpec flip, int cpg) {
-    __shared__ float red[8][33];
-    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const long long i = (long long)blockIdx.x * 32 + el;
-    int c0 = 0, c1 = chunks;
-    if (gridDim.y > 1) { c0 = blockIdx.y * cpg; c1 = c0 + cpg < chunks ? c0 + cpg : chunks; grad_out += (long long)blockIdx.y * n; }
-    float g = 0.f;
-    if (i < n)
-        for (int c = c0 + grp; c < c1; c += 8) g += slab[(long long)c * n + i];
-    red[grp][el] = g;
-    __syncthreads();
-    if (threadIdx.x < 32 && i < n) {
-        float t = 0.f;
-        for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
-        if (grad_out) grad_out[i] = t;
-        if (apply) { const float v = p[i] - lr * t; p[i] = v; store_flipped(flip, i, v); }
-    }
-}
+// All layers' slabs in ONE launch at the end of the backward pass (a launch per layer -- two above 64 chunks -- was 5-9 us each of
+// mostly latency, seven of them per CIFAR step).  Nothing updates a weight before every input-gradient kernel has read it, so the
+// jobs are independent.  Job q owns workgroups [first_block, next job's first_block); a workgroup of 1024 threads sums 1024 / g elements
+// in g chunk groups (g = the power of two at or above the chunk count, at most 32); groups are combined in order: bit-reproducible.
+constexpr int kMaxReduceJobs = 16;
+struct ReduceJob {
+    float* p;                 // [W | b] of the layer
+    float* grad;              // or nullptr
+    const float* slab;        // [chunks][n]
+    FlipSpec flip;
+    long long n;
+    int chunks, first_block;
+};
+struct ReduceJobs { ReduceJob j[kMaxReduceJobs]; int njobs; float lr; int apply; };
 
-// p <- p - lr * sum_chunks slab[c][i]   (or grad out when apply == 0); fixed chunk order
-__global__ void k_reduce_update(float* __restrict__ p, float* __restrict__ grad_out, const float* __restrict__ slab, long long n, int chunks,
-                                float lr, int apply, FlipSpec flip) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float g = 0.f;
-        for (int c = 0; c < chunks; ++c) g += slab[(long long)c * n + i];
-        if (grad_out) grad_out[i] = g;
-        if (apply) { const float v = p[i] - lr * g; p[i] = v; store_flipped(flip, i, v); }
+constexpr int kReduceThreads = 1024;
+// chunk groups of a job: the power of two at or above its chunk count, at most 32; a workgroup then covers 1024 / groups elements
+__host__ __device__ inline int reduce_job_groups(int chunks) { int g = 1; while (g < chunks && g < 32) g <<= 1; return g; }
+__host__ __device__ inline int reduce_job_elems(int chunks) { return kReduceThreads / reduce_job_groups(chunks); }
+
+__global__ __launch_bounds__(kReduceThreads) void k_reduce_all(ReduceJobs J) {
+    __shared__ float red[kReduceThreads];
+    int q = 0;
+    while (q + 1 < J.njobs && (int)blockIdx.x >= J.j[q + 1].first_block) ++q;
+    const ReduceJob jb = J.j[q];
+    const int lb = (int)blockIdx.x - jb.first_block;
+    // whole 128-byte rows of the slab per chunk group: 32 elements x 32 groups (many chunks) ... 1024 elements x 1 group (one chunk)
+    const int GR = reduce_job_groups(jb.chunks), EL = kReduceThreads / GR;
+    const int el = threadIdx.x % EL, grp = threadIdx.x / EL;
+    const long long i = (long long)lb * EL + el;
+    float g = 0.f;
+    if (i < jb.n) {
+        // eight loads in flight per thread (a load per loop trip, each waited for, left this kernel at 1.6 TB/s)
+        for (int c = grp; c < jb.chunks; c += 8 * GR) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = c + k * GR < jb.chunks ? jb.slab[(long long)(c + k * GR) * jb.n + i] : 0.f;
+            g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+    }
+    red[grp * EL + el] = g;
+    __syncthreads();
+    if ((int)threadIdx.x < EL && i < jb.n) {
+        float t = 0.f;
+        for (int r = 0; r < GR; ++r) t += red[r * EL + threadIdx.x];
+        if (jb.grad) jb.grad[i] = t;
+        if (J.apply) { const float v = jb.p[i] - J.lr * t; jb.p[i] = v; store_flipped(jb.flip, i, v); }
     }
 }
 

@@ -435,7 +435,7 @@ namespace rcnx {
 // the shared dZ fragments with the hardware transposed LDS read (the contraction index, the pixel, is the row of both LDS
 // images), accumulating dW[tap][ci][co] in registers across all the blocks of its chunk.  Global traffic per block: 180
 // input pixels + 128 dZ pixels instead of 9 x 128 + 128 per k-group.  Output: the same slab[chunk][K + 1][Cout] as
-// k_conv_wgrad (row K = bias partial, fp32 sums of the unrounded dZ), so k_reduce_update[_wide] finishes either.
+// k_conv_wgrad (row K = bias partial, fp32 sums of the unrounded dZ), so k_reduce_all finishes either.
 constexpr int kWgHaloThreads = 9 * 64;
 
 template <int CB, int BN, bool PDZ = false>

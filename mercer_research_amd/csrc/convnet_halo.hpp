@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
 // read and used by nine MFMAs.  The contraction index is the pixel = the row of both LDS images, so lane (r, h) reads element r of
 // pixel p + h: 32-float rows put the two half-waves on different halves of the banks with no padding, and every offset except the
 // lane's own is an immediate.  The four waves' tiles are summed in wave order through LDS at the end; the partial goes to
-// slab[chunk][K + 1][Cout] exactly as k_conv_wgrad's (row K = bias partial from the ci block 0 workgroups), so k_reduce_update[_wide]
+// slab[chunk][K + 1][Cout] exactly as k_conv_wgrad's (row K = bias partial from the ci block 0 workgroups), so k_reduce_all
 // finishes either.  PDZ: dZ exists only at pooled resolution (PooledGrad): a block has 32 pooled pixels x 8 channel chunks = one
 // chunk per thread, expanded into its window's four pixels while staging.
 template <int TW, bool PDZ = false>
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
 // gradient 14.8, weight gradient 10.6 us: latency, not arithmetic).  Here a workgroup owns 32 samples: their hidden activations,
 // the weights in both orientations (the flipped copy is kept current by the update kernels) and d logits stay in LDS between the
 // steps.  F = hidden width (multiple of 32, <= 256: LDS), classes <= 32 (one padded column block).  The weight-gradient partials go
-// to slab[workgroup][F + 1][32] like k_conv_wgrad's, so k_reduce_update[_wide] finishes; the loss like k_softmax_ce (last workgroup
+// to slab[workgroup][F + 1][32] like k_conv_wgrad's, so k_reduce_all finishes; the loss like k_softmax_ce (last workgroup
 // adds the partials in order).
 template <bool GATE>
 __global__ __launch_bounds__(kThreads) void k_head_f32(const float* __restrict__ Hin, const float* __restrict__ Wk, const float* __restrict__ Wt,

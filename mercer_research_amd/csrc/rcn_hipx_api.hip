@@ -46,6 +46,7 @@ struct Layer {
     long long lw_off = 0, lb_off = 0;     // logical flat layout
     bool pool_follows = false;
     Buf out, idx, dout;     // activation (post-ReLU / pooled), pool arg-max, gradient wrt the layer's OUTPUT
+    Buf slab;               // partial [W | b] tiles of the weight-gradient kernels (reduced for all layers at once: k_reduce_all)
 };
 
 struct Key { const void* x; const void* y; int B; float lr; const void* loss;
@@ -65,7 +66,9 @@ struct rcn_hipx_net {
     int overlap = 0;
     std::vector<Layer> L;
     long long n_pad = 0, n_log = 0;
-    Buf params, wt, slab, slab2, dz, loss_part, grad_tmp, dlogits, skbuf, wb;      // wt: tap-flipped transposed weights, laid out like params (w_off)
+    Buf params, wt, dz, loss_part, grad_tmp, dlogits, skbuf, wb;      // wt: tap-flipped transposed weights, laid out like params (w_off)
+    Buf* slab_sel = nullptr;                // where the weight-gradient launch in progress puts its partial tiles (a layer's slab)
+    ReduceJobs jobs{};                      // the step's pending slab reductions
     int precision = RCN_HIPX_FP32;          // GEMM operand precision of forward / dgrad (rcn_hipx_set_precision)
     int tiling = RCN_HIPX_TILING_AUTO;      // fp32 3x3 kernels: implicit GEMM only / by shape / LDS-tiled wherever they apply (rcn_hipx_set_tiling)
     std::map<Key, hipGraphExec_t> graphs;
@@ -274,7 +277,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 
 static int xcd_remap() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_XCD_REMAP"); return e ? std::atoi(e) : 0; }(); return v; }
 // Pixels per weight-gradient chunk.  Every chunk costs one (K+1) x Cout partial tile written to the slab and read back by
-// k_reduce_update[_wide], and a chunk is worked on by `tiles` workgroups (k-blocks x n-tiles), so the chunk size aims at a
+// k_reduce_all, and a chunk is worked on by `tiles` workgroups (k-blocks x n-tiles), so the chunk size aims at a
 // total number of workgroups -- wide layers need few chunks -- with 1024 pixels as the floor (measured best on the small
 // CIFAR / MNIST nets, where parallelism is what matters).
 static int pix_per_chunk(long long M, long long tiles) {
@@ -302,7 +305,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const int bn = (s.Cout % 64 == 0) ? 64 : 32;
     if (M > 0x7fff0000LL) return fail(n, -3, "too many output pixels in one layer (N*H*W must stay below 2^31)");
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
-    XTRY(n, scratch_ensure(n, n->slab, (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
+    XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
     if (pdz && !wgrad_halo_runs(n, s, ks)) return fail(n, -3, "internal: pooled-resolution dZ requested for a layer the LDS-tiled weight-gradient kernel does not cover");
     if (n->precision != RCN_HIPX_BF16 && wgrad_halo_runs(n, s, ks) && smallc) {
         // first layer (convnet_halo.hpp): one 32 x 32 tile (rows = patch entries) per (co block, chunk of pixel blocks)
@@ -313,11 +316,11 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         if (want > blocks) want = blocks;
         const int bpc = (int)((blocks + want - 1) / want);
         const int hchunks = (int)((blocks + bpc - 1) / bpc);
-        XTRY(n, scratch_ensure(n, n->slab, (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
+        XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
         const dim3 hgrid((unsigned)(s.Cout / 32), (unsigned)hchunks);
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
-#define W1_CASE(CIN_, TW_) do { if (pdz) hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tiles_w, tiles_h, bpc, pg); \
-                                else hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tiles_w, tiles_h, bpc, pg); } while (0)
+#define W1_CASE(CIN_, TW_) do { if (pdz) hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); \
+                                else hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); } while (0)
         if (s.Cin == 3) { if (tw == 16) W1_CASE(3, 16); else W1_CASE(3, 8); }
         else { if (tw == 16) W1_CASE(1, 16); else W1_CASE(1, 8); }
 #undef W1_CASE
@@ -339,11 +342,11 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         if (want > 32768) want = 32768;
         const int bpc = (int)((blocks + want - 1) / want);
         const int hchunks = (int)((blocks + bpc - 1) / bpc);
-        XTRY(n, scratch_ensure(n, n->slab, (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
+        XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
         const dim3 hgrid((unsigned)(s.Cin / 32), (unsigned)(s.Cout / 32), (unsigned)hchunks);
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
-#define WGF_CASE(TW_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_f32<TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tiles_w, tiles_h, bpc, pg); \
-                           else hipLaunchKernelGGL((k_wgrad3x3_halo_f32<TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tiles_w, tiles_h, bpc, pg); } while (0)
+#define WGF_CASE(TW_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_f32<TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); \
+                           else hipLaunchKernelGGL((k_wgrad3x3_halo_f32<TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); } while (0)
         if (tw == 16) WGF_CASE(16); else WGF_CASE(8);
 #undef WGF_CASE
         XTRY(n, hipGetLastError());
@@ -363,11 +366,11 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         int bpc = (int)((blocks * tiles + target - 1) / target);
         if (bpc < 8) bpc = blocks < 8 ? (int)blocks : 8;
         const int hchunks = (int)((blocks + bpc - 1) / bpc);
-        XTRY(n, scratch_ensure(n, n->slab, (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
+        XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
         const dim3 hgrid((unsigned)(s.Cin / hb), (unsigned)(s.Cout / hbn), (unsigned)hchunks);
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
-#define WGH_CASE(CB_, BN_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, true>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tw, th, bpc, hchunks, pg); \
-                                else hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, false>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, tw, th, bpc, hchunks, pg); } while (0)
+#define WGH_CASE(CB_, BN_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, true>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tw, th, bpc, hchunks, pg); \
+                                else hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, false>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tw, th, bpc, hchunks, pg); } while (0)
         if (hb == 32) { if (hbn == 64) WGH_CASE(32, 64); else WGH_CASE(32, 32); }
         else { if (hbn == 64) WGH_CASE(64, 64); else WGH_CASE(64, 32); }
 #undef WGH_CASE
@@ -381,7 +384,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         const int nk = nkb % 4 == 0 ? 4 : nkb % 3 == 0 ? 3 : nkb % 2 == 0 ? 2 : 1;
         const WgradGrid gdb{nkb / nk, s.Cout / bn, chunks, xcd_remap()};
         const dim3 gridb(gdb.launch_blocks());
-#define WGB_CASE(KS_, BN_, NK_) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)n->slab.p, s, kPixPerChunk, gdb)
+#define WGB_CASE(KS_, BN_, NK_) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, kPixPerChunk, gdb)
 #define WGB_NK(KS_, BN_) do { if (nk == 4) WGB_CASE(KS_, BN_, 4); else if (nk == 3) WGB_CASE(KS_, BN_, 3); else if (nk == 2) WGB_CASE(KS_, BN_, 2); else WGB_CASE(KS_, BN_, 1); } while (0)
 #define WGB_BN(KS_) do { if (bn == 64) WGB_NK(KS_, 64); else WGB_NK(KS_, 32); } while (0)
         if (ks == 3) WGB_BN(3); else WGB_BN(1);
@@ -394,7 +397,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     }
     const WgradGrid gd{smallc ? 1 : K / 32, s.Cout / bn, chunks, xcd_remap()};
     const dim3 grid(gd.launch_blocks());
-#define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)n->slab.p, s, kPixPerChunk, gd)
+#define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, kPixPerChunk, gd)
 #define WG_BN(KS_, SM_) do { if (bn == 64) WG_CASE(KS_, SM_, 64); else WG_CASE(KS_, SM_, 32); } while (0)
     if (ks == 3) { if (smallc) WG_BN(3, true); else WG_BN(3, false); }
     else { if (smallc) WG_BN(1, true); else WG_BN(1, false); }
@@ -454,29 +457,35 @@ int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1
     return 0;
 }
 
-// The slab of partial [W | b] tiles of layer i (chunks x (K + 1) x Cout, as the weight-gradient kernels leave it) summed in chunk
-// order, and either applied (p <- p - lr g, the flipped copy of the weights kept current) or written to grad.
-// [W | b] is contiguous (b_off == w_off + K * CoutP): one pass finishes both.
+// The slab of partial [W | b] tiles of layer i (chunks x (K + 1) x Cout, as the weight-gradient kernels leave it in the layer's slab)
+// is queued for the step's ONE reduction launch (run_reduce_jobs): summed in chunk order, and either applied (p <- p - lr g, the flipped
+// copy of the weights kept current) or written to grad.  [W | b] is contiguous (b_off == w_off + K * CoutP): one job finishes both.
 int reduce_slab(rcn_hipx_net* n, size_t i, int chunks, int ks, const ConvShape& s, float lr, float* grad, bool apply) {
+    (void)lr;
     Layer& l = n->L[i];
-    const long long wcount = ((long long)s.Cin * ks * ks + 1) * s.Cout;
-    const FlipSpec flip{(apply && i > 0) ? (float*)n->wt.p + l.w_off : (float*)nullptr, ks * ks, s.Cin, s.Cout};
-    float* gout = grad ? grad + l.w_off : (float*)nullptr;
-    int rchunks = chunks;
-    const float* rslab = (const float*)n->slab.p;
-    if (chunks > 64) {
-        // two stages: 32 chunks per slice into slab2, then the slices
-        const int cpg = 32, slices = (chunks + cpg - 1) / cpg;
-        XTRY(n, scratch_ensure(n, n->slab2, (size_t)slices * wcount * sizeof(float)));
-        hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32), (unsigned)slices), dim3(256), 0, n->stream, (float*)nullptr, (float*)n->slab2.p,
-                           rslab, wcount, chunks, 0.f, 0, FlipSpec{nullptr, 0, 0, 0}, cpg);
-        rslab = (const float*)n->slab2.p; rchunks = slices;
-    }
-    if (rchunks >= 8)
-        hipLaunchKernelGGL(k_reduce_update_wide, dim3((unsigned)((wcount + 31) / 32)), dim3(256), 0, n->stream, P(n, l.w_off), gout, rslab, wcount, rchunks, lr, apply ? 1 : 0, flip, 0);
-    else
-        hipLaunchKernelGGL(k_reduce_update, dim3(grid1d(wcount, 256)), dim3(256), 0, n->stream, P(n, l.w_off), gout, rslab, wcount, rchunks, lr, apply ? 1 : 0, flip);
+    if (n->jobs.njobs >= kMaxReduceJobs) return fail(n, -3, "too many layers with parameters for one reduction launch");
+    ReduceJob& jb = n->jobs.j[n->jobs.njobs];
+    jb.p = P(n, l.w_off);
+    jb.grad = grad ? grad + l.w_off : (float*)nullptr;
+    jb.slab = (const float*)l.slab.p;
+    jb.flip = FlipSpec{(apply && i > 0) ? (float*)n->wt.p + l.w_off : (float*)nullptr, ks * ks, s.Cin, s.Cout};
+    jb.n = ((long long)s.Cin * ks * ks + 1) * s.Cout;
+    jb.chunks = chunks;
+    int prev_end = 0;
+    if (n->jobs.njobs) { const ReduceJob& pj = n->jobs.j[n->jobs.njobs - 1]; prev_end = pj.first_block + (int)((pj.n + reduce_job_elems(pj.chunks) - 1) / reduce_job_elems(pj.chunks)); }
+    jb.first_block = prev_end;
+    ++n->jobs.njobs;
+    return 0;
+}
+
+int run_reduce_jobs(rcn_hipx_net* n, float lr, bool apply) {
+    if (!n->jobs.njobs) return 0;
+    const ReduceJob& last = n->jobs.j[n->jobs.njobs - 1];
+    const long long blocks = last.first_block + (last.n + reduce_job_elems(last.chunks) - 1) / reduce_job_elems(last.chunks);
+    n->jobs.lr = lr; n->jobs.apply = apply ? 1 : 0;
+    hipLaunchKernelGGL(k_reduce_all, dim3((unsigned)blocks), dim3(kReduceThreads), 0, n->stream, n->jobs);
     XTRY(n, hipGetLastError());
+    n->jobs.njobs = 0;
     return 0;
 }
 
@@ -527,7 +536,6 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         // input.  Not when dZ sits in the shared scratch buffer, which the main stream reuses for the next layer.
         const bool on_side = ov && dZ != (const float*)n->dz.p;
         if (on_side) { RTRY(stream_after(n, main_s, n->side)); side_busy = true; }
-        else if (side_busy) { RTRY(stream_after(n, n->side, main_s)); side_busy = false; }      // the slab is shared: one stream at a time
         // dgrad first (needs the weights BEFORE this step's update): dX = conv(dZ, flip(W)^T)
         if (din) {
             // the tap-flipped transposed weights are kept current by every kernel that writes a weight (FlipSpec, refresh_flipped)
@@ -542,14 +550,13 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         }
         int chunks = 0;
         if (on_side) n->stream = n->side;
+        n->slab_sel = &l.slab;
         RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks, pooled[i].dP ? &pooled[i] : nullptr));
-        // the update below writes the weights (and their flipped copy) that the input-gradient kernel on the main stream reads
-        if (on_side && din && apply) RTRY(stream_after(n, main_s, n->side));
         RTRY(reduce_slab(n, (size_t)i, chunks, ks, s, lr, grad, apply));
         n->stream = main_s;
     }
     if (side_busy) RTRY(stream_after(n, n->side, main_s));            // join: the step's next kernels (and an end of capture) find everything on the main stream
-    return 0;
+    return run_reduce_jobs(n, lr, apply);                             // every layer's slab in one launch; no weight was written before this point
 }
 
 // [partial sums of the loss, one per workgroup][counter of finished workgroups: zero between launches]
@@ -587,7 +594,7 @@ int launch_head(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, 
     Layer& l = n->L.back();
     Layer& b = n->L[n->L.size() - 2];
     const int F = l.K, blocks = (B + 31) / 32;
-    XTRY(n, scratch_ensure(n, n->slab, (size_t)blocks * (F + 1) * 32 * sizeof(float)));
+    XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)blocks * (F + 1) * 32 * sizeof(float)));
     unsigned* counter = nullptr;
     RTRY(ensure_loss_buf(n, &counter));
     const size_t lds = ((size_t)32 * (F + 1) + (size_t)F * 32 + (size_t)32 * (F + 32) + 4 * 1024 + 1024 + 32 * 33) * sizeof(float);
@@ -595,7 +602,7 @@ int launch_head(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, 
     static const hipError_t attr = hipFuncSetAttribute((const void*)k_head_f32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     XTRY(n, attr);
     hipLaunchKernelGGL((k_head_f32<true>), dim3(blocks), dim3(kThreads), lds, n->stream, (const float*)b.out.p, (const float*)P(n, l.w_off), (const float*)n->wt.p + l.w_off,
-                       (const float*)P(n, l.b_off), labels, B, F, n->classes, (float*)l.out.p, (float*)b.dout.p, (float*)n->slab.p, (float*)n->loss_part.p, counter,
+                       (const float*)P(n, l.b_off), labels, B, F, n->classes, (float*)l.out.p, (float*)b.dout.p, (float*)(*n->slab_sel).p, (float*)n->loss_part.p, counter,
                        1.0f / (float)B, loss_dev);
     XTRY(n, hipGetLastError());
     *chunks_out = blocks;
@@ -621,10 +628,12 @@ int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers);
 
 // forward + loss + backward of one batch: parameters updated in place (apply) or gradients written to grad (padded layout)
 int step_core(rcn_hipx_net* n, const float* x, const int32_t* labels, int B, float lr, float* grad, bool apply, float* loss_dev) {
+    n->jobs.njobs = 0;
     if (head_fusable(n)) {
         const int last = (int)n->L.size() - 1;
         RTRY(forward(n, x, B, (size_t)last));
         int chunks = 0;
+        n->slab_sel = &n->L[last].slab;
         RTRY(launch_head(n, labels, B, loss_dev, &chunks));
         RTRY(reduce_slab(n, (size_t)last, chunks, 1, ConvShape{B, 1, 1, n->L[last].K, n->L[last].CoutP}, lr, grad, apply));
         return backward(n, x, B, lr, grad, apply, last - 1, true);
@@ -708,8 +717,8 @@ void rcn_hipx_destroy(rcn_hipx_net* n) {
         Dev g(n->device);
         if (n->stream) (void)hipStreamSynchronize(n->stream);
         drop_graphs(n);
-        for (Layer& l : n->L) { l.out.release(); l.idx.release(); l.dout.release(); }
-        for (Buf* b : {&n->params, &n->wt, &n->slab, &n->slab2, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf, &n->wb}) b->release();
+        for (Layer& l : n->L) { l.out.release(); l.idx.release(); l.dout.release(); l.slab.release(); }
+        for (Buf* b : {&n->params, &n->wt, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf, &n->wb}) b->release();
         if (n->side) { (void)hipStreamSynchronize(n->side); (void)hipStreamDestroy(n->side); }
         for (hipEvent_t e : n->events) (void)hipEventDestroy(e);
         if (n->own_stream && n->stream) (void)hipStreamDestroy(n->stream);
