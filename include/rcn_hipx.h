@@ -55,9 +55,10 @@ int  rcn_hipx_set_precision(rcn_hipx_net* net, int mode);
  * The environment variable RCN_HIPX_HALO_F32 (0 / 1 / 2) only seeds a new net's mode. */
 enum { RCN_HIPX_TILING_GEMM = 0, RCN_HIPX_TILING_AUTO = 1, RCN_HIPX_TILING_LDS = 2 };
 int  rcn_hipx_set_tiling(rcn_hipx_net* net, int mode);
-/* Backward pass: run every layer's weight gradient (+ its slab reduction and update) on a second stream beside the input-gradient
- * chain.  Default OFF (measured slower on MI355X: the kernels fill the chip on their own); RCN_HIPX_OVERLAP=1 seeds a new net with it
- * on.  Same kernels, same sums, same results either way. */
+/* Backward pass: run the weight gradients on a second stream beside the input-gradient chain: 0 = no (default), 1 = every layer's,
+ * 2 = the dense layers' only.  Measured on MI355X (CIFAR shape, fp32): no gain (0.420 / 0.418 / 0.418 ms) -- the kernels fill the chip
+ * on their own; with a reduction launch per layer on the second stream (before k_reduce_all) mode 1 was 7 % slower.
+ * RCN_HIPX_OVERLAP seeds a new net's mode.  Same kernels, same sums, bit-identical results in every mode. */
 int  rcn_hipx_set_overlap(rcn_hipx_net* net, int on);
 int  rcn_hipx_set_params(rcn_hipx_net* net, const float* flat);
 int  rcn_hipx_get_params(rcn_hipx_net* net, float* flat);

@@ -116,9 +116,10 @@ class ConvNet:
         """fp32 3x3 kernels: "gemm" (implicit GEMM only), "auto" (by shape, the default) or "lds" (LDS-tiled wherever they apply)."""
         self._ck(self.lib.rcn_hipx_set_tiling(self.net, {"gemm": 0, "auto": 1, "lds": 2}[mode]))
 
-    def set_overlap(self, on: bool):
-        """Backward pass: weight gradients on a second stream beside the input-gradient chain (default off: measured slower)."""
-        self._ck(self.lib.rcn_hipx_set_overlap(self.net, 1 if on else 0))
+    def set_overlap(self, mode):
+        """Backward pass: weight gradients on a second stream beside the input-gradient chain: 0 / False = no (default: measured no
+        gain), 1 / True = every layer's, 2 = the dense layers' only."""
+        self._ck(self.lib.rcn_hipx_set_overlap(self.net, int(mode)))
 
     def set_params(self, flat: np.ndarray):
         f = np.ascontiguousarray(flat, dtype=np.float32)

@@ -57,10 +57,10 @@ struct Key { const void* x; const void* y; int B; float lr; const void* loss;
 struct rcn_hipx_net {
     int device = 0, in_h = 0, in_w = 0, in_c = 0, max_batch = 0, classes = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
-    // The backward pass can run a layer's weight gradient (+ slab reduction and update) on a second stream beside the input-gradient
-    // chain: the two only share dZ, and each of these kernels leaves CUs idle while it ramps up and drains (rcn_hipx_set_overlap).
-    // OFF by default: measured slower on the CIFAR step (fp32 0.494 vs 0.461 ms, bf16 0.511 vs 0.438 ms: the kernels are sized to fill
-    // the chip on their own, two of them share the CUs' LDS badly, and every cross-stream edge of the replayed graph costs).
+    // The backward pass can run a layer's weight gradient on a second stream beside the input-gradient chain: the two only share dZ,
+    // and each of these kernels leaves CUs idle while it ramps up and drains (rcn_hipx_set_overlap: 1 = every layer, 2 = dense layers).
+    // OFF by default: measured no gain on the CIFAR step (fp32 0.420 / 0.418 / 0.418 ms for 0 / 1 / 2; 7 % slower while a reduction
+    // launch per layer still ran on the second stream) -- the kernels are sized to fill the chip on their own.
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> events; size_t ev_next = 0;
     int overlap = 0;
@@ -534,7 +534,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         }
         // The weight gradient of this layer goes to the side stream: it needs dZ (ready on the main stream here) and the layer's
         // input.  Not when dZ sits in the shared scratch buffer, which the main stream reuses for the next layer.
-        const bool on_side = ov && dZ != (const float*)n->dz.p;
+        const bool on_side = ov && dZ != (const float*)n->dz.p && (n->overlap != 2 || !conv);     // 2: only the (latency-bound) dense layers
         if (on_side) { RTRY(stream_after(n, main_s, n->side)); side_busy = true; }
         // dgrad first (needs the weights BEFORE this step's update): dX = conv(dZ, flip(W)^T)
         if (din) {
@@ -695,7 +695,7 @@ int rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_lay
     n->classes = n->L.back().Cout;
     Dev g(device);
     if (stream) { n->stream = (hipStream_t)stream; } else { XTRY(n, hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking)); n->own_stream = true; }
-    { const char* e = std::getenv("RCN_HIPX_OVERLAP"); n->overlap = e ? (std::atoi(e) != 0) : 0; }
+    { const char* e = std::getenv("RCN_HIPX_OVERLAP"); n->overlap = e ? std::atoi(e) : 0; }
     XTRY(n, hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
     XTRY(n, n->params.ensure((size_t)n->n_pad * sizeof(float)));
     XTRY(n, hipMemsetAsync(n->params.p, 0, (size_t)n->n_pad * sizeof(float), n->stream));
@@ -752,8 +752,8 @@ int rcn_hipx_set_tiling(rcn_hipx_net* n, int mode) {
 int rcn_hipx_set_overlap(rcn_hipx_net* n, int on) {
     if (!n) return -1;
     Dev g(n->device);
-    if ((on != 0) != (n->overlap != 0)) { XTRY(n, hipStreamSynchronize(n->stream)); drop_graphs(n); }
-    n->overlap = on != 0;
+    if (on != n->overlap) { XTRY(n, hipStreamSynchronize(n->stream)); drop_graphs(n); }
+    n->overlap = on;
     return 0;
 }
 
