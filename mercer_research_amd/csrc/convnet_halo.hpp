@@ -583,6 +583,9 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
 
     int item = blockIdx.x;
     if (item >= n_items) return;
+    RCNX_STAMP(0);
+    RCNX_STAMP_HW();
+    int stamp_slot = 1;
     Pos pos = split(item);
     Item cur = item_of(pos);
     halo_load(cur);
@@ -606,7 +609,9 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
         first = false;
         halo_store();
         __syncthreads();
+        RCNX_STAMP(stamp_slot); ++stamp_slot;                         // halo staged
         if (nitem < n_items) halo_load(nxt);
+        RCNX_STAMP(stamp_slot); ++stamp_slot;                         // next loads issued
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -615,6 +620,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
             const float a = hb[h ? conv1_koff<CIN, Gm::HWD>(2 * ks + 1) : conv1_koff<CIN, Gm::HWD>(2 * ks)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[ks], acc, 0, 0, 0);
         }
+        RCNX_STAMP(stamp_slot); ++stamp_slot;                         // MFMAs issued
         const int img0 = cur.img0, oh0 = cur.oh0, ow0 = cur.ow0;
         const int co = cur.n0 + r;
         const float bb = bias[co];
@@ -654,8 +660,10 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
                 }
             }
         }
+        RCNX_STAMP(stamp_slot); ++stamp_slot;                         // epilogue issued
         cur = nxt;
     }
+    RCNX_STAMP(29);
 }
 
 // k_conv1_wgrad_f32: dW[k][co] = sum over pixels of patch element k times dZ[pixel][co], one 32 x 32 tile (rows k < 9 CIN real) per
