@@ -924,6 +924,38 @@ def trackx_leg(torch, dev):
         out[prec] = {"ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1), "step_gflop": round(flops / 1e9, 2), "tflops": round(tf, 2),
                      "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 4)}
         net.close()
+    # BASELINE configs[3] on one GPU: synthetic 224x224x3, 8 conv layers, 128 images per GPU (fewer timed steps: 20 ms each)
+    try:
+        in_shape, layers, B = CONFIGS["synth224"]
+        out["synth224"] = {"config": "synthetic 224x224x3, conv 3->32->32 | 64->64 | 128->128 | 256->256 (pool after each pair) -> 10, 128 images per GPU"}
+        for prec in ("fp32", "bf16"):
+            net = ConvNet(in_shape, layers, B, device=dev)
+            net.init_params(1)
+            net.set_precision(prec)
+            xs = [net.to_device(rng.standard_normal((B,) + in_shape).astype(np.float32)) for _ in range(2)]
+            ys = [net.to_device(rng.integers(0, 10, B).astype(np.int32)) for _ in range(2)]
+            loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+            for i in range(6):
+                net.train_step(xs[i % 2], ys[i % 2], 1e-6, loss)
+            net.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 20
+            a.record(net.stream)
+            for i in range(n):
+                net.train_step(xs[i % 2], ys[i % 2], 1e-6, loss)
+            b.record(net.stream)
+            net.synchronize()
+            ms = a.elapsed_time(b) / n
+            flops = net.step_flops(B)
+            tf = flops / (ms * 1e-3) / 1e12
+            peak = F32_MFMA_PEAK_TFLOPS if prec == "fp32" else BF16_MFMA_PEAK_TFLOPS
+            out["synth224"][prec] = {"ms_per_step": round(ms, 3), "images_per_s": round(B / ms * 1e3, 1), "step_gflop": round(flops / 1e9, 1), "tflops": round(tf, 2),
+                                     "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4)}
+            net.close()
+            del xs, ys
+            torch.cuda.empty_cache()
+    except Exception as ex:                                     # the extension must not take the BASELINE line down with it
+        out["synth224"] = {"error": str(ex)[:300]}
     # the conv-GEMM MFMA-busy figures are PMC measurements of a separate profiled run (tools/prof_trackx.sh), relayed here with the
     # fingerprint of the kernel sources they were taken on -- like roofline.traffic, the line says when the sources have changed since
     from tools.mfma_pmc_summary import trackx_sha16
