@@ -21,6 +21,8 @@ NETS = [
     ((16, 16, 32), (("conv", 64), ("conv", 96), ("pool",), ("conv", 32), ("dense_relu", 32), ("dense", 10)), 2),
     # first layer with two column blocks on an 8-wide map, then 64 -> 32
     ((24, 8, 3), (("conv", 64), ("pool",), ("conv", 32), ("pool",), ("dense", 4)), 4),
+    # a batch of 64 (two workgroups of the fused head, one more hidden dense layer in front of it)
+    ((8, 8, 3), (("conv", 32), ("pool",), ("dense_relu", 64), ("dense_relu", 32), ("dense", 10)), 64),
 ]
 
 
