@@ -41,8 +41,10 @@ const char* rcn_hipx_last_error(const rcn_hipx_net* net);
 int  rcn_hipx_synchronize(rcn_hipx_net* net);
 int  rcn_hipx_param_count(const rcn_hipx_net* net, int64_t* logical, int64_t* padded);
 int  rcn_hipx_classes(const rcn_hipx_net* net);
-/* GEMM operand precision of the forward, input-gradient and weight-gradient convolutions / dense layers (the weight gradient
- * of a first layer with 9*Cin <= 32 stays fp32).  RCN_HIPX_FP32 (default): fp32 MFMA
+/* GEMM operand precision of the forward, input-gradient and weight-gradient convolutions / dense layers.  Two places compute in
+ * fp32 in EITHER mode, by shape alone: a first layer whose whole 3x3xCin patch is one k-block (9*Cin <= 32: nothing of the MFMA
+ * rate to gain), and the classifier head when it is the fused one (logits layer of <= 32 classes on a ReLU dense layer of <= 256
+ * units).  RCN_HIPX_FP32 (default): fp32 MFMA
  * (v_mfma_f32_32x32x2_f32), exact fp32 products.  RCN_HIPX_BF16: operands rounded to bf16 on their way into LDS,
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations, gradients, parameters and the SGD update stay fp32 in HBM.
  * Results then agree with an f64 evaluation to ~1e-2 relative instead of ~1e-4. */

@@ -155,8 +155,9 @@ int conv3_f32_z(const rcn_hipx_net* n, const ConvShape& s) {
 // does the 2x2 max-pool that follows this 3x3 convolution run in the convolution kernel's epilogue (EPI 4: LDS-tiled kernels only)?
 bool conv_pool_fusable(const rcn_hipx_net* n, const ConvShape& s) {
     if (s.H % 2 || s.W % 2) return false;
+    if (conv1_f32_shape(n, s)) return true;                            // the first layer's kernels serve both precisions
     if (n->precision == RCN_HIPX_BF16) return halo_enabled() && (s.Cin == 32 || s.Cin % 64 == 0);
-    return conv_halo_f32_shape(n, s) || conv1_f32_shape(n, s);
+    return conv_halo_f32_shape(n, s);
 }
 
 // can the LDS-tiled kernel run this 3x3 convolution (as launch_conv would decide)?  Mirrors launch_conv's split-K rule.
@@ -169,12 +170,14 @@ bool conv_halo_runs(const rcn_hipx_net* n, const ConvShape& s) {
 }
 
 int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi, uint8_t* pool_idx = nullptr,
-                const PooledGrad* pin = nullptr) {
+                const PooledGrad* pin = nullptr, bool force_fp32 = false) {
     const long long M = (long long)s.N * s.H * s.W;
     const bool smallc = ks * ks * s.Cin <= 32 && s.Cin % 32 != 0;   // the per-element gather loader: only where a k-tile is not 32 whole channels
     if (!smallc && s.Cin % 32) return fail(n, -3, "input channels must be a multiple of 32 (or the whole 3x3xCin patch <= 32)");
     if (s.Cout % 32) return fail(n, -3, "output channels must be a multiple of 32");
-    const bool bf16 = n->precision == RCN_HIPX_BF16;
+    // bf16 mode rounds the operands of every GEMM EXCEPT the first layer's (its whole 3 x 3 x Cin patch is one k-block: nothing of the
+    // MFMA rate to gain, and its own fp32 kernels are the fast ones) and the fused classifier head's (head_fusable)
+    const bool bf16 = n->precision == RCN_HIPX_BF16 && !(ks == 3 && smallc) && !force_fp32;
     const int bn = (bf16 && s.Cout % 128 == 0) ? 128 : (s.Cout % 64 == 0) ? 64 : 32;
     const int nkt = smallc ? 1 : ks * ks * s.Cin / 32;
     const int Z = epi == 4 ? 1 : (!bf16 && ks == 3 && !smallc) ? conv3_f32_z(n, s) : splitk_z(M, s.Cout, bn, nkt);
@@ -294,6 +297,7 @@ static int pix_per_chunk(long long M, long long tiles) {
 static bool wgrad_halo_on() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO_WGRAD"); return e ? std::atoi(e) : 1; }(); return v != 0; }
 bool wgrad_halo_f32_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) { return ks == 3 && ((ks * ks * s.Cin > 32 && conv_halo_f32_shape(n, s)) || conv1_f32_shape(n, s)); }
 bool wgrad_halo_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) {
+    if (ks == 3 && ks * ks * s.Cin <= 32 && conv1_f32_shape(n, s)) return wgrad_halo_on();      // first layer: fp32 kernels in either precision
     if (n->precision != RCN_HIPX_BF16) return wgrad_halo_on() && wgrad_halo_f32_runs(n, s, ks);
     return n->precision == RCN_HIPX_BF16 && wgrad_halo_on() && ks == 3 && ks * ks * s.Cin > 32 && (s.Cin == 32 || s.Cin % 64 == 0) && s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2;
 }
@@ -307,7 +311,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
     XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
     if (pdz && !wgrad_halo_runs(n, s, ks)) return fail(n, -3, "internal: pooled-resolution dZ requested for a layer the LDS-tiled weight-gradient kernel does not cover");
-    if (n->precision != RCN_HIPX_BF16 && wgrad_halo_runs(n, s, ks) && smallc) {
+    if (wgrad_halo_runs(n, s, ks) && smallc) {
         // first layer (convnet_halo.hpp): one 32 x 32 tile (rows = patch entries) per (co block, chunk of pixel blocks)
         const int tw = halo_plan(n, s).tw, nimg = 16 / tw;
         const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
@@ -428,6 +432,8 @@ int stream_after(rcn_hipx_net* n, hipStream_t from, hipStream_t to) {
     return 0;
 }
 
+bool head_fusable(const rcn_hipx_net* n);
+
 // forward for batch B; returns pointer to logits (padded rows of CoutP)
 int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1) {
     const float* cur = x;
@@ -450,7 +456,9 @@ int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1
             }
             RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, cs, 3, 2));
         } else {
-            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, ConvShape{B, 1, 1, l.K, l.CoutP}, 1, l.kind == RCN_HIPX_DENSE_RELU ? 2 : 1));
+            // (the logits layer of a head that training runs as k_head_f32 is fp32 here too: what bf16 mode rounds is a matter of shape)
+            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, ConvShape{B, 1, 1, l.K, l.CoutP}, 1, l.kind == RCN_HIPX_DENSE_RELU ? 2 : 1, nullptr, nullptr,
+                             i + 1 == n->L.size() && head_fusable(n)));
         }
         cur = (const float*)l.out.p;
     }
@@ -579,11 +587,13 @@ int loss_and_dlogits(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_
     return 0;
 }
 
-// Does the classifier head run as one launch (k_head_f32)?  fp32 mode; logits layer of at most 32 classes on a ReLU dense layer of
-// at most 256 units.
+// Does the classifier head run as one launch (k_head_f32, fp32 arithmetic in either precision mode)?  Logits layer of at most 32 classes
+// on a ReLU dense layer of at most 256 units.
 bool head_fusable(const rcn_hipx_net* n) {
     static const int on = [] { const char* e = std::getenv("RCN_HIPX_HEAD"); return e ? std::atoi(e) : 1; }();
-    if (!on || n->precision != RCN_HIPX_FP32 || n->tiling == RCN_HIPX_TILING_GEMM || n->L.size() < 2) return false;
+    // (fp32: not in GEMM tiling mode, which keeps every layer on the implicit-GEMM kernels; bf16: by shape alone -- what the mode rounds
+    // must not depend on a tiling switch)
+    if (!on || (n->precision == RCN_HIPX_FP32 && n->tiling == RCN_HIPX_TILING_GEMM) || n->L.size() < 2) return false;
     const Layer& l = n->L.back();
     const Layer& b = n->L[n->L.size() - 2];
     return l.kind == RCN_HIPX_DENSE && l.CoutP == 32 && l.K % 32 == 0 && l.K <= 256 && b.kind == RCN_HIPX_DENSE_RELU && b.CoutP == l.K;

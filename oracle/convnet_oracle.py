@@ -61,15 +61,24 @@ def _im2col(x: np.ndarray) -> np.ndarray:
     return np.concatenate(cols, axis=-1).reshape(N * H * W, 9 * C)
 
 
+def head_is_fp32(layers) -> bool:
+    """The bf16 mode of the device library (include/rcn_hipx.h) rounds the operands of every GEMM except two places that run fp32
+    kernels in either mode: a first layer whose whole 3x3xCin patch is one k-block (9 * Cin <= 32), and the classifier head when it is
+    the fused one -- a logits layer of at most 32 classes on a ReLU dense layer of at most 256 units (csrc/rcn_hipx_api.hip head_fusable)."""
+    return len(layers) >= 2 and layers[-1][0] == "dense" and layers[-1][1] <= 32 and layers[-2][0] == "dense_relu" and layers[-2][1] <= 256
+
+
 def forward(x, ws, bs, layers, cache=None, operand="f64"):
-    """operand="bf16": both operands of every forward GEMM are rounded to bf16 first (products and sums stay f64)."""
+    """operand="bf16": both operands of every forward GEMM are rounded to bf16 first (products and sums stay f64) -- except in the
+    first layer when its patch is one k-block, and in the fused classifier head (head_is_fp32)."""
     a = np.asarray(x, dtype=np.float64)
     pi = 0
-    for l in layers:
+    for li, l in enumerate(layers):
         if l[0] == "conv":
             N, H, W, C = a.shape
             cols = _im2col(a)
-            z = _op(cols, operand) @ _op(ws[pi], operand) + bs[pi]
+            op = "f64" if cols.shape[1] <= 32 else operand
+            z = _op(cols, op) @ _op(ws[pi], op) + bs[pi]
             y = np.maximum(z, 0).reshape(N, H, W, -1)
             if cache is not None:
                 cache.append(("conv", cols, y, a.shape))
@@ -84,7 +93,8 @@ def forward(x, ws, bs, layers, cache=None, operand="f64"):
             a = p
         else:
             f = a.reshape(a.shape[0], -1)
-            z = _op(f, operand) @ _op(ws[pi], operand) + bs[pi]
+            op = "f64" if (li == len(layers) - 1 and head_is_fp32(layers)) else operand
+            z = _op(f, op) @ _op(ws[pi], op) + bs[pi]
             y = np.maximum(z, 0) if l[0] == "dense_relu" else z
             if cache is not None:
                 cache.append((l[0], f, y, a.shape))
@@ -93,9 +103,9 @@ def forward(x, ws, bs, layers, cache=None, operand="f64"):
 
 
 def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
-    """operand="bf16": every GEMM takes bf16-rounded operands -- forward, input gradient and weight gradient -- except the
-    weight gradient of a first layer whose whole patch fits one K-tile (9*Cin <= 32), which stays on the fp32 path on the
-    device.  Bias gradients are plain sums of the unrounded dZ."""
+    """operand="bf16": every GEMM takes bf16-rounded operands -- forward, input gradient and weight gradient -- except a first layer
+    whose whole patch fits one k-block (9*Cin <= 32) and the fused classifier head (head_is_fp32), which run fp32 kernels on the
+    device in either mode.  Bias gradients are plain sums of the unrounded dZ."""
     cache = []
     logits = forward(x, ws, bs, layers, cache, operand)
     B = logits.shape[0]
@@ -105,7 +115,8 @@ def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
     d = p.copy(); d[np.arange(B), labels] -= 1.0; d /= B
     gws, gbs = [None] * len(ws), [None] * len(bs)
     pi = len(ws) - 1
-    for l, c in zip(reversed(layers), reversed(cache)):
+    head32 = head_is_fp32(layers)
+    for bi, (l, c) in enumerate(zip(reversed(layers), reversed(cache))):
         if c[0] == "pool":
             _, idx, shp = c
             N, H, W, C = shp
@@ -129,8 +140,9 @@ def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
         else:
             kind, f, y, shp = c
             dz = d * (y > 0) if kind == "dense_relu" else d
-            gws[pi] = _op(f, operand).T @ _op(dz, operand); gbs[pi] = dz.sum(axis=0)
-            d = (_op(dz, operand) @ _op(ws[pi], operand).T).reshape(shp)
+            op = "f64" if (bi == 0 and head32) else operand
+            gws[pi] = _op(f, op).T @ _op(dz, op); gbs[pi] = dz.sum(axis=0)
+            d = (_op(dz, op) @ _op(ws[pi], op).T).reshape(shp)
             pi -= 1
     return loss, logits, gws, gbs
 
