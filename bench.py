@@ -912,17 +912,21 @@ def trackx_leg(torch, dev):
         net.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 100
-        a.record(net.stream)
-        for i in range(n):
-            net.train_step(xs[i % 4], ys[i % 4], 0.01, loss)
-        b.record(net.stream)
-        net.synchronize()
-        ms = a.elapsed_time(b) / n
+        runs = []
+        for _ in range(3):                                      # three stretches of 100 steps, the median reported (one stretch in ~20 read 1.7 x the others)
+            a.record(net.stream)
+            for i in range(n):
+                net.train_step(xs[i % 4], ys[i % 4], 0.01, loss)
+            b.record(net.stream)
+            net.synchronize()
+            runs.append(a.elapsed_time(b) / n)
+        ms = sorted(runs)[1]
         flops = net.step_flops(B)
         tf = flops / (ms * 1e-3) / 1e12
         peak = F32_MFMA_PEAK_TFLOPS if prec == "fp32" else BF16_MFMA_PEAK_TFLOPS
         out[prec] = {"ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1), "step_gflop": round(flops / 1e9, 2), "tflops": round(tf, 2),
-                     "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 4)}
+                     "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 4),
+                     "ms_per_step_of_each_stretch": [round(r, 4) for r in runs]}
         net.close()
     # BASELINE configs[3] on one GPU: synthetic 224x224x3, 8 conv layers, 128 images per GPU (fewer timed steps: 20 ms each)
     try:
