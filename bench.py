@@ -913,7 +913,7 @@ def trackx_leg(torch, dev):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 100
         runs = []
-        for _ in range(3):                                      # three stretches of 100 steps, the median reported (one stretch in ~20 read 1.7 x the others)
+        for _ in range(3):                                      # three stretches of 100 steps, the median reported (one single-stretch reading of this round came out 1.7 x its neighbours: 0.707 vs 0.421 ms)
             a.record(net.stream)
             for i in range(n):
                 net.train_step(xs[i % 4], ys[i % 4], 0.01, loss)
