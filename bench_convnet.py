@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="GEMM operand precision of forward / dgrad: fp32 MFMA, or bf16 MFMA with fp32 accumulate / storage / update")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (gradients -> all-reduce -> apply) even at one GPU: a group of one over RCCL")
+    ap.add_argument("--dp-graph", type=int, default=1, help="data-parallel step: 1 = replay it as a captured hipGraph (the all-reduce inside), 0 = launch it eagerly")
     args = ap.parse_args()
     from mercer_research_amd.launch import spawn_ranks, under_launcher
     if args.gpus > 1 and not under_launcher():
@@ -48,7 +50,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     real_stdout = None
-    if world > 1:
+    dp = world > 1 or args.force_dp
+    if dp:
         sys.stdout.flush()
         real_stdout = os.dup(1)                # RCCL's version banner goes to stdout: keep rank 0's stdout to the one JSON line
         os.dup2(2, 1)
@@ -68,16 +71,51 @@ def main():
     ys = [net.to_device(rng.integers(0, 10, B).astype(np.int32)) for _ in range(nbuf)]
     loss = torch.zeros(1, dtype=torch.float32, device=net.device)
     lr = 0.01 if args.config != "synth224" else 1e-6     # the un-normalised 8-conv stack on noise diverges at larger steps (speed does not depend on it)
-    if world > 1:
+    dp_graphs = {}
+    dp_mode = None
+    if dp:
         # one process per GPU: shard gradients of the mean loss -> ONE all-reduce (RCCL over xGMI) of the flat padded
         # gradient buffer -> identical update on every rank with lr / world (mean over the global batch)
         grad = torch.empty(net.n_padded, dtype=torch.float32, device=net.device)
 
-        def step(i):
+        def eager_step(i):
             with torch.cuda.stream(net.stream):
                 net.gradients(xs[i % nbuf], ys[i % nbuf], grad, loss)
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
                 net.apply(grad, lr / world)
+
+        def step(i):
+            g = dp_graphs.get(i % nbuf)
+            if g is None:
+                eager_step(i)
+            else:
+                g.replay()
+
+        dp_mode = "eager"
+        for i in range(2 * nbuf):                          # (in either form, so that both take the same number of steps)
+            eager_step(i)
+        net.synchronize()
+        if args.dp_graph:
+            # The ~40 launches of the step and the collective between them as ONE captured graph per batch buffer (the single-GPU step
+            # has always been one; eagerly the host issues every launch of every step).  The two eager steps per buffer above come first: scratch
+            # buffers reach their sizes and RCCL builds its channels outside the capture.  All ranks capture or none does.
+            try:
+                for b in range(nbuf):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=net.stream):
+                        net.gradients(xs[b], ys[b], grad, loss)
+                        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                        net.apply(grad, lr / world)
+                    dp_graphs[b] = g
+                ok = torch.ones(1, device=net.device)
+            except Exception as ex:                        # capture of the collective not supported here: the eager step stands
+                sys.stderr.write(f"[bench_convnet] data-parallel step not captured ({ex}); running it eagerly\n")
+                dp_graphs.clear()
+                ok = torch.zeros(1, device=net.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0:
+                dp_graphs.clear()
+            dp_mode = "hipGraph" if dp_graphs else "eager"
     else:
         def step(i):
             net.train_step(xs[i % nbuf], ys[i % nbuf], lr, loss)
@@ -85,18 +123,18 @@ def main():
     for i in range(max(args.warmup, 2 * nbuf)):            # first use of each (x, y) pair instantiates its graph
         step(i)
     net.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     net.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
         torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([el], dtype=torch.float64, device=net.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -116,12 +154,14 @@ def main():
                           "mfma_peak_tflops": peak, "mfma_peak_kind": "bf16 dense MFMA" if bf16 else "fp32 MFMA",
                           "frac_of_mfma_peak": round(tf / peak, 4),
                           "hbm_floor_ms": round(floor_ms, 4) if floor_ms else None, "frac_of_hbm_floor": round(floor_ms / (el / args.steps * 1e3), 4) if floor_ms else None,
-                          "dtype": "f32" if not bf16 else "bf16 MFMA operands (fwd, dgrad, wgrad), f32 accumulate/update", "data": "synthetic", "final_loss": round(loss.item(), 4)}) + "\n"
+                          "dtype": "f32" if not bf16 else "bf16 MFMA operands (fwd, dgrad, wgrad), f32 accumulate/update", "data": "synthetic", "final_loss": round(loss.item(), 4),
+                          "data_parallel_step": dp_mode}) + "\n"
         if real_stdout is not None:
             os.write(real_stdout, out_line.encode())
         else:
             sys.stdout.write(out_line)
-    if world > 1:
+    if dp:
+        dp_graphs.clear()
         dist.destroy_process_group()
 
 

@@ -4,6 +4,8 @@ No reference counterpart exists (include/rcn_hipx.h); at these sizes the f64 ora
 a few images, so each config is held by: the oracle on a sub-batch at full resolution, and size-independent properties on the full
 batch -- gradient additivity over a split of the batch, data-parallel halves == the full step, hipGraph replay == eager bit for bit.
 Tolerances as in test_gpu_convnet.py: fp32 MFMA |d| <= 2e-4 * scale + 1e-6; bf16 operands 5e-3 * scale."""
+import os
+
 import numpy as np
 import pytest
 
@@ -187,3 +189,22 @@ def test_mnist_bf16_b4096_hipgraph_step_workload_size():
     net.synchronize()
     assert np.isfinite(loss.item()) and loss.item() < l0
     net.close()
+
+
+def test_data_parallel_step_replays_as_one_graph_with_the_collective_inside():
+    """bench_convnet.py's data-parallel step (shard gradients -> ONE all-reduce over RCCL -> apply) is captured as a hipGraph per batch
+    buffer, the collective inside it, and replayed; --force-dp runs it on this box's one GPU as a group of one.  The line says which form
+    ran, and the captured form trains like the eager one (same loss after the same steps: same kernels, same order)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, MASTER_PORT=str(29600 + int(mode)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        pr = subprocess.run([sys.executable, os.path.join(root, "bench_convnet.py"), "--config", "mnist", "--steps", "12", "--warmup", "4", "--force-dp", "--dp-graph", mode],
+                            capture_output=True, text=True, timeout=240, env=env)
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        out[mode] = json.loads(pr.stdout.strip().splitlines()[-1])
+    assert out["1"]["data_parallel_step"] == "hipGraph" and out["0"]["data_parallel_step"] == "eager"
+    assert out["1"]["final_loss"] == out["0"]["final_loss"]
