@@ -638,14 +638,12 @@ struct PooledGrad {
     const uint8_t* idx;       // arg-max position 0..3 = dy * 2 + dx
 };
 
-__device__ inline f32x4 pooled_grad4(const PooledGrad& g, int img, int y, int x, int c, int H, int W, int C) {
-    const long long o = ((((long long)img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C) + c;
-    const f32x4 d = *reinterpret_cast<const f32x4*>(g.dP + o), pv = *reinterpret_cast<const f32x4*>(g.P + o);
-    const unsigned ii = *reinterpret_cast<const unsigned*>(g.idx + o);
-    const unsigned pos = (unsigned)(((y & 1) << 1) | (x & 1));
+// The four full-resolution values of one pooled gradient chunk: position pos = dy * 2 + dx of the window gets the pooled gradient
+// where it was the arg-max and the pooled activation is positive (k_pool_bwd's rule), zero elsewhere.
+__device__ inline f32x4 unpool4(const f32x4& d, const f32x4& p, unsigned idx4, unsigned pos) {
     f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (((ii >> (8 * i)) & 3u) == pos && pv[i] > 0.f) ? d[i] : 0.f;
+    for (int i = 0; i < 4; ++i) v[i] = (((idx4 >> (8 * i)) & 3u) == pos && p[i] > 0.f) ? d[i] : 0.f;
     return v;
 }
 

@@ -39,7 +39,7 @@ __device__ inline bf16x4 to_bf16x4(const f32x4& v) {
     return h;
 }
 
-// (PooledGrad / pooled_grad4 -- a gradient tensor that exists only at pooled resolution -- live in convnet.hpp: the fp32 LDS-tiled
+// (PooledGrad / unpool4 -- a gradient tensor that exists only at pooled resolution -- live in convnet.hpp: the fp32 LDS-tiled
 // kernels use them too)
 
 // Same tiling, split-K and epilogues as k_conv_fwd; WB = weights as bf16 [Cout][Kp], Kp = K rounded up to 32
@@ -333,14 +333,35 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __r
         if (cb) __syncthreads();                                      // the previous channel block's halo has been consumed
         // ---- halo: pixel (oh0 - 1 + hy, ow0 - 1 + hx), channels cb .. cb + CB - 1, zero outside the image; unconditional
         // loads from clamped addresses
-        for (int e = tid; e < HCH; e += kThreads) {
-            const int pix = e / (CB / 4), c4 = (e - pix * (CB / 4)) * 4;
-            const int hy = pix / HW, hx = pix - hy * HW;
-            const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
-            const bool ok = (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-            const f32x4 v = PIN ? pooled_grad4(pin, img, ok ? ih : 0, ok ? iw : 0, cb + c4, s.H, s.W, Cin)    // the input is a pooled-resolution gradient
-                                : *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
-            *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(ok ? v : f32x4{0, 0, 0, 0});
+        if (PIN) {
+            // the input is a pooled-resolution gradient: one thread loads (dP, P, arg-max) of ONE pooled pixel's four channels -- the 6 x 10
+            // pooled pixels under the halo -- and expands it into the up to four halo pixels of its window (round 3: a load triple per
+            // halo pixel had fetched every pooled value four times; these kernels were 1.6 x their forward twins)
+            constexpr int PPW = kHaloTW / 2 + 2, PCH = 6 * PPW * (CB / 4);
+            for (int e = tid; e < PCH; e += kThreads) {
+                const int pp = e / (CB / 4), c4 = (e - pp * (CB / 4)) * 4;
+                const int pr = pp / PPW, pc = pp - pr * PPW;
+                const int poh = (oh0 >> 1) - 1 + pr, pow_ = (ow0 >> 1) - 1 + pc;
+                const bool ok = (unsigned)poh < (unsigned)(s.H >> 1) && (unsigned)pow_ < (unsigned)(s.W >> 1);
+                const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * Cin + cb + c4 : 0;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(pin.dP + o), pv = *reinterpret_cast<const f32x4*>(pin.P + o);
+                const unsigned ii = *reinterpret_cast<const unsigned*>(pin.idx + o);
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const int hy = 2 * pr - 1 + (pos >> 1), hx = 2 * pc - 1 + (pos & 1);
+                    if ((unsigned)hy < (unsigned)HH && (unsigned)hx < (unsigned)HW)
+                        *reinterpret_cast<bf16x4*>(&Hs[(hy * HW + hx) * LDC + c4]) = to_bf16x4(ok ? unpool4(d, pv, ii, (unsigned)pos) : f32x4{0, 0, 0, 0});
+                }
+            }
+        } else {
+            for (int e = tid; e < HCH; e += kThreads) {
+                const int pix = e / (CB / 4), c4 = (e - pix * (CB / 4)) * 4;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+                const bool ok = (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
+                *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(ok ? v : f32x4{0, 0, 0, 0});
+            }
         }
 #pragma unroll 1
         for (int kh = 0; kh < 3; ++kh) {
@@ -479,15 +500,33 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
             const f32x4 v = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
             *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(ok ? v : f32x4{0, 0, 0, 0});
         }
-        for (int e = tid; e < DCH; e += kWgHaloThreads) {             // dZ of the block's pixels, channels n0 .. n0 + BN - 1
-            const int pix = e / (BN / 4), c4 = (e - pix * (BN / 4)) * 4;
-            const int oh = oh0 + pix / kHaloTW, ow = ow0 + pix % kHaloTW;
-            const bool ok = oh < s.H && ow < s.W;
-            f32x4 v = PDZ ? pooled_grad4(pdz, img, ok ? oh : 0, ok ? ow : 0, n0 + c4, s.H, s.W, s.Cout)
-                          : *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
-            v = ok ? v : f32x4{0, 0, 0, 0};
-            *reinterpret_cast<bf16x4*>(&Ds[pix * LDD + c4]) = to_bf16x4(v);
-            colsum += v;                                              // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
+        if (PDZ) {
+            // dZ exists only at pooled resolution: the block's 4 x 8 pooled pixels, one load triple each, expanded into their windows
+            for (int e = tid; e < 32 * (BN / 4); e += kWgHaloThreads) {
+                const int pp = e / (BN / 4), c4 = (e - pp * (BN / 4)) * 4;
+                const int ppy = pp >> 3, ppx = pp & 7;
+                const int poh = (oh0 >> 1) + ppy, pow_ = (ow0 >> 1) + ppx;
+                const bool ok = poh < (s.H >> 1) && pow_ < (s.W >> 1);
+                const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(pdz.dP + o), pv = *reinterpret_cast<const f32x4*>(pdz.P + o);
+                const unsigned ii = *reinterpret_cast<const unsigned*>(pdz.idx + o);
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const f32x4 v = ok ? unpool4(d, pv, ii, (unsigned)pos) : f32x4{0, 0, 0, 0};
+                    *reinterpret_cast<bf16x4*>(&Ds[((2 * ppy + (pos >> 1)) * kHaloTW + 2 * ppx + (pos & 1)) * LDD + c4]) = to_bf16x4(v);
+                    colsum += v;                                      // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
+                }
+            }
+        } else {
+            for (int e = tid; e < DCH; e += kWgHaloThreads) {         // dZ of the block's pixels, channels n0 .. n0 + BN - 1
+                const int pix = e / (BN / 4), c4 = (e - pix * (BN / 4)) * 4;
+                const int oh = oh0 + pix / kHaloTW, ow = ow0 + pix % kHaloTW;
+                const bool ok = oh < s.H && ow < s.W;
+                f32x4 v = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+                v = ok ? v : f32x4{0, 0, 0, 0};
+                *reinterpret_cast<bf16x4*>(&Ds[pix * LDD + c4]) = to_bf16x4(v);
+                colsum += v;                                          // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
+            }
         }
         __syncthreads();
 #pragma unroll

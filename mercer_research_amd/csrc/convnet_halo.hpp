@@ -41,15 +41,6 @@ template <int TW> struct HaloGeom {
     __device__ static int lds_pix(int pix) { return TW == 16 ? pix : pix + (pix >= IMG_PIX ? IS - IMG_PIX : 0); }
 };
 
-// The four full-resolution values of one pooled gradient chunk: position pos = dy * 2 + dx of the window gets the pooled gradient
-// where it was the arg-max and the pooled activation is positive (k_pool_bwd's rule), zero elsewhere.
-__device__ inline f32x4 unpool4(const f32x4& d, const f32x4& p, unsigned idx4, unsigned pos) {
-    f32x4 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (((idx4 >> (8 * i)) & 3u) == pos && p[i] > 0.f) ? d[i] : 0.f;
-    return v;
-}
-
 // Reading the thread index through an empty asm makes it opaque: what is computed from it is redone where it is used instead of
 // being hoisted out of the loops into registers that then spill (first-layer kernels: a handful of integer instructions).
 __device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
