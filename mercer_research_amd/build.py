@@ -48,7 +48,7 @@ def build_experiments(force: bool = False, verbose: bool = False) -> str:
 
 LIBX = os.path.join(HERE, "librcn_hipx.so")          # Track X (trainable conv net; include/rcn_hipx.h)
 LIBX_SRC = os.path.join(CSRC, "rcn_hipx_api.hip")
-LIBX_DEPS = [LIBX_SRC, os.path.join(CSRC, "convnet.hpp"), os.path.join(CSRC, "convnet_bf16.hpp"), os.path.join(CSRC, "convnet_halo.hpp"), os.path.join(HERE, "..", "include", "rcn_hipx.h")]
+LIBX_DEPS = [LIBX_SRC, os.path.join(CSRC, "convnet.hpp"), os.path.join(CSRC, "convnet_bf16.hpp"), os.path.join(CSRC, "convnet_halo.hpp"), os.path.join(CSRC, "convnet_halo_bf16.hpp"), os.path.join(HERE, "..", "include", "rcn_hipx.h")]
 
 
 def build_x(force: bool = False, verbose: bool = False) -> str:

@@ -52,11 +52,11 @@ __device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 template <int NQ> struct StageMap {
     int pk[NQ];               // row | column << 8 | image << 16 of the chunk's pixel; negative: no such pixel
 };
-template <int NQ, int ROWS, int COLS, int NIMG>
+template <int NQ, int ROWS, int COLS, int NIMG, int CPP = 8>          // CPP = 16-byte chunks per pixel (channels of the block / 4)
 __device__ inline void stage_map_init(StageMap<NQ>& m, int tid) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int pix = (tid >> 3) + 32 * q;
+        const int pix = tid / CPP + (kThreads / CPP) * q;
         const int i = pix / (ROWS * COLS), pr = pix - i * (ROWS * COLS);
         const int y = pr / COLS, x = pr - y * COLS;
         m.pk[q] = pix < NIMG * ROWS * COLS ? (y | (x << 8) | (i << 16)) : -1;
@@ -65,11 +65,71 @@ __device__ inline void stage_map_init(StageMap<NQ>& m, int tid) {
 // Element offset of a packed pixel relative to the grid's origin, and whether it lies inside the image, for a grid whose origin is
 // pixel (y0, x0) of image img0.  Callers pass pk through opaque(): otherwise these few instructions are hoisted out of the loops
 // too, into registers the kernels do not have.
-__device__ inline int stage_rel(int pk, int tid, int Himg, int Wimg, int C) {
-    return (((pk >> 16) * Himg + (pk & 255)) * Wimg + ((pk >> 8) & 255)) * C + (tid & 7) * 4;
+template <int CPP = 8> __device__ inline int stage_rel(int pk, int tid, int Himg, int Wimg, int C) {
+    return (((pk >> 16) * Himg + (pk & 255)) * Wimg + ((pk >> 8) & 255)) * C + (tid % CPP) * 4;
 }
 __device__ inline bool stage_ok(int pk, int y0, int x0, int img0, int Himg, int Wimg, int N) {
     return pk >= 0 && (unsigned)(y0 + (pk & 255)) < (unsigned)Himg && (unsigned)(x0 + ((pk >> 8) & 255)) < (unsigned)Wimg && img0 + (pk >> 16) < N;
+}
+
+// Epilogue of the LDS-tiled forward / input-gradient kernels (fp32 and bf16 operands alike: the accumulators are fp32): accumulator
+// row i of a lane is block pixel mfma32_row(lane, i) of its wave's 32 pixels (block rows 2 wave, 2 wave + 1).
+template <int TW, int NT, int EPI>
+__device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave, int img0, int oh0, int ow0, int n0, const ConvShape& s,
+                                     const float* __restrict__ bias, float* __restrict__ Y, uint8_t* __restrict__ pool_idx) {
+    const int h = lane >> 5;
+    if (EPI == 4) {
+        // bias + ReLU + the 2x2 max-pool that follows: a lane's sixteen rows are block columns 4h..4h+3 and 8+4h..8+4h+3 of BOTH
+        // pixel rows of its wave -- four complete pooling windows (TW = 8: columns 0..7 are image 0, 8..15 image 1: still whole
+        // windows).  First maximum in the order 00, 01, 10, 11, as k_pool_fwd.
+        const int OH = s.H / 2, OW = s.W / 2;
+        const int poh = oh0 / 2 + wave;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co = n0 + 32 * t + (lane & 31);
+            const float bb = bias[co];
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    // max-pool of relu(x + b) = relu(max(x) + b): the maximum (first of equals) is taken on the raw sums
+                    const int i0 = 4 * gq + 2 * pp;
+                    const float v[4] = {acc[t][i0], acc[t][i0 + 1], acc[t][8 + i0], acc[t][8 + i0 + 1]};
+                    float best = v[0];
+                    int bk = 0;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+                        if (v[k] > best) { best = v[k]; bk = k; }
+                    best += bb;
+                    best = best > 0.f ? best : 0.f;
+                    const int colb = 4 * h + 8 * gq + 2 * pp;                   // block column of the window's left pixel
+                    const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
+                    const bool ok = img < s.N && poh < OH && pow_ < OW;         // the same for the 32 lanes of a half-wave
+                    const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co);
+                    if (ok) Y[o] = best;
+                    store_idx_quad(pool_idx, o, bk, ok, lane);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co = n0 + 32 * t + (lane & 31);
+            const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pr = mfma32_row(lane, i);
+                const int colb = pr & 15;
+                const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+                if (img < s.N && oh < s.H && ow < s.W) {
+                    const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co);      // the host keeps tensors below 2^31 elements
+                    float v = acc[t][i] + bb;
+                    if (EPI == 2) v = v > 0.f ? v : 0.f;
+                    if (EPI == 3) v = bias[o] > 0.f ? v : 0.f;
+                    Y[o] = v;
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -257,60 +317,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
             kh = nkh; cb = ncb;
         }
         RCNX_STAMP(stamp_slot); ++stamp_slot;                         // the item's MFMAs issued
-        // ---- epilogue: accumulator row i of lane = block pixel mfma32_row(lane, i) of this wave's 32
-        const int img0 = cur.img0, oh0 = cur.oh0, ow0 = cur.ow0, n0 = cur.n0;
-        if (EPI == 4) {
-            // bias + ReLU + the 2x2 max-pool that follows: a lane's sixteen rows are block columns 4h..4h+3 and 8+4h..8+4h+3 of BOTH
-            // pixel rows of its wave -- four complete pooling windows (TW = 8: columns 0..7 are image 0, 8..15 image 1: still whole
-            // windows).  First maximum in the order 00, 01, 10, 11, as k_pool_fwd.
-            const int OH = s.H / 2, OW = s.W / 2;
-            const int poh = oh0 / 2 + wave;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int co = n0 + 32 * t + (lane & 31);
-                const float bb = bias[co];
-#pragma unroll
-                for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        // max-pool of relu(x + b) = relu(max(x) + b): the maximum (first of equals) is taken on the raw sums
-                        const int i0 = 4 * gq + 2 * pp;
-                        const float v[4] = {acc[t][i0], acc[t][i0 + 1], acc[t][8 + i0], acc[t][8 + i0 + 1]};
-                        float best = v[0];
-                        int bk = 0;
-#pragma unroll
-                        for (int k = 1; k < 4; ++k)
-                            if (v[k] > best) { best = v[k]; bk = k; }
-                        best += bb;
-                        best = best > 0.f ? best : 0.f;
-                        const int colb = 4 * h + 8 * gq + 2 * pp;                   // block column of the window's left pixel
-                        const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
-                        const bool ok = img < s.N && poh < OH && pow_ < OW;         // the same for the 32 lanes of a half-wave
-                        const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co);
-                        if (ok) Y[o] = best;
-                        store_idx_quad(pool_idx, o, bk, ok, lane);
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int co = n0 + 32 * t + (lane & 31);
-                const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int pr = mfma32_row(lane, i);
-                    const int colb = pr & 15;
-                    const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
-                    if (img < s.N && oh < s.H && ow < s.W) {
-                        const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co);      // the host keeps tensors below 2^31 elements
-                        float v = acc[t][i] + bb;
-                        if (EPI == 2) v = v > 0.f ? v : 0.f;
-                        if (EPI == 3) v = bias[o] > 0.f ? v : 0.f;
-                        Y[o] = v;
-                    }
-                }
-            }
-        }
+        halo_epilogue<TW, NT, EPI>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx);
         RCNX_STAMP(stamp_slot); ++stamp_slot;                         // epilogue stores issued
         cur = nxt;
     }

@@ -1,0 +1,179 @@
+// convnet_halo_bf16.hpp -- Track X, bf16 MFMA path: the LDS-tiled 3x3 forward / input-gradient kernel as a software pipeline
+// (round 3).  No reference counterpart.
+//
+// k_conv3x3_halo_bf16 (convnet_bf16.hpp) has the right data flow -- one staged halo per 8 x 16 pixel block serves all nine taps --
+// but loads, waits, converts and stores every operand in place, with two barriers per filter row and one work item per workgroup:
+// on the 224 x 224 net it ran at 15 % of the bf16 MFMA rate AND 4.7 x its HBM floor, i.e. on latency and integer instructions.
+// k_conv3x3_halo_bf16p is the same kernel on the frame round 3 built for the fp32 path (convnet_halo.hpp): work items walked by a
+// resident grid, phases (item, channel block, filter row) whose operands are loaded into registers one phase ahead of their use --
+// across item boundaries too --, every thread's share of the staged grids decoded once (StageMap), the epilogues shared.  Same LDS
+// images, same operand rounding (RNE to bf16 on the way into LDS, fp32 accumulation), same MFMA order as k_conv3x3_halo_bf16:
+// bit-identical results.
+#pragma once
+
+#include "convnet_bf16.hpp"
+#include "convnet_halo.hpp"
+
+namespace rcnx {
+
+template <int CB, int BN, int EPI, bool PIN = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 64 && BN == 64 ? 2 : 3))) void k_conv3x3_halo_bf16p(
+    const float* __restrict__ X, const __bf16* __restrict__ WB, const float* __restrict__ bias, float* __restrict__ Y, ConvShape s, int tiles_w,
+    int tiles_h, int n_items, uint8_t* __restrict__ pool_idx, PooledGrad pin) {
+    static_assert(CB % 16 == 0 && BN % 32 == 0, "channel blocks of the 32x32x16 MFMA");
+    using Gm = HaloGeom<16>;
+    constexpr int TW = 16, NT = BN / 32, LDC = CB + 8;                // halves per pixel / per weight row in LDS (16-byte aligned, bank-skewed)
+    constexpr int CPP = CB / 4;                                       // f32x4 chunks per pixel of a channel block
+    constexpr int PPW = TW / 2 + 2;                                   // PIN: pooled pixels under the halo: 6 rows x 10
+    constexpr int GR = PIN ? 6 : Gm::HH, GC = PIN ? PPW : Gm::HWD;    // the grid that is loaded: pooled pixels, or the halo itself
+    constexpr int NH = (GR * GC * CPP + kThreads - 1) / kThreads;
+    constexpr int BCH = 3 * BN * (CB / 8);                            // 16-byte chunks of one filter row's weights for a channel block
+    constexpr int NB = (BCH + kThreads - 1) / kThreads;
+    __shared__ __attribute__((aligned(16))) __bf16 Hs[Gm::NPIX * LDC];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[3 * BN * LDC];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Cin = s.Cin, K = 9 * Cin, nblk = s.Cout / BN;
+    const int GH = PIN ? s.H >> 1 : s.H, GW = PIN ? s.W >> 1 : s.W;   // image size of the loaded grid
+    const int r = lane & 31, h = lane >> 5;
+    const int py = 2 * wave + (r >> 4), px = r & 15;                  // this lane's A row = output pixel (py, px) of the block
+
+    struct Item { int img0, oh0, ow0, n0; };
+    struct Pos { int nb, tw, th, g; };
+    auto split = [&](int item) { Pos p; p.nb = item % nblk; item /= nblk; p.tw = item % tiles_w; item /= tiles_w; p.th = item % tiles_h; p.g = item / tiles_h; return p; };
+    const Pos stride = split((int)gridDim.x);
+    auto advance = [&](Pos p) {
+        p.nb += stride.nb; if (p.nb >= nblk) { p.nb -= nblk; ++p.tw; }
+        p.tw += stride.tw; if (p.tw >= tiles_w) { p.tw -= tiles_w; ++p.th; }
+        p.th += stride.th; if (p.th >= tiles_h) { p.th -= tiles_h; ++p.g; }
+        p.g += stride.g;
+        return p;
+    };
+    auto item_of = [&](const Pos& p) { return Item{p.g, p.th * Gm::TH, p.tw * TW, p.nb * BN}; };
+
+    // ---- staging: registers first (loads fly under the MFMAs), LDS after the barrier
+    StageMap<NH> hm;
+    stage_map_init<NH, GR, GC, 1, CPP>(hm, tid);
+    f32x4 hv[NH], hp[PIN ? NH : 1];
+    unsigned hi[PIN ? NH : 1];
+    unsigned okm = 0;
+    auto halo_load = [&](const Item& it, int cb) {
+        const int y0 = PIN ? (it.oh0 >> 1) - 1 : it.oh0 - 1, x0 = PIN ? (it.ow0 >> 1) - 1 : it.ow0 - 1;
+        const int base = ((it.img0 * GH + y0) * GW + x0) * Cin + cb;
+        okm = 0;
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int pk = opaque(hm.pk[q]);
+            const bool ok = stage_ok(pk, y0, x0, it.img0, GH, GW, s.N);
+            okm |= (ok ? 1u : 0u) << q;
+            const unsigned off = ok ? (unsigned)(base + stage_rel<CPP>(pk, tid, GH, GW, Cin)) : 0u;
+            if (PIN) {
+                hv[q] = *reinterpret_cast<const f32x4*>(pin.dP + off);
+                hp[q] = *reinterpret_cast<const f32x4*>(pin.P + off);
+                hi[q] = *reinterpret_cast<const unsigned*>(pin.idx + off);
+            } else {
+                hv[q] = *reinterpret_cast<const f32x4*>(X + off);
+            }
+        }
+    };
+    auto halo_store = [&]() {
+        const int c4 = (tid % CPP) * 4;
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const bool ok = (okm >> q) & 1u;
+            const int pk = hm.pk[q];
+            if (pk < 0) continue;
+            if (PIN) {
+                const int pr = pk & 255, pc = (pk >> 8) & 255;
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const int hy = 2 * pr - 1 + (pos >> 1), hx = 2 * pc - 1 + (pos & 1);          // halo pixel of window position pos
+                    if ((unsigned)hy < (unsigned)Gm::HH && (unsigned)hx < (unsigned)Gm::HWD)
+                        *reinterpret_cast<bf16x4*>(&Hs[(hy * Gm::HWD + hx) * LDC + c4]) = to_bf16x4(ok ? unpool4(hv[q], hp[q], hi[q], (unsigned)pos) : f32x4{0, 0, 0, 0});
+                }
+            } else {
+                *reinterpret_cast<bf16x4*>(&Hs[(tid / CPP + (kThreads / CPP) * q) * LDC + c4]) = to_bf16x4(ok ? hv[q] : f32x4{0, 0, 0, 0});
+            }
+        }
+    };
+    // weights of one filter row for a channel block: chunk q of the thread is 8 halves of row (kw * BN + co) of the [3 BN][CB] tile,
+    // straight out of the transposed bf16 copy WB[Cout][K].  Row of chunk q = r0 + RQ q with r0 = tid / (CB/8) < RQ and RQ a multiple
+    // or a divisor of BN, so (kw, co) of every q is the thread's own (kw0, co0) plus compile-time steps: one register for the global
+    // offset, one for the LDS address.
+    bf16x8 bv[NB];
+    constexpr int RQ = kThreads / (CB / 8);
+    static_assert(RQ % BN == 0 || BN % RQ == 0, "rows per step and column block must divide one another");
+    const int br0 = tid / (CB / 8), bc8 = (tid % (CB / 8)) * 8;
+    const int b_goff = (br0 % BN) * K + (br0 / BN) * Cin + bc8;       // (co0, kw0) of the thread
+    const __bf16* const b_lds = &Bs[br0 * LDC + bc8];
+    auto b_valid = [&](int q) { return NB * kThreads == BCH || tid + kThreads * q < BCH; };
+    auto b_load = [&](const Item& it, int cb, int kh) {
+        const __bf16* wp = WB + (long long)it.n0 * K + kh * 3 * Cin + cb + b_goff;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            // row step RQ q: RQ >= BN: kw += (RQ / BN) q; RQ < BN: co += RQ (q mod BN/RQ), kw += q / (BN/RQ)
+            const int dkw = RQ >= BN ? (RQ / BN) * q : q / (BN / RQ), dco = RQ >= BN ? 0 : RQ * (q % (BN / RQ));
+            if (b_valid(q)) bv[q] = *reinterpret_cast<const bf16x8*>(wp + (long long)dco * K + dkw * Cin);
+        }
+    };
+    auto b_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            if (b_valid(q)) *reinterpret_cast<bf16x8*>(const_cast<__bf16*>(b_lds) + RQ * q * LDC) = bv[q];
+    };
+
+    const int nph = (Cin / CB) * 3;                                   // phases of one item: (channel block, filter row)
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    Pos pos = split(item);
+    Item cur = item_of(pos);
+    halo_load(cur, 0);
+    b_load(cur, 0, 0);
+    bool first = true;
+#pragma unroll 1
+    for (; item < n_items; item += gridDim.x) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        const int nitem = item + gridDim.x;
+        pos = advance(pos);
+        const Item nxt = item_of(pos);
+        int cb = 0, kh = 0;
+#pragma unroll 1
+        for (int ph = 0; ph < nph; ++ph) {
+            if (!first) __syncthreads();                              // the previous phase's operands have been consumed
+            first = false;
+            if (kh == 0) halo_store();
+            b_store();
+            __syncthreads();
+            const int nkh = kh == 2 ? 0 : kh + 1, ncb = kh == 2 ? cb + CB : cb;
+            if (ph + 1 < nph) {
+                b_load(cur, ncb, nkh);
+                if (nkh == 0) halo_load(cur, ncb);
+            } else if (nitem < n_items) {                             // the next item's first phase
+                b_load(nxt, 0, 0);
+                halo_load(nxt, 0);
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const __bf16* a = &Hs[((py + kh) * Gm::HWD + px + kw) * LDC + 8 * h];
+                const __bf16* b = &Bs[(kw * BN + r) * LDC + 8 * h];
+#pragma unroll
+                for (int ks = 0; ks < CB / 16; ++ks) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a + 16 * ks);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(b + 32 * t * LDC + 16 * ks);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            kh = nkh; cb = ncb;
+        }
+        halo_epilogue<TW, NT, EPI>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx);
+        cur = nxt;
+    }
+}
+
+}  // namespace rcnx

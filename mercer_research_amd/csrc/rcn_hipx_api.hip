@@ -17,6 +17,7 @@
 #include "convnet.hpp"
 #include "convnet_bf16.hpp"
 #include "convnet_halo.hpp"
+#include "convnet_halo_bf16.hpp"
 
 using namespace rcnx;
 
@@ -201,6 +202,25 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
             const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
             const dim3 hgrid((unsigned)(tw * th * s.N), (unsigned)(s.Cout / hbn));
             const PooledGrad pg = pin ? *pin : PooledGrad{nullptr, nullptr, nullptr};
+            static const int pipe = [] { const char* e = std::getenv("RCN_HIPX_BF16_PIPE"); return e ? std::atoi(e) : 1; }();
+            if (pipe && (long long)(s.N + 1) * s.H * s.W * (s.Cin > s.Cout ? s.Cin : s.Cout) < 0x7fffffffLL) {
+                // the pipelined form (convnet_halo_bf16.hpp): work items (pixel block, column block) on a resident grid, operands loaded a
+                // phase ahead; same LDS images, rounding and MFMA order as k_conv3x3_halo_bf16 below
+                const long long items = (long long)tw * th * s.N * (s.Cout / hbn);
+#define HBP_LAUNCH(CI_, BN_, EPI_, PIN_) do { const long long slots = resident_slots(n, (const void*)k_conv3x3_halo_bf16p<CI_, BN_, EPI_, PIN_>); \
+                hipLaunchKernelGGL((k_conv3x3_halo_bf16p<CI_, BN_, EPI_, PIN_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, (int)items, pool_idx, pg); } while (0)
+#define HBP_EPI(CI_, BN_) do { if (pin) { if (kepi == 3) HBP_LAUNCH(CI_, BN_, 3, true); else if (kepi == 0) HBP_LAUNCH(CI_, BN_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
+                               else if (kepi == 0) HBP_LAUNCH(CI_, BN_, 0, false); else if (kepi == 1) HBP_LAUNCH(CI_, BN_, 1, false); else if (kepi == 2) HBP_LAUNCH(CI_, BN_, 2, false); \
+                               else if (kepi == 3) HBP_LAUNCH(CI_, BN_, 3, false); else HBP_LAUNCH(CI_, BN_, 4, false); } while (0)
+                if (items <= 0x7fffffffLL) {
+                    if (s.Cin == 32) { if (hbn == 64) HBP_EPI(32, 64); else HBP_EPI(32, 32); }
+                    else { if (hbn == 64) HBP_EPI(64, 64); else HBP_EPI(64, 32); }
+                    XTRY(n, hipGetLastError());
+                    return 0;
+                }
+#undef HBP_EPI
+#undef HBP_LAUNCH
+            }
 #define HALO_CASE(CI_, BN_, EPI_) do { if (pin) hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_, true>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx, pg); \
                                        else hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_, false>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx, pg); } while (0)
 #define HALO_EPI(CI_, BN_) do { if (kepi == 0) HALO_CASE(CI_, BN_, 0); else if (kepi == 1) HALO_CASE(CI_, BN_, 1); else if (kepi == 2) HALO_CASE(CI_, BN_, 2); else if (kepi == 3) HALO_CASE(CI_, BN_, 3); else HALO_CASE(CI_, BN_, 4); } while (0)

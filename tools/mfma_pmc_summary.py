@@ -12,7 +12,7 @@ import csv, glob, hashlib, json, statistics, sys
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TRACKX_SOURCES = ("convnet.hpp", "convnet_bf16.hpp", "convnet_halo.hpp", "rcn_hipx_api.hip")
+TRACKX_SOURCES = ("convnet.hpp", "convnet_bf16.hpp", "convnet_halo.hpp", "convnet_halo_bf16.hpp", "rcn_hipx_api.hip")
 
 
 def trackx_sha16() -> str:
