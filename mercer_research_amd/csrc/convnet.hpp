@@ -638,13 +638,18 @@ struct PooledGrad {
     const uint8_t* idx;       // arg-max position 0..3 = dy * 2 + dx
 };
 
-// The four full-resolution values of one pooled gradient chunk: position pos = dy * 2 + dx of the window gets the pooled gradient
-// where it was the arg-max and the pooled activation is positive (k_pool_bwd's rule), zero elsewhere.
-__device__ inline f32x4 unpool4(const f32x4& d, const f32x4& p, unsigned idx4, unsigned pos) {
-    f32x4 v;
+// The full-resolution values of one pooled gradient chunk (four channels): position pos = dy * 2 + dx of the window gets the pooled
+// gradient where it was the arg-max and the pooled activation is positive (k_pool_bwd's rule), zero elsewhere.  All four positions at
+// once: the ReLU gate and the arg-max field are taken once per channel, a compare + select per (position, channel) is what is left.
+__device__ inline void unpool4x4(const f32x4& d, const f32x4& p, unsigned idx4, f32x4 (&v)[4]) {
+    float m[4];
+    unsigned k[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (((idx4 >> (8 * i)) & 3u) == pos && p[i] > 0.f) ? d[i] : 0.f;
-    return v;
+    for (int i = 0; i < 4; ++i) { m[i] = p[i] > 0.f ? d[i] : 0.f; k[i] = (idx4 >> (8 * i)) & 3u; }
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[pos][i] = k[i] == (unsigned)pos ? m[i] : 0.f;
 }
 
 // Arg-max bytes of four adjacent channels (the four lanes of a quad) as ONE dword store by the quad's first lane.  As byte stores --

@@ -346,11 +346,13 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16(const float* __r
                 const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * Cin + cb + c4 : 0;
                 const f32x4 d = *reinterpret_cast<const f32x4*>(pin.dP + o), pv = *reinterpret_cast<const f32x4*>(pin.P + o);
                 const unsigned ii = *reinterpret_cast<const unsigned*>(pin.idx + o);
+                f32x4 v[4];
+                unpool4x4(ok ? d : f32x4{0, 0, 0, 0}, pv, ii, v);
 #pragma unroll
                 for (int pos = 0; pos < 4; ++pos) {
                     const int hy = 2 * pr - 1 + (pos >> 1), hx = 2 * pc - 1 + (pos & 1);
                     if ((unsigned)hy < (unsigned)HH && (unsigned)hx < (unsigned)HW)
-                        *reinterpret_cast<bf16x4*>(&Hs[(hy * HW + hx) * LDC + c4]) = to_bf16x4(ok ? unpool4(d, pv, ii, (unsigned)pos) : f32x4{0, 0, 0, 0});
+                        *reinterpret_cast<bf16x4*>(&Hs[(hy * HW + hx) * LDC + c4]) = to_bf16x4(v[pos]);
                 }
             }
         } else {
@@ -510,11 +512,12 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
                 const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
                 const f32x4 d = *reinterpret_cast<const f32x4*>(pdz.dP + o), pv = *reinterpret_cast<const f32x4*>(pdz.P + o);
                 const unsigned ii = *reinterpret_cast<const unsigned*>(pdz.idx + o);
+                f32x4 v[4];
+                unpool4x4(ok ? d : f32x4{0, 0, 0, 0}, pv, ii, v);
 #pragma unroll
                 for (int pos = 0; pos < 4; ++pos) {
-                    const f32x4 v = ok ? unpool4(d, pv, ii, (unsigned)pos) : f32x4{0, 0, 0, 0};
-                    *reinterpret_cast<bf16x4*>(&Ds[((2 * ppy + (pos >> 1)) * kHaloTW + 2 * ppx + (pos & 1)) * LDD + c4]) = to_bf16x4(v);
-                    colsum += v;                                      // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
+                    *reinterpret_cast<bf16x4*>(&Ds[((2 * ppy + (pos >> 1)) * kHaloTW + 2 * ppx + (pos & 1)) * LDD + c4]) = to_bf16x4(v[pos]);
+                    colsum += v[pos];                                 // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
                 }
             }
         } else {

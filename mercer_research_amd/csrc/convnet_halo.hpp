@@ -227,11 +227,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
             if (PIN) {
                 if (pk >= 0) {
                     const int pr = pk & 255, pc = (pk >> 8) & 255, i = pk >> 16;
+                    f32x4 v[4];
+                    unpool4x4(ok ? hv[q] : f32x4{0, 0, 0, 0}, hp[q], hi[q], v);
+                    float* w0 = &Hs[(i * Gm::IS + (2 * pr - 1) * Gm::HWD + 2 * pc - 1) * LDC + c4];      // window position 0 (may lie outside the halo)
 #pragma unroll
                     for (int pos = 0; pos < 4; ++pos) {
-                        const int hy = 2 * pr - 1 + (pos >> 1), hx = 2 * pc - 1 + (pos & 1);      // halo pixel of window position pos
-                        if ((unsigned)hy < (unsigned)Gm::HH && (unsigned)hx < (unsigned)Gm::HWD)
-                            *reinterpret_cast<f32x4*>(&Hs[(i * Gm::IS + hy * Gm::HWD + hx) * LDC + c4]) = ok ? unpool4(hv[q], hp[q], hi[q], (unsigned)pos) : f32x4{0, 0, 0, 0};
+                        // halo pixel of window position pos: row 2 pr - 1 + dy in [0, HH), column 2 pc - 1 + dx in [0, HWD)
+                        const bool in = ((pos >> 1) ? pr < Gm::HH / 2 : pr > 0) && ((pos & 1) ? pc < Gm::HWD / 2 : pc > 0);
+                        if (in) *reinterpret_cast<f32x4*>(w0 + ((pos >> 1) * Gm::HWD + (pos & 1)) * LDC) = v[pos];
                     }
                 }
             } else if (pk >= 0) {
@@ -421,11 +424,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2))) v
             if ((NH * kThreads == HCH) || (tid >> 3) + 32 * q < Gm::NPIX) *reinterpret_cast<f32x4*>(&Hs[Gm::lds_pix((tid >> 3) + 32 * q) * CB + c4]) = ((okm >> q) & 1u) ? hv[q] : f32x4{0, 0, 0, 0};
         if (PDZ) {
             const bool ok = (okm >> 16) & 1u;
+            f32x4 v[4];
+            unpool4x4(ok ? dv[0] : f32x4{0, 0, 0, 0}, dp[0], di, v);
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos) {
-                const f32x4 v = ok ? unpool4(dv[0], dp[0], di, (unsigned)pos) : f32x4{0, 0, 0, 0};
-                *reinterpret_cast<f32x4*>(&Ds[((2 * drow0 + (pos >> 1)) * 16 + dcolb + (pos & 1)) * BN + c4]) = v;
-                colsum += v;
+                *reinterpret_cast<f32x4*>(&Ds[((2 * drow0 + (pos >> 1)) * 16 + dcolb + (pos & 1)) * BN + c4]) = v[pos];
+                colsum += v[pos];
             }
         } else {
 #pragma unroll
@@ -736,11 +740,12 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
             if (hm.pk[q] >= 0) Hs[hm.lds[q]] = ((okm >> q) & 1u) ? hv[q] : 0.f;
         if (PDZ) {
             const bool ok = (okm >> 16) & 1u;
+            f32x4 v[4];
+            unpool4x4(ok ? dv[0] : f32x4{0, 0, 0, 0}, dp[0], di, v);
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos) {
-                const f32x4 v = ok ? unpool4(dv[0], dp[0], di, (unsigned)pos) : f32x4{0, 0, 0, 0};
-                *reinterpret_cast<f32x4*>(&Ds[((2 * drow0 + (pos >> 1)) * 16 + dcolb + (pos & 1)) * BN + c4]) = v;
-                colsum += v;
+                *reinterpret_cast<f32x4*>(&Ds[((2 * drow0 + (pos >> 1)) * 16 + dcolb + (pos & 1)) * BN + c4]) = v[pos];
+                colsum += v[pos];
             }
         } else {
 #pragma unroll

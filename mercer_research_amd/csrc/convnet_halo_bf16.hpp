@@ -84,11 +84,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             if (pk < 0) continue;
             if (PIN) {
                 const int pr = pk & 255, pc = (pk >> 8) & 255;
+                f32x4 v[4];
+                unpool4x4(ok ? hv[q] : f32x4{0, 0, 0, 0}, hp[q], hi[q], v);
+                __bf16* w0 = &Hs[((2 * pr - 1) * Gm::HWD + 2 * pc - 1) * LDC + c4];              // window position 0 (may lie outside the halo)
 #pragma unroll
                 for (int pos = 0; pos < 4; ++pos) {
-                    const int hy = 2 * pr - 1 + (pos >> 1), hx = 2 * pc - 1 + (pos & 1);          // halo pixel of window position pos
-                    if ((unsigned)hy < (unsigned)Gm::HH && (unsigned)hx < (unsigned)Gm::HWD)
-                        *reinterpret_cast<bf16x4*>(&Hs[(hy * Gm::HWD + hx) * LDC + c4]) = to_bf16x4(ok ? unpool4(hv[q], hp[q], hi[q], (unsigned)pos) : f32x4{0, 0, 0, 0});
+                    const bool in = ((pos >> 1) ? pr < Gm::HH / 2 : pr > 0) && ((pos & 1) ? pc < Gm::HWD / 2 : pc > 0);
+                    if (in) *reinterpret_cast<bf16x4*>(w0 + ((pos >> 1) * Gm::HWD + (pos & 1)) * LDC) = to_bf16x4(v[pos]);
                 }
             } else {
                 *reinterpret_cast<bf16x4*>(&Hs[(tid / CPP + (kThreads / CPP) * q) * LDC + c4]) = to_bf16x4(ok ? hv[q] : f32x4{0, 0, 0, 0});
