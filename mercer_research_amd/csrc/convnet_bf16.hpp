@@ -487,51 +487,99 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
     f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
 
-    for (int blk = b0; blk < b1; ++blk) {
-        int q = blk;
-        const int tw = q % tiles_w; q /= tiles_w;
-        const int th = q % tiles_h;
-        const int img = q / tiles_h;
+    // Staging in two steps (round 3): the global loads of block blk + 1 are issued into registers before block blk is contracted and
+    // stored to LDS after it -- with one 576-thread workgroup per CU (64 accumulator registers per wave) nothing else covered their
+    // latency.  A thread's chunks: halo chunk q = 4 channels of halo pixel (tid + 576 q) / (CB/4); dZ chunk q likewise over the block's
+    // 128 pixels, or, PDZ, ONE pooled pixel's (dP, P, arg-max), expanded into its window when stored.
+    constexpr int NHQ = (HCH + kWgHaloThreads - 1) / kWgHaloThreads, NDQ = PDZ ? 1 : (DCH + kWgHaloThreads - 1) / kWgHaloThreads;
+    static_assert(!PDZ || 32 * (BN / 4) <= kWgHaloThreads, "one pooled chunk per thread");
+    int hrel[NHQ];                                                    // (hy * W + hx) * Cin + c4, or -1: no such chunk; hy | hx << 8 in hpk
+    int hpk[NHQ];
+#pragma unroll
+    for (int q = 0; q < NHQ; ++q) {
+        const int e = tid + kWgHaloThreads * q;
+        const int pix = e / (CB / 4), c4 = (e - pix * (CB / 4)) * 4;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        hpk[q] = e < HCH ? (hy | (hx << 8)) : -1;
+        hrel[q] = (hy * s.W + hx) * Cin + c4;
+    }
+    f32x4 hv[NHQ], dv[NDQ], dpv = {0.f, 0.f, 0.f, 0.f};
+    unsigned dii = 0, okm = 0;
+    auto gload = [&](int blk) {
+        int q0 = blk;
+        const int tw = q0 % tiles_w; q0 /= tiles_w;
+        const int th = q0 % tiles_h;
+        const int img = q0 / tiles_h;
         const int oh0 = th * kHaloTH, ow0 = tw * kHaloTW;
-        if (blk != b0) __syncthreads();                               // the previous block's images have been consumed
-        for (int e = tid; e < HCH; e += kWgHaloThreads) {             // input halo, channels cb .. cb + CB - 1
-            const int pix = e / (CB / 4), c4 = (e - pix * (CB / 4)) * 4;
-            const int hy = pix / HW, hx = pix - hy * HW;
-            const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
-            const bool ok = (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (ok ? (((long long)img * s.H + ih) * s.W + iw) * Cin + cb + c4 : 0));
-            *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(ok ? v : f32x4{0, 0, 0, 0});
+        const long long hbase = (((long long)img * s.H + oh0 - 1) * s.W + ow0 - 1) * Cin + cb;
+        okm = 0;
+#pragma unroll
+        for (int q = 0; q < NHQ; ++q) {
+            const int pk = hpk[q];
+            const bool ok = pk >= 0 && (unsigned)(oh0 - 1 + (pk & 255)) < (unsigned)s.H && (unsigned)(ow0 - 1 + (pk >> 8)) < (unsigned)s.W;
+            okm |= (ok ? 1u : 0u) << q;
+            hv[q] = *reinterpret_cast<const f32x4*>(X + (ok ? hbase + hrel[q] : 0));
         }
         if (PDZ) {
-            // dZ exists only at pooled resolution: the block's 4 x 8 pooled pixels, one load triple each, expanded into their windows
-            for (int e = tid; e < 32 * (BN / 4); e += kWgHaloThreads) {
-                const int pp = e / (BN / 4), c4 = (e - pp * (BN / 4)) * 4;
+            const int pp = tid / (BN / 4), c4 = (tid - pp * (BN / 4)) * 4;
+            const int poh = (oh0 >> 1) + (pp >> 3), pow_ = (ow0 >> 1) + (pp & 7);
+            const bool ok = tid < 32 * (BN / 4) && poh < (s.H >> 1) && pow_ < (s.W >> 1);
+            okm |= (ok ? 1u : 0u) << 16;
+            const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
+            dv[0] = *reinterpret_cast<const f32x4*>(pdz.dP + o);
+            dpv = *reinterpret_cast<const f32x4*>(pdz.P + o);
+            dii = *reinterpret_cast<const unsigned*>(pdz.idx + o);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NDQ; ++q) {
+                const int e = tid + kWgHaloThreads * q;
+                const int pix = e / (BN / 4), c4 = (e - pix * (BN / 4)) * 4;
+                const int oh = oh0 + pix / kHaloTW, ow = ow0 + pix % kHaloTW;
+                const bool ok = e < DCH && oh < s.H && ow < s.W;
+                okm |= (ok ? 1u : 0u) << (16 + q);
+                dv[q] = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NHQ; ++q) {
+            const int e = tid + kWgHaloThreads * q;
+            const int pix = e / (CB / 4), c4 = (e - pix * (CB / 4)) * 4;
+            if (NHQ * kWgHaloThreads == HCH || e < HCH) *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(((okm >> q) & 1u) ? hv[q] : f32x4{0, 0, 0, 0});
+        }
+        if (PDZ) {
+            if (tid < 32 * (BN / 4)) {
+                const int pp = tid / (BN / 4), c4 = (tid - pp * (BN / 4)) * 4;
                 const int ppy = pp >> 3, ppx = pp & 7;
-                const int poh = (oh0 >> 1) + ppy, pow_ = (ow0 >> 1) + ppx;
-                const bool ok = poh < (s.H >> 1) && pow_ < (s.W >> 1);
-                const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
-                const f32x4 d = *reinterpret_cast<const f32x4*>(pdz.dP + o), pv = *reinterpret_cast<const f32x4*>(pdz.P + o);
-                const unsigned ii = *reinterpret_cast<const unsigned*>(pdz.idx + o);
                 f32x4 v[4];
-                unpool4x4(ok ? d : f32x4{0, 0, 0, 0}, pv, ii, v);
+                unpool4x4(((okm >> 16) & 1u) ? dv[0] : f32x4{0, 0, 0, 0}, dpv, dii, v);
 #pragma unroll
                 for (int pos = 0; pos < 4; ++pos) {
                     *reinterpret_cast<bf16x4*>(&Ds[((2 * ppy + (pos >> 1)) * kHaloTW + 2 * ppx + (pos & 1)) * LDD + c4]) = to_bf16x4(v[pos]);
-                    colsum += v[pos];                                 // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
+                    colsum += v[pos];                                 // fp32, unrounded: the bias gradient (a thread's columns are the same for every block)
                 }
             }
         } else {
-            for (int e = tid; e < DCH; e += kWgHaloThreads) {         // dZ of the block's pixels, channels n0 .. n0 + BN - 1
+#pragma unroll
+            for (int q = 0; q < NDQ; ++q) {
+                const int e = tid + kWgHaloThreads * q;
                 const int pix = e / (BN / 4), c4 = (e - pix * (BN / 4)) * 4;
-                const int oh = oh0 + pix / kHaloTW, ow = ow0 + pix % kHaloTW;
-                const bool ok = oh < s.H && ow < s.W;
-                f32x4 v = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
-                v = ok ? v : f32x4{0, 0, 0, 0};
-                *reinterpret_cast<bf16x4*>(&Ds[pix * LDD + c4]) = to_bf16x4(v);
-                colsum += v;                                          // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
+                if (NDQ * kWgHaloThreads == DCH || e < DCH) {
+                    const f32x4 v = ((okm >> (16 + q)) & 1u) ? dv[q] : f32x4{0, 0, 0, 0};
+                    *reinterpret_cast<bf16x4*>(&Ds[pix * LDD + c4]) = to_bf16x4(v);
+                    colsum += v;                                      // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
+                }
             }
         }
+    };
+
+    if (b0 < b1) gload(b0);
+    for (int blk = b0; blk < b1; ++blk) {
+        if (blk != b0) __syncthreads();                               // the previous block's images have been consumed
+        lstore();
         __syncthreads();
+        if (blk + 1 < b1) gload(blk + 1);                             // the next block's loads fly under this block's MFMAs
 #pragma unroll
         for (int py = 0; py < kHaloTH; ++py) {                        // one 16-pixel contraction step per block row
             bf16x8 af[NA], bf[NT];
