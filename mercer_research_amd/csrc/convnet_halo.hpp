@@ -74,9 +74,30 @@ __device__ inline bool stage_ok(int pk, int y0, int x0, int img0, int Himg, int 
 
 // Epilogue of the LDS-tiled forward / input-gradient kernels (fp32 and bf16 operands alike: the accumulators are fp32): accumulator
 // row i of a lane is block pixel mfma32_row(lane, i) of its wave's 32 pixels (block rows 2 wave, 2 wave + 1).
+// EPI 3's gate values (the layer below's output at the positions this lane is about to write) loaded AHEAD of the item's last MFMAs:
+// inside the epilogue their latency sat on every item's critical path (a 32-channel layer at 224 x 224: 18 MFMAs per item, then
+// sixteen dependent loads, then the stores).
+template <int TW, int NT>
+__device__ inline void halo_gate_prefetch(float (&g)[NT][16], int lane, int wave, int img0, int oh0, int ow0, int n0, const ConvShape& s,
+                                          const float* __restrict__ G) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = n0 + 32 * t + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int pr = mfma32_row(lane, i);
+            const int colb = pr & 15;
+            const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+            const bool ok = img < s.N && oh < s.H && ow < s.W;
+            g[t][i] = G[ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co) : 0u];
+        }
+    }
+}
+
 template <int TW, int NT, int EPI>
 __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave, int img0, int oh0, int ow0, int n0, const ConvShape& s,
-                                     const float* __restrict__ bias, float* __restrict__ Y, uint8_t* __restrict__ pool_idx) {
+                                     const float* __restrict__ bias, float* __restrict__ Y, uint8_t* __restrict__ pool_idx,
+                                     const float (*gate)[16] = nullptr) {
     const int h = lane >> 5;
     if (EPI == 4) {
         // bias + ReLU + the 2x2 max-pool that follows: a lane's sixteen rows are block columns 4h..4h+3 and 8+4h..8+4h+3 of BOTH
@@ -124,7 +145,7 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                     const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co);      // the host keeps tensors below 2^31 elements
                     float v = acc[t][i] + bb;
                     if (EPI == 2) v = v > 0.f ? v : 0.f;
-                    if (EPI == 3) v = bias[o] > 0.f ? v : 0.f;
+                    if (EPI == 3) v = (gate ? gate[t][i] : bias[o]) > 0.f ? v : 0.f;
                     Y[o] = v;
                 }
             }

@@ -178,4 +178,146 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
     }
 }
 
+// k_conv3x3_halo_bf16_1cb -- the same for layers of exactly 32 input channels (one channel block).  A phase of the kernel above is then
+// 6 / 12 MFMAs between two barriers and a restaged weight row -- on the 224 x 224 net's 32-channel layers (6.4 M pixels each) it ran
+// at 2.2 x its HBM floor.  Here ALL nine taps' weights of a column block (9 x BN x 32 halves: 23 / 46 KB) are staged once and stay
+// while the workgroup walks its items (the column block only changes when the layer has more than BN output channels); an item is its
+// halo (prefetched under the previous item's MFMAs), 18 / 36 MFMAs, its epilogue: two barriers per item.
+template <int BN, int EPI, bool PIN = false>
+__global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const float* __restrict__ X, const __bf16* __restrict__ WB, const float* __restrict__ bias,
+                                                                   float* __restrict__ Y, ConvShape s, int tiles_w, int tiles_h, int n_items,
+                                                                   uint8_t* __restrict__ pool_idx, PooledGrad pin) {
+    using Gm = HaloGeom<16>;
+    constexpr int CB = 32, TW = 16, NT = BN / 32, LDC = CB + 8, CPP = CB / 4, K = 9 * CB;
+    constexpr int PPW = TW / 2 + 2;
+    constexpr int GR = PIN ? 6 : Gm::HH, GC = PIN ? PPW : Gm::HWD;
+    constexpr int NH = (GR * GC * CPP + kThreads - 1) / kThreads;
+    constexpr int BCH = BN * (K / 8), NB = (BCH + kThreads - 1) / kThreads;          // 16-byte chunks of the column block's weights: 36 per output channel
+    __shared__ __attribute__((aligned(16))) __bf16 Hs[Gm::NPIX * LDC];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[9 * BN * LDC];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nblk = s.Cout / BN;
+    const int GH = PIN ? s.H >> 1 : s.H, GW = PIN ? s.W >> 1 : s.W;
+    const int r = lane & 31, h = lane >> 5;
+    const int py = 2 * wave + (r >> 4), px = r & 15;
+
+    struct Item { int img0, oh0, ow0, n0; };
+    struct Pos { int nb, tw, th, g; };
+    auto split = [&](int item) { Pos p; p.nb = item % nblk; item /= nblk; p.tw = item % tiles_w; item /= tiles_w; p.th = item % tiles_h; p.g = item / tiles_h; return p; };
+    const Pos stride = split((int)gridDim.x);
+    auto advance = [&](Pos p) {
+        p.nb += stride.nb; if (p.nb >= nblk) { p.nb -= nblk; ++p.tw; }
+        p.tw += stride.tw; if (p.tw >= tiles_w) { p.tw -= tiles_w; ++p.th; }
+        p.th += stride.th; if (p.th >= tiles_h) { p.th -= tiles_h; ++p.g; }
+        p.g += stride.g;
+        return p;
+    };
+    auto item_of = [&](const Pos& p) { return Item{p.g, p.th * Gm::TH, p.tw * TW, p.nb * BN}; };
+
+    StageMap<NH> hm;
+    stage_map_init<NH, GR, GC, 1, CPP>(hm, tid);
+    f32x4 hv[NH], hp[PIN ? NH : 1];
+    unsigned hi[PIN ? NH : 1];
+    unsigned okm = 0;
+    auto halo_load = [&](const Item& it) {
+        const int y0 = PIN ? (it.oh0 >> 1) - 1 : it.oh0 - 1, x0 = PIN ? (it.ow0 >> 1) - 1 : it.ow0 - 1;
+        const int base = ((it.img0 * GH + y0) * GW + x0) * CB;
+        okm = 0;
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int pk = hm.pk[q];
+            const bool ok = stage_ok(pk, y0, x0, it.img0, GH, GW, s.N);
+            okm |= (ok ? 1u : 0u) << q;
+            const unsigned off = ok ? (unsigned)(base + stage_rel<CPP>(pk, tid, GH, GW, CB)) : 0u;
+            if (PIN) {
+                hv[q] = *reinterpret_cast<const f32x4*>(pin.dP + off);
+                hp[q] = *reinterpret_cast<const f32x4*>(pin.P + off);
+                hi[q] = *reinterpret_cast<const unsigned*>(pin.idx + off);
+            } else {
+                hv[q] = *reinterpret_cast<const f32x4*>(X + off);
+            }
+        }
+    };
+    auto halo_store = [&]() {
+        const int c4 = (tid % CPP) * 4;
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const bool ok = (okm >> q) & 1u;
+            const int pk = hm.pk[q];
+            if (pk < 0) continue;
+            if (PIN) {
+                const int pr = pk & 255, pc = (pk >> 8) & 255;
+                f32x4 v[4];
+                unpool4x4(ok ? hv[q] : f32x4{0, 0, 0, 0}, hp[q], hi[q], v);
+                __bf16* w0 = &Hs[((2 * pr - 1) * Gm::HWD + 2 * pc - 1) * LDC + c4];
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const bool in = ((pos >> 1) ? pr < Gm::HH / 2 : pr > 0) && ((pos & 1) ? pc < Gm::HWD / 2 : pc > 0);
+                    if (in) *reinterpret_cast<bf16x4*>(w0 + ((pos >> 1) * Gm::HWD + (pos & 1)) * LDC) = to_bf16x4(v[pos]);
+                }
+            } else {
+                *reinterpret_cast<bf16x4*>(&Hs[(tid / CPP + (kThreads / CPP) * q) * LDC + c4]) = to_bf16x4(ok ? hv[q] : f32x4{0, 0, 0, 0});
+            }
+        }
+    };
+    // the column block's weights: output channel co's nine taps x 32 channels are 288 consecutive halves of WB; chunk e = 8 of them
+    auto weights_in = [&](int n0) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int e = tid + kThreads * q;
+            if (NB * kThreads == BCH || e < BCH) {
+                const int co = e / (K / 8), j = e - co * (K / 8);
+                *reinterpret_cast<bf16x8*>(&Bs[((j >> 2) * BN + co) * LDC + (j & 3) * 8]) = *reinterpret_cast<const bf16x8*>(WB + (long long)(n0 + co) * K + j * 8);
+            }
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    Pos pos = split(item);
+    Item cur = item_of(pos);
+    halo_load(cur);
+    int loaded_n0 = -1;
+    bool first = true;
+#pragma unroll 1
+    for (; item < n_items; item += gridDim.x) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        const int nitem = item + gridDim.x;
+        pos = advance(pos);
+        const Item nxt = item_of(pos);
+        if (!first) __syncthreads();                                  // the previous item's operands have been consumed
+        first = false;
+        if (cur.n0 != loaded_n0) { weights_in(cur.n0); loaded_n0 = cur.n0; }
+        halo_store();
+        __syncthreads();
+        if (nitem < n_items) halo_load(nxt);
+        // (EPI 3, one column tile: the gate values are loaded ahead of the MFMAs -- sixteen registers; with two tiles they spill)
+        constexpr bool GATE_AHEAD = EPI == 3 && NT == 1;
+        float gate[NT][16];
+        if constexpr (GATE_AHEAD) halo_gate_prefetch<TW, NT>(gate, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const __bf16* a = &Hs[((py + kh) * Gm::HWD + px + kw) * LDC + 8 * h];
+                const __bf16* b = &Bs[((kh * 3 + kw) * BN + r) * LDC + 8 * h];
+#pragma unroll
+                for (int ks = 0; ks < CB / 16; ++ks) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a + 16 * ks);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(b + 32 * t * LDC + 16 * ks);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        halo_epilogue<TW, NT, EPI>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx, GATE_AHEAD ? gate : nullptr);
+        cur = nxt;
+    }
+}
+
 }  // namespace rcnx

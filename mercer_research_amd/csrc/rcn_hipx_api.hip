@@ -212,12 +212,23 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #define HBP_EPI(CI_, BN_) do { if (pin) { if (kepi == 3) HBP_LAUNCH(CI_, BN_, 3, true); else if (kepi == 0) HBP_LAUNCH(CI_, BN_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
                                else if (kepi == 0) HBP_LAUNCH(CI_, BN_, 0, false); else if (kepi == 1) HBP_LAUNCH(CI_, BN_, 1, false); else if (kepi == 2) HBP_LAUNCH(CI_, BN_, 2, false); \
                                else if (kepi == 3) HBP_LAUNCH(CI_, BN_, 3, false); else HBP_LAUNCH(CI_, BN_, 4, false); } while (0)
+#define HB1_LAUNCH(BN_, EPI_, PIN_) do { const long long slots = resident_slots(n, (const void*)k_conv3x3_halo_bf16_1cb<BN_, EPI_, PIN_>); \
+                hipLaunchKernelGGL((k_conv3x3_halo_bf16_1cb<BN_, EPI_, PIN_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, (int)items, pool_idx, pg); } while (0)
+#define HB1_EPI(BN_) do { if (pin) { if (kepi == 3) HB1_LAUNCH(BN_, 3, true); else if (kepi == 0) HB1_LAUNCH(BN_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
+                          else if (kepi == 0) HB1_LAUNCH(BN_, 0, false); else if (kepi == 1) HB1_LAUNCH(BN_, 1, false); else if (kepi == 2) HB1_LAUNCH(BN_, 2, false); \
+                          else if (kepi == 3) HB1_LAUNCH(BN_, 3, false); else HB1_LAUNCH(BN_, 4, false); } while (0)
+                static const int onecb = [] { const char* e = std::getenv("RCN_HIPX_BF16_1CB"); return e ? std::atoi(e) : 1; }();
                 if (items <= 0x7fffffffLL) {
-                    if (s.Cin == 32) { if (hbn == 64) HBP_EPI(32, 64); else HBP_EPI(32, 32); }
+                    // one channel block and one 32-wide column tile: all nine taps' weights stay in LDS (with a 64-wide tile the 46 KB of weights
+                    // cost a third workgroup per CU: measured 190 vs 158 us on the 32 -> 64 layer of the 224 x 224 net)
+                    if (s.Cin == 32 && onecb && hbn == 32) HB1_EPI(32);
+                    else if (s.Cin == 32) { if (hbn == 64) HBP_EPI(32, 64); else HBP_EPI(32, 32); }
                     else { if (hbn == 64) HBP_EPI(64, 64); else HBP_EPI(64, 32); }
                     XTRY(n, hipGetLastError());
                     return 0;
                 }
+#undef HB1_EPI
+#undef HB1_LAUNCH
 #undef HBP_EPI
 #undef HBP_LAUNCH
             }
