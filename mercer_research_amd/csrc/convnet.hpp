@@ -444,7 +444,7 @@ __device__ inline void store_flipped(const FlipSpec& f, long long i, float v) {
 // All layers' slabs in ONE launch at the end of the backward pass (a launch per layer -- two above 64 chunks -- was 5-9 us each of
 // mostly latency, seven of them per CIFAR step).  Nothing updates a weight before every input-gradient kernel has read it, so the
 // jobs are independent.  Job q owns workgroups [first_block, next job's first_block); a workgroup of 1024 threads sums 1024 / g elements
-// in g chunk groups (g = the power of two at or above the chunk count, at most 32); groups are combined in order: bit-reproducible.
+// in g chunk groups (g = the power of two at or above the chunk count, at most 32); groups are combined as a fixed tree: bit-reproducible.
 constexpr int kMaxReduceJobs = 16;
 struct ReduceJob {
     float* p;                 // [W | b] of the layer
@@ -482,10 +482,15 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_all(ReduceJobs J) {
         }
     }
     red[grp * EL + el] = g;
+    // the chunk groups combined as a fixed binary tree by all threads (instead of one thread per element walking up to 32 partial sums
+    // in LDS; measured: no difference -- the kernel's time is the slab's bytes, 224 us for ~300 MB on the 224 x 224 net)
+    for (int st = GR >> 1; st >= 1; st >>= 1) {
+        __syncthreads();
+        if (grp < st) red[grp * EL + el] += red[(grp + st) * EL + el];
+    }
     __syncthreads();
     if ((int)threadIdx.x < EL && i < jb.n) {
-        float t = 0.f;
-        for (int r = 0; r < GR; ++r) t += red[r * EL + threadIdx.x];
+        const float t = red[threadIdx.x];
         if (jb.grad) jb.grad[i] = t;
         if (J.apply) { const float v = jb.p[i] - J.lr * t; jb.p[i] = v; store_flipped(jb.flip, i, v); }
     }
