@@ -396,7 +396,9 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         // Pixel blocks per chunk: every chunk costs one (K+1) x Cout partial tile written and read back by the reduce, so aim at
         // `target` workgroups in total (tiles per chunk x chunks) rather than at a fixed chunk count -- wide layers have many
         // tiles per chunk and need few chunks.
-        static const int target = [] { const char* e = std::getenv("RCN_HIPX_WGH_TARGET"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 512; }();
+        // (256 = one per CU: the 576-thread workgroup with its 64+ accumulator registers per wave is alone on its CU anyway, and every
+        // chunk fewer is a partial [W | b] less to write and reduce: synth-224 bf16 5.20 ms at 512, 5.05 at 256, 5.49 at 384 -- 1.5 per CU)
+        static const int target = [] { const char* e = std::getenv("RCN_HIPX_WGH_TARGET"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
         const long long tiles = (long long)(s.Cin / hb) * (s.Cout / hbn);
         int bpc = (int)((blocks * tiles + target - 1) / target);
         if (bpc < 8) bpc = blocks < 8 ? (int)blocks : 8;
