@@ -33,6 +33,37 @@ __global__ void k_prep_weights_bf16(const float* __restrict__ src, int R, int C,
     }
 }
 
+// The same for every layer and both orientations in ONE launch at the start of a step (a launch per layer and pass was 5 us each, six of
+// them on the CIFAR net: 9 % of the bf16 step).  The weights only change in the step's last kernel, so copies made at its start
+// serve the forward and the backward pass.  Job q owns workgroups [first_block, next job's first_block), one 32 x 32 tile each.
+constexpr int kMaxPrepJobs = 32;
+struct PrepJob { const float* src; __bf16* dst; int R, C, Rp, first_block; };
+struct PrepJobs { PrepJob j[kMaxPrepJobs]; int njobs; };
+__host__ __device__ inline int prep_job_blocks(int C, int Rp) { return ((C + 31) / 32) * (Rp / 32); }      // 32 x 32 tiles (Rp is a multiple of 32)
+__global__ __launch_bounds__(256) void k_prep_all_bf16(PrepJobs J) {
+    // a workgroup transposes one 32 (r) x 32 (c) tile through LDS: rows of src read along c, rows of dst written along r -- both sides in
+    // whole 64 / 128-byte pieces (element by element one side is strided: the 16 per-layer launches of the 224 x 224 net took 88 us, one
+    // launch of the same loop 100)
+    __shared__ float tile[32][33];
+    int q = 0;
+    while (q + 1 < J.njobs && (int)blockIdx.x >= J.j[q + 1].first_block) ++q;
+    const PrepJob jb = J.j[q];
+    const int lb = (int)blockIdx.x - jb.first_block, tiles_r = jb.Rp / 32;
+    const int r0 = (lb % tiles_r) * 32, c0 = (lb / tiles_r) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = r0 + ty + 8 * u, c = c0 + tx;
+        tile[ty + 8 * u][tx] = (r < jb.R && c < jb.C) ? jb.src[(long long)r * jb.C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = c0 + ty + 8 * u, r = r0 + tx;
+        if (c < jb.C) jb.dst[(long long)c * jb.Rp + r] = (__bf16)tile[tx][ty + 8 * u];
+    }
+}
+
 __device__ inline bf16x4 to_bf16x4(const f32x4& v) {
     bf16x4 h;
     h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];

@@ -48,6 +48,7 @@ struct Layer {
     bool pool_follows = false;
     Buf out, idx, dout;     // activation (post-ReLU / pooled), pool arg-max, gradient wrt the layer's OUTPUT
     Buf slab;               // partial [W | b] tiles of the weight-gradient kernels (reduced for all layers at once: k_reduce_all)
+    long long wbf_off = -1, wbb_off = -1;   // bf16 mode: this layer's transposed bf16 weight copies in net->wb16 (forward / input-gradient operand)
 };
 
 struct Key { const void* x; const void* y; int B; float lr; const void* loss;
@@ -70,6 +71,7 @@ struct rcn_hipx_net {
     Buf params, wt, dz, loss_part, grad_tmp, dlogits, skbuf, wb;      // wt: tap-flipped transposed weights, laid out like params (w_off)
     Buf* slab_sel = nullptr;                // where the weight-gradient launch in progress puts its partial tiles (a layer's slab)
     ReduceJobs jobs{};                      // the step's pending slab reductions
+    Buf wb16; PrepJobs prep{}; long long prep_blocks = 0;      // bf16 mode: every layer's bf16 operand copies, made by ONE launch per step
     int precision = RCN_HIPX_FP32;          // GEMM operand precision of forward / dgrad (rcn_hipx_set_precision)
     int tiling = RCN_HIPX_TILING_AUTO;      // fp32 3x3 kernels: implicit GEMM only / by shape / LDS-tiled wherever they apply (rcn_hipx_set_tiling)
     std::map<Key, hipGraphExec_t> graphs;
@@ -171,7 +173,7 @@ bool conv_halo_runs(const rcn_hipx_net* n, const ConvShape& s) {
 }
 
 int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi, uint8_t* pool_idx = nullptr,
-                const PooledGrad* pin = nullptr, bool force_fp32 = false) {
+                const PooledGrad* pin = nullptr, bool force_fp32 = false, const __bf16* wb_ready = nullptr) {
     const long long M = (long long)s.N * s.H * s.W;
     const bool smallc = ks * ks * s.Cin <= 32 && s.Cin % 32 != 0;   // the per-element gather loader: only where a k-tile is not 32 whole channels
     if (!smallc && s.Cin % 32) return fail(n, -3, "input channels must be a multiple of 32 (or the whole 3x3xCin patch <= 32)");
@@ -192,9 +194,12 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     if (bf16) {
         // operands rounded to bf16: the weights once here, transposed to [Cout][Kp]; the activations inside the kernel
         const int K = ks * ks * s.Cin, Kp = (K + 31) / 32 * 32;
-        XTRY(n, scratch_ensure(n, n->wb, (size_t)s.Cout * Kp * sizeof(__bf16)));
-        hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
-        const __bf16* WB = (const __bf16*)n->wb.p;
+        const __bf16* WB = wb_ready;                                    // made for all layers at the start of the step (prep_bf16_weights)
+        if (!WB) {
+            XTRY(n, scratch_ensure(n, n->wb, (size_t)s.Cout * Kp * sizeof(__bf16)));
+            hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
+            WB = (const __bf16*)n->wb.p;
+        }
         // thin 3x3 layers: the LDS-tiled kernel (one halo per 8x16 output block serves all nine taps)
         if (epi == 4 && !(ks == 3 && conv_pool_fusable(n, s))) return fail(n, -3, "internal: fused conv+pool epilogue requested for a layer the LDS-tiled kernel does not cover");
         if (halo_enabled() && ks == 3 && !smallc && Z == 1 && (s.Cin == 32 || s.Cin % 64 == 0)) {
@@ -467,6 +472,58 @@ int stream_after(rcn_hipx_net* n, hipStream_t from, hipStream_t to) {
 
 bool head_fusable(const rcn_hipx_net* n);
 
+// bf16 mode: a layer's prepared bf16 operand copy (nullptr: none -- launch_conv then makes its own)
+const __bf16* wb_of(const rcn_hipx_net* n, long long off) {
+    return (n->precision == RCN_HIPX_BF16 && n->wb16.p && off >= 0) ? (const __bf16*)n->wb16.p + off : (const __bf16*)nullptr;
+}
+
+// bf16 mode, once per step / forward call: the transposed bf16 copies of every layer's weights -- [Cout][Kp] for the forward pass from W,
+// [Cin][Kp'] for the input gradient from the flipped copy (which the update kernel keeps current) -- in ONE launch.  The first layer
+// (fp32 kernels in either mode) has none.
+int prep_bf16_weights(rcn_hipx_net* n) {
+    if (n->precision != RCN_HIPX_BF16) return 0;
+    if (!n->wb16.p) {
+        long long off = 0;
+        int q = 0;
+        long long blocks = 0;
+        std::vector<std::tuple<size_t, int, long long>> plan;      // (layer, orientation, offset)
+        for (size_t i = 1; i < n->L.size(); ++i) {
+            Layer& l = n->L[i];
+            if (l.kind == RCN_HIPX_MAXPOOL2) continue;
+            const int ks = l.kind == RCN_HIPX_CONV3X3_RELU ? 3 : 1;
+            const long long cin = l.kind == RCN_HIPX_CONV3X3_RELU ? l.Cin : l.K;
+            const long long Kf = (long long)ks * ks * cin, Kpf = (Kf + 31) / 32 * 32;                 // forward: [CoutP][Kpf]
+            const long long Kb = (long long)ks * ks * l.CoutP, Kpb = (Kb + 31) / 32 * 32;              // input gradient: [cin][Kpb]
+            l.wbf_off = off; off += (long long)l.CoutP * Kpf;
+            l.wbb_off = off; off += cin * Kpb;
+            off = (off + 63) / 64 * 64;
+            q += 2;
+        }
+        if (q > kMaxPrepJobs) { for (Layer& l : n->L) l.wbf_off = l.wbb_off = -1; return 0; }       // more layers than one launch takes: per-layer copies as before
+        XTRY(n, n->wb16.ensure((size_t)(off > 0 ? off : 1) * sizeof(__bf16)));
+        n->prep.njobs = 0;
+        for (size_t i = 1; i < n->L.size(); ++i) {
+            Layer& l = n->L[i];
+            if (l.kind == RCN_HIPX_MAXPOOL2) continue;
+            const int ks = l.kind == RCN_HIPX_CONV3X3_RELU ? 3 : 1;
+            const long long cin = l.kind == RCN_HIPX_CONV3X3_RELU ? l.Cin : l.K;
+            const long long Kf = (long long)ks * ks * cin, Kpf = (Kf + 31) / 32 * 32, Kb = (long long)ks * ks * l.CoutP, Kpb = (Kb + 31) / 32 * 32;
+            PrepJob& a = n->prep.j[n->prep.njobs++];
+            a = PrepJob{(const float*)P(n, l.w_off), (__bf16*)n->wb16.p + l.wbf_off, (int)Kf, l.CoutP, (int)Kpf, (int)blocks};
+            blocks += prep_job_blocks(l.CoutP, (int)Kpf);
+            PrepJob& b = n->prep.j[n->prep.njobs++];
+            b = PrepJob{(const float*)n->wt.p + l.w_off, (__bf16*)n->wb16.p + l.wbb_off, (int)Kb, (int)cin, (int)Kpb, (int)blocks};
+            blocks += prep_job_blocks((int)cin, (int)Kpb);
+        }
+        n->prep_blocks = blocks;
+    }
+    if (n->prep.njobs) {
+        hipLaunchKernelGGL(k_prep_all_bf16, dim3((unsigned)n->prep_blocks), dim3(256), 0, n->stream, n->prep);
+        XTRY(n, hipGetLastError());
+    }
+    return 0;
+}
+
 // forward for batch B; returns pointer to logits (padded rows of CoutP)
 int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1) {
     const float* cur = x;
@@ -482,16 +539,16 @@ int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1
             if (l.pool_follows && conv_pool_fusable(n, cs)) {
                 // the pool that follows runs in this kernel's epilogue: only the pooled map (and its arg-max image) is written
                 Layer& pl = n->L[i + 1];
-                RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)pl.out.p, cs, 3, 4, (uint8_t*)pl.idx.p));
+                RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)pl.out.p, cs, 3, 4, (uint8_t*)pl.idx.p, nullptr, false, wb_of(n, l.wbf_off)));
                 cur = (const float*)pl.out.p;
                 ++i;
                 continue;
             }
-            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, cs, 3, 2));
+            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, cs, 3, 2, nullptr, nullptr, false, wb_of(n, l.wbf_off)));
         } else {
             // (the logits layer of a head that training runs as k_head_f32 is fp32 here too: what bf16 mode rounds is a matter of shape)
             RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, ConvShape{B, 1, 1, l.K, l.CoutP}, 1, l.kind == RCN_HIPX_DENSE_RELU ? 2 : 1, nullptr, nullptr,
-                             i + 1 == n->L.size() && head_fusable(n)));
+                             i + 1 == n->L.size() && head_fusable(n), wb_of(n, l.wbf_off)));
         }
         cur = (const float*)l.out.p;
     }
@@ -586,7 +643,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
             const Layer& below = n->L[i - 1];
             const bool gate = below.kind == RCN_HIPX_CONV3X3_RELU || below.kind == RCN_HIPX_DENSE_RELU;
             RTRY(launch_conv(n, dZ, wt, gate ? (const float*)below.out.p : nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, gate ? 3 : 0,
-                             nullptr, pooled[i].dP ? &pooled[i] : nullptr));
+                             nullptr, pooled[i].dP ? &pooled[i] : nullptr, false, wb_of(n, l.wbb_off)));
             gated[i - 1] = gate;
         }
         int chunks = 0;
@@ -672,6 +729,7 @@ int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers);
 // forward + loss + backward of one batch: parameters updated in place (apply) or gradients written to grad (padded layout)
 int step_core(rcn_hipx_net* n, const float* x, const int32_t* labels, int B, float lr, float* grad, bool apply, float* loss_dev) {
     n->jobs.njobs = 0;
+    RTRY(prep_bf16_weights(n));
     if (head_fusable(n)) {
         const int last = (int)n->L.size() - 1;
         RTRY(forward(n, x, B, (size_t)last));
@@ -761,7 +819,7 @@ void rcn_hipx_destroy(rcn_hipx_net* n) {
         if (n->stream) (void)hipStreamSynchronize(n->stream);
         drop_graphs(n);
         for (Layer& l : n->L) { l.out.release(); l.idx.release(); l.dout.release(); l.slab.release(); }
-        for (Buf* b : {&n->params, &n->wt, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf, &n->wb}) b->release();
+        for (Buf* b : {&n->params, &n->wt, &n->wb16, &n->dz, &n->loss_part, &n->grad_tmp, &n->dlogits, &n->skbuf, &n->wb}) b->release();
         if (n->side) { (void)hipStreamSynchronize(n->side); (void)hipStreamDestroy(n->side); }
         for (hipEvent_t e : n->events) (void)hipEventDestroy(e);
         if (n->own_stream && n->stream) (void)hipStreamDestroy(n->stream);
@@ -846,6 +904,7 @@ int rcn_hipx_forward_dev(rcn_hipx_net* n, const float* x, int B, float* logits) 
     if (!n || !x || !logits) return -1;
     RTRY(ensure_batch(n, B));
     Dev g(n->device);
+    RTRY(prep_bf16_weights(n));
     RTRY(forward(n, x, B));
     const Layer& l = n->L.back();
     XTRY(n, hipMemcpy2DAsync(logits, (size_t)n->classes * sizeof(float), l.out.p, (size_t)l.CoutP * sizeof(float), (size_t)n->classes * sizeof(float), (size_t)B,
