@@ -130,6 +130,9 @@ int splitk_z(long long M, int Cout, int bn, int nkt) {
     const long long tiles = ((M + kBM - 1) / kBM) * (Cout / bn);
     int Z = 1;
     if (tiles < 256 && nkt >= 8) { Z = (int)(512 / tiles); if (Z > nkt / 4) Z = nkt / 4; if (Z < 1) Z = 1; }
+    // every partial is summed by ONE thread per element in k_splitk_epilogue: 392 of them on a 128 x 32 output (the 50176 -> 10 layer of the
+    // 224 x 224 net) made that kernel 101 us for 4096 sums
+    if (Z > 64) Z = 64;
     return Z;
 }
 
