@@ -76,6 +76,10 @@ int  rcn_hipx_gradients_dev(rcn_hipx_net* net, const float* x_dev, const int32_t
 int  rcn_hipx_apply_dev(rcn_hipx_net* net, const float* grad_dev, float scale);
 /* logical-layout copy of a padded gradient buffer (tests) */
 int  rcn_hipx_unpad_host(rcn_hipx_net* net, const float* padded_dev, float* logical_host);
+/* Which kernels a training step of this net WOULD launch, one line per launch, written to `out` (NUL-terminated, truncated at `cap`).
+ * Pure host code -- no GPU is needed or touched: the dispatch code of the step runs with its launches replaced by notes, so the text is
+ * the library's own decision, not a restatement of it (tests/test_convnet_plan.py holds the BASELINE configurations' plans). */
+int  rcn_hipx_plan(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int batch, int precision, int tiling, char* out, int cap);
 /* algorithmic FLOPs of one training step at batch B (2 * MACs; forward + dgrad + wgrad) */
 int  rcn_hipx_step_flops(const rcn_hipx_net* net, int B, double* flops);
 

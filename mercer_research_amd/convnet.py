@@ -39,6 +39,7 @@ SIGNATURES = {
     "rcn_hipx_set_tiling": (_i, [_vp, _i]),
     "rcn_hipx_set_overlap": (_i, [_vp, _i]),
     "rcn_hipx_step_flops": (_i, [_vp, _i, C.POINTER(C.c_double)]),
+    "rcn_hipx_plan": (_i, [_i, _i, _i, C.POINTER(XLayer), _i, _i, _i, _i, C.c_char_p, _i]),
 }
 _libx = None
 
@@ -59,6 +60,20 @@ def load():
 
 class ConvNetError(RuntimeError):
     pass
+
+
+def plan(in_shape: Tuple[int, int, int], layers: Sequence[tuple], batch: int, precision: str = "fp32", tiling: str = "auto") -> str:
+    """Which kernels a training step of this net would launch, one line per launch (rcn_hipx_plan): the library's own dispatch code run
+    with its launches replaced by notes.  Needs no GPU."""
+    lib = load()
+    arr = (XLayer * len(layers))()
+    for i, l in enumerate(layers):
+        arr[i].kind, arr[i].out = KIND[l[0]], int(l[1]) if len(l) > 1 else 0
+    buf = C.create_string_buffer(1 << 16)
+    st = lib.rcn_hipx_plan(in_shape[0], in_shape[1], in_shape[2], arr, len(layers), batch, {"fp32": 0, "bf16": 1}[precision], {"gemm": 0, "auto": 1, "lds": 2}[tiling], buf, len(buf))
+    if st != 0:
+        raise ConvNetError(f"rcn_hipx_plan: {st}: {buf.value.decode()}")
+    return buf.value.decode()
 
 
 class ConvNet:

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -66,6 +68,8 @@ struct rcn_hipx_net {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> events; size_t ev_next = 0;
     int overlap = 0;
+    bool dry = false;                       // rcn_hipx_plan: walk a step's dispatch decisions, record what WOULD be launched, touch no device
+    std::string plan;
     std::vector<Layer> L;
     long long n_pad = 0, n_log = 0;
     Buf params, wt, dz, loss_part, grad_tmp, dlogits, skbuf, wb;      // wt: tap-flipped transposed weights, laid out like params (w_off)
@@ -81,6 +85,18 @@ struct rcn_hipx_net {
 namespace {
 
 int fail(rcn_hipx_net* n, int code, const std::string& m) { if (n) n->err = m; return code; }
+// dry run (rcn_hipx_plan): note the launch that the code in front of this call has decided on and tell the caller to return
+bool dry_note(rcn_hipx_net* n, const char* fmt, ...) {
+    if (!n->dry) return false;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    n->plan += buf;
+    n->plan += "\n";
+    return true;
+}
 #define XTRY(net, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(net, e_ == hipErrorOutOfMemory ? -7 : -4, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 #define RTRY(expr) do { int s_ = (expr); if (s_ != 0) return s_; } while (0)
 
@@ -88,6 +104,7 @@ void drop_graphs(rcn_hipx_net* n);
 // scratch buffers that captured graphs point into: one that grows moves, and every cached graph would replay on freed memory --
 // drop them, they are re-captured on demand (sizes are settled by the eager step that precedes every capture)
 hipError_t scratch_ensure(rcn_hipx_net* n, Buf& b, size_t bytes) {
+    if (n->dry) return hipSuccess;
     const void* before = b.p;
     const hipError_t e = b.ensure(bytes);
     if (e == hipSuccess && before && b.p != before) drop_graphs(n);
@@ -200,7 +217,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
         const __bf16* WB = wb_ready;                                    // made for all layers at the start of the step (prep_bf16_weights)
         if (!WB) {
             XTRY(n, scratch_ensure(n, n->wb, (size_t)s.Cout * Kp * sizeof(__bf16)));
-            hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
+            if (!n->dry) hipLaunchKernelGGL(k_prep_weights_bf16, dim3(grid1d((long long)s.Cout * Kp, 256)), dim3(256), 0, n->stream, Wk, K, s.Cout, (__bf16*)n->wb.p, Kp);
             WB = (const __bf16*)n->wb.p;
         }
         // thin 3x3 layers: the LDS-tiled kernel (one halo per 8x16 output block serves all nine taps)
@@ -226,6 +243,8 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
                           else if (kepi == 0) HB1_LAUNCH(BN_, 0, false); else if (kepi == 1) HB1_LAUNCH(BN_, 1, false); else if (kepi == 2) HB1_LAUNCH(BN_, 2, false); \
                           else if (kepi == 3) HB1_LAUNCH(BN_, 3, false); else HB1_LAUNCH(BN_, 4, false); } while (0)
                 static const int onecb = [] { const char* e = std::getenv("RCN_HIPX_BF16_1CB"); return e ? std::atoi(e) : 1; }();
+                if (items <= 0x7fffffffLL && dry_note(n, "  %s %dx%dx%d->%d epi %d%s: %s, %lld items", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, kepi, pin ? " pooled-in" : "",
+                                                      (s.Cin == 32 && onecb && hbn == 32) ? "k_conv3x3_halo_bf16_1cb<32>" : "k_conv3x3_halo_bf16p", items)) return 0;
                 if (items <= 0x7fffffffLL) {
                     // one channel block and one 32-wide column tile: all nine taps' weights stay in LDS (with a 64-wide tile the 46 KB of weights
                     // cost a third workgroup per CU: measured 190 vs 158 us on the 32 -> 64 layer of the 224 x 224 net)
@@ -243,6 +262,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #define HALO_CASE(CI_, BN_, EPI_) do { if (pin) hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_, true>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx, pg); \
                                        else hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_, false>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx, pg); } while (0)
 #define HALO_EPI(CI_, BN_) do { if (kepi == 0) HALO_CASE(CI_, BN_, 0); else if (kepi == 1) HALO_CASE(CI_, BN_, 1); else if (kepi == 2) HALO_CASE(CI_, BN_, 2); else if (kepi == 3) HALO_CASE(CI_, BN_, 3); else HALO_CASE(CI_, BN_, 4); } while (0)
+            if (dry_note(n, "  conv3x3 %dx%dx%d->%d epi %d%s: k_conv3x3_halo_bf16", s.H, s.W, s.Cin, s.Cout, kepi, pin ? " pooled-in" : "")) return 0;
             if (s.Cin == 32) { if (hbn == 64) HALO_EPI(32, 64); else HALO_EPI(32, 32); }
             else { if (hbn == 64) HALO_EPI(64, 64); else HALO_EPI(64, 32); }
 #undef HALO_EPI
@@ -254,6 +274,8 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #define CONVB_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd_bf16<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s)
 #define CONVB_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONVB_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONVB_CASE(KS_, SM_, BN_, 1); else if (kepi == 2) CONVB_CASE(KS_, SM_, BN_, 2); else CONVB_CASE(KS_, SM_, BN_, 3); } while (0)
 #define CONVB_BN(KS_, SM_) do { if (bn == 128) CONVB_EPI(KS_, SM_, 128); else if (bn == 64) CONVB_EPI(KS_, SM_, 64); else CONVB_EPI(KS_, SM_, 32); } while (0)
+        if (dry_note(n, "  %s %dx%dx%d->%d epi %d: k_conv_fwd_bf16<%d, %s, %d>%s", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, epi, ks, smallc ? "gather" : "tile", bn,
+                     Z > 1 ? (" split-K " + std::to_string(Z) + " + k_splitk_epilogue").c_str() : "")) return 0;
         if (ks == 3) { if (smallc) CONVB_BN(3, true); else CONVB_BN(3, false); }
         else { if (smallc) CONVB_BN(1, true); else CONVB_BN(1, false); }
 #undef CONVB_BN
@@ -270,6 +292,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #define C1_LAUNCH(CIN_, TW_, EPI_) do { const long long slots = resident_slots(n, (const void*)k_conv1_fwd_f32<CIN_, TW_, EPI_>); \
             hipLaunchKernelGGL((k_conv1_fwd_f32<CIN_, TW_, EPI_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, Wk, bias, Y, s, tiles_w, tiles_h, (int)items, pool_idx); } while (0)
 #define C1_EPI(CIN_, TW_) do { if (epi == 4) C1_LAUNCH(CIN_, TW_, 4); else C1_LAUNCH(CIN_, TW_, 2); } while (0)
+            if (dry_note(n, "  conv3x3 %dx%dx%d->%d epi %d: k_conv1_fwd_f32<%d, %d>, %lld items", s.H, s.W, s.Cin, s.Cout, epi, s.Cin, tw, items)) return 0;
             if (s.Cin == 3) { if (tw == 16) C1_EPI(3, 16); else C1_EPI(3, 8); }
             else { if (tw == 16) C1_EPI(1, 16); else C1_EPI(1, 8); }
 #undef C1_EPI
@@ -292,6 +315,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #define HF_EPI(TW_, BN_) do { if (pin) { if (kepi == 3) HF_LAUNCH(TW_, BN_, 3, true); else if (kepi == 0) HF_LAUNCH(TW_, BN_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
                               else if (kepi == 0) HF_LAUNCH(TW_, BN_, 0, false); else if (kepi == 1) HF_LAUNCH(TW_, BN_, 1, false); else if (kepi == 2) HF_LAUNCH(TW_, BN_, 2, false); \
                               else if (kepi == 3) HF_LAUNCH(TW_, BN_, 3, false); else HF_LAUNCH(TW_, BN_, 4, false); } while (0)
+            if (dry_note(n, "  conv3x3 %dx%dx%d->%d epi %d%s: k_conv3x3_halo_f32<%d, %d>, %lld items", s.H, s.W, s.Cin, s.Cout, kepi, pin ? " pooled-in" : "", tw, bn, items)) return 0;
             if (tw == 16) { if (bn == 64) HF_EPI(16, 64); else HF_EPI(16, 32); }
             else { if (bn == 64) HF_EPI(8, 64); else HF_EPI(8, 32); }
 #undef HF_EPI
@@ -303,6 +327,8 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #define CONV_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, Wk, bias, out, s)
 #define CONV_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONV_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONV_CASE(KS_, SM_, BN_, 1); else if (kepi == 2) CONV_CASE(KS_, SM_, BN_, 2); else CONV_CASE(KS_, SM_, BN_, 3); } while (0)
 #define CONV_BN(KS_, SM_) do { if (bn == 64) CONV_EPI(KS_, SM_, 64); else CONV_EPI(KS_, SM_, 32); } while (0)
+        if (dry_note(n, "  %s %dx%dx%d->%d epi %d: k_conv_fwd<%d, %s, %d>%s", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, epi, ks, smallc ? "gather" : "tile", bn,
+                     Z > 1 ? (" split-K " + std::to_string(Z) + " + k_splitk_epilogue").c_str() : "")) return 0;
         if (ks == 3) { if (smallc) CONV_BN(3, true); else CONV_BN(3, false); }
         else { if (smallc) CONV_BN(1, true); else CONV_BN(1, false); }
 #undef CONV_BN
@@ -364,6 +390,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
 #define W1_CASE(CIN_, TW_) do { if (pdz) hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); \
                                 else hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); } while (0)
+        if (dry_note(n, "  wgrad conv3x3 %dx%dx%d->%d%s: k_conv1_wgrad_f32<%d, %d>, %d chunks", s.H, s.W, s.Cin, s.Cout, pdz ? " pooled-dZ" : "", s.Cin, tw, hchunks)) { *chunks_out = hchunks; return 0; }
         if (s.Cin == 3) { if (tw == 16) W1_CASE(3, 16); else W1_CASE(3, 8); }
         else { if (tw == 16) W1_CASE(1, 16); else W1_CASE(1, 8); }
 #undef W1_CASE
@@ -390,6 +417,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
 #define WGF_CASE(TW_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_f32<TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); \
                            else hipLaunchKernelGGL((k_wgrad3x3_halo_f32<TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); } while (0)
+        if (dry_note(n, "  wgrad conv3x3 %dx%dx%d->%d%s: k_wgrad3x3_halo_f32<%d>, %d chunks x %lld tiles", s.H, s.W, s.Cin, s.Cout, pdz ? " pooled-dZ" : "", tw, hchunks, combos)) { *chunks_out = hchunks; return 0; }
         if (tw == 16) WGF_CASE(16); else WGF_CASE(8);
 #undef WGF_CASE
         XTRY(n, hipGetLastError());
@@ -416,6 +444,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
 #define WGH_CASE(CB_, BN_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, true>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tw, th, bpc, hchunks, pg); \
                                 else hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, false>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tw, th, bpc, hchunks, pg); } while (0)
+        if (dry_note(n, "  wgrad conv3x3 %dx%dx%d->%d%s: k_wgrad3x3_halo_bf16<%d, %d>, %d chunks x %lld tiles", s.H, s.W, s.Cin, s.Cout, pdz ? " pooled-dZ" : "", hb, hbn, hchunks, tiles)) { *chunks_out = hchunks; return 0; }
         if (hb == 32) { if (hbn == 64) WGH_CASE(32, 64); else WGH_CASE(32, 32); }
         else { if (hbn == 64) WGH_CASE(64, 64); else WGH_CASE(64, 32); }
 #undef WGH_CASE
@@ -432,6 +461,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
 #define WGB_CASE(KS_, BN_, NK_) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, kPixPerChunk, gdb)
 #define WGB_NK(KS_, BN_) do { if (nk == 4) WGB_CASE(KS_, BN_, 4); else if (nk == 3) WGB_CASE(KS_, BN_, 3); else if (nk == 2) WGB_CASE(KS_, BN_, 2); else WGB_CASE(KS_, BN_, 1); } while (0)
 #define WGB_BN(KS_) do { if (bn == 64) WGB_NK(KS_, 64); else WGB_NK(KS_, 32); } while (0)
+        if (dry_note(n, "  wgrad %s %dx%dx%d->%d: k_conv_wgrad_bf16<%d, %d, %d>, %d chunks", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, ks, bn, nk, chunks)) { *chunks_out = chunks; return 0; }
         if (ks == 3) WGB_BN(3); else WGB_BN(1);
 #undef WGB_BN
 #undef WGB_NK
@@ -444,6 +474,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const dim3 grid(gd.launch_blocks());
 #define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, kPixPerChunk, gd)
 #define WG_BN(KS_, SM_) do { if (bn == 64) WG_CASE(KS_, SM_, 64); else WG_CASE(KS_, SM_, 32); } while (0)
+    if (dry_note(n, "  wgrad %s %dx%dx%d->%d: k_conv_wgrad<%d, %s, %d>, %d chunks", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, ks, smallc ? "gather" : "tile", bn, chunks)) { *chunks_out = chunks; return 0; }
     if (ks == 3) { if (smallc) WG_BN(3, true); else WG_BN(3, false); }
     else { if (smallc) WG_BN(1, true); else WG_BN(1, false); }
 #undef WG_BN
@@ -485,6 +516,7 @@ const __bf16* wb_of(const rcn_hipx_net* n, long long off) {
 // (fp32 kernels in either mode) has none.
 int prep_bf16_weights(rcn_hipx_net* n) {
     if (n->precision != RCN_HIPX_BF16) return 0;
+    if (dry_note(n, "  bf16 operand copies of every layer's weights, both orientations: k_prep_all_bf16 (one launch)")) return 0;
     if (!n->wb16.p) {
         long long off = 0;
         int q = 0;
@@ -535,6 +567,7 @@ int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1
         Layer& l = n->L[i];
         if (l.kind == RCN_HIPX_MAXPOOL2) {
             const long long tot = (long long)B * l.oH * l.oW * (l.Cin / 4);
+            if (dry_note(n, "  pool %dx%dx%d: k_pool_fwd", l.H, l.W, l.Cin)) { cur = (const float*)l.out.p; continue; }
             hipLaunchKernelGGL(k_pool_fwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, cur, (float*)l.out.p, (uint8_t*)l.idx.p, B, l.H, l.W, l.Cin);
             XTRY(n, hipGetLastError());
         } else if (l.kind == RCN_HIPX_CONV3X3_RELU) {
@@ -584,6 +617,7 @@ int run_reduce_jobs(rcn_hipx_net* n, float lr, bool apply) {
     const ReduceJob& last = n->jobs.j[n->jobs.njobs - 1];
     const long long blocks = last.first_block + (last.n + reduce_job_elems(last.chunks) - 1) / reduce_job_elems(last.chunks);
     n->jobs.lr = lr; n->jobs.apply = apply ? 1 : 0;
+    if (dry_note(n, "  update: k_reduce_all, %d layers' slabs in one launch, %lld workgroups", n->jobs.njobs, blocks)) { n->jobs.njobs = 0; return 0; }
     hipLaunchKernelGGL(k_reduce_all, dim3((unsigned)blocks), dim3(kReduceThreads), 0, n->stream, n->jobs);
     XTRY(n, hipGetLastError());
     n->jobs.njobs = 0;
@@ -603,7 +637,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
     for (int i = first >= 0 ? first : (int)n->L.size() - 1; i >= 0; --i) {
         Layer& l = n->L[i];
         const float* in = i == 0 ? x : (const float*)n->L[i - 1].out.p;
-        float* din = i == 0 ? nullptr : (float*)n->L[i - 1].dout.p;
+        float* din = i == 0 ? nullptr : n->dry ? reinterpret_cast<float*>(sizeof(float)) : (float*)n->L[i - 1].dout.p;     // (dry run: no buffers; non-null = "has an input gradient")
         if (l.kind == RCN_HIPX_MAXPOOL2) {
             // When the LDS-tiled kernels run both consumers of the convolution's dZ (its weight gradient, and its input gradient if
             // it has one), they rebuild dZ from (dP, P, arg-max) at pooled resolution while staging: no k_pool_bwd, no full-size dZ.
@@ -612,10 +646,13 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
             const ConvShape cs{B, cl.H, cl.W, cl.Cin, cl.CoutP};
             if (fuse_on && wgrad_halo_runs(n, cs, 3) && (i - 1 == 0 || conv_halo_runs(n, ConvShape{B, cl.H, cl.W, cl.CoutP, cl.Cin}))) {
                 pooled[i - 1] = PooledGrad{(const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p};
+                if (dry_note(n, "  pool-bwd %dx%dx%d: none (the convolution's gradient kernels unpool while staging)", l.H, l.W, l.Cin))
+                    pooled[i - 1].dP = reinterpret_cast<const float*>(sizeof(float));      // (dry run: no buffers; any non-null marks "pooled")
                 continue;
             }
             // gradient wrt the pool INPUT, with the preceding conv's ReLU mask folded in (pooled value > 0)
             const long long tot = (long long)B * l.oH * l.oW * (l.Cin / 4);
+            if (dry_note(n, "  pool-bwd %dx%dx%d: k_pool_bwd", l.H, l.W, l.Cin)) continue;
             hipLaunchKernelGGL(k_pool_bwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p,
                                din, B, l.H, l.W, l.Cin);
             XTRY(n, hipGetLastError());
@@ -629,8 +666,10 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         const float* dZ = (const float*)l.dout.p;
         if (l.kind != RCN_HIPX_DENSE && !l.pool_follows && !gated[i]) {
             XTRY(n, scratch_ensure(n, n->dz, (size_t)M * l.CoutP * sizeof(float)));
-            hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d(M * l.CoutP, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (float*)n->dz.p, M * l.CoutP);
-            XTRY(n, hipGetLastError());
+            if (!dry_note(n, "  relu-bwd: k_relu_bwd")) {
+                hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d(M * l.CoutP, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (float*)n->dz.p, M * l.CoutP);
+                XTRY(n, hipGetLastError());
+            }
             dZ = (const float*)n->dz.p;
         }
         // The weight gradient of this layer goes to the side stream: it needs dZ (ready on the main stream here) and the layer's
@@ -672,6 +711,7 @@ int ensure_loss_buf(rcn_hipx_net* n, unsigned** counter) {
 int loss_and_dlogits(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, bool want_grad) {
     Layer& l = n->L.back();
     const int blocks = (B + 7) / 8;                       // eight samples per workgroup
+    if (dry_note(n, "  loss: k_softmax_ce, %d workgroups", blocks)) return 0;
     unsigned* counter = nullptr;
     RTRY(ensure_loss_buf(n, &counter));
     hipLaunchKernelGGL(k_softmax_ce, dim3(blocks), dim3(256), 0, n->stream, (const float*)l.out.p, labels, B, n->classes, l.CoutP, want_grad ? (float*)l.dout.p : (float*)nullptr,
@@ -697,6 +737,10 @@ int launch_head(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_dev, 
     Layer& l = n->L.back();
     Layer& b = n->L[n->L.size() - 2];
     const int F = l.K, blocks = (B + 31) / 32;
+    if (dry_note(n, "  head %d -> %d classes (logits, softmax + cross-entropy, gradient into the hidden layer, weight-gradient partials): k_head_f32, %d workgroups", F, n->classes, blocks)) {
+        *chunks_out = blocks;
+        return 0;
+    }
     XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)blocks * (F + 1) * 32 * sizeof(float)));
     unsigned* counter = nullptr;
     RTRY(ensure_loss_buf(n, &counter));
@@ -751,18 +795,9 @@ void drop_graphs(rcn_hipx_net* n) { for (auto& kv : n->graphs) (void)hipGraphExe
 
 }  // namespace
 
-extern "C" {
-
-int rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int max_batch, void* stream, rcn_hipx_net** out) {
-    if (!out || !layers || n_layers < 1 || in_h < 1 || in_w < 1 || in_c < 1 || max_batch < 1) return -1;
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -5;
-    rcn_hipx_net* n = new (std::nothrow) rcn_hipx_net();
-    if (!n) return -7;
-    *out = n;
-    n->device = device; n->in_h = in_h; n->in_w = in_w; n->in_c = in_c; n->max_batch = max_batch;
-    n->tiling = halo_f32_default();
+namespace {
+// the layer table of a net (shapes, padded sizes, parameter offsets) from its description; no device involved
+int describe_layers(rcn_hipx_net* n, int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers) {
     int H = in_h, W = in_w, C = in_c;
     bool flat = false;
     for (int i = 0; i < n_layers; ++i) {
@@ -797,6 +832,24 @@ int rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_lay
     }
     if (n->L.back().kind != RCN_HIPX_DENSE) return fail(n, -2, "the last layer must be RCN_HIPX_DENSE (logits)");
     n->classes = n->L.back().Cout;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int max_batch, void* stream, rcn_hipx_net** out) {
+    if (!out || !layers || n_layers < 1 || in_h < 1 || in_w < 1 || in_c < 1 || max_batch < 1) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -5;
+    rcn_hipx_net* n = new (std::nothrow) rcn_hipx_net();
+    if (!n) return -7;
+    *out = n;
+    n->device = device; n->in_h = in_h; n->in_w = in_w; n->in_c = in_c; n->max_batch = max_batch;
+    n->tiling = halo_f32_default();
+    RTRY(describe_layers(n, in_h, in_w, in_c, layers, n_layers));
     Dev g(device);
     if (stream) { n->stream = (hipStream_t)stream; } else { XTRY(n, hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking)); n->own_stream = true; }
     { const char* e = std::getenv("RCN_HIPX_OVERLAP"); n->overlap = e ? std::atoi(e) : 0; }
@@ -973,6 +1026,22 @@ int rcn_hipx_step_flops(const rcn_hipx_net* n, int B, double* flops) {
     }
     *flops = f;
     return 0;
+}
+
+int rcn_hipx_plan(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int batch, int precision, int tiling, char* out, int cap) {
+    if (!layers || n_layers < 1 || in_h < 1 || in_w < 1 || in_c < 1 || batch < 1 || !out || cap < 1) return -1;
+    if ((precision != RCN_HIPX_FP32 && precision != RCN_HIPX_BF16) || tiling < RCN_HIPX_TILING_GEMM || tiling > RCN_HIPX_TILING_LDS) return -1;
+    rcn_hipx_net net;                                   // host-only: no device, no stream, no buffers
+    net.in_h = in_h; net.in_w = in_w; net.in_c = in_c; net.max_batch = batch;
+    net.precision = precision; net.tiling = tiling; net.overlap = 0; net.dry = true;
+    int st = describe_layers(&net, in_h, in_w, in_c, layers, n_layers);
+    if (st == 0) {
+        net.plan = "forward + loss + backward of one batch of " + std::to_string(batch) + " (" + (precision == RCN_HIPX_BF16 ? "bf16" : "fp32") + " operands), launch by launch:\n";
+        st = step_core(&net, nullptr, nullptr, batch, 0.f, nullptr, true, nullptr);
+    }
+    const std::string& text = st == 0 ? net.plan : net.err;
+    std::snprintf(out, (size_t)cap, "%s", text.c_str());
+    return st;
 }
 
 }  // extern "C"
