@@ -778,6 +778,51 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
         }
     };
     if (tid < kHalo - Gm::LPIX * CIN) Hs[Gm::LPIX * CIN + tid] = 0.f;    // the slack is read (by rows that are dropped) but never staged
+    float* out = slab + (long long)chunk * (K + 1) * s.Cout;
+    float* Red = Ds;
+    if constexpr (CIN == 1) {
+        // One input channel: the patch has 9 entries, so the 32-row MFMA would carry 23 empty rows.  v_mfma_f32_16x16x4_f32 instead: rows =
+        // patch entries (9 of 16), columns = 16 output channels (two MFMAs for the 32), contraction = FOUR pixels per instruction -- half
+        // the matrix-pipe time per block (the MNIST-shape first layer's weight gradient at B = 4096 took 103 us on the 32-row form).
+        using f32x4v = __attribute__((ext_vector_type(4))) float;
+        const int r16 = lane & 15, kq = lane >> 4;
+        int ko = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ko = r16 == k ? conv1_koff<1, Gm::HWD>(k) : ko;
+        const float* al = Hs + ko + kq;                               // patch entry r16 of pixel p + kq
+        const float* dl = Ds + 32 * kq + r16;                         // dZ[pixel p + kq][16 t + r16]
+        f32x4v acc4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (b0 < b1) gload(b0);
+#pragma unroll 1
+        for (int blk = b0; blk < b1; ++blk) {
+            if (blk != b0) __syncthreads();
+            lstore();
+            __syncthreads();
+            if (blk + 1 < b1) gload(blk + 1);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {                          // the wave's 32 pixels, four at a time: row 2 wave + (ks >> 2), block columns 4 (ks & 3) ..
+                const int xb = 4 * (ks & 3);
+                const float a = al[(xb / TW) * Gm::IS + (xb % TW) + (ks >> 2) * Gm::HWD + wave * (2 * Gm::HWD)];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc4[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dl[((ks >> 2) * 16 + xb) * 32 + wave * (2 * 16 * 32) + 16 * t], acc4[t], 0, 0, 0);
+            }
+        }
+        // D layout of the 16x16x4 MFMA: lane l holds column l & 15, rows 4 (l >> 4) + i, i = 0..3
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Red[((wave * 2 + t) * 4 + i) * 64 + lane] = acc4[t][i];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + kThreads * u, ti = e >> 6, ln = e & 63;              // ti = t * 4 + i
+            const int k = 4 * (ln >> 4) + (ti & 3), co = 16 * (ti >> 2) + (ln & 15);
+            const float v = (Red[(0 * 8 + ti) * 64 + ln] + Red[(1 * 8 + ti) * 64 + ln]) + (Red[(2 * 8 + ti) * 64 + ln] + Red[(3 * 8 + ti) * 64 + ln]);
+            if (k < K) out[(long long)k * s.Cout + n0 + co] = v;
+        }
+    } else {
     const int r = lane & 31, h = lane >> 5;
     // lane's A element: patch entry r (clamped for the padding rows 9 CIN .. 31, which are not written back) of pixel p + h
     int ko = 0;
@@ -800,8 +845,6 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
     }
-    float* out = slab + (long long)chunk * (K + 1) * s.Cout;
-    float* Red = Ds;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) Red[(wave * 16 + i) * 64 + lane] = acc[i];
@@ -812,6 +855,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
         const int k = mfma32_row(ln, i);
         const float v = (Red[(0 * 16 + i) * 64 + ln] + Red[(1 * 16 + i) * 64 + ln]) + (Red[(2 * 16 + i) * 64 + ln] + Red[(3 * 16 + i) * 64 + ln]);
         if (k < K) out[(long long)k * s.Cout + n0 + (ln & 31)] = v;
+    }
     }
     __syncthreads();
     *reinterpret_cast<f32x4*>(&Red[tid * 4]) = colsum;
