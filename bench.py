@@ -773,8 +773,9 @@ def small_batch_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, dev):
     for B in (10, 32):
         nb = N_IMAGES // B                                  # chunks_exact(B): the tail is dropped (rcn.rs:147)
         row = {}
-        for name, path in (("default_path", 0), ("sample_tile_kernels", 1)):
-            d = DeviceRCN(classes=10, feedforward_cfg=[30], input_shape=(28, 28), dtype=amd.F32, device=dev)
+        # f64_default_path: the reference's own arithmetic type at its own batch size (no resident-kernel instantiation: the sample-tile kernels)
+        for name, path, dt in (("default_path", 0, amd.F32), ("sample_tile_kernels", 1, amd.F32), ("f64_default_path", 0, amd.F64)):
+            d = DeviceRCN(classes=10, feedforward_cfg=[30], input_shape=(28, 28), dtype=dt, device=dev)
             d.set_params(ws, bs)
             if path:
                 d.set_dense_path(path)
@@ -788,7 +789,7 @@ def small_batch_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, dev):
             epochs(1, 11)
             d.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 3 if path == 0 else 1
+            n = 3 if name == "default_path" else 1
             a.record(d.stream)
             epochs(n, 100)
             b.record(d.stream)

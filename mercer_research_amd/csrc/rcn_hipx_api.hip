@@ -371,9 +371,9 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     const long long M = (long long)s.N * s.H * s.W;
     const int K = ks * ks * s.Cin;
     const bool smallc = K <= 32 && s.Cin % 32 != 0;
-    const int bn = (s.Cout % 64 == 0) ? 64 : 32;
+    const int bn = (s.Cout % 64 == 0) ? 64 : 32, bn0 = bn;
     if (M > 0x7fff0000LL) return fail(n, -3, "too many output pixels in one layer (N*H*W must stay below 2^31)");
-    const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk);
+    const int chunks = (int)((M + kPixPerChunk - 1) / kPixPerChunk), chunks0 = chunks;
     XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
     if (pdz && !wgrad_halo_runs(n, s, ks)) return fail(n, -3, "internal: pooled-resolution dZ requested for a layer the LDS-tiled weight-gradient kernel does not cover");
     if (wgrad_halo_runs(n, s, ks) && smallc) {
@@ -456,9 +456,19 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         // bf16 operands, transposed LDS reads (convnet_bf16.hpp); NKB waves per workgroup, one 32-row k-block each
         const int nkb = K / 32;
         const int nk = nkb % 4 == 0 ? 4 : nkb % 3 == 0 ? 3 : nkb % 2 == 0 ? 2 : 1;
+        // A wave owns one 32-row k-block x bn columns over the chunk's pixels, so a dense layer behind a pooled map is FEW waves (MNIST shape
+        // 3136 -> 128 at B = 4096: 98 x 2 x 4 chunks = 784 on the chip's 1024 SIMDs, 62 us for 7 us of traffic).  Below two waves per SIMD
+        // take 32-wide column blocks (no more slab, X re-read from L2), below one per SIMD also shorter chunks (down to 256 pixels).
+        static const int policy = [] { const char* e = std::getenv("RCN_HIPX_WGB_POLICY"); return e ? std::atoi(e) : 1; }();
+        int bn = bn0, ppc = kPixPerChunk, chunks = chunks0;
+        if (policy) {
+            if ((long long)nkb * (s.Cout / bn) * chunks < 2048) bn = 32;
+            while ((long long)nkb * (s.Cout / bn) * chunks < 1024 && ppc > 256) { ppc /= 2; chunks = (int)((M + ppc - 1) / ppc); }
+            XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
+        }
         const WgradGrid gdb{nkb / nk, s.Cout / bn, chunks, xcd_remap()};
         const dim3 gridb(gdb.launch_blocks());
-#define WGB_CASE(KS_, BN_, NK_) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, kPixPerChunk, gdb)
+#define WGB_CASE(KS_, BN_, NK_) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, ppc, gdb)
 #define WGB_NK(KS_, BN_) do { if (nk == 4) WGB_CASE(KS_, BN_, 4); else if (nk == 3) WGB_CASE(KS_, BN_, 3); else if (nk == 2) WGB_CASE(KS_, BN_, 2); else WGB_CASE(KS_, BN_, 1); } while (0)
 #define WGB_BN(KS_) do { if (bn == 64) WGB_NK(KS_, 64); else WGB_NK(KS_, 32); } while (0)
         if (dry_note(n, "  wgrad %s %dx%dx%d->%d: k_conv_wgrad_bf16<%d, %d, %d>, %d chunks", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, ks, bn, nk, chunks)) { *chunks_out = chunks; return 0; }
