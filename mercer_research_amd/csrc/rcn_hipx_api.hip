@@ -480,11 +480,15 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         *chunks_out = chunks;
         return 0;
     }
-    const WgradGrid gd{smallc ? 1 : K / 32, s.Cout / bn, chunks, xcd_remap()};
+    // (as in the bf16 branch above: below two waves per SIMD the column blocks are 32 wide -- CIFAR net's 2048 -> 256 at B = 512: 256 -> 512
+    // workgroups, step 0.419 -> 0.417 ms; MNIST shape B = 256: 0.165 -> 0.1625 ms)
+    static const int f32_policy = [] { const char* e = std::getenv("RCN_HIPX_WGF_POLICY"); return e ? std::atoi(e) : 1; }();
+    const int bnf = (f32_policy && !smallc && 4LL * (K / 32) * (s.Cout / bn0) * chunks < 2048) ? 32 : bn0;
+    const WgradGrid gd{smallc ? 1 : K / 32, s.Cout / bnf, chunks, xcd_remap()};
     const dim3 grid(gd.launch_blocks());
 #define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, kPixPerChunk, gd)
-#define WG_BN(KS_, SM_) do { if (bn == 64) WG_CASE(KS_, SM_, 64); else WG_CASE(KS_, SM_, 32); } while (0)
-    if (dry_note(n, "  wgrad %s %dx%dx%d->%d: k_conv_wgrad<%d, %s, %d>, %d chunks", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, ks, smallc ? "gather" : "tile", bn, chunks)) { *chunks_out = chunks; return 0; }
+#define WG_BN(KS_, SM_) do { if (bnf == 64) WG_CASE(KS_, SM_, 64); else WG_CASE(KS_, SM_, 32); } while (0)
+    if (dry_note(n, "  wgrad %s %dx%dx%d->%d: k_conv_wgrad<%d, %s, %d>, %d chunks", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, ks, smallc ? "gather" : "tile", bnf, chunks)) { *chunks_out = chunks; return 0; }
     if (ks == 3) { if (smallc) WG_BN(3, true); else WG_BN(3, false); }
     else { if (smallc) WG_BN(1, true); else WG_BN(1, false); }
 #undef WG_BN

@@ -23,6 +23,9 @@ NETS = [
     ((24, 8, 3), (("conv", 64), ("pool",), ("conv", 32), ("pool",), ("dense", 4)), 4),
     # a batch of 64 (two workgroups of the fused head, one more hidden dense layer in front of it)
     ((8, 8, 3), (("conv", 32), ("pool",), ("dense_relu", 64), ("dense_relu", 32), ("dense", 10)), 64),
+    # the MNIST-shape first layer: ONE channel with the pool right behind it (weight gradient on the 16-row MFMA from a pooled-resolution
+    # gradient), 64 filters = two column blocks, a 28 x 12 map (blocks that are not full in either direction), several blocks per chunk
+    ((28, 12, 1), (("conv", 64), ("pool",), ("conv", 32), ("pool",), ("dense", 10)), 6),
 ]
 
 
