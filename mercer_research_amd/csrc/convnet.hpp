@@ -457,42 +457,51 @@ struct ReduceJob {
 struct ReduceJobs { ReduceJob j[kMaxReduceJobs]; int njobs; float lr; int apply; };
 
 constexpr int kReduceThreads = 1024;
-// chunk groups of a job: the power of two at or above its chunk count, at most 32; a workgroup then covers 1024 / groups elements
+// chunk groups of a job: the power of two at or above its chunk count, at most 32; a workgroup then covers 4 * 1024 / groups elements
+// (a thread owns FOUR consecutive elements, 16-byte loads: with one element per thread a workgroup of the 64-chunk CIFAR layer had 8 KB
+// in flight per residency and the kernel ran at 1.8 TB/s of slab, latency times rounds)
 __host__ __device__ inline int reduce_job_groups(int chunks) { int g = 1; while (g < chunks && g < 32) g <<= 1; return g; }
-__host__ __device__ inline int reduce_job_elems(int chunks) { return kReduceThreads / reduce_job_groups(chunks); }
+__host__ __device__ inline int reduce_job_elems(int chunks) { return 4 * kReduceThreads / reduce_job_groups(chunks); }
 
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_all(ReduceJobs J) {
-    __shared__ float red[kReduceThreads];
+    __shared__ f32x4 red[kReduceThreads];
     int q = 0;
     while (q + 1 < J.njobs && (int)blockIdx.x >= J.j[q + 1].first_block) ++q;
     const ReduceJob jb = J.j[q];
     const int lb = (int)blockIdx.x - jb.first_block;
-    // whole 128-byte rows of the slab per chunk group: 32 elements x 32 groups (many chunks) ... 1024 elements x 1 group (one chunk)
+    // whole 128-byte rows of the slab per chunk group and wave instruction: 32 threads x 16 bytes x 32 groups (many chunks) ... 1024 threads x 1 group (one chunk)
     const int GR = reduce_job_groups(jb.chunks), EL = kReduceThreads / GR;
     const int el = threadIdx.x % EL, grp = threadIdx.x / EL;
-    const long long i = (long long)lb * EL + el;
-    float g = 0.f;
+    const long long i = ((long long)lb * EL + el) * 4;               // jb.n % 4 == 0 (host)
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
     if (i < jb.n) {
         // eight loads in flight per thread (a load per loop trip, each waited for, left this kernel at 1.6 TB/s)
         for (int c = grp; c < jb.chunks; c += 8 * GR) {
-            float v[8];
+            f32x4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = c + k * GR < jb.chunks ? jb.slab[(long long)(c + k * GR) * jb.n + i] : 0.f;
+            for (int k = 0; k < 8; ++k) v[k] = c + k * GR < jb.chunks ? *reinterpret_cast<const f32x4*>(jb.slab + (long long)(c + k * GR) * jb.n + i) : f32x4{0.f, 0.f, 0.f, 0.f};
             g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
     }
     red[grp * EL + el] = g;
     // the chunk groups combined as a fixed binary tree by all threads (instead of one thread per element walking up to 32 partial sums
-    // in LDS; measured: no difference -- the kernel's time is the slab's bytes, 224 us for ~300 MB on the 224 x 224 net)
+    // in LDS; measured: no difference)
     for (int st = GR >> 1; st >= 1; st >>= 1) {
         __syncthreads();
         if (grp < st) red[grp * EL + el] += red[(grp + st) * EL + el];
     }
     __syncthreads();
     if ((int)threadIdx.x < EL && i < jb.n) {
-        const float t = red[threadIdx.x];
-        if (jb.grad) jb.grad[i] = t;
-        if (J.apply) { const float v = jb.p[i] - J.lr * t; jb.p[i] = v; store_flipped(jb.flip, i, v); }
+        const f32x4 t = red[threadIdx.x];
+        if (jb.grad) *reinterpret_cast<f32x4*>(jb.grad + i) = t;
+        if (J.apply) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(jb.p + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] - J.lr * t[k];
+            *reinterpret_cast<f32x4*>(jb.p + i) = v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) store_flipped(jb.flip, i + k, v[k]);
+        }
     }
 }
 

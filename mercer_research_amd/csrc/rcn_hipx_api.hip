@@ -618,6 +618,7 @@ int reduce_slab(rcn_hipx_net* n, size_t i, int chunks, int ks, const ConvShape& 
     jb.slab = (const float*)l.slab.p;
     jb.flip = FlipSpec{(apply && i > 0) ? (float*)n->wt.p + l.w_off : (float*)nullptr, ks * ks, s.Cin, s.Cout};
     jb.n = ((long long)s.Cin * ks * ks + 1) * s.Cout;
+    if (jb.n % 4 != 0 || l.w_off % 4 != 0) return fail(n, -3, "internal: a layer's [W | b] is not a whole number of 16-byte pieces");
     jb.chunks = chunks;
     int prev_end = 0;
     if (n->jobs.njobs) { const ReduceJob& pj = n->jobs.j[n->jobs.njobs - 1]; prev_end = pj.first_block + (int)((pj.n + reduce_job_elems(pj.chunks) - 1) / reduce_job_elems(pj.chunks)); }
