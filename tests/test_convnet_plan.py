@@ -73,3 +73,19 @@ def test_plan_reports_shape_errors_like_create():
     assert lib.rcn_hipx_plan(8, 8, 3, arr, 2, 4, 0, 1, buf, len(buf)) == -3
     assert b"multiple of 32" in buf.value
     assert lib.rcn_hipx_plan(8, 8, 3, arr, 2, 4, 7, 1, buf, len(buf)) == -1
+
+
+def test_dense_weight_gradients_are_sized_by_waves(plan):
+    """A wave of the generic weight-gradient kernels owns one 32-row k-block x bn columns over a chunk: the dense layer behind a pooled map is
+    few waves.  Below two waves per SIMD the column blocks are 32 wide, below one per SIMD (bf16 kernel) the chunks shorten too."""
+    shp, layers, _ = CONFIGS["mnist"]
+    L = _lines(plan(shp, layers, 4096, "bf16", "auto"))
+    assert any(l.startswith("wgrad dense 1x1x3136->128: k_conv_wgrad_bf16<1, 32, 2>, 4 chunks") for l in L)      # 98 x 4 x 4 = 1568 waves, chunks of 1024 kept
+    shp, layers, B = CONFIGS["cifar"]
+    L = _lines(plan(shp, layers, B, "bf16", "auto"))
+    assert any(l.startswith("wgrad dense 1x1x2048->256: k_conv_wgrad_bf16<1, 32, 4>, 2 chunks") for l in L)      # 64 x 8 x 1 = 512 waves -> chunks of 256
+    L = _lines(plan(shp, layers, B, "fp32", "auto"))
+    assert any(l.startswith("wgrad dense 1x1x2048->256: k_conv_wgrad<1, tile, 32>, 1 chunks") for l in L)
+    # a large layer keeps the 64-wide blocks: synth-224's convolutions never reach this kernel, its dense layer has 32 padded columns anyway
+    shp, layers, B = CONFIGS["synth224"]
+    assert not any("k_conv_wgrad_bf16<3" in l for l in _lines(plan(shp, layers, B, "bf16", "auto")))
