@@ -95,6 +95,7 @@ SIGNATURES = {
     "rcn_hip_dp_admission_rehearse": (_i, [_i, _i, C.c_char_p, _vp, _vp, _vp, _ip, _ip]),
     "rcn_hip_dp_epoch_steps_dev": (_i, [_vp, _sz, _sz, _d, _vp]),
     "rcn_hip_train_epoch_gathers": (_i, [_vp, _sz]),
+    "rcn_hip_train_epoch_resident": (_i, [_vp, _sz]),
     "rcn_hip_dp_resident": (_i, [_vp, _sz]),
     "rcn_hip_dp_p2p_active": (_i, [_vp]),
     "rcn_hip_dp_prepare_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),

@@ -1,5 +1,6 @@
 // dense_xcd.hpp -- the feature-sliced pipeline of dense_p2.hpp as ONE resident kernel per epoch segment whose workgroups all sit
-// on ONE XCD (f32, the reference's own network shape class, batch 256).
+// on ONE XCD (the reference's own network shape class; f32 for batches of 1..256, and -- round 4 -- f64, the reference's own arithmetic
+// type, for batches of 1..128: LDS holds 2 x the bytes per sample).
 //
 // Why.  The two-kernel step (k_p2_b, k_p2_a) is bound by what surrounds its arithmetic: two dependent launch boundaries (~1.5 us
 // each), W_0 and the batch leaving and re-entering the chip, and a 1.6 MB slab of partial sums written to and read back from
@@ -47,15 +48,16 @@ namespace rcn {
 constexpr int kXcdWorkers = 32, kXcdThreads = 512, kXcdFlagStride = 32;      // flags: one 128-byte line each
 constexpr int kXcdSl = 2;                                                      // 16-feature slices per feature worker
 
-struct XcdBufs {
-    float* slab;       // [B/8][NA][8][32]   partial z_1 of one batch, consumer-major
-    float* d1;         // [B][32]            delta_1, a_1 [B][32], delta_2 [B][16], cost parts [B/8]: written by the sample groups
-    float* a1;
-    float* d2;
-    float* loss;
-    float* a2;         // [B][16]            two hidden layers only: a_2 and delta_3 (then d2 holds delta_2 of the middle layer)
-    float* d3;
-    float* fragimg;    // [28 | 40][64]      tail parameters as the sample groups' MFMA operand fragments
+template <typename T>
+struct XcdBufsT {
+    T* slab;           // [B/8][NA][8][32]   partial z_1 of one batch, consumer-major
+    T* d1;             // [B][32]            delta_1, a_1 [B][32], delta_2 [B][16], cost parts [B/8]: written by the sample groups
+    T* a1;
+    T* d2;
+    T* loss;
+    T* a2;             // [B][16]            two hidden layers only: a_2 and delta_3 (then d2 holds delta_2 of the middle layer)
+    T* d3;
+    T* fragimg;        // [28 | 40][64]      tail parameters as the sample groups' MFMA operand fragments
     unsigned* flagA;   // [32 x stride]      step tag of the newest complete slab part of feature worker w
     unsigned* flagB;   // [32 x stride]      step tag of the newest complete outputs of sample group w
     unsigned* flagT;   // [8 x stride]       step tag for which tail tile e's share of the fragment image is current
@@ -64,6 +66,7 @@ struct XcdBufs {
     unsigned* errd;    // [1]                device copy of the sticky error word
     unsigned* done;    // pinned host word: id of the newest launch whose workers ALL finished (its parameters are in memory when it ends)
 };
+using XcdBufs = XcdBufsT<float>;
 
 inline int xcd_na(const NetDesc& nd) { return (pipe_slices(nd) + kXcdSl - 1) / kXcdSl; }
 // one hidden layer (<= 32 units, <= 16 classes: the shape class of the two-kernel pipeline), or two (<= 32, <= 16 units, <= 16 classes)
@@ -78,9 +81,13 @@ inline bool xcd_one_hidden(const NetDesc& nd) {
 // the samples between B and BT are rows of zeros whose deltas are masked to zero, so they add nothing to any sum, and the update
 // divides by the real batch.len() (rcn.rs:214).
 constexpr int kXcdMaxB = 256;
+// f64 (round 4): every LDS image is twice the bytes, so the instantiations stop at 128 samples (152 KB with the tail tiles' partials laid
+// over the batch buffers they never use); a batch above that runs the two-kernel pipeline as before
+constexpr int kXcdMaxB64 = 128;
+inline int xcd_max_b(size_t esz) { return esz == 8 ? kXcdMaxB64 : kXcdMaxB; }
 inline int xcd_bt(size_t B) { return B <= 32 ? 32 : B <= 64 ? 64 : B <= 128 ? 128 : 256; }
-inline bool xcd_supported(const NetDesc& nd, size_t B) {
-    return (xcd_one_hidden(nd) || xcd_two_hidden(nd)) && B >= 1 && B <= (size_t)kXcdMaxB && xcd_na(nd) + pipe_extra_wgs(nd) <= kXcdWorkers &&
+inline bool xcd_supported(const NetDesc& nd, size_t B, size_t esz = 4) {
+    return (xcd_one_hidden(nd) || xcd_two_hidden(nd)) && B >= 1 && B <= (size_t)xcd_max_b(esz) && xcd_na(nd) + pipe_extra_wgs(nd) <= kXcdWorkers &&
            pipe_extra_wgs(nd) <= 8;
 }
 // workers of a launch: every feature worker and tail tile, and at least one worker per sample group of eight (BT / 8 <= 32)
@@ -88,19 +95,25 @@ inline int xcd_workers(const NetDesc& nd, int BT) {
     const int roles = xcd_na(nd) + pipe_extra_wgs(nd), groups = BT / kP2Ts;
     return roles > groups ? roles : groups;
 }
-inline size_t xcd_buf_bytes(const NetDesc& nd, size_t BT) {
+inline size_t xcd_buf_bytes(const NetDesc& nd, size_t BT, size_t esz = 4) {
     const size_t NS = BT / kP2Ts, NA = (size_t)xcd_na(nd);
-    return (NS * NA * kP2Ts * kP2H + 2 * BT * kP2H + 3 * BT * kP2C + NS + (size_t)kP3BFrag * 64) * sizeof(float) +
+    return (NS * NA * kP2Ts * kP2H + 2 * BT * kP2H + 3 * BT * kP2C + NS + (size_t)kP3BFrag * 64) * esz +
            (size_t)(4 * kXcdWorkers + 8) * kXcdFlagStride * sizeof(unsigned) + 512;       // flagA, flagB, xcc, flagD, flagT, error word
 }
-// LDS (floats): two batch buffers of a slice pair, delta_1 of the whole batch (rows padded to 48: conflict-free MFMA operand reads),
+// LDS (elements): two batch buffers of a slice pair, delta_1 of the whole batch (rows padded to 48: conflict-free MFMA operand reads),
 // the tail tiles' K-split partials, the slice pair of W_0, and the sample group's scratch (slab partial sums, a_1 / delta_2 tiles,
-// target fragments): 148 KB of the CU's 160 at BT = 256 -- one worker per CU -- 94 / 66 / 51 KB at BT = 128 / 64 / 32
+// target fragments): f32 148 KB of the CU's 160 at BT = 256 -- one worker per CU -- 94 / 66 / 51 KB at BT = 128 / 64 / 32;
+// f64 152 / 130 / 101 KB at BT = 128 / 64 / 32
 constexpr int kXcdD1Ld = 48;
-constexpr size_t xcd_lds_floats(int BT) {
-    return 2 * (size_t)kXcdSl * BT * 16 + (size_t)BT * kXcdD1Ld + (size_t)kDenseWaves * kMtp * kRedTile + (size_t)kXcdSl * 16 * kP2H +
+// the tail tiles' partials over the batch buffers (a tail tile is never a feature worker): only where the LDS would not fit otherwise
+template <typename T, int BT> constexpr bool xcd_red_aliased() { return sizeof(T) == 8 && BT >= 128; }
+constexpr size_t xcd_lds_floats(int BT, bool red_aliased = false) {
+    return 2 * (size_t)kXcdSl * BT * 16 + (size_t)BT * kXcdD1Ld + (red_aliased ? 0 : (size_t)kDenseWaves * kMtp * kRedTile) + (size_t)kXcdSl * 16 * kP2H +
            (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + 3 * kP2C * kLd + 4 * 64 + 64;
 }
+template <typename T, int BT> constexpr size_t xcd_lds_bytes() { return xcd_lds_floats(BT, xcd_red_aliased<T, BT>()) * sizeof(T); }
+static_assert(xcd_lds_bytes<double, 128>() + 64 <= 160 * 1024 && xcd_lds_bytes<float, 256>() + 64 <= 160 * 1024, "k_xcd_epoch: LDS of the largest instantiations");
+static_assert((size_t)2 * kXcdSl * 128 * 16 >= (size_t)kDenseWaves * kMtp * kRedTile, "k_xcd_epoch: the partials fit the batch buffers they are laid over");
 
 // diagnostic build only (-DRCN_STAMPS, tools/stamps_xcd.py): where each worker is at each point of the launch's last-but-one step
 #ifdef RCN_STAMPS
@@ -113,17 +126,33 @@ constexpr size_t xcd_lds_floats(int BT) {
 
 using xu4 = __attribute__((ext_vector_type(4))) unsigned;
 #define XCD_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
-// L1-bypassing (sc1, aux 16) reads of what another CU of this XCD stored in this launch; served by the shared L2
-__device__ inline Vec4<float>::type xcd_ld4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+// L1-bypassing (sc1, aux 16) reads of what another CU of this XCD stored in this launch; served by the shared L2.  byte_off is in BYTES
+// of the buffer (an f64 quadruple is two 16-byte loads, an f64 word one 8-byte load).
+template <typename T> __device__ inline typename Vec4<T>::type xcd_ld4(__amdgpu_buffer_rsrc_t r, int byte_off);
+template <> __device__ inline Vec4<float>::type xcd_ld4<float>(__amdgpu_buffer_rsrc_t r, int byte_off) {
     const xu4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
     Vec4<float>::type f;
     __builtin_memcpy(&f, &v, 16);
     return f;
 }
-__device__ inline float xcd_ld1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+template <> __device__ inline Vec4<double>::type xcd_ld4<double>(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const xu4 v[2] = {__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16), __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16, 0, 16)};
+    Vec4<double>::type f;
+    __builtin_memcpy(&f, v, 32);
+    return f;
+}
+template <typename T> __device__ inline T xcd_ld1(__amdgpu_buffer_rsrc_t r, int byte_off);
+template <> __device__ inline float xcd_ld1<float>(__amdgpu_buffer_rsrc_t r, int byte_off) {
     const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16);
     float f;
     __builtin_memcpy(&f, &v, 4);
+    return f;
+}
+template <> __device__ inline double xcd_ld1<double>(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    typedef unsigned xu2 __attribute__((ext_vector_type(2)));
+    const xu2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16);
+    double f;
+    __builtin_memcpy(&f, &v, 8);
     return f;
 }
 __device__ inline void xcd_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -164,6 +193,39 @@ __device__ inline bool xcd_wait(const unsigned* f0, int n0, const unsigned* f1, 
     }
 }
 
+// The tail parameters as the sample groups' operand fragments, in the context's type.  f32: dense.hpp's image (shared with k_p2_b).
+// f64: the same word / lane places for the A-operand words (the f64 MFMA reads A and B like the f32 one) and for b_0 (one word per
+// element of the slab quadruple a lane sums); the words held per ACCUMULATOR element (b_1, b_2) follow the f64 accumulator map
+// row = (lane >> 4) + 4 i (common.hpp) instead of 4 (lane >> 4) + i.
+__device__ inline void xcd_frag_scatter2(int jl, int cc, int m, int H, float v, float* __restrict__ img) { p2_frag_scatter(jl, cc, m, H, v, img); }
+__device__ inline void xcd_frag_scatter3(int cc, int m, int H2, float v, float* __restrict__ img) { p3_frag_scatter(cc, m, H2, v, img); }
+__device__ inline void xcd_frag_scatter2(int jl, int cc, int m, int H, double v, double* __restrict__ img) {
+    if (jl == 1 && cc < H) {
+        const int h = cc, c = m;
+        img[(h >> 2) * 64 + (h & 3) * 16 + c] = v;
+        img[(8 + (h >> 4) * 4 + (c >> 2)) * 64 + (c & 3) * 16 + (h & 15)] = v;
+    } else if (jl == 1) {
+        const int c = m;                                                          // b_1[c]: element c >> 2 of the lanes with lane >> 4 == c & 3
+#pragma unroll
+        for (int nn = 0; nn < 16; ++nn) img[(16 + (c >> 2)) * 64 + (c & 3) * 16 + nn] = v;
+    } else {
+        const int h = m;                                                          // b_0[h] (bias column of W_0)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) img[(24 + (h & 3)) * 64 + (h >> 2) + 8 * s] = v;
+    }
+}
+__device__ inline void xcd_frag_scatter3(int cc, int m, int H2, double v, double* __restrict__ img) {
+    if (cc < H2) {
+        const int h2 = cc, c = m;
+        img[(28 + (h2 >> 2)) * 64 + (h2 & 3) * 16 + c] = v;
+        img[(32 + (c >> 2)) * 64 + (c & 3) * 16 + h2] = v;
+    } else {
+        const int c = m;                                                          // b_2[c]
+#pragma unroll
+        for (int nn = 0; nn < 16; ++nn) img[(36 + (c >> 2)) * 64 + (c & 3) * 16 + nn] = v;
+    }
+}
+
 // nb consecutive train_batch steps (rcn.rs:176-223) over the packed batches xs[j] (slice-major, k_pack_epoch), ys[j].
 //
 // DP = true: the data-parallel step (one rank per GPU, this rank's shard of every global batch in xs / ys).  Between the gradient
@@ -189,21 +251,26 @@ template <bool DP> using XcdDpArgs = typename XcdDpSel<DP>::type;
 // LDS and their deltas are masked, `scale` / `loss_scale` are formed from B on the host (rcn.rs:214).
 // FULL: B == BT, known at compile time (measured: with the batch length a run-time value the BT = 256 step is 0.2 us slower -- the
 // address arithmetic of the prefetch and of the targets, and the padding masks, sit on the step's critical waves).
-template <int BT, bool FULL, bool DP, bool L3 = false, bool GA = false>
+// T: the context's arithmetic type.  f64 (the reference's own, rcn.rs:28,31,49) runs the same roles on v_mfma_f64_16x16x4_f64: the
+// accumulator's row map differs (Mfma16<T>::row), so a feature-worker lane owns parameters hidden g4 + 4 i instead of 4 g4 + i, and
+// 16-byte L2 reads become two per quadruple; single-GPU forms only (the exchange's words carry f32 values).
+template <typename T, int BT, bool FULL, bool DP, bool L3 = false, bool GA = false>
 __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
-    NetDesc nd, float* __restrict__ params, const float* __restrict__ xs_all, const float* __restrict__ ys_all, int B_arg, int nb, int G, float scale,
-    float loss_scale, float* __restrict__ loss_dev, XcdBufs bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, XcdDpArgs<DP> dp,
+    NetDesc nd, T* __restrict__ params, const T* __restrict__ xs_all, const T* __restrict__ ys_all, int B_arg, int nb, int G, T scale,
+    T loss_scale, T* __restrict__ loss_dev, XcdBufsT<T> bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, XcdDpArgs<DP> dp,
     int xsel, const int* __restrict__ gperm, unsigned launch_id) {
     constexpr bool gather = GA;
     const int B = FULL ? BT : B_arg;
     static_assert(!GA || FULL, "the gather form exists for the full batch only");
     static_assert(BT == 32 || BT == 64 || BT == 128 || BT == 256, "k_xcd_epoch: batch instantiations");
     static_assert(!GA || BT == 256, "the gather form exists for batch 256 only");
+    static_assert(sizeof(T) == 4 || (!DP && !GA && BT <= kXcdMaxB64), "f64: single-GPU forms on the packed image, batches up to 128");
+    constexpr int ES = (int)sizeof(T), VS = 4 * ES;                  // bytes of an element / of a quadruple in the L2 buffers
+    constexpr int RI = sizeof(T) == 4 ? 1 : 4;                       // Mfma16<T>::row(lane, i) = row(lane, 0) + RI * i
     constexpr size_t kXs = (size_t)kXcdSl * BT * 16;              // one LDS batch buffer of a slice pair
     constexpr int NS = BT / kP2Ts;                                  // sample groups of eight
-    using T = float;
-    using acc_t = Mfma16<T>::acc_t;
-    using vec4 = Vec4<T>::type;
+    using acc_t = typename Mfma16<T>::acc_t;
+    using vec4 = typename Vec4<T>::type;
     if ((int)(blockIdx.x & 7) != xsel) return;                      // the other seven XCDs' blocks
     const int w = (int)(blockIdx.x >> 3);
     const int F = nd.dims[0], H = nd.dims[1], Cm = nd.dims[2], C = nd.dims[L3 ? 3 : 2];     // Cm: the units after W_1 (the classes, or h2)
@@ -215,8 +282,9 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     T* smem = reinterpret_cast<T*>(smem_dyn);
     T* xbuf = smem;                                                 // [2][kXcdSl][B][16]
     T* d1s = xbuf + 2 * kXs;                                        // delta_1 of the batch [BT][48] (32 used)
-    T* red = d1s + BT * kXcdD1Ld;                                   // tail tiles: [wave][mt][16 x kLd]
-    T* wsl = red + kDenseWaves * kMtp * kRedTile;                   // [slice][feature 0..15][32]
+    constexpr bool RA = xcd_red_aliased<T, BT>();                   // (f64, BT = 128: laid over the batch buffers a tail tile never uses)
+    T* red = RA ? xbuf : d1s + BT * kXcdD1Ld;                       // tail tiles: [wave][mt][16 x kLd]
+    T* wsl = d1s + BT * kXcdD1Ld + (RA ? 0 : kDenseWaves * kMtp * kRedTile);     // [slice][feature 0..15][32]
     vec4* zred = reinterpret_cast<vec4*>(wsl + kXcdSl * 16 * kP2H); // [8 waves][64 lanes]
     T* a1s = reinterpret_cast<T*>(zred) + kP2BWaves * 64 * 4;       // a_1 tile  [hidden 32][kLd]
     T* d2s = a1s + kP2H * kLd;                                      // delta_2   [class 16][kLd]
@@ -229,11 +297,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     const int e = w - NA;                                           // tail tile index when is_t
     const int nsl = is_a ? (G - kXcdSl * w < kXcdSl ? G - kXcdSl * w : kXcdSl) : 0;
     const size_t xs_stride = (size_t)G * B * 16, ys_stride = (size_t)B * C;
-    const auto r_slab = XCD_RSRC(bufs.slab, (size_t)NS * NA * kP2Ts * kP2H * 4);
-    const auto r_d1 = XCD_RSRC(bufs.d1, (size_t)BT * kP2H * 4), r_a1 = XCD_RSRC(bufs.a1, (size_t)BT * kP2H * 4);
-    const auto r_d2 = XCD_RSRC(bufs.d2, (size_t)BT * kP2C * 4), r_loss = XCD_RSRC(bufs.loss, (size_t)NS * 4);
-    const auto r_img = XCD_RSRC(bufs.fragimg, (size_t)(L3 ? kP3BFrag : kP2BFrag) * 64 * 4);
-    const auto r_a2 = XCD_RSRC(bufs.a2, (size_t)BT * kP2C * 4), r_d3 = XCD_RSRC(bufs.d3, (size_t)BT * kP2C * 4);
+    const auto r_slab = XCD_RSRC(bufs.slab, (size_t)NS * NA * kP2Ts * kP2H * ES);
+    const auto r_d1 = XCD_RSRC(bufs.d1, (size_t)BT * kP2H * ES), r_a1 = XCD_RSRC(bufs.a1, (size_t)BT * kP2H * ES);
+    const auto r_d2 = XCD_RSRC(bufs.d2, (size_t)BT * kP2C * ES), r_loss = XCD_RSRC(bufs.loss, (size_t)NS * ES);
+    const auto r_img = XCD_RSRC(bufs.fragimg, (size_t)(L3 ? kP3BFrag : kP2BFrag) * 64 * ES);
+    const auto r_a2 = XCD_RSRC(bufs.a2, (size_t)BT * kP2C * ES), r_d3 = XCD_RSRC(bufs.d3, (size_t)BT * kP2C * ES);
 
     if (tid == 0) s_abort = 0;
     __syncthreads();
@@ -287,7 +355,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     // ---- feature worker: its slice pair of W_0 into LDS and registers; the first two batches into the two LDS buffers.
     // The gradient of the slice pair is four 16 x 16 tiles (slice sl, hidden half mt); wave u owns tile u & 3 for the samples of K-half
     // u >> 2, and waves 0..3 also own the tile's parameters, in the accumulator's layout: lane (n, g4), element i <-> hidden
-    // 16 mt + 4 g4 + i, feature 16 sl + n.
+    // 16 mt + Mfma16<T>::row(lane, i) (f32: 4 g4 + i, four consecutive parameters; f64: g4 + 4 i), feature 16 sl + n.
     // gather form (no packed image: xs_all = X[rows][F] as stored, ys_all = Y[rows][C], gperm = the epoch's order or NULL for the
     // stored order): element i of this worker's LDS image of batch b -- slice i / 4B of the pair, sample (i / 4) % B, 16-byte chunk
     // i % 4 -- straight from row gperm[b B + sample]; four neighbouring threads fetch one 64-byte run of a row, and the sample's
@@ -304,20 +372,20 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     const int tl = wave & 3, kh = wave >> 2, usl = tl >> 1, umt = tl & 1;
     T wcur[4] = {0, 0, 0, 0};
     bool wvalid[4] = {false, false, false, false};
-    unsigned woff0 = 0;                                              // this lane's four parameters are consecutive in W_0 (hidden 4 g4 + i)
+    unsigned woff0 = 0;                                              // this lane's four parameters in W_0: woff0 + RI i (f32: consecutive, hidden 4 g4 + i)
     if (is_a) {
         if (kh == 0) {
             const int f0 = (kXcdSl * w + usl) * 16;
             const int nf = usl < nsl ? (F - f0 < 16 ? F - f0 : 16) : 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int hid = umt * 16 + 4 * g4 + i;
+                const int hid = umt * 16 + Mfma16<T>::row(lane, i);
                 wvalid[i] = hid < H && n < nf;
-                if (i == 0) woff0 = wvalid[0] ? (unsigned)((f0 + n) * H + hid) : 0u;      // (wvalid[0] false => all four are)
-                const T v = W0[wvalid[i] ? woff0 + i : 0u];
+                if (i == 0) woff0 = wvalid[0] ? (unsigned)((f0 + n) * H + hid) : 0u;      // (wvalid[0] false => all four are: hid grows with i)
+                const T v = W0[wvalid[i] ? woff0 + RI * i : 0u];
                 wcur[i] = wvalid[i] ? v : (T)0;
             }
-            *reinterpret_cast<vec4*>(wsl + (usl * 16 + n) * kP2H + umt * 16 + 4 * g4) = vec4{wcur[0], wcur[1], wcur[2], wcur[3]};
+            store4<T>(wsl + (usl * 16 + n) * kP2H + umt * 16, lane, acc_t{wcur[0], wcur[1], wcur[2], wcur[3]});
         }
         // batches 0 and 1 of this launch: [slice pair][sample][16] is one contiguous run of nsl * B * 16 floats per batch
         // (in LDS a slice holds BT rows: rows B .. BT-1, and a missing second slice, are zeros)
@@ -400,8 +468,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             int jl, n0;
             tile_of(jl, n0);
             const int o = tid & 255;
-            if (L3 && jl == 2) p3_frag_scatter(n0 + (o >> 4), mt * 16 + (o & 15), Cm, tcur, bufs.fragimg);
-            else p2_frag_scatter(jl, n0 + (o >> 4), mt * 16 + (o & 15), H, tcur, bufs.fragimg);
+            if (L3 && jl == 2) xcd_frag_scatter3(n0 + (o >> 4), mt * 16 + (o & 15), Cm, tcur, bufs.fragimg);
+            else xcd_frag_scatter2(jl, n0 + (o >> 4), mt * 16 + (o & 15), H, tcur, bufs.fragimg);
         }
         xcd_drain();
         __syncthreads();
@@ -458,7 +526,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 // fetched under the wait for the slab
                 bool ok = xcd_wait(bufs.flagT, NT, nullptr, 0, tag, timeout, bufs.errd);
 #pragma unroll
-                for (int q = 0; q < (L3 ? kP3BFrag : kP2BFrag); ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1(r_img, (q * 64 + lane) * 4);
+                for (int q = 0; q < (L3 ? kP3BFrag : kP2BFrag); ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1<T>(r_img, (q * 64 + lane) * ES);
                 ok = ok && xcd_wait(bufs.flagA, NA, nullptr, 0, tag, timeout, bufs.errd);
                 if (!ok && lane == 0) {
                     s_abort = 1;
@@ -485,7 +553,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int p = wave + kP2BWaves * q;
-                    t[q] = xcd_ld4(r_slab, (int)((((size_t)w * NA + (p < NA ? p : wave)) * 64 + lane) * 16));
+                    t[q] = xcd_ld4<T>(r_slab, (int)((((size_t)w * NA + (p < NA ? p : wave)) * 64 + lane) * VS));
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -642,7 +710,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 constexpr int DR = (BT * 8 + kXcdThreads - 1) / kXcdThreads;
                 vec4 dv[DR];
 #pragma unroll
-                for (int r = 0; r < DR; ++r) dv[r] = xcd_ld4(r_d1, (tid + r * kXcdThreads) * 16);       // (past the buffer: zeros, not stored)
+                for (int r = 0; r < DR; ++r) dv[r] = xcd_ld4<T>(r_d1, (tid + r * kXcdThreads) * VS);    // (past the buffer: zeros, not stored)
 #pragma unroll
                 for (int r = 0; r < DR; ++r) {
                     const int idx = tid + r * kXcdThreads;                 // vec4 index in [BT][8]
@@ -705,7 +773,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     const T wn = wcur[i] - scale * gsum[i];
                     wcur[i] = wvalid[i] ? wn : (T)0;
                 }
-                *reinterpret_cast<vec4*>(wsl + (usl * 16 + n) * kP2H + umt * 16 + 4 * g4) = vec4{wcur[0], wcur[1], wcur[2], wcur[3]};
+                store4<T>(wsl + (usl * 16 + n) * kP2H + umt * 16, lane, acc_t{wcur[0], wcur[1], wcur[2], wcur[3]});
                 if (wave == 1) XSTAMP(9);
             }
             // (DP: a barrier that orders LDS only -- __syncthreads would also wait for the exchange's system-scope stores to reach
@@ -736,7 +804,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             if (e == 0 && wave == 0 && (loss_dev || DP)) {
                 // the batch's cost: the sample groups' NS (<= 32) shares, one per lane, summed by a fixed butterfly (every lane ends
                 // with the same bits); lane 0 publishes.  One load latency, not NS of them, between flagB and this tile's gradient
-                T t = lane < NS ? xcd_ld1(r_loss, lane * 4) : (T)0;
+                T t = lane < NS ? xcd_ld1<T>(r_loss, lane * ES) : (T)0;
 #pragma unroll
                 for (int sh = 16; sh >= 1; sh >>= 1) t += __shfl_xor(t, sh, 64);
                 t *= loss_scale;
@@ -768,11 +836,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int s = kc + 4 * q + g4;
-                    bv[q] = xcd_ld1(r_act, (int)(((size_t)s * ldA + cc_ld) * 4));
+                    bv[q] = xcd_ld1<T>(r_act, (int)(((size_t)s * ldA + cc_ld) * ES));
 #pragma unroll
                     for (int t = 0; t < kMtp; ++t) {
                         const int row = t * 16 + n;
-                        av[q][t] = xcd_ld1(r_del, (int)(((size_t)s * ldD + (row < M ? row : M - 1)) * 4));
+                        av[q][t] = xcd_ld1<T>(r_del, (int)(((size_t)s * ldD + (row < M ? row : M - 1)) * ES));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -800,8 +868,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     tcur -= scale * gsum;                                    // rcn.rs:214,221
                     int tmo = tm;                                            // opaque: the image addresses are recomputed per step, not
                     asm volatile("" : "+v"(tmo));                            // kept in two dozen register pairs across the whole loop
-                    if (L3 && jl == 2) p3_frag_scatter(cc, tmo, Cm, tcur, bufs.fragimg);
-                    else p2_frag_scatter(jl, cc, tmo, H, tcur, bufs.fragimg);
+                    if (L3 && jl == 2) xcd_frag_scatter3(cc, tmo, Cm, tcur, bufs.fragimg);
+                    else xcd_frag_scatter2(jl, cc, tmo, H, tcur, bufs.fragimg);
                 }
             }
             xcd_drain();
@@ -830,7 +898,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     if (is_a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (wvalid[i]) W0[woff0 + i] = wcur[i];
+            if (wvalid[i]) W0[woff0 + RI * i] = wcur[i];
     } else if (is_t && tvalid) {
         params[tp] = tcur;
     }

@@ -347,6 +347,12 @@ int rcn_hip_train_epoch_gathers(rcn_hip_ctx* c, size_t B) {
     return use_xcd(c, B) && xcd_gather(c) ? 1 : 0;
 }
 
+int rcn_hip_train_epoch_resident(rcn_hip_ctx* c, size_t B) {
+    if (!c || B == 0) return 0;
+    DevGuard g(c->device);
+    return need_dense(c) == RCN_HIP_OK && use_pipe(c, B) && use_xcd(c, B) ? 1 : 0;
+}
+
 int rcn_hip_dp_resident(rcn_hip_ctx* c, size_t B_shard) {
     if (!c) return 0;
     DevGuard g(c->device);

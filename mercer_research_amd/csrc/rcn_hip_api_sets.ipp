@@ -182,15 +182,16 @@ int rcn_hip_time_kernels_dev(rcn_hip_ctx* c, const void* x, const void* y, size_
         RCN_TRY(ensure_xcd_ws(c, B));
         // the form the last training call ran in: rows gathered by the kernel itself (over that call's rows), or the packed image
         // (only over the matrix the caller hands in now: the remembered pointers are not trusted to be alive otherwise)
-        const bool tg = xcd_gather(c) && c->xg.B == B && c->xg.nb >= 2 && c->xg.X == (const float*)x && c->xg.Y == (const float*)y;
+        const bool tg = !f64 && xcd_gather(c) && c->xg.B == B && c->xg.nb >= 2 && c->xg.X == (const float*)x && c->xg.Y == (const float*)y;
         size_t n = tg ? (c->xg.nb < 64 ? c->xg.nb : 64) : ((c->packed_B == B && c->packed_nb >= 2) ? c->packed_nb : 0);
         auto timed_launch = [&]() {
-            return tg ? enqueue_xcd_steps(c, c->xg.X, c->xg.Y, B, n, 0.0, nullptr, false, c->xg.perm, true)
-                      : enqueue_xcd_steps(c, (const float*)c->xpack.p, (const float*)c->ypack.p, B, n, 0.0, nullptr);
+            if (f64) return enqueue_xcd_steps<double>(c, (const double*)c->xpack.p, (const double*)c->ypack.p, B, n, 0.0, nullptr);
+            return tg ? enqueue_xcd_steps<float>(c, c->xg.X, c->xg.Y, B, n, 0.0, nullptr, false, c->xg.perm, true)
+                      : enqueue_xcd_steps<float>(c, (const float*)c->xpack.p, (const float*)c->ypack.p, B, n, 0.0, nullptr);
         };
         if (n == 0) {
             RCN_TRY(ensure_pack_ws(c, B, 1));
-            RCN_TRY(launch_pack<float>(c, x, y, nullptr, B, 0, 1, 0, 1));
+            RCN_TRY(f64 ? launch_pack<double>(c, x, y, nullptr, B, 0, 1, 0, 1) : launch_pack<float>(c, x, y, nullptr, B, 0, 1, 0, 1));
             n = 1;
         }
         const size_t saved_nb = c->epoch_nb;      // timing on the image does not end a begun epoch (nothing is re-packed unless n was 0)

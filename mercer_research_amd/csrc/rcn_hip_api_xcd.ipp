@@ -34,7 +34,7 @@ int xcd_probe(rcn_hip_ctx* c) {
 }
 
 bool use_xcd(rcn_hip_ctx* c, size_t B) {
-    if (c->dtype != RCN_HIP_F32 || !xcd_supported(c->nd, B)) return false;
+    if (!xcd_supported(c->nd, B, c->esz())) return false;           // (f64: batches up to 128 -- dense_xcd.hpp)
     if (c->dense_path != 0 && c->dense_path != 5) return false;
     if (c->xcd_stepped_down) return false;                              // (rcn_hip_set_dense_path(ctx, 5) arms it again)
     if (c->dense_path == 0 && c->opt.xcd == 0) return false;
@@ -64,7 +64,7 @@ int ensure_xcd_ws(rcn_hip_ctx* c, size_t B) {
                                                            : "train_epoch: a bounded wait inside the resident kernel expired in an earlier call (is the device shared?); "
                                                              "that call's segment was not applied.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline");
     const size_t BT = (size_t)xcd_bt(B);
-    const size_t bytes = xcd_buf_bytes(c->nd, BT);
+    const size_t bytes = xcd_buf_bytes(c->nd, BT, c->esz());
     if (c->xcd_B != BT || c->xcdbuf.cap < bytes) {
         HIP_TRY(c, c->xcdbuf.ensure(bytes));
         HIP_TRY(c, hipMemsetAsync(c->xcdbuf.p, 0, c->xcdbuf.cap, c->stream));      // flags 0: tags start at 1; error word 0
@@ -78,10 +78,11 @@ P2PDesc p2p_desc(const rcn_hip_ctx* c);
 static long long p2p_timeout_ticks(const rcn_hip_ctx* c);
 
 // the workspace of one batch instantiation, carved out of c->xcdbuf
-static XcdBufs xcd_bufs(rcn_hip_ctx* c, size_t BT) {
+template <typename T>
+static XcdBufsT<T> xcd_bufs(rcn_hip_ctx* c, size_t BT) {
     const size_t NS = BT / kP2Ts, NA = (size_t)xcd_na(c->nd);
-    XcdBufs xb;
-    float* f = (float*)c->xcdbuf.p;
+    XcdBufsT<T> xb;
+    T* f = (T*)c->xcdbuf.p;
     xb.slab = f; f += NS * NA * kP2Ts * kP2H;
     xb.d1 = f;   f += BT * kP2H;
     xb.a1 = f;   f += BT * kP2H;
@@ -103,35 +104,35 @@ static XcdBufs xcd_bufs(rcn_hip_ctx* c, size_t BT) {
 
 // One launch of the instantiation for batch BT.  The kernel asks for at least half a CU's LDS plus one byte so that no two of its
 // workers share a CU (option "xcd_exact_lds" = 1: exactly what it uses -- two contexts' resident kernels can then be on one device).
-template <int BT, bool FULL>
-int xcd_launch_bt(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, float scale, float loss_scale, float* loss_dev, bool dp,
-                  const int32_t* gperm, bool gather, const XcdBufs& xb, unsigned tag0, unsigned launch_id) {
+template <typename T, int BT, bool FULL>
+int xcd_launch_bt(rcn_hip_ctx* c, const T* xs, const T* ys, size_t B, size_t nb, T scale, T loss_scale, T* loss_dev, bool dp,
+                  const int32_t* gperm, bool gather, const XcdBufsT<T>& xb, unsigned tag0, unsigned launch_id) {
     const NetDesc& nd = c->nd;
-    size_t lds = xcd_lds_floats(BT) * sizeof(float);
+    size_t lds = xcd_lds_bytes<T, BT>();
     if (!c->opt.xcd_exact_lds && lds < 81 * 1024) lds = 81 * 1024;
     const long long to = c->opt.xcd_timeout_ticks;
     const int xsel = (int)c->opt.xcd_select;
 #define RCN_XCD_LAUNCH(KERN, TO, DPARG)                                                                                                                   \
     do {                                                                                                                                                  \
         RCN_TRY(set_dyn_lds(c, KERN, lds));                                                                                                               \
-        hipLaunchKernelGGL(KERN, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (float*)c->params.p, xs, ys, (int)B, (int)nb,              \
+        hipLaunchKernelGGL(KERN, dim3(8 * kXcdWorkers), dim3(kXcdThreads), lds, c->stream, nd, (T*)c->params.p, xs, ys, (int)B, (int)nb,                  \
                            pipe_slices(nd), scale, loss_scale, loss_dev, xb, tag0, c->xerr_dev, TO, DPARG, xsel, (const int*)gperm, launch_id);           \
     } while (0)
     if (dp) {
-        // (the data-parallel form exists for whole instantiation sizes: a shard of 32 / 64 / 128 / 256 samples per rank)
-        if constexpr (FULL) {
-            RCN_XCD_LAUNCH((k_xcd_epoch<BT, true, true>), to + 2 * p2p_timeout_ticks(c),
+        // (the data-parallel form exists for whole instantiation sizes: a shard of 32 / 64 / 128 / 256 samples per rank, f32)
+        if constexpr (FULL && sizeof(T) == 4) {
+            RCN_XCD_LAUNCH((k_xcd_epoch<float, BT, true, true>), to + 2 * p2p_timeout_ticks(c),
                            (XcdDpOn{PushDesc{p2p_desc(c), c->p2p.stride, c->p2p.push_off}, c->p2p.seq + 1, p2p_timeout_ticks(c)}));
             c->p2p.seq += (unsigned)nb;
             c->xcd_dp_used = true;
-        } else return fail(c, RCN_HIP_ERR_UNSUPPORTED, "the resident kernel's data-parallel form needs a shard of 32, 64, 128 or 256 samples");
+        } else return fail(c, RCN_HIP_ERR_UNSUPPORTED, "the resident kernel's data-parallel form needs an f32 context and a shard of 32, 64, 128 or 256 samples");
     } else if (nd.L == 3) {
-        RCN_XCD_LAUNCH((k_xcd_epoch<BT, FULL, false, true>), to, XcdDpOff{});
+        RCN_XCD_LAUNCH((k_xcd_epoch<T, BT, FULL, false, true>), to, XcdDpOff{});
     } else if (gather) {
-        if constexpr (BT == 256 && FULL) RCN_XCD_LAUNCH((k_xcd_epoch<256, true, false, false, true>), to, XcdDpOff{});
-        else return fail(c, RCN_HIP_ERR_UNSUPPORTED, "the gather form of the resident kernel exists for batch 256 only");
+        if constexpr (BT == 256 && FULL && sizeof(T) == 4) RCN_XCD_LAUNCH((k_xcd_epoch<float, 256, true, false, false, true>), to, XcdDpOff{});
+        else return fail(c, RCN_HIP_ERR_UNSUPPORTED, "the gather form of the resident kernel exists for batch 256, f32 only");
     } else {
-        RCN_XCD_LAUNCH((k_xcd_epoch<BT, FULL, false>), to, XcdDpOff{});
+        RCN_XCD_LAUNCH((k_xcd_epoch<T, BT, FULL, false>), to, XcdDpOff{});
     }
 #undef RCN_XCD_LAUNCH
     HIP_TRY(c, hipGetLastError());
@@ -143,10 +144,11 @@ int xcd_launch_bt(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, si
 // gather: xs / ys are the caller's X[rows][F] / Y[rows][C] as stored and gperm the order of their rows (NULL: stored order) -- the kernel
 // fetches every batch's rows itself, a step ahead; else they are the packed epoch image (k_pack_epoch) and gperm is unused.
 // *id_out (nullable): the launch's id, which the kernel reports in `done` once all of its workers have finished.
-int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B, size_t nb, double eta, float* loss_dev, bool dp = false,
+template <typename T>
+int enqueue_xcd_steps(rcn_hip_ctx* c, const T* xs, const T* ys, size_t B, size_t nb, double eta, T* loss_dev, bool dp = false,
                       const int32_t* gperm = nullptr, bool gather = false, unsigned* id_out = nullptr) {
     const int BT = xcd_bt(B);
-    const XcdBufs xb = xcd_bufs(c, (size_t)BT);
+    const XcdBufsT<T> xb = xcd_bufs<T>(c, (size_t)BT);
     // (the tail parameters as the sample groups' operand fragments -- xb.fragimg -- are written by the kernel's own tail tiles: at its
     // start from the parameter vector, then after every update; its pads are the zeros the buffer was created with)
     const unsigned tag0 = c->xcd_tag + 1;
@@ -160,17 +162,20 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const float* xs, const float* ys, size_t B
     const bool faulty = c->opt.xcd_fault_launch != 0 && (long long)c->xcd_launches == c->opt.xcd_fault_launch;
     const unsigned id_arg = id | (faulty ? 0x80000000u : 0u);
     const double Bg = (double)B * (dp ? (double)c->dp_world : 1.0);          // the global batch.len() of rcn.rs:214
-    const float scale = (float)(eta / Bg), loss_scale = (float)(1.0 / (2.0 * Bg));
-    int st;
+    const T scale = (T)(eta / Bg), loss_scale = (T)(1.0 / (2.0 * Bg));
+    int st = RCN_HIP_ERR_UNSUPPORTED;
     const bool full = (size_t)BT == B;
 #define RCN_XCD_BT(N)                                                                                                                        \
-    st = full ? xcd_launch_bt<N, true>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg)                  \
-              : xcd_launch_bt<N, false>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg)
+    st = full ? xcd_launch_bt<T, N, true>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg)               \
+              : xcd_launch_bt<T, N, false>(c, xs, ys, B, nb, scale, loss_scale, loss_dev, dp, gperm, gather, xb, tag0, id_arg)
     switch (BT) {
     case 32:  RCN_XCD_BT(32); break;
     case 64:  RCN_XCD_BT(64); break;
     case 128: RCN_XCD_BT(128); break;
-    default:  RCN_XCD_BT(256); break;
+    default:
+        if constexpr (sizeof(T) == 4) RCN_XCD_BT(256);
+        else st = fail(c, RCN_HIP_ERR_UNSUPPORTED, "the resident kernel's f64 form covers batches up to 128");
+        break;
     }
 #undef RCN_XCD_BT
     RCN_TRY(st);
@@ -205,8 +210,9 @@ static void note_perm_source(rcn_hip_ctx* c, rcn_hip_ctx::PermSource&& src) {
 }
 
 // a whole call on the resident kernel: batches [j0, j0 + nb) of the call, packed segment by segment (or already packed)
-int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool from_images,
-                      bool prepacked, size_t j0, size_t pre_seg, bool dp = false) {
+template <typename T>
+int enqueue_xcd_epoch_t(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool from_images,
+                        bool prepacked, size_t j0, size_t pre_seg, bool dp) {
     const size_t G = pipe_slices(c->nd), Cc = c->nd.dims[c->nd.L];
     // single-GPU calls are journalled until their launches have been seen complete (xcd_verify): what a failed launch did not apply is
     // re-run from here on the two-kernel pipeline
@@ -227,17 +233,17 @@ int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
         else rec->begin = c->last_begin;
     }
     auto note = [&](unsigned id, size_t k0, size_t n) { if (rec) rec->launches.push_back({id, k0, n}); };
-    if (!prepacked && !from_images && !dp && xcd_gather(c)) {
+    if (sizeof(T) == 4 && !prepacked && !from_images && !dp && xcd_gather(c)) {
         c->xg.X = (const float*)X; c->xg.Y = (const float*)Y; c->xg.perm = perm; c->xg.B = B; c->xg.nb = nb;
         // feature vectors as stored: no packed image at all -- ONE launch walks the whole call, every worker gathering its 128 bytes of
         // each row of the batch after next while it works on the current one (the bytes k_pack_epoch would read, write and hand back)
         for (size_t k = 0; k < nb;) {
             const size_t n = nb - k < kXcdMaxStepsPerLaunch ? nb - k : kXcdMaxStepsPerLaunch;
             unsigned id = 0;
-            RCN_TRY(enqueue_xcd_steps(c, (const float*)X, (const float*)Y, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr, dp,
-                                      perm ? perm + k * B : nullptr, true, &id));
+            RCN_TRY(enqueue_xcd_steps<T>(c, (const T*)X, (const T*)Y, B, n, eta, loss_dev ? (T*)loss_dev + k : nullptr, dp,
+                                         perm ? perm + k * B : nullptr, true, &id));
             note(id, k, n);
-            if (!perm) { X = (const float*)X + n * B * c->nd.dims[0]; Y = (const float*)Y + n * B * Cc; }
+            if (!perm) { X = (const T*)X + n * B * c->nd.dims[0]; Y = (const T*)Y + n * B * Cc; }
             k += n;
         }
         return RCN_HIP_OK;
@@ -248,16 +254,21 @@ int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_
         const size_t in_seg = seg - j % seg, n = end - j < in_seg ? end - j : in_seg;       // up to the end of this segment of the image
         if (!prepacked) {
             const int half = (int)((j / seg) % 2);
-            RCN_TRY(from_images ? launch_feat_pack<float>(c, (const uint8_t*)X, Y, perm, B, j, n, half, seg) : launch_pack<float>(c, X, Y, perm, B, j, n, half, seg));
+            RCN_TRY(from_images ? launch_feat_pack<T>(c, (const uint8_t*)X, Y, perm, B, j, n, half, seg) : launch_pack<T>(c, X, Y, perm, B, j, n, half, seg));
         }
-        const float* xs = (const float*)c->xpack.p + slot(j) * G * B * 16;
-        const float* ys = (const float*)c->ypack.p + slot(j) * B * Cc;
+        const T* xs = (const T*)c->xpack.p + slot(j) * G * B * 16;
+        const T* ys = (const T*)c->ypack.p + slot(j) * B * Cc;
         unsigned id = 0;
-        RCN_TRY(enqueue_xcd_steps(c, xs, ys, B, n, eta, loss_dev ? (float*)loss_dev + k : nullptr, dp, nullptr, false, &id));
+        RCN_TRY(enqueue_xcd_steps<T>(c, xs, ys, B, n, eta, loss_dev ? (T*)loss_dev + k : nullptr, dp, nullptr, false, &id));
         note(id, k, n);
         j += n; k += n;
     }
     return RCN_HIP_OK;                      // (the sticky error word lives in pinned host memory: current once the stream has drained)
+}
+int enqueue_xcd_epoch(rcn_hip_ctx* c, const void* X, const void* Y, const int32_t* perm, size_t B, size_t nb, double eta, void* loss_dev, bool from_images,
+                      bool prepacked, size_t j0, size_t pre_seg, bool dp = false) {
+    return c->dtype == RCN_HIP_F64 ? enqueue_xcd_epoch_t<double>(c, X, Y, perm, B, nb, eta, loss_dev, from_images, prepacked, j0, pre_seg, dp)
+                                   : enqueue_xcd_epoch_t<float>(c, X, Y, perm, B, nb, eta, loss_dev, from_images, prepacked, j0, pre_seg, dp);
 }
 
 // one train_batch (rcn.rs:176-223) on device-resident data; idx selects the batch's rows (or NULL)

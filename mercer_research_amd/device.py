@@ -220,6 +220,10 @@ class DeviceRCN:
         """True when train_epoch at this batch size fetches its rows inside the resident kernel (no packed epoch image)."""
         return bool(self.lib.rcn_hip_train_epoch_gathers(self.ctx, B))
 
+    def train_epoch_resident(self, B: int) -> bool:
+        """True when train_epoch / epoch_steps at this batch size run on the resident one-XCD kernel (f32: 1..256, f64: 1..128)."""
+        return bool(self.lib.rcn_hip_train_epoch_resident(self.ctx, B))
+
     def dp_resident(self, B_shard: int) -> bool:
         """True when dp_train_epoch at this shard size runs on the resident one-XCD kernel with the exchange inside it."""
         return bool(self.lib.rcn_hip_dp_resident(self.ctx, B_shard))

@@ -123,6 +123,7 @@ extern "C" {
                                          form_out: *mut c_int, resident_out: *mut c_int) -> c_int;
     pub fn rcn_hip_dp_epoch_steps_dev(ctx: *mut rcn_hip_ctx, first_batch: usize, n_batches: usize, eta: f64, loss_dev: *mut c_void) -> c_int;
     pub fn rcn_hip_train_epoch_gathers(ctx: *mut rcn_hip_ctx, b: usize) -> c_int;
+    pub fn rcn_hip_train_epoch_resident(ctx: *mut rcn_hip_ctx, b: usize) -> c_int;
     pub fn rcn_hip_dp_resident(ctx: *mut rcn_hip_ctx, b_shard: usize) -> c_int;
     pub fn rcn_hip_dp_p2p_active(ctx: *const rcn_hip_ctx) -> c_int;
     pub fn rcn_hip_set_feature_kernel(ctx: *mut rcn_hip_ctx, mode: c_int) -> c_int;

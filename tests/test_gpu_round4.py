@@ -1,0 +1,198 @@
+"""GPU tests added in round 4 (run with -m gpu on an MI355X), all through the C ABI:
+
+* the resident one-XCD kernel in the reference's OWN arithmetic type (f64: rcn.rs:28,31,49) at its own operating points -- batch_size
+  10 (rcn/src/main.rs:36-37, rcn.rs:581), 32 (BASELINE configs[0]) -- and at every other batch of 1..128 samples, both reference nets,
+  against the CPU restatement at the f64 tolerance (1e-11 per step);
+* the 256-step f64 loss curve at B = 10 and B = 32 on the resident kernel (<= 1e-9 per step);
+* the self-healing step-down in f64.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle.rcn_oracle import DEFAULT_LAYERS, one_hot, synthetic_images, synthetic_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32, F64 = 0, 1
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import mercer_research_amd as m
+    return m
+
+
+def _xcd_or_skip(d):
+    import mercer_research_amd as amd
+    try:
+        d.set_dense_path(5)
+    except amd.RcnHipError as e:
+        pytest.skip(f"the resident one-XCD kernel does not apply on this device: {e}")
+
+
+def _oracle_steps(oracle, ws, bs, X, Y, perm, B, nb, eta):
+    rw, rb, costs = ws, bs, []
+    for j in range(nb):
+        sel = perm[j * B:(j + 1) * B]
+        rw, rb, c = oracle.train_batch(rw, rb, X[sel], Y[sel], eta)
+        costs.append(c)
+    return rw, rb, np.array(costs)
+
+
+def test_f64_context_reaches_the_resident_kernel_by_default(amd):
+    """The drop-in crate opens an F64 context (rust/rcn-hip/src/rcn.rs) and trains at batch_size 10: that context, with no option set,
+    must land on the resident kernel for batches of 1..128 and on the pipeline above."""
+    from mercer_research_amd.device import DeviceRCN
+    d = DeviceRCN(dtype=F64)
+    _xcd_or_skip(d)
+    d.set_dense_path(0)
+    for B in (1, 10, 32, 64, 100, 128):
+        assert d.train_epoch_resident(B), B
+    for B in (129, 200, 256, 512):
+        assert not d.train_epoch_resident(B), B
+    d.rcn.close()
+    d = DeviceRCN(dtype=F32)
+    for B in (1, 10, 32, 128, 200, 256):
+        assert d.train_epoch_resident(B), B
+    assert not d.train_epoch_resident(257)
+    d.rcn.close()
+    d = DeviceRCN(dtype=F64, feedforward_cfg=[40])                       # outside the kernel's shape class
+    assert not d.train_epoch_resident(10)
+    d.rcn.close()
+
+
+@pytest.mark.parametrize("hidden", [[30], [10, 10]], ids=["784-30-10", "reference-test-net-784-10-10-10"])
+@pytest.mark.parametrize("B", [10, 32, 1, 8, 33, 64, 100, 128])
+def test_resident_kernel_f64_at_any_batch_of_1_to_128_is_the_reference_loop(amd, oracle, hidden, B):
+    """train_batch (rcn.rs:176-223, 260-314; sigmoid rcn.rs:478-492) in f64 on the resident kernel's v_mfma_f64_16x16x4_f64
+    instantiations for 32 / 64 / 128 samples: one step from identical parameters within 1e-11 of the CPU restatement, six chained steps
+    in a shuffled order within 1e-10, and the same calls on the sample-tile kernels (dense path 1)."""
+    from mercer_research_amd.device import DeviceRCN
+    dims = [784] + hidden + [10]
+    N, nb = 1024, 6
+    rng = np.random.default_rng(300 + B)
+    X = np.maximum(rng.standard_normal((N, 784)), 0.0)
+    Y = one_hot(rng.integers(0, 10, N))
+    ws, bs = synthetic_params(dims, seed=21)
+    ws = [w * 0.1 for w in ws]
+    perm = rng.permutation(N).astype(np.int32)
+    got = {}
+    for path in (5, 1):
+        d = DeviceRCN(dtype=F64, feedforward_cfg=hidden)
+        if path == 5:
+            _xcd_or_skip(d)
+            assert d.train_epoch_resident(B)
+        else:
+            d.set_dense_path(1)
+            assert not d.train_epoch_resident(B)
+        d.set_params(ws, bs)
+        Xd, Yd, pd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype), d.to_device(perm)
+        loss = d.empty(nb + 1)
+        d.train_epoch(Xd, Yd, None, B, 1, 3.0, loss)                   # one step, stored order
+        p1 = sum(d.get_params(), [])
+        d.train_epoch(Xd, Yd, pd, B, nb, 3.0, loss[1:])                 # six more, shuffled
+        d.synchronize()
+        got[path] = (p1, sum(d.get_params(), []), loss.cpu().numpy().astype(np.float64))
+        assert d.fallbacks_taken() == 0
+        d.rcn.close()
+    rw, rb, c0 = oracle.train_batch(ws, bs, X[:B], Y[:B], 3.0)
+    for path in (5, 1):
+        for a, b in zip(got[path][0], rw + rb):
+            assert np.all(np.abs(a - b) <= 1e-11 * np.abs(b) + 1e-12), (path, float(np.abs(a - b).max()))
+        assert abs(got[path][2][0] - c0) <= 1e-11 * c0
+    rw, rb, cs = _oracle_steps(oracle, rw, rb, X, Y, perm, B, nb, 3.0)
+    for path in (5, 1):
+        np.testing.assert_allclose(got[path][2][1:], cs, rtol=1e-10)
+        for a, b in zip(got[path][1], rw + rb):
+            assert np.all(np.abs(a - b) <= 1e-10 * np.abs(b) + 1e-11), (path, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("B", [10, 32], ids=["B10-reference-default", "B32-baseline-config0"])
+def test_f64_loss_curve_256_steps_on_the_resident_kernel(amd, oracle, B):
+    """256 consecutive steps in the reference's own type at its own batch sizes, from the resident u8 pictures through load_data, on the
+    resident kernel against oracle/rcn_oracle.c on the identical batches: the cost within 1e-9 relative at EVERY step, the final
+    parameters within 1e-8 (the f64 bar of DESIGN section 5)."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    N, steps, eta = 8192, 256, 3.0
+    imgs, labels = synthetic_images(N, seed=77)
+    feats = oracle.features(imgs, DEFAULT_LAYERS)
+    m, s = oracle.gen_scales(feats)
+    X, Y = oracle.standardize(feats, m, s), one_hot(labels)
+    ws, bs = synthetic_params([784, 30, 10], seed=42)
+    d = DeviceRCN(dtype=F64)
+    _xcd_or_skip(d)
+    d.set_dense_path(0)                                                 # the default selection, as the drop-in crate gets it
+    assert d.train_epoch_resident(B)
+    d.set_params(ws, bs)
+    Xd, Yd = d.load_data(d.to_device(imgs), d.to_device(labels))
+    perm = torch.empty(N, dtype=torch.int32, device=d.device)
+    loss = d.empty(steps)
+    d.shuffle(perm, N, 1, seed=0xABCD)
+    d.synchronize()
+    p = perm.cpu().numpy().astype(np.int64)
+    d.epoch_begin(Xd, Yd, perm, B, steps)
+    d.epoch_steps(0, 100, eta, loss)
+    d.epoch_steps(100, steps - 100, eta, loss[100:])
+    gw, gb = d.get_params()
+    gpu = loss.double().cpu().numpy()
+    assert d.fallbacks_taken() == 0
+    d.rcn.close()
+    h = oracle.net(ws, bs)
+    cpu = np.zeros(steps)
+    for j in range(steps):
+        idx = p[j * B:(j + 1) * B]
+        xb, yb = np.ascontiguousarray(X[idx]), np.ascontiguousarray(Y[idx])
+        cpu[j] = oracle.lib.rcn_o_train_batch(C.byref(h.net), xb.ctypes.data_as(C.POINTER(C.c_double)), yb.ctypes.data_as(C.POINTER(C.c_double)), B, eta)
+    rel = np.abs(gpu - cpu) / np.abs(cpu)
+    assert rel.max() <= 1e-9, (rel.max(), int(rel.argmax()))
+    for a, b in zip(gw + gb, h.weights() + h.biases()):
+        assert np.all(np.abs(a - b) <= 1e-8 * np.abs(b) + 1e-9), float(np.abs(a - b).max())
+
+
+@pytest.mark.steps_down
+@pytest.mark.parametrize("fail_launch", [1, 2])
+def test_f64_resident_kernel_steps_down_by_itself(amd, oracle, fail_launch):
+    """The forced expiry of tests/test_gpu_round3.py in the f64 context at B = 32: the library re-runs what the failed launch had not applied
+    on the two-kernel pipeline; the epochs equal the oracle at the f64 tolerance and the counter reads 1."""
+    import torch
+    from mercer_research_amd.device import DeviceRCN
+    B, nb, N = 32, 8, 512
+    imgs, labels = synthetic_images(N, seed=9)
+    ws, bs = synthetic_params([784, 30, 10], seed=3)
+    ws = [w * 0.1 for w in ws]
+    d = DeviceRCN(dtype=F64)
+    _xcd_or_skip(d)
+    d.set_dense_path(0)
+    d.set_option("xcd_timeout_ticks", 300000)
+    d.set_option("xcd_fault_launch", fail_launch)
+    d.set_params(ws, bs)
+    Xd, Yd = d.load_data(d.to_device(imgs), d.to_device(labels))
+    Xh, Yh = Xd.double().cpu().numpy(), one_hot(labels)
+    perm = torch.empty(N, dtype=torch.int32, device=d.device)
+    loss = d.empty(2 * nb)
+    perms = []
+    for e in range(2):
+        d.shuffle(perm, N, 1, seed=900 + e)
+        d.synchronize()
+        perms.append(perm.cpu().numpy().astype(np.int64))
+    assert d.fallbacks_taken() == 0
+    for e in range(2):                                                  # nothing synchronises in here
+        d.shuffle(perm, N, 1, seed=900 + e)
+        d.train_epoch(Xd, Yd, perm, B, nb, 3.0, loss[e * nb:])
+    d.synchronize()                                                     # heals
+    assert d.fallbacks_taken() == 1
+    assert not d.train_epoch_resident(B)
+    got = sum(d.get_params(), [])
+    costs = loss.double().cpu().numpy()
+    rw, rb, cs = ws, bs, []
+    for e in range(2):
+        rw, rb, c = _oracle_steps(oracle, rw, rb, Xh, Yh, perms[e], B, nb, 3.0)
+        cs.extend(c)
+    np.testing.assert_allclose(costs, cs, rtol=1e-9)
+    for a, b in zip(got, rw + rb):
+        assert np.all(np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-10), float(np.abs(a - b).max())
+    d.rcn.close()

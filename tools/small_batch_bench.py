@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Device-timed step time of train_batch at the reference's own batch sizes (10: rcn/src/main.rs:36-37; 32: BASELINE configs[0]) and
+"""(--dtype f64: the reference's own arithmetic type.)  Device-timed step time of train_batch at the reference's own batch sizes (10: rcn/src/main.rs:36-37; 32: BASELINE configs[0]) and
 the sizes between, on the default path (the resident one-XCD kernel's instantiation for the next of 32/64/128/256) and on the
 two-kernel pipeline / sample-tile kernels it replaces there.  One JSON line.
 
@@ -14,9 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(torch, amd, DeviceRCN, imgs_d, labels_d, dims, B, path, n_images, epochs=8):
+def measure(torch, amd, DeviceRCN, imgs_d, labels_d, dims, B, path, n_images, epochs=8, dtype=0):
     from mercer_research_amd.synth import synthetic_params
-    d = DeviceRCN(classes=dims[-1], feedforward_cfg=dims[1:-1], input_shape=(28, 28), dtype=amd.F32)
+    d = DeviceRCN(classes=dims[-1], feedforward_cfg=dims[1:-1], input_shape=(28, 28), dtype=dtype)
     ws, bs = synthetic_params(dims, seed=42)
     d.set_params(ws, bs)
     if path:
@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--batches", default="10,32,64,128,256")
     ap.add_argument("--dims", default="784,30,10")
     ap.add_argument("--images", type=int, default=16384)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     args = ap.parse_args()
     import torch
     import mercer_research_amd as amd
@@ -58,10 +59,11 @@ def main():
     imgs, labels = synthetic_images(args.images, seed=1234)
     dev = torch.device("cuda", 0)
     imgs_d, labels_d = torch.from_numpy(imgs).to(dev), torch.from_numpy(labels).to(dev)
-    out = {"dims": dims}
+    dt = amd.F64 if args.dtype == "f64" else amd.F32
+    out = {"dims": dims, "dtype": args.dtype}
     for B in [int(v) for v in args.batches.split(",")]:
-        out[f"B{B}"] = {"default_path": measure(torch, amd, DeviceRCN, imgs_d, labels_d, dims, B, 0, args.images),
-                        "two_kernel_or_sample_tile": measure(torch, amd, DeviceRCN, imgs_d, labels_d, dims, B, 2 if B % 256 == 0 else 1, args.images)}
+        out[f"B{B}"] = {"default_path": measure(torch, amd, DeviceRCN, imgs_d, labels_d, dims, B, 0, args.images, dtype=dt),
+                        "two_kernel_or_sample_tile": measure(torch, amd, DeviceRCN, imgs_d, labels_d, dims, B, 2 if B % 256 == 0 else 1, args.images, dtype=dt)}
     print(json.dumps(out))
 
 
