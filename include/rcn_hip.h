@@ -321,18 +321,32 @@ int  rcn_hip_classify_images(rcn_hip_ctx* ctx, const uint8_t* imgs, size_t n, in
  * within the stated tolerances). */
 int  rcn_hip_set_dense_path(rcn_hip_ctx* ctx, int mode);
 int  rcn_hip_fallbacks_taken(const rcn_hip_ctx* ctx);      /* not a status: the number of step-downs described above */
+/* The record of the newest bounded wait of the resident one-XCD kernel that expired in this context -- written by the first worker that
+ * gave up (csrc/dense_xcd.hpp: xcd_raise), kept after the library has healed the context.  words[0..12] = site (1 placement vote,
+ * 2 tail-tile flag, 3 slab flag, 4 delta flag, 5 pushed reduce-scatter, 6 pushed all-gather, 7 tail all-to-all, 8 cost all-to-all,
+ * 9 closing round), worker, step within the launch, launch id, missing producers / workers / ranks (low, high 32 bits; closing round:
+ * the arrivals seen), awaited tag or exchange step, XCC_ID of the worker, rank, world, which blocks were workers (blockIdx % 8), workers
+ * of the launch, error code (1 expired, 2 workers on different XCDs).  Returns the number of words written, 0 when nothing is on record.
+ * _text: the same in words plus the workspace's placement / flag tables as the failed launch left them ("" when nothing is on record). */
+int  rcn_hip_last_timeout(const rcn_hip_ctx* ctx, uint32_t* words, size_t cap);
+const char* rcn_hip_last_timeout_text(const rcn_hip_ctx* ctx);
 
 /* Per-context options.  The environment variable named beside an option only seeds its default when the context is created; nothing
  * reads the environment afterwards, so two contexts of one process can differ.  RCN_HIP_ERR_INVALID_ARG for an unknown name or a value
  * out of range.  Changing an option drops the context's captured graphs.
  *   "xcd"                 RCN_HIP_XCD                 0 | 1     dense path 0 may select the resident one-XCD kernel (1)
- *   "xcd_select"          RCN_HIP_XCD_SELECT          0..7      which blocks of a resident launch are its workers (blockIdx.x % 8); tests
+ *   "xcd_select"          RCN_HIP_XCD_SELECT          0..7      TEST-ONLY (ranks sharing ONE device in the test harness): which blocks of a resident
+ *                                                               launch are its workers (blockIdx.x % 8); a GPU per rank keeps 0
  *   "xcd_gather"          RCN_HIP_XCD_GATHER          0 | 1     rows fetched by the resident kernel itself, batch 256 (measured slower; 0)
  *   "xcd_timeout_ticks"   RCN_HIP_XCD_TIMEOUT_TICKS   >= 1      bound of every wait inside the resident kernel, 100 MHz ticks (20000000 = 0.2 s)
- *   "xcd_exact_lds"       RCN_HIP_XCD_EXACT_LDS       0 | 1     the resident kernel asks for exactly the LDS it uses, so that two contexts'
- *                                                               kernels fit on one device at batches <= 64 (0: one worker per CU)
+ *   "xcd_exact_lds"       RCN_HIP_XCD_EXACT_LDS       0 | 1     TEST-ONLY (same harness): the resident kernel asks for exactly the LDS it uses, so that
+ *                                                               two contexts' kernels fit on one device at batches <= 64 (0: one worker per CU)
  *   "xcd_auto_fallback"   RCN_HIP_XCD_AUTO_FALLBACK   0 | 1     self-healing step-down of the single-GPU resident kernel (1)
- *   "xcd_fault_launch"    RCN_HIP_XCD_FAULT_LAUNCH    >= 0      test hook: the n-th resident launch of the context loses a worker and fails (0: none)
+ *   "xcd_replay_caller_rows" RCN_HIP_XCD_REPLAY_CALLER_ROWS 0 | 1  the step-down may also re-run steps whose index rows the CALLER wrote (taken as unchanged
+ *                                                               since the call); 0: only stored-order calls and rows from rcn_hip_shuffle_dev / an upload of
+ *                                                               the library are re-run, anything else keeps the sticky error (0)
+ *   "xcd_fault_launch"    RCN_HIP_XCD_FAULT_LAUNCH    >= 0      TEST HOOK, never set in production: the n-th resident launch of the context fails (0: none)
+ *   "xcd_fault_mode"      RCN_HIP_XCD_FAULT_MODE      0 | 1     TEST HOOK: how -- 0 a worker never becomes resident, 1 a worker reaches the closing round late
  *   "dp_p2p"              RCN_HIP_DP_P2P              0 | 1 | 2 peer exchange over xGMI: never / when world > 1 / also at world 1 (tests)
  *   "dp_fused"            RCN_HIP_DP_FUSED            0 | 1     the exchange may run inside a step kernel (1)
  *   "dp_timeout_ticks"    RCN_HIP_DP_TIMEOUT_TICKS    >= 1      bound of a peer wait (100000000 = 1 s)

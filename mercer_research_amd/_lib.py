@@ -112,6 +112,8 @@ SIGNATURES = {
     "rcn_hip_classify_images": (_i, [_vp, _u8p, _sz, _i32p]),
     "rcn_hip_set_dense_path": (_i, [_vp, _i]),
     "rcn_hip_fallbacks_taken": (_i, [_vp]),
+    "rcn_hip_last_timeout": (_i, [_vp, C.POINTER(C.c_uint32), _sz]),
+    "rcn_hip_last_timeout_text": (C.c_char_p, [_vp]),
     "rcn_hip_set_option": (_i, [_vp, C.c_char_p, C.c_int64]),
     "rcn_hip_get_option": (_i, [_vp, C.c_char_p, _i64p]),
     "rcn_hip_set_feature_kernel": (_i, [_vp, _i]),

@@ -64,7 +64,9 @@ struct XcdBufsT {
     unsigned* xcc;     // [32 x stride]      (launch tag << 4) | XCC_ID of worker w
     unsigned* flagD;   // [32 x stride]      tag of the last step of the newest launch worker w finished computing (before any write-back)
     unsigned* errd;    // [1]                device copy of the sticky error word
-    unsigned* done;    // pinned host word: id of the newest launch whose workers ALL finished (its parameters are in memory when it ends)
+    unsigned* done;    // pinned host word: id of the newest launch whose workers ALL decided to commit (its parameters are in memory when it ends)
+    unsigned* cw;      // [1]                the closing round's decision word: arrivals in the low half, the poison bit above (xcd_commit)
+    unsigned* cdone;   // [32]               id of the newest launch whose write-back worker w completed (the host cross-checks `done` with it)
 };
 using XcdBufs = XcdBufsT<float>;
 
@@ -166,9 +168,31 @@ __device__ inline void xcd_flag_wt(unsigned* f, unsigned v) { __hip_atomic_store
 
 // The sticky error word lives twice: in pinned host memory (the host reads it after a synchronise without a copy in the stream) and in
 // device memory (what the waits of this and every later launch look at: a launch that finds it set leaves at once, writing nothing).
-__device__ inline void xcd_raise(unsigned* err_host, unsigned* err_dev, unsigned code) {
-    __hip_atomic_store(err_dev, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// Round 4: the FIRST worker that gives up (compare-and-swap on the device word) also writes a record next to the host word -- which
+// wait, who waited, for whom, at which step of which launch -- so that an expired wait names its site instead of reading "1".
+enum XcdSite : unsigned {
+    kXcdSitePlacement = 1,      // the placement vote: a worker's XCC answer never came (that worker is not resident), or the answers differ
+    kXcdSiteTailFlag = 2,       // a sample group waiting for a tail tile's share of the fragment image (flagT)
+    kXcdSiteSlabFlag = 3,       // a sample group waiting for a feature worker's slab part (flagA)
+    kXcdSiteDeltaFlag = 4,      // a feature worker / tail tile waiting for a sample group's deltas (flagB)
+    kXcdSitePushOwner = 5,      // data-parallel: the owner of a slice pair waiting for the other ranks' partial sums (reduce-scatter)
+    kXcdSitePushMember = 6,     // data-parallel: a rank waiting for the owner's totals (all-gather)
+    kXcdSitePushTail = 7,       // data-parallel: a tail parameter's all-to-all
+    kXcdSitePushCost = 8,       // data-parallel: the cost's all-to-all
+    kXcdSiteClosing = 9,        // the closing round: not every worker finished the launch's last step in time
+};
+constexpr int kXcdRecWords = 12;    // record at err_host + 4: site, worker, step, launch id, missing lo, missing hi, awaited tag, XCC_ID, rank, world, xsel, NW
+__device__ inline void xcd_raise(unsigned* err_host, unsigned* err_dev, unsigned code, unsigned site, int worker, int step, unsigned launch,
+                                 unsigned long long missing, unsigned tag, int rank = 0, int world = 1, int xsel = 0, int nw = 0) {
+    unsigned expect = 0u;
+    if (!__hip_atomic_compare_exchange_strong(err_dev, &expect, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    const unsigned rec[kXcdRecWords] = {site, (unsigned)worker, (unsigned)step, launch & 0x3fffffffu, (unsigned)missing, (unsigned)(missing >> 32), tag, id & 0xfu,
+                                        (unsigned)rank, (unsigned)world, (unsigned)xsel, (unsigned)nw};
+#pragma unroll
+    for (int i = 0; i < kXcdRecWords; ++i) __hip_atomic_store(err_host + 4 + i, rec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_host, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // a workgroup barrier for data exchanged through LDS only: outstanding global stores are not waited for
@@ -176,20 +200,58 @@ __device__ inline void xcd_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\
 
 // ONE wave waits until every flag its lanes look at (lane < n0: f0[lane]; n0 <= lane < n0 + n1: f1[lane - n0]) carries a tag >= tag.
 // Bounded: gives up after `timeout` ticks of the 100 MHz clock or when another worker raised the sticky error word.
-__device__ inline bool xcd_wait(const unsigned* f0, int n0, const unsigned* f1, int n1, unsigned tag, long long timeout, const unsigned* err) {
+// Returns 0 when every flag arrived, else the lanes (producers) whose flag was still behind when the wait gave up.
+__device__ inline unsigned long long xcd_wait(const unsigned* f0, int n0, const unsigned* f1, int n1, unsigned tag, long long timeout, const unsigned* err) {
     const int lane = threadIdx.x & 63;
     const unsigned* p = lane < n0 ? f0 + lane * kXcdFlagStride : (lane < n0 + n1 ? f1 + (lane - n0) * kXcdFlagStride : nullptr);
     long long t0 = 0;
     for (unsigned it = 0;; ++it) {
         const unsigned f = p ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
-        if (__all((int)(f - tag) >= 0)) return true;
+        if (__all((int)(f - tag) >= 0)) return 0ull;
         if ((it & 255u) == 255u) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            else if (now - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return __ballot((int)(f - tag) < 0);
         }
         // (no s_sleep between polls: measured 6.42 against 6.49 us per step with s_sleep(1); a SECOND poll in flight, issued before the
         // first is looked at, measured slower -- 6.64 -- the extra loads queue in front of the payload loads that follow)
+    }
+}
+
+// The closing round as ONE decision every worker reads the same way (round 4; before, every worker waited for all flagD under its own
+// clock, and a worker that arrived just after another had given up saw all flags set and wrote its slice: a torn parameter vector
+// under a completed-looking launch).  Arrivals are counted in the low half of one word; a worker that gives up sets the poison bit
+// by compare-and-swap, which succeeds only while the count is still short of NW.  So either the count reached NW unpoisoned -- then
+// every worker, also one whose clock has run out, sees exactly that and writes back -- or the word was poisoned first, and then every
+// worker, also one that arrives later, sees the poison and writes nothing.  Called by ONE lane per worker; worker 0 clears the word
+// before it answers the placement vote (no worker arrives here before it has seen all answers).
+constexpr unsigned kXcdPoison = 0x10000u;
+__device__ inline bool xcd_commit(unsigned* cw, int NW, long long timeout, const unsigned* err, bool& gave_up, unsigned& seen) {
+    unsigned v = __hip_atomic_fetch_add(cw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    long long t0 = 0;
+    gave_up = false;
+    for (unsigned it = 0;; ++it) {
+        if (v & kXcdPoison) { seen = v; return false; }
+        if ((int)(v & 0xffffu) == NW) { seen = v; return true; }
+        if ((it & 63u) == 63u) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                for (;;) {                                                // give up -- unless everybody has arrived in the meantime
+                    if (v & kXcdPoison) { seen = v; return false; }
+                    if ((int)(v & 0xffffu) == NW) { seen = v; return true; }
+                    unsigned expect = v;
+                    if (__hip_atomic_compare_exchange_strong(cw, &expect, v | kXcdPoison, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        gave_up = true;
+                        seen = v;
+                        return false;
+                    }
+                    v = expect;
+                }
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -294,6 +356,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
     const bool is_a = w < NA, is_t = w >= NA && w < NA + NT, is_s = w < NS;
+    int dp_rank = 0, dp_world = 1;                                  // (for the time-out record)
+    if constexpr (DP) { dp_rank = dp.pd.pd.rank; dp_world = dp.pd.pd.world; }
     const int e = w - NA;                                           // tail tile index when is_t
     const int nsl = is_a ? (G - kXcdSl * w < kXcdSl ? G - kXcdSl * w : kXcdSl) : 0;
     const size_t xs_stride = (size_t)G * B * 16, ys_stride = (size_t)B * C;
@@ -319,6 +383,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         xcd_flag(bufs.flagB + w * kXcdFlagStride, tag0 - 1u);
         xcd_flag(bufs.flagD + w * kXcdFlagStride, tag0 - 1u);
         if (w < 8) xcd_flag(bufs.flagT + w * kXcdFlagStride, tag0 - 1u);
+        if (w == 0) __hip_atomic_store(bufs.cw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the closing round's decision word (xcd_commit)
         xcd_drain();
         xcd_flag_wt(bufs.xcc + w * kXcdFlagStride, (vtag << 4) | (id & 0xfu));
     }
@@ -341,9 +406,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         }
         mine = __shfl(v, w < 64 ? w : 0, 64) & 0xfu;
         const bool same = __all(lane >= NW || (v & 0xfu) == mine);
+        // (missing: the workers whose answer never came -- or, code 2, the workers that answered from another XCD than this one)
+        const unsigned long long absent = ok ? __ballot(lane < NW && (v & 0xfu) != mine) : __ballot(lane < NW && (v >> 4) != vtag);
         if (lane == 0 && !stale && !(ok && same)) {
             s_abort = 1;
-            xcd_raise(err, bufs.errd, ok ? 2u : 1u);      // 2: workers on different XCDs; 1: a wait expired
+            xcd_raise(err, bufs.errd, ok ? 2u : 1u, kXcdSitePlacement, w, -1, launch_id, absent, vtag, dp_rank, dp_world, xsel, NW);      // 2: workers on different XCDs; 1: a wait expired
         }
     }
     __syncthreads();
@@ -351,6 +418,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     // (test hook, option "xcd_fault_launch": bit 31 of the launch id makes worker 1 leave here, as a worker that never became resident
     // would -- every wait for it expires and the launch fails without having written anything)
     if ((launch_id >> 31) != 0u && w == 1) return;
+    // (second test hook, bit 30: worker 1 reaches the closing round late -- after every other worker's wait there has expired)
+    const bool late_closer = ((launch_id >> 30) & 1u) != 0u && w == 1;
 
     // ---- feature worker: its slice pair of W_0 into LDS and registers; the first two batches into the two LDS buffers.
     // The gradient of the slice pair is four 16 x 16 tiles (slice sl, hidden half mt); wave u owns tile u & 3 for the samples of K-half
@@ -524,13 +593,13 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 XSTAMP(0);
                 // the tail tiles finish well before the feature workers: their flags first, the 24 parameter words of the image
                 // fetched under the wait for the slab
-                bool ok = xcd_wait(bufs.flagT, NT, nullptr, 0, tag, timeout, bufs.errd);
+                const unsigned long long mT = xcd_wait(bufs.flagT, NT, nullptr, 0, tag, timeout, bufs.errd);
 #pragma unroll
                 for (int q = 0; q < (L3 ? kP3BFrag : kP2BFrag); ++q) fr[q] = (q >= 20 && q < 24) ? (T)0 : xcd_ld1<T>(r_img, (q * 64 + lane) * ES);
-                ok = ok && xcd_wait(bufs.flagA, NA, nullptr, 0, tag, timeout, bufs.errd);
-                if (!ok && lane == 0) {
+                const unsigned long long mA = mT ? 0ull : xcd_wait(bufs.flagA, NA, nullptr, 0, tag, timeout, bufs.errd);
+                if ((mT | mA) != 0ull && lane == 0) {
                     s_abort = 1;
-                    xcd_raise(err, bufs.errd, 1u);
+                    xcd_raise(err, bufs.errd, 1u, mT ? kXcdSiteTailFlag : kXcdSiteSlabFlag, w, j, launch_id, mT ? mT : mA, tag, dp_rank, dp_world, xsel, NW);
                 }
                 XSTAMP(1);
             } else if (wave == 6) {                                   // targets per accumulator element: no flag to wait for
@@ -692,9 +761,12 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 
         // =============================================================== second half of step j: needs every sample group's outputs
         if (is_a || is_t) {
-            if (wave == 1 && !xcd_wait(bufs.flagB, NS, nullptr, 0, tag, timeout, bufs.errd) && lane == 0) {
-                s_abort = 1;
-                xcd_raise(err, bufs.errd, 1u);
+            if (wave == 1) {
+                const unsigned long long mB = xcd_wait(bufs.flagB, NS, nullptr, 0, tag, timeout, bufs.errd);
+                if (mB != 0ull && lane == 0) {
+                    s_abort = 1;
+                    xcd_raise(err, bufs.errd, 1u, kXcdSiteDeltaFlag, w, j, launch_id, mB, tag, dp_rank, dp_world, xsel, NW);
+                }
             }
         }
         if (wave == 1) XSTAMP(6);
@@ -762,10 +834,12 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     asm volatile("" : "+v"(wo));                             // here, per step, instead of living in registers all loop long
                     const size_t i0 = (size_t)nd.w_off[0] + wo;
                     const bool gw[4] = {wvalid[0], wvalid[1], wvalid[2], wvalid[3]};
-                    const bool ok = push_reduce4(dp.pd, w, seq, i0, gw, gsum, dp.ptimeout);
+                    unsigned pmiss = 0u;
+                    const bool ok = push_reduce4(dp.pd, w, seq, i0, gw, gsum, dp.ptimeout, &pmiss);
                     if (!ok) {
                         s_abort = 1;
-                        xcd_raise(err, bufs.errd, 1u);
+                        xcd_raise(err, bufs.errd, 1u, push_owner_of(w, dp_world) == dp_rank ? kXcdSitePushOwner : kXcdSitePushMember, w, j, launch_id, pmiss, seq,
+                                  dp_rank, dp_world, xsel, NW);
                     }
                 }
 #pragma unroll
@@ -812,8 +886,9 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                 if constexpr (DP) {                                          // the global cost: every shard's share, element P of the exchange
                     const unsigned seq = dp.seq0 + (unsigned)j;
                     T g = t;
-                    if (dp.pd.pd.world == 1 || push_all1(dp.pd, seq, (size_t)nd.P, t, dp.ptimeout, g)) t = g;
-                    else { s_abort = 1; xcd_raise(err, bufs.errd, 1u); }
+                    unsigned pmiss = 0u;
+                    if (dp.pd.pd.world == 1 || push_all1(dp.pd, seq, (size_t)nd.P, t, dp.ptimeout, g, &pmiss)) t = g;
+                    else { s_abort = 1; xcd_raise(err, bufs.errd, 1u, kXcdSitePushCost, w, j, launch_id, pmiss, seq, dp_rank, dp_world, xsel, NW); }
                 }
                 if (loss_dev) loss_dev[j] = t;
                 }
@@ -862,8 +937,9 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                         size_t tpo = tp;                                     // (opaque, as in the feature workers' exchange)
                         asm volatile("" : "+v"(tpo));
                         T g = gsum;
-                        if (dp.pd.pd.world == 1 || push_all1(dp.pd, seq, tpo, gsum, dp.ptimeout, g)) gsum = g;
-                        else { s_abort = 1; xcd_raise(err, bufs.errd, 1u); }
+                        unsigned pmiss = 0u;
+                        if (dp.pd.pd.world == 1 || push_all1(dp.pd, seq, tpo, gsum, dp.ptimeout, g, &pmiss)) gsum = g;
+                        else { s_abort = 1; xcd_raise(err, bufs.errd, 1u, kXcdSitePushTail, w, j, launch_id, pmiss, seq, dp_rank, dp_world, xsel, NW); }
                     }
                     tcur -= scale * gsum;                                    // rcn.rs:214,221
                     int tmo = tm;                                            // opaque: the image addresses are recomputed per step, not
@@ -880,19 +956,29 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         }
     }
 
-    // ---- all or nothing: a worker writes its parameters back only after EVERY worker has finished the last step (one more flag
-    // round per launch) -- a wait that expires in the last step on one worker leaves the whole parameter vector as the launch found it
+    // ---- all or nothing: a worker writes its parameters back only if EVERY worker finished the last step -- decided on ONE word that all
+    // workers read the same way (xcd_commit): a wait that expires anywhere leaves the whole parameter vector as the launch found it,
+    // and no worker that arrives later can write its slice under it
     {
         const unsigned tagD = tag0 + (unsigned)nb - 1u;
         __syncthreads();
-        if (tid == 0) xcd_flag(bufs.flagD + w * kXcdFlagStride, tagD);
-        if (wave == 0 && !xcd_wait(bufs.flagD, NW, nullptr, 0, tagD, timeout, bufs.errd) && lane == 0) {
-            s_abort = 1;
-            xcd_raise(err, bufs.errd, 1u);
+        if (tid == 0) {
+            if (late_closer) {                                               // (test hook: arrive after the others' waits have expired)
+                const long long t0 = wall_clock64();
+                while (wall_clock64() - t0 < 3 * timeout) __builtin_amdgcn_s_sleep(8);
+            }
+            xcd_flag(bufs.flagD + w * kXcdFlagStride, tagD);                  // (diagnostic only: who had arrived -- the host reads the table after a failure)
+            bool gave_up;
+            unsigned seen;
+            const bool commit = xcd_commit(bufs.cw, NW, timeout, bufs.errd, gave_up, seen);
+            if (!commit) {
+                s_abort = 1;
+                if (gave_up) xcd_raise(err, bufs.errd, 1u, kXcdSiteClosing, w, nb - 1, launch_id, (unsigned long long)(seen & 0xffffu), tagD, dp_rank, dp_world, xsel, NW);
+            }
         }
         __syncthreads();
         if (s_abort) return;
-        if (w == 0 && tid == 0) __hip_atomic_store(bufs.done, launch_id & 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (w == 0 && tid == 0) __hip_atomic_store(bufs.done, launch_id & 0x3fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- the slice pair of W_0 and the tail parameters go back to the parameter vector
     if (is_a) {
@@ -901,6 +987,12 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             if (wvalid[i]) W0[woff0 + RI * i] = wcur[i];
     } else if (is_t && tvalid) {
         params[tp] = tcur;
+    }
+    // (cross-check for the host: this worker's write-back of this launch is complete)
+    __syncthreads();
+    if (tid == 0) {
+        xcd_drain();
+        __hip_atomic_store(bufs.cdone + w, launch_id & 0x3fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

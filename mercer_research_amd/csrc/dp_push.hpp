@@ -52,7 +52,9 @@ __device__ inline int push_owner_of(int worker, int world) { return worker % wor
 // OWNER of four consecutive parameters idx0 .. idx0 + 3 (the resident kernel's accumulator layout): collect the other ranks' rows out of
 // this rank's own memory -- batches of four ranks, all missing words of a batch in flight together, the answers looked at afterwards
 // (dense_p2_dp.hpp: why) -- add in rank order, then push the sums to every peer.  own[]: in this rank's partial sums, out the totals.
-__device__ inline bool push_owner4(const PushDesc& d, unsigned seq, size_t idx0, const bool (&want)[4], float (&own)[4], long long timeout_ticks) {
+// *miss_out (nullable; written only when the wait expires): the ranks whose rows were still missing.
+__device__ inline bool push_owner4(const PushDesc& d, unsigned seq, size_t idx0, const bool (&want)[4], float (&own)[4], long long timeout_ticks,
+                                   unsigned* miss_out = nullptr) {
     const unsigned par = seq & 1u;
     const int world = d.pd.world, rank = d.pd.rank;
     const unsigned peers = ((1u << world) - 1u) & ~(1u << rank);
@@ -87,7 +89,10 @@ __device__ inline bool push_owner4(const PushDesc& d, unsigned seq, size_t idx0,
             if ((miss[0] | miss[1] | miss[2] | miss[3]) != 0u && (it & 31u) == 31u) {
                 const long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
-                else if (now - t0 > timeout_ticks) return false;
+                else if (now - t0 > timeout_ticks) {
+                    if (miss_out) *miss_out = (miss[0] | miss[1] | miss[2] | miss[3]) << q0;
+                    return false;
+                }
             }
         }
 #pragma unroll
@@ -114,7 +119,8 @@ __device__ inline bool push_owner4(const PushDesc& d, unsigned seq, size_t idx0,
 
 // MEMBER (not the owner): push this rank's four partial sums into the owner's row for this rank, then wait for the totals in this rank's
 // own memory.
-__device__ inline bool push_member4(const PushDesc& d, int owner, unsigned seq, size_t idx0, const bool (&want)[4], float (&own)[4], long long timeout_ticks) {
+__device__ inline bool push_member4(const PushDesc& d, int owner, unsigned seq, size_t idx0, const bool (&want)[4], float (&own)[4], long long timeout_ticks,
+                                    unsigned* miss_out = nullptr) {
     const unsigned par = seq & 1u;
     {
         u64* dst = push_rs(d, owner, par, d.pd.rank) + idx0;
@@ -140,21 +146,25 @@ __device__ inline bool push_member4(const PushDesc& d, int owner, unsigned seq, 
         if (miss != 0u && (it & 31u) == 31u) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > timeout_ticks) return false;
+            else if (now - t0 > timeout_ticks) {
+                if (miss_out) *miss_out = 1u << owner;                // (the totals come from the owner)
+                return false;
+            }
         }
     }
     return true;
 }
 
 // the two together, for the lanes of feature worker `worker`
-__device__ inline bool push_reduce4(const PushDesc& d, int worker, unsigned seq, size_t idx0, const bool (&want)[4], float (&own)[4], long long timeout_ticks) {
+__device__ inline bool push_reduce4(const PushDesc& d, int worker, unsigned seq, size_t idx0, const bool (&want)[4], float (&own)[4], long long timeout_ticks,
+                                    unsigned* miss_out = nullptr) {
     if (d.pd.world == 1) return true;                                  // (0 + own = own: the single-GPU kernel's bits)
     const int owner = push_owner_of(worker, d.pd.world);              // (uniform per workgroup)
-    return owner == d.pd.rank ? push_owner4(d, seq, idx0, want, own, timeout_ticks) : push_member4(d, owner, seq, idx0, want, own, timeout_ticks);
+    return owner == d.pd.rank ? push_owner4(d, seq, idx0, want, own, timeout_ticks, miss_out) : push_member4(d, owner, seq, idx0, want, own, timeout_ticks, miss_out);
 }
 
 // ONE value, all-to-all: push it into every peer's row for this rank, collect the peers' out of this rank's own rows, add in rank order.
-__device__ inline bool push_all1(const PushDesc& d, unsigned seq, size_t idx, float own, long long timeout_ticks, float& sum) {
+__device__ inline bool push_all1(const PushDesc& d, unsigned seq, size_t idx, float own, long long timeout_ticks, float& sum, unsigned* miss_out = nullptr) {
     const unsigned par = seq & 1u;
     const int world = d.pd.world, rank = d.pd.rank;
 #pragma unroll
@@ -182,7 +192,10 @@ __device__ inline bool push_all1(const PushDesc& d, unsigned seq, size_t idx, fl
         if (ready != all && (it & 31u) == 31u) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > timeout_ticks) return false;
+            else if (now - t0 > timeout_ticks) {
+                if (miss_out) *miss_out = all & ~ready;
+                return false;
+            }
         }
     }
     float g = 0.f;

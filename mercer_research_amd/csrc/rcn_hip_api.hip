@@ -77,8 +77,11 @@ struct CtxOptions {
     long long xcd_timeout_ticks = 20000000;   // "xcd_timeout_ticks"            bound of every wait inside the resident kernel, 100 MHz ticks (0.2 s)
     long long xcd_exact_lds = 0;        // "xcd_exact_lds"                            1: the resident kernel asks for exactly the LDS it uses (two workers may share a CU:
                                         //                                            what lets two contexts' kernels be resident on ONE device); 0: at least half a CU's
-    long long xcd_fault_launch = 0;     // "xcd_fault_launch"                         test hook: the n-th resident launch of the context (1-based) loses a worker
+    long long xcd_fault_launch = 0;     // "xcd_fault_launch"                         TEST HOOK: the n-th resident launch of the context (1-based) loses a worker
+    long long xcd_fault_mode = 0;       // "xcd_fault_mode"                           TEST HOOK: how -- 0 worker 1 never becomes resident, 1 it reaches the closing round late
     long long xcd_auto_fallback = 1;    // "xcd_auto_fallback"                        1: an expired wait of the single-GPU resident kernel re-runs the segment on the two-kernel pipeline
+    long long xcd_replay_caller_rows = 0;   // "xcd_replay_caller_rows"               1: that re-run may also read index rows the CALLER wrote (taken as unchanged since the call); 0: only
+                                        //                                            stored-order calls and rows the library shuffled / uploaded itself are re-run, anything else is an error
     long long dp_p2p = 1;               // "dp_p2p"            RCN_HIP_DP_P2P         0: no peer exchange (ncclAllReduce), 1: when world > 1, 2: also at world 1
     long long dp_fused = 1;             // "dp_fused"          RCN_HIP_DP_FUSED       0: the exchange never runs inside a step kernel
     long long dp_timeout_ticks = 100000000;   // "dp_timeout_ticks" RCN_HIP_DP_TIMEOUT_TICKS  bound of a peer wait, 100 MHz ticks (1 s)
@@ -99,7 +102,9 @@ const OptDesc kOptTable[] = {
     {"xcd_timeout_ticks", "RCN_HIP_XCD_TIMEOUT_TICKS", &CtxOptions::xcd_timeout_ticks, 1, 1LL << 40},
     {"xcd_exact_lds", "RCN_HIP_XCD_EXACT_LDS", &CtxOptions::xcd_exact_lds, 0, 1},
     {"xcd_auto_fallback", "RCN_HIP_XCD_AUTO_FALLBACK", &CtxOptions::xcd_auto_fallback, 0, 1},
+    {"xcd_replay_caller_rows", "RCN_HIP_XCD_REPLAY_CALLER_ROWS", &CtxOptions::xcd_replay_caller_rows, 0, 1},
     {"xcd_fault_launch", "RCN_HIP_XCD_FAULT_LAUNCH", &CtxOptions::xcd_fault_launch, 0, 0x7fffffff},
+    {"xcd_fault_mode", "RCN_HIP_XCD_FAULT_MODE", &CtxOptions::xcd_fault_mode, 0, 1},
     {"dp_p2p", "RCN_HIP_DP_P2P", &CtxOptions::dp_p2p, 0, 2},
     {"dp_fused", "RCN_HIP_DP_FUSED", &CtxOptions::dp_fused, 0, 1},
     {"dp_timeout_ticks", "RCN_HIP_DP_TIMEOUT_TICKS", &CtxOptions::dp_timeout_ticks, 1, 1LL << 40},
@@ -197,12 +202,16 @@ struct rcn_hip_ctx {
         size_t B = 0, nb = 0, j0 = 0; double eta = 0; void* loss_dev = nullptr; bool from_images = false;
         PermSource src;
         BeginRec begin;
+        bool caller_rows = false;            // the call's index rows were written by the caller (not by rcn_hip_shuffle_dev / an upload of the library)
         std::vector<XcdLaunchRec> launches;
     };
     std::vector<RedoRec> redo;
     std::vector<PermSource> perm_sources;    // newest source per index buffer
     BeginRec last_begin;
     unsigned* xerrd = nullptr;               // device copy of the resident kernel's sticky error word (outlives every workspace reset)
+    unsigned xrec[16] = {};                  // the newest time-out record (dense_xcd.hpp: xcd_raise; [kXcdRecWords] = the error code), kept past a heal
+    bool xrec_valid = false;
+    std::string xlast;                       // ... and its text with the workspace's tables (rcn_hip_last_timeout_text)
     int xcd_probe = 0;                      // 0 not probed, 1 the blocks with equal b % 8 share one XCD and the eight classes sit on eight XCDs, -1 not so
     struct ResidentSet {                     // rcn_hip_load_data: one of RCN::train's two data sets, kept in HBM (rcn.rs:134-137)
         DevBuf imgs, X, Y, perm, loss;

@@ -347,6 +347,14 @@ int rcn_hip_train_epoch_gathers(rcn_hip_ctx* c, size_t B) {
     return use_xcd(c, B) && xcd_gather(c) ? 1 : 0;
 }
 
+int rcn_hip_last_timeout(const rcn_hip_ctx* c, uint32_t* words, size_t cap) {
+    if (!c || !words || !c->xrec_valid) return 0;
+    const size_t n = cap < (size_t)kXcdRecWords + 1 ? cap : (size_t)kXcdRecWords + 1;
+    for (size_t i = 0; i < n; ++i) words[i] = c->xrec[i];
+    return (int)n;
+}
+const char* rcn_hip_last_timeout_text(const rcn_hip_ctx* c) { return c ? c->xlast.c_str() : ""; }
+
 int rcn_hip_train_epoch_resident(rcn_hip_ctx* c, size_t B) {
     if (!c || B == 0) return 0;
     DevGuard g(c->device);

@@ -33,6 +33,70 @@ int xcd_probe(rcn_hip_ctx* c) {
     return RCN_HIP_OK;
 }
 
+template <typename T> static XcdBufsT<T> xcd_bufs(rcn_hip_ctx* c, size_t BT);
+// What the first expired wait of the resident kernel recorded (dense_xcd.hpp: xcd_raise), as text for rcn_hip_last_error; with_tables
+// (the stream is drained): also the placement and flag tables of the workspace as the failed launch left them.
+static const char* xcd_site_name(unsigned site) {
+    switch (site) {
+    case kXcdSitePlacement: return "placement vote";
+    case kXcdSiteTailFlag: return "tail-tile flag (flagT), awaited by a sample group";
+    case kXcdSiteSlabFlag: return "slab flag (flagA), awaited by a sample group";
+    case kXcdSiteDeltaFlag: return "delta flag (flagB), awaited by a feature worker / tail tile";
+    case kXcdSitePushOwner: return "pushed reduce-scatter: the owner waiting for the other ranks' partial sums";
+    case kXcdSitePushMember: return "pushed all-gather: a rank waiting for the owner's totals";
+    case kXcdSitePushTail: return "pushed all-to-all of a tail parameter";
+    case kXcdSitePushCost: return "pushed all-to-all of the cost";
+    case kXcdSiteClosing: return "closing round";
+    default: return "unknown site";
+    }
+}
+static void xcd_capture_record(rcn_hip_ctx* c) {
+    if (!c->xerr_host || c->xerr_host[0] == 0) return;
+    for (int i = 0; i < kXcdRecWords; ++i) c->xrec[i] = c->xerr_host[4 + i];
+    c->xrec[kXcdRecWords] = c->xerr_host[0];
+    c->xrec_valid = true;
+}
+static std::string hex_mask(unsigned long long m) {
+    char b[32];
+    std::snprintf(b, sizeof b, "0x%llx", m);
+    return b;
+}
+std::string xcd_describe(rcn_hip_ctx* c, bool with_tables) {
+    if (!c->xerr_host || c->xerr_host[0] == 0) return "";
+    xcd_capture_record(c);
+    const unsigned* r = c->xrec;
+    const unsigned site = r[0];
+    const unsigned long long missing = (unsigned long long)r[4] | ((unsigned long long)r[5] << 32);
+    std::string s = " [first expired wait: site " + std::to_string(site) + " (" + xcd_site_name(site) + "), worker " + std::to_string(r[1]) + " of " + std::to_string(r[11]) +
+                    " on XCC " + std::to_string(r[7]) + ", step " + std::to_string((int)r[2]) + " of launch " + std::to_string(r[3]) + ", rank " + std::to_string(r[8]) + " of " +
+                    std::to_string(r[9]) + ", worker blocks = blockIdx % 8 == " + std::to_string(r[10]);
+    if (site == kXcdSiteClosing) s += ", arrivals seen " + std::to_string(missing) + " of " + std::to_string(r[11]);
+    else if (site >= kXcdSitePushOwner && site <= kXcdSitePushCost) s += ", ranks still missing " + hex_mask(missing) + ", exchange step " + std::to_string(r[6]);
+    else s += std::string(site == kXcdSitePlacement ? ", workers absent / elsewhere " : ", producers still behind ") + hex_mask(missing) + ", awaited tag " + std::to_string(r[6]);
+    if (with_tables && c->xcdbuf.p && c->xcd_B) {
+        // the tables as the failed launch left them (one word per 128-byte line): XCC answers, newest tags per producer, committed ids
+        const XcdBufsT<float> xb = xcd_bufs<float>(c, c->xcd_B);       // (the flag region's place depends on the element size)
+        const XcdBufsT<double> xb8 = xcd_bufs<double>(c, c->xcd_B);
+        const unsigned* base = c->dtype == RCN_HIP_F64 ? xb8.flagA : xb.flagA;
+        const size_t words = (size_t)(4 * kXcdWorkers + 8 + 2) * kXcdFlagStride;
+        std::vector<unsigned> t(words);
+        if (hipMemcpy(t.data(), base, words * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+            auto row = [&](const char* name, size_t first, int n, bool low4) {
+                s += std::string("; ") + name + " =";
+                for (int i = 0; i < n; ++i) s += " " + std::to_string(low4 ? (t[(first + (size_t)i) * kXcdFlagStride] & 0xfu) : t[(first + (size_t)i) * kXcdFlagStride]);
+            };
+            const int NW = (int)r[11] > 0 && (int)r[11] <= kXcdWorkers ? (int)r[11] : kXcdWorkers;
+            row("xcc", 2 * kXcdWorkers, NW, true);
+            row("flagA", 0, NW, false);
+            row("flagB", kXcdWorkers, NW, false);
+            row("flagD", 3 * kXcdWorkers, NW, false);
+            row("flagT", 4 * kXcdWorkers, 8, false);
+            s += "; decision word = " + hex_mask(t[(size_t)(4 * kXcdWorkers + 8) * kXcdFlagStride]);
+        }
+    }
+    return s + "]";
+}
+
 bool use_xcd(rcn_hip_ctx* c, size_t B) {
     if (!xcd_supported(c->nd, B, c->esz())) return false;           // (f64: batches up to 128 -- dense_xcd.hpp)
     if (c->dense_path != 0 && c->dense_path != 5) return false;
@@ -51,18 +115,19 @@ bool dp_on_xcd(rcn_hip_ctx* c, size_t B) {
 
 int ensure_xcd_ws(rcn_hip_ctx* c, size_t B) {
     if (!c->xerr_host) {
-        HIP_TRY(c, hipHostMalloc((void**)&c->xerr_host, 64, hipHostMallocMapped));
-        c->xerr_host[0] = 0;                    // [0] the sticky error word, [1] id of the newest launch all of whose workers finished
-        c->xerr_host[1] = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->xerr_host, 256, hipHostMallocMapped));
+        std::memset(c->xerr_host, 0, 256);      // [0] the sticky error word, [1] id of the newest launch all of whose workers decided to commit,
+                                                // [4 .. 4 + kXcdRecWords) the record of the first wait that expired (dense_xcd.hpp: xcd_raise)
         HIP_TRY(c, hipHostGetDevicePointer((void**)&c->xerr_dev, c->xerr_host, 0));
         HIP_TRY(c, hipMalloc((void**)&c->xerrd, 256));
         HIP_TRY(c, hipMemsetAsync(c->xerrd, 0, 256, c->stream));
     }
     if (*c->xerr_host != 0)
-        return fail(c, RCN_HIP_ERR_HIP, *c->xerr_host == 2 ? "train_epoch: the resident kernel's workgroups did not share one XCD in an earlier call; nothing was "
-                                                             "updated by it.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline"
-                                                           : "train_epoch: a bounded wait inside the resident kernel expired in an earlier call (is the device shared?); "
-                                                             "that call's segment was not applied.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline");
+        return fail(c, RCN_HIP_ERR_HIP, std::string(*c->xerr_host == 2 ? "train_epoch: the resident kernel's workgroups did not share one XCD in an earlier call; nothing was "
+                                                                         "updated by it.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline"
+                                                                       : "train_epoch: a bounded wait inside the resident kernel expired in an earlier call (is the device shared?); "
+                                                                         "that call's segment was not applied.  rcn_hip_set_dense_path(ctx, 2) selects the two-kernel pipeline") +
+                                            xcd_describe(c, false));
     const size_t BT = (size_t)xcd_bt(B);
     const size_t bytes = xcd_buf_bytes(c->nd, BT, c->esz());
     if (c->xcd_B != BT || c->xcdbuf.cap < bytes) {
@@ -96,7 +161,9 @@ static XcdBufsT<T> xcd_bufs(rcn_hip_ctx* c, size_t BT) {
     xb.flagB = u; u += kXcdWorkers * kXcdFlagStride;
     xb.xcc = u;   u += kXcdWorkers * kXcdFlagStride;
     xb.flagD = u; u += kXcdWorkers * kXcdFlagStride;
-    xb.flagT = u;
+    xb.flagT = u; u += 8 * kXcdFlagStride;
+    xb.cw = u;    u += kXcdFlagStride;          // (the 512 spare bytes of xcd_buf_bytes: the decision word's line, then 32 committed ids)
+    xb.cdone = u;
     xb.errd = c->xerrd;
     xb.done = c->xerr_dev + 1;
     return xb;
@@ -155,12 +222,13 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const T* xs, const T* ys, size_t B, size_t
     // launch ids are unique in the process (the placement vote of a launch accepts only answers that carry its id: dense_xcd.hpp) and
     // increase along a context's stream (the redo journal compares them with the id the kernel reports complete)
     static std::atomic<unsigned> g_launch{0};
-    unsigned id = (g_launch.fetch_add(1) + 1u) & 0x7fffffffu;
-    if (id == 0) id = (g_launch.fetch_add(1) + 1u) & 0x7fffffffu;
+    unsigned id = (g_launch.fetch_add(1) + 1u) & 0x3fffffffu;
+    if (id == 0) id = (g_launch.fetch_add(1) + 1u) & 0x3fffffffu;
     c->xcd_launch_id = id;
     c->xcd_launches += 1;
+    // (test hooks: bit 31 -- worker 1 of this launch never becomes resident; bit 30 -- it reaches the closing round after the others gave up)
     const bool faulty = c->opt.xcd_fault_launch != 0 && (long long)c->xcd_launches == c->opt.xcd_fault_launch;
-    const unsigned id_arg = id | (faulty ? 0x80000000u : 0u);
+    const unsigned id_arg = id | (faulty ? (c->opt.xcd_fault_mode == 1 ? 0x40000000u : 0x80000000u) : 0u);
     const double Bg = (double)B * (dp ? (double)c->dp_world : 1.0);          // the global batch.len() of rcn.rs:214
     const T scale = (T)(eta / Bg), loss_scale = (T)(1.0 / (2.0 * Bg));
     int st = RCN_HIP_ERR_UNSUPPORTED;
@@ -231,6 +299,7 @@ int enqueue_xcd_epoch_t(rcn_hip_ctx* c, const void* X, const void* Y, const int3
         rec->X = X; rec->Y = Y; rec->perm = perm; rec->B = B; rec->nb = nb; rec->j0 = j0; rec->eta = eta; rec->loss_dev = loss_dev; rec->from_images = from_images;
         if (!prepacked) rec->src = perm_source_of(c, perm);
         else rec->begin = c->last_begin;
+        rec->caller_rows = prepacked ? (rec->begin.perm != nullptr && rec->begin.src.kind == 0) : (perm != nullptr && rec->src.kind == 0);
     }
     auto note = [&](unsigned id, size_t k0, size_t n) { if (rec) rec->launches.push_back({id, k0, n}); };
     if (sizeof(T) == 4 && !prepacked && !from_images && !dp && xcd_gather(c)) {
@@ -321,6 +390,31 @@ static int redo_begin(rcn_hip_ctx* c, const rcn_hip_ctx::BeginRec& b) {
 }
 int xcd_heal(rcn_hip_ctx* c) {
     const unsigned code = c->xerr_host[0], done = c->xerr_host[1];
+    c->xlast = xcd_describe(c, true);            // (kept: rcn_hip_last_timeout / the step-down's reason stay readable after the heal)
+    // cross-check of `done` (decided on one word by all workers) with the ids the workers stored behind their write-backs: a worker that
+    // wrote back a launch newer than `done` would mean a torn parameter vector -- reported, never replayed over
+    if (c->xcdbuf.p && c->xcd_B) {
+        unsigned cd[kXcdWorkers];
+        const unsigned* src = c->dtype == RCN_HIP_F64 ? xcd_bufs<double>(c, c->xcd_B).cdone : xcd_bufs<float>(c, c->xcd_B).cdone;
+        HIP_TRY(c, hipMemcpy(cd, src, sizeof cd, hipMemcpyDeviceToHost));
+        const int NW = xcd_workers(c->nd, (int)c->xcd_B);
+        for (int w = 0; w < NW; ++w)
+            if (cd[w] != 0 && (int)(cd[w] - done) > 0)
+                return fail(c, RCN_HIP_ERR_HIP, "the resident kernel failed and worker " + std::to_string(w) + " wrote back launch " + std::to_string(cd[w]) +
+                                                    " although the launch was not committed (newest committed: " + std::to_string(done) + "): the parameters are torn" + c->xlast);
+    }
+    // Index rows the caller wrote may legally have been overwritten in stream order since the call (a fresh torch.randperm per epoch):
+    // steps that would be re-run on them are NOT re-run silently -- the error stays, as with xcd_auto_fallback = 0
+    if (!c->opt.xcd_replay_caller_rows)
+        for (const auto& r : c->redo) {
+            bool open_steps = false;
+            for (const auto& l : r.launches)
+                if ((int)(l.id - done) > 0) open_steps = true;
+            if (open_steps && r.caller_rows)
+                return fail(c, RCN_HIP_ERR_HIP, "a bounded wait inside the resident one-XCD kernel expired and the steps it had not applied read index rows the caller wrote, "
+                                                "which the library cannot know to be unchanged: not re-run (rows from rcn_hip_shuffle_dev or an upload of the library are; "
+                                                "option xcd_replay_caller_rows = 1 re-runs these too)" + c->xlast);
+        }
     RCN_TRY(xcd_clear_error(c));
     c->xcd_stepped_down = true;
     c->fallbacks_taken += 1;
@@ -378,9 +472,10 @@ int sticky_errors(rcn_hip_ctx* c) {
         return fail(c, RCN_HIP_ERR_HIP, "a bounded wait inside the resident / one-launch step kernel expired; the last call's updates are incomplete");
     if (c->xerr_host && *c->xerr_host != 0) {
         if (!c->xcd_dp_used && c->opt.xcd_auto_fallback && !c->replaying) return xcd_heal(c);
-        return fail(c, RCN_HIP_ERR_HIP, *c->xerr_host == 2 ? "the resident one-XCD kernel found its workgroups on different XCDs; what it had not applied is lost"
-                                                           : (c->xcd_dp_used ? "a bounded wait inside the resident one-XCD kernel expired in a data-parallel step; the replicas are no longer in step"
-                                                                             : "a bounded wait inside the resident one-XCD kernel expired; what it had not applied is lost"));
+        c->xlast = xcd_describe(c, true);
+        return fail(c, RCN_HIP_ERR_HIP, std::string(*c->xerr_host == 2 ? "the resident one-XCD kernel found its workgroups on different XCDs; what it had not applied is lost"
+                                                                       : (c->xcd_dp_used ? "a bounded wait inside the resident one-XCD kernel expired in a data-parallel step; the replicas are no longer in step"
+                                                                                         : "a bounded wait inside the resident one-XCD kernel expired; what it had not applied is lost")) + c->xlast);
     }
     if (c->xerr_host) c->redo.clear();          // the stream is drained and nothing failed: every journalled launch is complete
     return RCN_HIP_OK;

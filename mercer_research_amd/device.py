@@ -83,6 +83,9 @@ class DeviceRCN:
     def fallbacks_taken(self) -> int:
         return self.rcn.fallbacks_taken()
 
+    def last_timeout(self):
+        return self.rcn.last_timeout()
+
     # ---- feature pipeline --------------------------------------------------------------------------------------
     def features(self, imgs_u8: torch.Tensor, standardize: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert imgs_u8.dtype == torch.uint8 and imgs_u8.is_contiguous() and imgs_u8.device == self.device

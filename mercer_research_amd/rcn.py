@@ -152,6 +152,22 @@ class RCN:
         """How often this context stepped down from the resident one-XCD kernel to the two-kernel pipeline by itself."""
         return int(self._lib.rcn_hip_fallbacks_taken(self._ctx))
 
+    TIMEOUT_FIELDS = ("site", "worker", "step", "launch", "missing_lo", "missing_hi", "tag", "xcc", "rank", "world", "xsel", "workers", "code")
+
+    def last_timeout(self):
+        """The record of the newest expired wait of the resident kernel in this context (rcn_hip_last_timeout), or None; `text` adds the
+        workspace's placement / flag tables as the failed launch left them."""
+        import ctypes as C
+        w = (C.c_uint32 * 16)()
+        n = int(self._lib.rcn_hip_last_timeout(self._ctx, w, 16))
+        if n == 0:
+            return None
+        rec = {k: int(w[i]) for i, k in enumerate(self.TIMEOUT_FIELDS[:n])}
+        rec["step"] = rec["step"] - (1 << 32) if rec["step"] >= (1 << 31) else rec["step"]
+        rec["missing"] = rec.pop("missing_lo") | (rec.pop("missing_hi") << 32)
+        rec["text"] = (self._lib.rcn_hip_last_timeout_text(self._ctx) or b"").decode()
+        return rec
+
     def set_feature_kernel(self, mode: int):
         """0 auto (specialised fused kernel for the default stack on 28x28), 1 always the generic kernel."""
         self._ck(self._lib.rcn_hip_set_feature_kernel(self._ctx, int(mode)))

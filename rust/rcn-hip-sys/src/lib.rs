@@ -144,6 +144,8 @@ extern "C" {
     pub fn rcn_hip_classify_images(ctx: *mut rcn_hip_ctx, imgs: *const u8, n: usize, class_out: *mut i32) -> c_int;
     pub fn rcn_hip_set_dense_path(ctx: *mut rcn_hip_ctx, mode: c_int) -> c_int;
     pub fn rcn_hip_fallbacks_taken(ctx: *const rcn_hip_ctx) -> c_int;
+    pub fn rcn_hip_last_timeout(ctx: *const rcn_hip_ctx, words: *mut u32, cap: usize) -> c_int;
+    pub fn rcn_hip_last_timeout_text(ctx: *const rcn_hip_ctx) -> *const c_char;
     pub fn rcn_hip_set_option(ctx: *mut rcn_hip_ctx, name: *const c_char, value: i64) -> c_int;
     pub fn rcn_hip_get_option(ctx: *const rcn_hip_ctx, name: *const c_char, value: *mut i64) -> c_int;
     pub fn rcn_hip_time_kernels_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, b: usize, reps: c_int,

@@ -99,14 +99,24 @@ def main():
         # step (rcn_hip_epoch_begin_dev + rcn_hip_dp_epoch_steps_dev), and let every kernel of a call drain before the next call.
         # With a GPU per rank none of this matters and rcn_hip_dp_train_epoch_dev does both.
         order = d.to_device(np.arange(Bs * nb, dtype=np.int32))
-        for ep, (first, n, ls) in enumerate(((0, nb, loss), (0, 2, None), (2, nb - 2, None))):   # the second epoch in two calls
-            if first == 0:
-                d.epoch_begin(X, Y, order, Bs, nb)
-            d.synchronize()
-            dist.barrier()
-            d.dp_epoch_steps(first, n, 3.0, ls)
-            d.synchronize()
-            dist.barrier()
+        try:
+            for ep, (first, n, ls) in enumerate(((0, nb, loss), (0, 2, None), (2, nb - 2, None))):   # the second epoch in two calls
+                if first == 0:
+                    d.epoch_begin(X, Y, order, Bs, nb)
+                d.synchronize()
+                dist.barrier()
+                d.dp_epoch_steps(first, n, 3.0, ls)
+                d.synchronize()
+                dist.barrier()
+        except amd.RcnHipError:
+            # an expired wait names its site (rcn_hip_last_timeout): kept beside the outputs so that the test -- and whoever reads a
+            # first multi-GPU run -- sees which wait, which worker, which peer, and where every worker of this rank sat
+            import json
+            rec = d.last_timeout()
+            with open(os.path.join(outdir, f"timeout{rank}.json"), "w") as f:
+                json.dump(rec, f)
+            print(f"TIMEOUT rank {rank}: {json.dumps(rec)}", flush=True)
+            raise
     elif mode != 0:
         d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, loss)
         d.dp_train_epoch(X, Y, None, Bs, nb, 3.0, None)           # a second call: sequence numbers carry over

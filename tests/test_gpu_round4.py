@@ -196,3 +196,120 @@ def test_f64_resident_kernel_steps_down_by_itself(amd, oracle, fail_launch):
     for a, b in zip(got, rw + rb):
         assert np.all(np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-10), float(np.abs(a - b).max())
     d.rcn.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# an expired wait says where; the closing round is one decision (torn write-back)
+
+def _faulty_context(amd, mode, auto, B=256, N=1024, seed=3, dtype=F32):
+    from mercer_research_amd.device import DeviceRCN
+    d = DeviceRCN(dtype=dtype)
+    _xcd_or_skip(d)
+    d.set_dense_path(0)
+    d.set_option("xcd_timeout_ticks", 300000)                          # 3 ms per expired wait
+    d.set_option("xcd_auto_fallback", auto)
+    d.set_option("xcd_fault_mode", mode)
+    d.set_option("xcd_fault_launch", 1)
+    ws, bs = synthetic_params([784, 30, 10], seed=seed)
+    ws = [w * 0.1 for w in ws]
+    d.set_params(ws, bs)
+    return d, ws, bs
+
+
+def test_an_expired_wait_names_its_site_worker_and_producer(amd):
+    """The first worker that gives up writes ONE record (site, worker, step, launch, who was missing) and the host adds the workspace's
+    tables: a launch whose worker 1 never becomes resident (test hook) fails at step 0 on a wait for producer 1 -- the slab flag a
+    sample group polls or the delta flag a feature worker / tail tile polls, whichever clock runs out first -- and says so."""
+    B, nb, N = 256, 2, 512
+    d, ws, bs = _faulty_context(amd, 0, 0)
+    rng = np.random.default_rng(0)
+    X, Y = np.maximum(rng.standard_normal((N, 784)), 0.0), one_hot(rng.integers(0, 10, N))
+    Xd, Yd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype)
+    assert d.last_timeout() is None
+    d.train_epoch(Xd, Yd, None, B, nb, 3.0, None)
+    with pytest.raises(amd.RcnHipError) as ei:
+        d.synchronize()
+    rec = d.last_timeout()
+    assert rec is not None and rec["code"] == 1
+    assert rec["site"] in (3, 4), rec                                   # slab flag or delta flag
+    assert rec["missing"] == 0b10, rec                                  # producer 1 (feature worker 1 / sample group 1) never delivered
+    assert rec["step"] == 0 and rec["worker"] != 1 and rec["workers"] == 32 and rec["world"] == 1 and rec["xsel"] == 0
+    msg = str(ei.value)
+    assert "first expired wait: site %d" % rec["site"] in msg and "producers still behind 0x2" in msg, msg
+    assert "xcc =" in msg and "flagA =" in msg and "flagB =" in msg and "decision word" in msg, msg
+    xcc = msg.split("xcc =")[1].split(";")[0].split()
+    assert len(xcc) == 32 and len(set(xcc)) == 1, xcc                  # the table shows all 32 workers on one XCC
+    d.rcn.close()
+
+
+@pytest.mark.steps_down
+def test_a_worker_that_reaches_the_closing_round_late_cannot_tear_the_parameters(amd, oracle):
+    """every worker used to wait for all closing flags under its OWN clock, so a worker that arrived after another had
+    given up saw all flags set and wrote its slice -- a torn parameter vector under a launch the host then took for complete.  The
+    closing round is now one decision on one word (arrivals counted, poisoned by the first worker that gives up): with worker 1 held
+    back past everyone's time-out (test hook, mode 1) NO worker writes, the record names the closing round with 31 of 32 arrivals,
+    and the healed epochs equal the oracle."""
+    import torch
+    B, nb, N = 256, 3, 1024
+    d, ws, bs = _faulty_context(amd, 1, 0)
+    imgs, labels = synthetic_images(N, seed=9)
+    Xd, Yd = d.load_data(d.to_device(imgs), d.to_device(labels))
+    Xh, Yh = Xd.double().cpu().numpy(), one_hot(labels)
+    perm = torch.empty(N, dtype=torch.int32, device=d.device)
+    d.shuffle(perm, N, 1, seed=41)
+    d.synchronize()
+    p = perm.cpu().numpy().astype(np.int64)
+    loss = d.empty(nb)
+    d.train_epoch(Xd, Yd, perm, B, nb, 3.0, loss)
+    with pytest.raises(amd.RcnHipError) as ei:
+        d.synchronize()
+    rec = d.last_timeout()
+    assert rec["site"] == 9 and rec["missing"] == 31 and rec["workers"] == 32 and rec["worker"] != 1 and rec["step"] == nb - 1, rec
+    assert "closing round" in str(ei.value) and "arrivals seen 31 of 32" in str(ei.value)
+    d.set_dense_path(2)                                                 # the recovery the message names: clears the word
+    d.synchronize()
+    got = sum(d.get_params(), [])
+    for a, b in zip(got, ws + bs):
+        assert np.array_equal(a, b.astype(np.float32).astype(np.float64)), "a worker wrote its slice although the launch was not committed"
+    d.rcn.close()
+    # the same fault with the self-healing step-down on: the epoch equals the oracle, one step-down
+    d, ws, bs = _faulty_context(amd, 1, 1)
+    Xd, Yd = d.load_data(d.to_device(imgs), d.to_device(labels))
+    perm = torch.empty(N, dtype=torch.int32, device=d.device)
+    d.shuffle(perm, N, 1, seed=41)
+    d.train_epoch(Xd, Yd, perm, B, nb, 3.0, loss)
+    d.synchronize()
+    assert d.fallbacks_taken() == 1 and d.last_timeout()["site"] == 9
+    rw, rb, cs = _oracle_steps(oracle, ws, bs, Xh, Yh, p, B, nb, 3.0)
+    np.testing.assert_allclose(loss.double().cpu().numpy(), cs, rtol=2e-3)
+    for a, b in zip(sum(d.get_params(), []), rw + rb):
+        assert np.all(np.abs(a - b) <= 5e-4 * np.abs(b) + 5e-5), float(np.abs(a - b).max())
+    d.rcn.close()
+
+
+@pytest.mark.steps_down
+def test_steps_on_index_rows_the_caller_wrote_are_not_replayed_silently(amd, oracle):
+    """the step-down journals raw pointers; index rows the CALLER wrote may legally have been overwritten in stream order
+    since the call.  Such steps are not re-run silently: the error stays and says why; rows from rcn_hip_shuffle_dev (re-drawn from
+    their seed) are re-run as before, and option xcd_replay_caller_rows = 1 opts in."""
+    B, nb, N = 256, 2, 512
+    rng = np.random.default_rng(5)
+    X, Y = np.maximum(rng.standard_normal((N, 784)), 0.0), one_hot(rng.integers(0, 10, N))
+    order = rng.permutation(N).astype(np.int32)
+    d, ws, bs = _faulty_context(amd, 0, 1)
+    Xd, Yd, pd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype), d.to_device(order)
+    d.train_epoch(Xd, Yd, pd, B, nb, 3.0, None)
+    with pytest.raises(amd.RcnHipError) as ei:
+        d.synchronize()
+    assert "index rows the caller wrote" in str(ei.value) and d.fallbacks_taken() == 0
+    d.rcn.close()
+    d, ws, bs = _faulty_context(amd, 0, 1)
+    d.set_option("xcd_replay_caller_rows", 1)
+    Xd, Yd, pd = d.to_device(X, d.tdtype), d.to_device(Y, d.tdtype), d.to_device(order)
+    d.train_epoch(Xd, Yd, pd, B, nb, 3.0, None)
+    d.synchronize()
+    assert d.fallbacks_taken() == 1
+    rw, rb, _ = _oracle_steps(oracle, ws, bs, X.astype(np.float32).astype(np.float64), Y, order.astype(np.int64), B, nb, 3.0)
+    for a, b in zip(sum(d.get_params(), []), rw + rb):
+        assert np.all(np.abs(a - b) <= 5e-4 * np.abs(b) + 5e-5), float(np.abs(a - b).max())
+    d.rcn.close()
