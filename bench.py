@@ -708,6 +708,34 @@ def main():
                 result["trackx"] = trackx_leg(torch, local_rank)
             except Exception as ex:
                 result["trackx"] = {"error": str(ex)[:300]}
+        # the round's figures once more as FLAT scalar keys of `config` (the driver's record keeps scalars of `config` only and the last
+        # 2000 characters of the line; the nested objects above stay for readers)
+        def _g(obj, *path):
+            for k in path:
+                if not isinstance(obj, dict) or k not in obj:
+                    return None
+                obj = obj[k]
+            return obj
+        cfg = result["config"]
+        sb, tx = cfg.get("small_batch"), result.get("trackx")
+        flat = {
+            "sb_b10_f32_us": _g(sb, "B10", "default_path", "us_per_step"), "sb_b32_f32_us": _g(sb, "B32", "default_path", "us_per_step"),
+            "sb_b10_f64_us": _g(sb, "B10", "f64_default_path", "us_per_step"), "sb_b32_f64_us": _g(sb, "B32", "f64_default_path", "us_per_step"),
+            "sb_b10_f32_resident": _g(sb, "B10", "default_path", "resident_kernel"), "sb_b32_f32_resident": _g(sb, "B32", "default_path", "resident_kernel"),
+            "sb_b10_f64_resident": _g(sb, "B10", "f64_default_path", "resident_kernel"), "sb_b32_f64_resident": _g(sb, "B32", "f64_default_path", "resident_kernel"),
+            "sb_b10_cpu_steps_per_s": _g(sb, "B10", "cpu_restatement_f64", "one_thread", "steps_per_s"),
+            "curve_max_rel_dev": _g(cfg, "loss_curve", "max_rel_dev_over_curve"),
+            "testnet_us": _g(cfg, "reference_test_net", "default_path", "us_per_step"),
+            "x_cifar_f32_ms": _g(tx, "fp32", "ms_per_step"), "x_cifar_f32_frac": _g(tx, "fp32", "frac_of_mfma_peak"), "x_cifar_bf16_ms": _g(tx, "bf16", "ms_per_step"),
+            "x_224_f32_ms": _g(tx, "synth224", "fp32", "ms_per_step"), "x_224_f32_frac": _g(tx, "synth224", "fp32", "frac_of_mfma_peak"),
+            "x_224_bf16_ms": _g(tx, "synth224", "bf16", "ms_per_step"), "x_mnist4096_bf16_ms": _g(tx, "mnist4096_bf16", "ms_per_step"),
+            "x_conv_gemm_mfma_busy": _g(tx, "conv_gemm_mfma_busy", "time_weighted_over_3x3_conv_gemm_kernels"),
+        }
+        for k, v in flat.items():
+            if isinstance(v, bool):
+                v = int(v)
+            if v is not None:
+                cfg[k] = v
         if not args.no_cpu_baseline and world == 1:      # the CPU path is timed beside the N = 1 run only
             result["cpu_baseline"] = cpu_baseline()
             result["config"]["gpu_over_cpu"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
@@ -773,7 +801,7 @@ def small_batch_leg(torch, amd, DeviceRCN, imgs_d, labels_d, ws, bs, dev):
     for B in (10, 32):
         nb = N_IMAGES // B                                  # chunks_exact(B): the tail is dropped (rcn.rs:147)
         row = {}
-        # f64_default_path: the reference's own arithmetic type at its own batch size (no resident-kernel instantiation: the sample-tile kernels)
+        # f64_default_path: the reference's own arithmetic type at its own batch size -- since round 4 on the resident kernel's f64 instantiation
         for name, path, dt in (("default_path", 0, amd.F32), ("sample_tile_kernels", 1, amd.F32), ("f64_default_path", 0, amd.F64)):
             d = DeviceRCN(classes=10, feedforward_cfg=[30], input_shape=(28, 28), dtype=dt, device=dev)
             d.set_params(ws, bs)
@@ -961,6 +989,36 @@ def trackx_leg(torch, dev):
             torch.cuda.empty_cache()
     except Exception as ex:                                     # the extension must not take the BASELINE line down with it
         out["synth224"] = {"error": str(ex)[:300]}
+    # BASELINE configs[4] on one GPU: MNIST shape, bf16 MFMA, batch 4096, the step replayed as a captured hipGraph
+    try:
+        in_shape, layers, _ = CONFIGS["mnist"]
+        B = 4096
+        net = ConvNet(in_shape, layers, B, device=dev)
+        net.init_params(1)
+        net.set_precision("bf16")
+        xs = [net.to_device(rng.standard_normal((B,) + in_shape).astype(np.float32)) for _ in range(2)]
+        ys = [net.to_device(rng.integers(0, 10, B).astype(np.int32)) for _ in range(2)]
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        for i in range(8):
+            net.train_step(xs[i % 2], ys[i % 2], 0.01, loss)
+        net.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 50
+        a.record(net.stream)
+        for i in range(n):
+            net.train_step(xs[i % 2], ys[i % 2], 0.01, loss)
+        b.record(net.stream)
+        net.synchronize()
+        ms = a.elapsed_time(b) / n
+        flops = net.step_flops(B)
+        out["mnist4096_bf16"] = {"config": "MNIST shape 28x28x1, conv 1->32, pool, 32->64, pool -> 128 -> 10, batch 4096, bf16 MFMA operands, hipGraph step",
+                                 "ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1), "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                                 "frac_of_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
+        net.close()
+        del xs, ys
+        torch.cuda.empty_cache()
+    except Exception as ex:
+        out["mnist4096_bf16"] = {"error": str(ex)[:300]}
     # the conv-GEMM MFMA-busy figures are PMC measurements of a separate profiled run (tools/prof_trackx.sh), relayed here with the
     # fingerprint of the kernel sources they were taken on -- like roofline.traffic, the line says when the sources have changed since
     from tools.mfma_pmc_summary import trackx_sha16
