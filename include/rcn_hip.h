@@ -335,8 +335,10 @@ const char* rcn_hip_last_timeout_text(const rcn_hip_ctx* ctx);
  * reads the environment afterwards, so two contexts of one process can differ.  RCN_HIP_ERR_INVALID_ARG for an unknown name or a value
  * out of range.  Changing an option drops the context's captured graphs.
  *   "xcd"                 RCN_HIP_XCD                 0 | 1     dense path 0 may select the resident one-XCD kernel (1)
- *   "xcd_select"          RCN_HIP_XCD_SELECT          0..7      TEST-ONLY (ranks sharing ONE device in the test harness): which blocks of a resident
- *                                                               launch are its workers (blockIdx.x % 8); a GPU per rank keeps 0
+ *   "xcd_select"          RCN_HIP_XCD_SELECT          0..15     TEST-ONLY (ranks sharing ONE device in the test harness): which blocks of a resident
+ *                                                               launch are its workers -- 0..7: blockIdx.x % 8 == value; 8..15: the blocks that landed on
+ *                                                               PHYSICAL XCD value - 8 (which XCD a dispatch starts its round-robin on differs from queue
+ *                                                               to queue: profiles/r4_dp_4rank_timeout_record.txt); a GPU per rank keeps 0
  *   "xcd_gather"          RCN_HIP_XCD_GATHER          0 | 1     rows fetched by the resident kernel itself, batch 256 (measured slower; 0)
  *   "xcd_timeout_ticks"   RCN_HIP_XCD_TIMEOUT_TICKS   >= 1      bound of every wait inside the resident kernel, 100 MHz ticks (20000000 = 0.2 s)
  *   "xcd_exact_lds"       RCN_HIP_XCD_EXACT_LDS       0 | 1     TEST-ONLY (same harness): the resident kernel asks for exactly the LDS it uses, so that

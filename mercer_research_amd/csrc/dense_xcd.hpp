@@ -333,7 +333,13 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     constexpr int NS = BT / kP2Ts;                                  // sample groups of eight
     using acc_t = typename Mfma16<T>::acc_t;
     using vec4 = typename Vec4<T>::type;
-    if ((int)(blockIdx.x & 7) != xsel) return;                      // the other seven XCDs' blocks
+    // the workers: the blocks of ONE residue class of blockIdx.x % 8 (they share an XCD, whichever the dispatch started on) -- xsel < 8:
+    // that class; xsel >= 8 (several ranks sharing ONE device in the test harness): the class that landed on PHYSICAL XCD xsel - 8,
+    // so that the ranks' kernels sit on different XCDs whatever XCD each rank's dispatch happened to start its round-robin on
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xfu;
+    if (xsel < 8 ? (int)(blockIdx.x & 7) != xsel : (int)my_xcc != xsel - 8) return;      // the other seven XCDs' blocks
     const int w = (int)(blockIdx.x >> 3);
     const int F = nd.dims[0], H = nd.dims[1], Cm = nd.dims[2], C = nd.dims[L3 ? 3 : 2];     // Cm: the units after W_1 (the classes, or h2)
     const int NA = (G + kXcdSl - 1) / kXcdSl, NT = 1 + nd.tile_start[nd.L] - nd.tile_start[1];    // = pipe_extra_wgs(nd)
@@ -375,17 +381,17 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     // context had been destroyed, flag words of that context's workspace at the same address, which let sample groups of the new
     // context's first step run ahead of their slab).  The answer carries the launch's process-wide id, so an answer left by any
     // earlier launch of any context never counts.
-    const unsigned vtag = launch_id & 0x0fffffffu;
+    // (an answer: launch id << 8 | residue class of the block << 4 | XCC_ID -- all workers of a launch must agree on the low byte)
+    const unsigned vtag = launch_id & 0x00ffffffu;
     if (tid == 0) {
-        unsigned id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        const unsigned id = ((blockIdx.x & 7u) << 4) | my_xcc;
         xcd_flag(bufs.flagA + w * kXcdFlagStride, tag0 - 1u);
         xcd_flag(bufs.flagB + w * kXcdFlagStride, tag0 - 1u);
         xcd_flag(bufs.flagD + w * kXcdFlagStride, tag0 - 1u);
         if (w < 8) xcd_flag(bufs.flagT + w * kXcdFlagStride, tag0 - 1u);
         if (w == 0) __hip_atomic_store(bufs.cw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the closing round's decision word (xcd_commit)
         xcd_drain();
-        xcd_flag_wt(bufs.xcc + w * kXcdFlagStride, (vtag << 4) | (id & 0xfu));
+        xcd_flag_wt(bufs.xcc + w * kXcdFlagStride, (vtag << 8) | id);
     }
     if (wave == 0) {
         long long t0 = 0;
@@ -395,8 +401,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         if (stale && lane == 0) s_abort = 1;                          // parameters in memory are not this launch's starting point -> leave
         if (!stale)
         for (unsigned it = 0;; ++it) {
-            v = lane < NW ? __hip_atomic_load(bufs.xcc + lane * kXcdFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (vtag << 4);
-            if (__all((v >> 4) == vtag)) break;
+            v = lane < NW ? __hip_atomic_load(bufs.xcc + lane * kXcdFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (vtag << 8);
+            if (__all((v >> 8) == vtag)) break;
             if ((it & 255u) == 255u) {
                 const long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
@@ -404,10 +410,10 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        mine = __shfl(v, w < 64 ? w : 0, 64) & 0xfu;
-        const bool same = __all(lane >= NW || (v & 0xfu) == mine);
-        // (missing: the workers whose answer never came -- or, code 2, the workers that answered from another XCD than this one)
-        const unsigned long long absent = ok ? __ballot(lane < NW && (v & 0xfu) != mine) : __ballot(lane < NW && (v >> 4) != vtag);
+        mine = __shfl(v, w < 64 ? w : 0, 64) & 0xffu;
+        const bool same = __all(lane >= NW || (v & 0xffu) == mine);
+        // (missing: the workers whose answer never came -- or, code 2, the workers that answered from another XCD / residue class than this one)
+        const unsigned long long absent = ok ? __ballot(lane < NW && (v & 0xffu) != mine) : __ballot(lane < NW && (v >> 8) != vtag);
         if (lane == 0 && !stale && !(ok && same)) {
             s_abort = 1;
             xcd_raise(err, bufs.errd, ok ? 2u : 1u, kXcdSitePlacement, w, -1, launch_id, absent, vtag, dp_rank, dp_world, xsel, NW);      // 2: workers on different XCDs; 1: a wait expired

@@ -72,7 +72,8 @@ struct EpochKey {
 // when the context is created; two contexts of one process can differ, and nothing reads the environment afterwards.
 struct CtxOptions {
     long long xcd = 1;                  // "xcd"               RCN_HIP_XCD            0: dense path 0 (auto) never selects the resident one-XCD kernel
-    long long xcd_select = 0;           // "xcd_select"        RCN_HIP_XCD_SELECT     which blocks are the workers: blockIdx.x % 8 == this (0..7)
+    long long xcd_select = 0;           // "xcd_select"        RCN_HIP_XCD_SELECT     TEST-ONLY: which blocks are the workers -- 0..7: blockIdx.x % 8 == this; 8..15: the
+                                        //                                            blocks that landed on PHYSICAL XCD this - 8 (ranks sharing one device)
     long long xcd_gather = 0;           // "xcd_gather"        RCN_HIP_XCD_GATHER     1: rows fetched by the resident kernel itself (B = 256; measured slower)
     long long xcd_timeout_ticks = 20000000;   // "xcd_timeout_ticks"            bound of every wait inside the resident kernel, 100 MHz ticks (0.2 s)
     long long xcd_exact_lds = 0;        // "xcd_exact_lds"                            1: the resident kernel asks for exactly the LDS it uses (two workers may share a CU:
@@ -97,7 +98,7 @@ namespace {
 struct OptDesc { const char* name; const char* env; long long CtxOptions::*field; long long lo, hi; };
 const OptDesc kOptTable[] = {
     {"xcd", "RCN_HIP_XCD", &CtxOptions::xcd, 0, 1},
-    {"xcd_select", "RCN_HIP_XCD_SELECT", &CtxOptions::xcd_select, 0, 7},
+    {"xcd_select", "RCN_HIP_XCD_SELECT", &CtxOptions::xcd_select, 0, 15},
     {"xcd_gather", "RCN_HIP_XCD_GATHER", &CtxOptions::xcd_gather, 0, 1},
     {"xcd_timeout_ticks", "RCN_HIP_XCD_TIMEOUT_TICKS", &CtxOptions::xcd_timeout_ticks, 1, 1LL << 40},
     {"xcd_exact_lds", "RCN_HIP_XCD_EXACT_LDS", &CtxOptions::xcd_exact_lds, 0, 1},

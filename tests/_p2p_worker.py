@@ -28,7 +28,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # ranks share one GPU here: were the resident one-XCD kernel chosen, every rank's workers must sit on an XCD of their own (two
     # resident kernels cannot share compute units: each workgroup takes a whole CU's LDS).  On a node every rank has its GPU and XCD 0.
-    os.environ.setdefault("RCN_HIP_XCD_SELECT", str(rank))
+    os.environ.setdefault("RCN_HIP_XCD_SELECT", str(8 + rank % 8))
     import torch
     import torch.distributed as dist
     import mercer_research_amd as amd
@@ -43,7 +43,10 @@ def main():
     # Ranks that SHARE this box's one GPU: every rank's resident workers on an XCD of their own, and the kernel asking for exactly the
     # LDS it uses -- at a shard of <= 64 samples that is under half a CU's, so a rank's idle blocks (same launch, same LDS request)
     # fit beside a peer's workers instead of queueing behind them.  With a GPU per rank neither option is needed.
-    d.set_option("xcd_select", rank % 8)
+    # (8 + r: the blocks that landed on PHYSICAL XCD r.  Round 3 selected the residue class blockIdx % 8 == rank, and the record of an expired
+    # wait showed why three / four ranks sometimes failed: which XCD a dispatch starts its round-robin on differs from queue to queue, so two
+    # ranks' classes landed on ONE XCD -- 56 workgroups that each need a CU of their own on 32 CUs: profiles/r4_dp_4rank_timeout_record.txt)
+    d.set_option("xcd_select", 8 + rank % 8)
     d.set_option("xcd_exact_lds", 1)
     d.set_params(ws, bs)
     X, Y = d.to_device(case[f"X{rank}"], d.tdtype), d.to_device(case[f"Y{rank}"], d.tdtype)

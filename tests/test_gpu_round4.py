@@ -313,3 +313,30 @@ def test_steps_on_index_rows_the_caller_wrote_are_not_replayed_silently(amd, ora
     for a, b in zip(sum(d.get_params(), []), rw + rb):
         assert np.all(np.abs(a - b) <= 5e-4 * np.abs(b) + 5e-5), float(np.abs(a - b).max())
     d.rcn.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the resident data-parallel form at the BENCH's shard size between processes
+
+@pytest.mark.parametrize("world,Bs", [(2, 256), (2, 128)], ids=["2-ranks-shard-256-the-bench-shard", "2-ranks-shard-128"])
+def test_resident_data_parallel_form_at_the_bench_shard_between_processes(amd, oracle, tmp_path, world, Bs):
+    """bench.py --gpus N runs 256 images per rank: k_xcd_epoch<float, 256, true, true> -- 32 workers, 25 owners of slice pairs, 148 KB of
+    LDS each -- had exchanged between processes only at shards of 64 and 32.  Two processes on this box's one device, rank r's workers on
+    PHYSICAL XCD r (xcd_select = 8 + r): each rank's 32 workers fill their XCD's 32 CUs, and a rank's 32 idle blocks bound for the peer's
+    XCD can only start once the peer's workers have left -- which works because every XCD dispatches its share of a launch on its own.
+    Replicas bit-identical; two epochs equal the oracle's train_batch on the concatenated global batches."""
+    from test_gpu_round3 import _oracle_global_epochs, _spawn_ranks
+    nb, dims = 3, (784, 30, 10)
+    env = {"RCN_HIP_XCD_TIMEOUT_TICKS": "400000000", "RCN_HIP_DP_TIMEOUT_TICKS": "400000000"}
+    Xs, Ys, logs = _spawn_ranks(tmp_path, world, 0, "default", env, dims=dims, Bs=Bs, nb=nb)
+    outs = [np.load(tmp_path / f"out{r}.npz") for r in range(world)]
+    for o in outs:
+        assert int(o["bad"]) == 0 and int(o["timed_out"]) == 0 and int(o["active"]) == 2, logs
+        assert int(o["resident"]) == 1, "the data-parallel epoch did not run on the resident kernel"
+    for r in range(1, world):
+        for k in ("w0", "w1", "b0", "b1", "loss"):
+            assert np.array_equal(outs[0][k], outs[r][k]), (r, k)
+    rw, rb, costs = _oracle_global_epochs(oracle, list(dims), Xs, Ys, Bs, nb)
+    for a, b in zip([outs[0]["w0"], outs[0]["w1"], outs[0]["b0"], outs[0]["b1"]], [rw[0], rw[1], rb[0], rb[1]]):
+        assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5), float(np.abs(a - b).max())
+    np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-4)
