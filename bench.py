@@ -209,6 +209,17 @@ def main():
     epoch_no = [0]
     perm = torch.empty(N_IMAGES, dtype=torch.int32, device=d.device)
     fallbacks = []
+    dp_timeouts = []                 # records of expired in-kernel waits (rcn_hip_last_timeout): which wait, which worker, which peer
+
+    def note_timeout(where: str):
+        try:
+            rec = d.last_timeout()
+        except Exception:
+            rec = None
+        if rec and (not dp_timeouts or dp_timeouts[-1].get("launch") != rec.get("launch")):
+            rec = dict(rec, during=where)
+            dp_timeouts.append(rec)
+            print(f"[bench] rank {rank}: expired wait during {where}: {rec.get('text', '')}", file=sys.stderr, flush=True)
 
     def epoch_seed():
         return 0x5DEECE66D + rank * 7919 + epoch_no[0]
@@ -343,6 +354,7 @@ def main():
                 d.synchronize()
             except Exception as e:
                 print(f"[bench] rank {rank}: data-parallel loop failed its rehearsal: {e}", file=sys.stderr, flush=True)
+                note_timeout("rehearsal")
                 ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -357,6 +369,7 @@ def main():
                 val = fn()
             except Exception as e:
                 print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
+                note_timeout("a voted stretch")
                 ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -568,6 +581,25 @@ def main():
         e2e = args.steps * B / (time.perf_counter() - t0)
         d.synchronize()
 
+    # where a data-parallel step on the resident kernel waits (diagnostic launches with per-worker clocks, AFTER everything timed): what a
+    # first run on more than one GPU needs to explain itself -- rcn_hip_dp_phase_us
+    dp_phase = None
+    if use_dp and args.dp_impl == "native":
+        def clocked():
+            if not (d.dp_p2p_mode() != 0 and d.dp_resident(B)):
+                return None
+            d.set_option("xcd_dp_phase", 1)
+            try:
+                step_no[0] = 0
+                run(nb_epoch)
+                d.synchronize()
+                return d.dp_phase_us()
+            finally:
+                d.set_option("xcd_dp_phase", 0)
+        ok_ph, dp_phase = voted(clocked)
+        if not ok_ph:
+            dp_phase = None
+
     # data-parallel runs: every rank must hold bit-identical parameters (identical update from rank-ordered sums); a stale or
     # torn read in the exchange would show up here as diverged replicas
     replicas_identical = replicas_check() if use_dp else None
@@ -594,6 +626,17 @@ def main():
                    "end_to_end_steady_state_images_per_s": round(e2e_steady, 1) if e2e_steady else None,   # 32 passes over the set, device-timed
                    "allreduce": allreduce_kind if use_dp else None, "replicas_identical": replicas_identical,
                    "dp_fallbacks_taken": fallbacks if use_dp else None, "dp_form_trial": dp_form_trial,
+                   # an in-kernel wait that expired on rank 0 while the forms were rehearsed / tried (rcn_hip_last_timeout: site 1 placement vote,
+                   # 2 tail flag, 3 slab flag, 4 delta flag, 5 pushed reduce-scatter, 6 pushed all-gather, 7 tail all-to-all, 8 cost all-to-all, 9 closing round)
+                   # where a step of the resident data-parallel form waits, microseconds per step on rank 0 (clocked diagnostic launches: each clock read
+                   # costs most of a microsecond, so `step` here is NOT the timed step): owners wait for the ranks' partial sums, members for the totals
+                   "dp_phase_us": dp_phase,
+                   "dp_rs_wait_us": dp_phase["owner_wait_mean"] if dp_phase else None, "dp_ag_wait_us": dp_phase["member_wait_mean"] if dp_phase else None,
+                   "dp_tail_wait_us": dp_phase["tail_all_to_all_mean"] if dp_phase else None,
+                   "dp_timeout_site": (dp_timeouts[0]["site"] if dp_timeouts else None) if use_dp else None,
+                   "dp_timeout_worker": (dp_timeouts[0]["worker"] if dp_timeouts else None) if use_dp else None,
+                   "dp_timeout_missing": (dp_timeouts[0]["missing"] if dp_timeouts else None) if use_dp else None,
+                   "dp_timeout_record": (dp_timeouts[0].get("text", "")[:600] if dp_timeouts else None) if use_dp else None,
                    "timing": ("barrier + synchronise, clock started on every rank; K steps; synchronise, clock stopped on every rank, closing barrier + "
                               "synchronise; value uses the MAX over the ranks") if use_dp else "synchronise; K steps; one device-wide synchronise"},
     }

@@ -274,6 +274,13 @@ int  rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* ctx, size_t first_batch, size_t n_b
  * step and rank at eight ranks instead of the 7 P of an all-to-all read).  Needs: the pushed exchange admitted by its own
  * known-answer vote, an f32 context, one hidden layer, a shard of exactly 32, 64, 128 or 256 samples.  Else 0. */
 int  rcn_hip_dp_resident(rcn_hip_ctx* ctx, size_t B_shard);
+/* Diagnostic for a first run on more than one GPU: with option "xcd_dp_phase" = 1 the resident kernel's data-parallel launches at a shard
+ * of 256 carry per-worker clocks (two reads of the 100 MHz clock per step and worker: the figures say where a step WAITS, they are not
+ * the cost of an unclocked step).  After such a call: out[0], out[1] = mean / max over the feature workers that OWN their slice pair of
+ * the microseconds per step between entering the exchange and having pushed the totals (waiting for the other ranks' partial sums:
+ * the reduce-scatter); out[2], out[3] = the same for the member workers (push the partials, wait for the owner's totals: both hops);
+ * out[4], out[5] = the tail tiles' all-to-all; out[6] = microseconds per step of the whole loop; out[7] = steps of the launch. Blocks. */
+int  rcn_hip_dp_phase_us(rcn_hip_ctx* ctx, double* out, size_t cap);
 int  rcn_hip_dp_p2p_active(const rcn_hip_ctx* ctx);   /* 0 ncclAllReduce, 1 peer exchange at kernel boundaries, 2 also inside the gradient kernel */
 /* ---- RCN::train's data flow with both data sets RESIDENT in HBM (rcn.rs:126-167): what a host-language `RCN::train` calls.
  * rcn_hip_load_data = the arithmetic of load_data after the image decode (rcn.rs:399-414) for `n` images: imgs n x in_h x in_w u8,
@@ -349,6 +356,7 @@ const char* rcn_hip_last_timeout_text(const rcn_hip_ctx* ctx);
  *                                                               the library are re-run, anything else keeps the sticky error (0)
  *   "xcd_fault_launch"    RCN_HIP_XCD_FAULT_LAUNCH    >= 0      TEST HOOK, never set in production: the n-th resident launch of the context fails (0: none)
  *   "xcd_fault_mode"      RCN_HIP_XCD_FAULT_MODE      0 | 1     TEST HOOK: how -- 0 a worker never becomes resident, 1 a worker reaches the closing round late
+ *   "xcd_dp_phase"        RCN_HIP_XCD_DP_PHASE        0 | 1     DIAGNOSTIC: data-parallel launches at a shard of 256 carry phase clocks (rcn_hip_dp_phase_us; 0)
  *   "dp_p2p"              RCN_HIP_DP_P2P              0 | 1 | 2 peer exchange over xGMI: never / when world > 1 / also at world 1 (tests)
  *   "dp_fused"            RCN_HIP_DP_FUSED            0 | 1     the exchange may run inside a step kernel (1)
  *   "dp_timeout_ticks"    RCN_HIP_DP_TIMEOUT_TICKS    >= 1      bound of a peer wait (100000000 = 1 s)

@@ -97,6 +97,7 @@ SIGNATURES = {
     "rcn_hip_train_epoch_gathers": (_i, [_vp, _sz]),
     "rcn_hip_train_epoch_resident": (_i, [_vp, _sz]),
     "rcn_hip_dp_resident": (_i, [_vp, _sz]),
+    "rcn_hip_dp_phase_us": (_i, [_vp, _dp, _sz]),
     "rcn_hip_dp_p2p_active": (_i, [_vp]),
     "rcn_hip_dp_prepare_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),
     "rcn_hip_dp_train_epoch_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _d, _vp]),

@@ -67,6 +67,8 @@ struct XcdBufsT {
     unsigned* done;    // pinned host word: id of the newest launch whose workers ALL decided to commit (its parameters are in memory when it ends)
     unsigned* cw;      // [1]                the closing round's decision word: arrivals in the low half, the poison bit above (xcd_commit)
     unsigned* cdone;   // [32]               id of the newest launch whose write-back worker w completed (the host cross-checks `done` with it)
+    long long* phase;  // [32][4]            diagnostic launches only (template parameter PH): per worker -- ticks spent inside the exchange, ticks of
+                       //                    the whole step loop, steps, role (1 owner of its slice pair, 2 member, 3 tail tile)
 };
 using XcdBufs = XcdBufsT<float>;
 
@@ -100,7 +102,7 @@ inline int xcd_workers(const NetDesc& nd, int BT) {
 inline size_t xcd_buf_bytes(const NetDesc& nd, size_t BT, size_t esz = 4) {
     const size_t NS = BT / kP2Ts, NA = (size_t)xcd_na(nd);
     return (NS * NA * kP2Ts * kP2H + 2 * BT * kP2H + 3 * BT * kP2C + NS + (size_t)kP3BFrag * 64) * esz +
-           (size_t)(4 * kXcdWorkers + 8) * kXcdFlagStride * sizeof(unsigned) + 512;       // flagA, flagB, xcc, flagD, flagT, error word
+           (size_t)(4 * kXcdWorkers + 8) * kXcdFlagStride * sizeof(unsigned) + 512 + 1024;   // flagA, flagB, xcc, flagD, flagT; decision word, committed ids; phase clocks
 }
 // LDS (elements): two batch buffers of a slice pair, delta_1 of the whole batch (rows padded to 48: conflict-free MFMA operand reads),
 // the tail tiles' K-split partials, the slice pair of W_0, and the sample group's scratch (slab partial sums, a_1 / delta_2 tiles,
@@ -316,7 +318,10 @@ template <bool DP> using XcdDpArgs = typename XcdDpSel<DP>::type;
 // T: the context's arithmetic type.  f64 (the reference's own, rcn.rs:28,31,49) runs the same roles on v_mfma_f64_16x16x4_f64: the
 // accumulator's row map differs (Mfma16<T>::row), so a feature-worker lane owns parameters hidden g4 + 4 i instead of 4 g4 + i, and
 // 16-byte L2 reads become two per quadruple; single-GPU forms only (the exchange's words carry f32 values).
-template <typename T, int BT, bool FULL, bool DP, bool L3 = false, bool GA = false>
+// PH (diagnostic, data-parallel form only; option "xcd_dp_phase"): every worker clocks the time it spends inside the exchange and the
+// whole step loop (two reads of the 100 MHz clock per step -- most of a microsecond each, so the figures describe where a step waits,
+// not what an unclocked step costs) and leaves them in bufs.phase: what rcn_hip_dp_phase_us reports after a first multi-GPU run.
+template <typename T, int BT, bool FULL, bool DP, bool L3 = false, bool GA = false, bool PH = false>
 __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     NetDesc nd, T* __restrict__ params, const T* __restrict__ xs_all, const T* __restrict__ ys_all, int B_arg, int nb, int G, T scale,
     T loss_scale, T* __restrict__ loss_dev, XcdBufsT<T> bufs, unsigned tag0, unsigned* __restrict__ err, long long timeout, XcdDpArgs<DP> dp,
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     static_assert(BT == 32 || BT == 64 || BT == 128 || BT == 256, "k_xcd_epoch: batch instantiations");
     static_assert(!GA || BT == 256, "the gather form exists for batch 256 only");
     static_assert(sizeof(T) == 4 || (!DP && !GA && BT <= kXcdMaxB64), "f64: single-GPU forms on the packed image, batches up to 128");
+    static_assert(!PH || DP, "the phase clocks exist for the data-parallel form");
     constexpr int ES = (int)sizeof(T), VS = 4 * ES;                  // bytes of an element / of a quadruple in the L2 buffers
     constexpr int RI = sizeof(T) == 4 ? 1 : 4;                       // Mfma16<T>::row(lane, i) = row(lane, 0) + RI * i
     constexpr size_t kXs = (size_t)kXcdSl * BT * 16;              // one LDS batch buffer of a slice pair
@@ -557,6 +563,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         const unsigned at = (unsigned)(w * kP2Ts + (n & 7));
         yrow = gperm ? (unsigned)gperm[at] : at;
     }
+    long long ph_x = 0, ph_t0 = 0;                                    // (PH) ticks inside the exchange; the loop's start
+    if constexpr (PH) { if (tid == 0) ph_t0 = wall_clock64(); }
     for (int j = 0; j < nb; ++j) {
         const unsigned tag = tag0 + (unsigned)j;
         if (j == 8) XCLOCK(0);
@@ -841,7 +849,10 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     const size_t i0 = (size_t)nd.w_off[0] + wo;
                     const bool gw[4] = {wvalid[0], wvalid[1], wvalid[2], wvalid[3]};
                     unsigned pmiss = 0u;
+                    long long ph0 = 0;
+                    if constexpr (PH) { if (tid == 0) ph0 = wall_clock64(); }
                     const bool ok = push_reduce4(dp.pd, w, seq, i0, gw, gsum, dp.ptimeout, &pmiss);
+                    if constexpr (PH) { if (tid == 0) ph_x += wall_clock64() - ph0; }
                     if (!ok) {
                         s_abort = 1;
                         xcd_raise(err, bufs.errd, 1u, push_owner_of(w, dp_world) == dp_rank ? kXcdSitePushOwner : kXcdSitePushMember, w, j, launch_id, pmiss, seq,
@@ -944,7 +955,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                         asm volatile("" : "+v"(tpo));
                         T g = gsum;
                         unsigned pmiss = 0u;
-                        if (dp.pd.pd.world == 1 || push_all1(dp.pd, seq, tpo, gsum, dp.ptimeout, g, &pmiss)) gsum = g;
+                        long long ph0 = 0;
+                        if constexpr (PH) { if (tid == 0) ph0 = wall_clock64(); }
+                        const bool pok = dp.pd.pd.world == 1 || push_all1(dp.pd, seq, tpo, gsum, dp.ptimeout, g, &pmiss);
+                        if constexpr (PH) { if (tid == 0) ph_x += wall_clock64() - ph0; }
+                        if (pok) gsum = g;
                         else { s_abort = 1; xcd_raise(err, bufs.errd, 1u, kXcdSitePushTail, w, j, launch_id, pmiss, seq, dp_rank, dp_world, xsel, NW); }
                     }
                     tcur -= scale * gsum;                                    // rcn.rs:214,221
@@ -962,6 +977,14 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         }
     }
 
+    if constexpr (PH) {
+        if (tid == 0) {
+            bufs.phase[w * 4 + 0] = ph_x;
+            bufs.phase[w * 4 + 1] = wall_clock64() - ph_t0;
+            bufs.phase[w * 4 + 2] = nb;
+            bufs.phase[w * 4 + 3] = is_a ? (push_owner_of(w, dp_world) == dp_rank ? 1 : 2) : (is_t ? 3 : 0);
+        }
+    }
     // ---- all or nothing: a worker writes its parameters back only if EVERY worker finished the last step -- decided on ONE word that all
     // workers read the same way (xcd_commit): a wait that expires anywhere leaves the whole parameter vector as the launch found it,
     // and no worker that arrives later can write its slice under it

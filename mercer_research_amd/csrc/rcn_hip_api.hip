@@ -78,6 +78,7 @@ struct CtxOptions {
     long long xcd_timeout_ticks = 20000000;   // "xcd_timeout_ticks"            bound of every wait inside the resident kernel, 100 MHz ticks (0.2 s)
     long long xcd_exact_lds = 0;        // "xcd_exact_lds"                            1: the resident kernel asks for exactly the LDS it uses (two workers may share a CU:
                                         //                                            what lets two contexts' kernels be resident on ONE device); 0: at least half a CU's
+    long long xcd_dp_phase = 0;         // "xcd_dp_phase"                             DIAGNOSTIC: data-parallel launches at a shard of 256 carry per-worker phase clocks
     long long xcd_fault_launch = 0;     // "xcd_fault_launch"                         TEST HOOK: the n-th resident launch of the context (1-based) loses a worker
     long long xcd_fault_mode = 0;       // "xcd_fault_mode"                           TEST HOOK: how -- 0 worker 1 never becomes resident, 1 it reaches the closing round late
     long long xcd_auto_fallback = 1;    // "xcd_auto_fallback"                        1: an expired wait of the single-GPU resident kernel re-runs the segment on the two-kernel pipeline
@@ -106,6 +107,7 @@ const OptDesc kOptTable[] = {
     {"xcd_replay_caller_rows", "RCN_HIP_XCD_REPLAY_CALLER_ROWS", &CtxOptions::xcd_replay_caller_rows, 0, 1},
     {"xcd_fault_launch", "RCN_HIP_XCD_FAULT_LAUNCH", &CtxOptions::xcd_fault_launch, 0, 0x7fffffff},
     {"xcd_fault_mode", "RCN_HIP_XCD_FAULT_MODE", &CtxOptions::xcd_fault_mode, 0, 1},
+    {"xcd_dp_phase", "RCN_HIP_XCD_DP_PHASE", &CtxOptions::xcd_dp_phase, 0, 1},
     {"dp_p2p", "RCN_HIP_DP_P2P", &CtxOptions::dp_p2p, 0, 2},
     {"dp_fused", "RCN_HIP_DP_FUSED", &CtxOptions::dp_fused, 0, 1},
     {"dp_timeout_ticks", "RCN_HIP_DP_TIMEOUT_TICKS", &CtxOptions::dp_timeout_ticks, 1, 1LL << 40},

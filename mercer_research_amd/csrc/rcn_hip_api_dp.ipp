@@ -347,6 +347,32 @@ int rcn_hip_train_epoch_gathers(rcn_hip_ctx* c, size_t B) {
     return use_xcd(c, B) && xcd_gather(c) ? 1 : 0;
 }
 
+int rcn_hip_dp_phase_us(rcn_hip_ctx* c, double* out, size_t cap) {
+    RCN_TRY(check_ctx(c));
+    if (!out || cap < 8) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_phase_us: out must hold 8 doubles");
+    if (!c->xcdbuf.p || c->xcd_B != 256 || c->dtype != RCN_HIP_F32) return fail(c, RCN_HIP_ERR_STATE, "dp_phase_us: no clocked data-parallel launch at a shard of 256 has run (option xcd_dp_phase)");
+    DevGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    long long ph[kXcdWorkers * 4];
+    HIP_TRY(c, hipMemcpy(ph, xcd_bufs<float>(c, 256).phase, sizeof ph, hipMemcpyDeviceToHost));
+    double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, step = 0, steps = 0;
+    int cnt[4] = {0, 0, 0, 0}, nstep = 0;
+    for (int w = 0; w < kXcdWorkers; ++w) {
+        const long long nb = ph[w * 4 + 2], role = ph[w * 4 + 3];
+        if (nb <= 0) continue;
+        step += (double)ph[w * 4 + 1] * 0.01 / (double)nb; ++nstep; steps = (double)nb;
+        if (role < 1 || role > 3) continue;
+        const double us = (double)ph[w * 4 + 0] * 0.01 / (double)nb;              // 100 MHz ticks -> us per step
+        sum[role] += us; ++cnt[role];
+        if (us > mx[role]) mx[role] = us;
+    }
+    if (nstep == 0) return fail(c, RCN_HIP_ERR_STATE, "dp_phase_us: no clocked data-parallel launch has run since the option was set");
+    for (int r = 1; r <= 3; ++r) { out[2 * (r - 1)] = cnt[r] ? sum[r] / cnt[r] : 0.0; out[2 * (r - 1) + 1] = mx[r]; }
+    out[6] = step / nstep;
+    out[7] = steps;
+    return RCN_HIP_OK;
+}
+
 int rcn_hip_last_timeout(const rcn_hip_ctx* c, uint32_t* words, size_t cap) {
     if (!c || !words || !c->xrec_valid) return 0;
     const size_t n = cap < (size_t)kXcdRecWords + 1 ? cap : (size_t)kXcdRecWords + 1;

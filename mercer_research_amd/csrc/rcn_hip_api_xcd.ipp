@@ -163,7 +163,8 @@ static XcdBufsT<T> xcd_bufs(rcn_hip_ctx* c, size_t BT) {
     xb.flagD = u; u += kXcdWorkers * kXcdFlagStride;
     xb.flagT = u; u += 8 * kXcdFlagStride;
     xb.cw = u;    u += kXcdFlagStride;          // (the 512 spare bytes of xcd_buf_bytes: the decision word's line, then 32 committed ids)
-    xb.cdone = u;
+    xb.cdone = u; u += kXcdFlagStride;
+    xb.phase = (long long*)u;
     xb.errd = c->xerrd;
     xb.done = c->xerr_dev + 1;
     return xb;
@@ -188,6 +189,16 @@ int xcd_launch_bt(rcn_hip_ctx* c, const T* xs, const T* ys, size_t B, size_t nb,
     if (dp) {
         // (the data-parallel form exists for whole instantiation sizes: a shard of 32 / 64 / 128 / 256 samples per rank, f32)
         if constexpr (FULL && sizeof(T) == 4) {
+            bool clocked = false;
+            if constexpr (BT == 256) {
+                if (c->opt.xcd_dp_phase) {          // diagnostic: the same launch with per-worker phase clocks (rcn_hip_dp_phase_us)
+                    HIP_TRY(c, hipMemsetAsync(xb.phase, 0, (size_t)kXcdWorkers * 4 * sizeof(long long), c->stream));
+                    RCN_XCD_LAUNCH((k_xcd_epoch<float, 256, true, true, false, false, true>), to + 2 * p2p_timeout_ticks(c),
+                                   (XcdDpOn{PushDesc{p2p_desc(c), c->p2p.stride, c->p2p.push_off}, c->p2p.seq + 1, p2p_timeout_ticks(c)}));
+                    clocked = true;
+                }
+            }
+            if (!clocked)
             RCN_XCD_LAUNCH((k_xcd_epoch<float, BT, true, true>), to + 2 * p2p_timeout_ticks(c),
                            (XcdDpOn{PushDesc{p2p_desc(c), c->p2p.stride, c->p2p.push_off}, c->p2p.seq + 1, p2p_timeout_ticks(c)}));
             c->p2p.seq += (unsigned)nb;

@@ -227,6 +227,13 @@ class DeviceRCN:
         """True when train_epoch / epoch_steps at this batch size run on the resident one-XCD kernel (f32: 1..256, f64: 1..128)."""
         return bool(self.lib.rcn_hip_train_epoch_resident(self.ctx, B))
 
+    def dp_phase_us(self) -> dict:
+        """After a data-parallel call with option xcd_dp_phase = 1 at a shard of 256: where a step waits (rcn_hip_dp_phase_us)."""
+        out = (C.c_double * 8)()
+        self._ck(self.lib.rcn_hip_dp_phase_us(self.ctx, out, 8))
+        keys = ("owner_wait_mean", "owner_wait_max", "member_wait_mean", "member_wait_max", "tail_all_to_all_mean", "tail_all_to_all_max", "step", "steps")
+        return {k: round(float(out[i]), 3) for i, k in enumerate(keys)}
+
     def dp_resident(self, B_shard: int) -> bool:
         """True when dp_train_epoch at this shard size runs on the resident one-XCD kernel with the exchange inside it."""
         return bool(self.lib.rcn_hip_dp_resident(self.ctx, B_shard))

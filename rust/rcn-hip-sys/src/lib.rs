@@ -125,6 +125,7 @@ extern "C" {
     pub fn rcn_hip_train_epoch_gathers(ctx: *mut rcn_hip_ctx, b: usize) -> c_int;
     pub fn rcn_hip_train_epoch_resident(ctx: *mut rcn_hip_ctx, b: usize) -> c_int;
     pub fn rcn_hip_dp_resident(ctx: *mut rcn_hip_ctx, b_shard: usize) -> c_int;
+    pub fn rcn_hip_dp_phase_us(ctx: *mut rcn_hip_ctx, out: *mut c_double, cap: usize) -> c_int;
     pub fn rcn_hip_dp_p2p_active(ctx: *const rcn_hip_ctx) -> c_int;
     pub fn rcn_hip_set_feature_kernel(ctx: *mut rcn_hip_ctx, mode: c_int) -> c_int;
     pub fn rcn_hip_dp_prepare_epoch_dev(ctx: *mut rcn_hip_ctx, x: *const c_void, y: *const c_void, perm: *const i32, b_shard: usize, n_batches: usize,

@@ -141,7 +141,22 @@ def main():
                 d.apply_gradient(grad, 3.0 / (Bs * world))
     gw, gb = d.get_params()
     d.synchronize()
-    np.savez(os.path.join(outdir, f"out{rank}.npz"), bad=bad, timed_out=timed_out, active=mode, resident=resident, loss=loss.cpu().numpy(),
+    phase = np.zeros(8)
+    if mode != 0 and resident and Bs == 256 and case_name == "default":
+        # the diagnostic a first multi-GPU run would use: one more call with per-worker phase clocks (rcn_hip_dp_phase_us); the results above
+        # are already taken, the parameters move on by these steps on every rank alike
+        d.set_option("xcd_dp_phase", 1)
+        d.epoch_begin(X, Y, d.to_device(np.arange(Bs * nb, dtype=np.int32)), Bs, nb)
+        d.synchronize()
+        dist.barrier()
+        d.dp_epoch_steps(0, nb, 3.0, None)
+        d.synchronize()
+        ph = d.dp_phase_us()
+        phase = np.array([ph[k] for k in ("owner_wait_mean", "owner_wait_max", "member_wait_mean", "member_wait_max", "tail_all_to_all_mean", "tail_all_to_all_max", "step", "steps")])
+        print(f"PHASE rank {rank}: {ph}", flush=True)
+        d.set_option("xcd_dp_phase", 0)
+        dist.barrier()
+    np.savez(os.path.join(outdir, f"out{rank}.npz"), bad=bad, timed_out=timed_out, active=mode, resident=resident, loss=loss.cpu().numpy(), phase=phase,
              **{f"w{i}": w for i, w in enumerate(gw)}, **{f"b{i}": b for i, b in enumerate(gb)})
     dist.barrier()                                             # nobody unmaps while a peer may still read
     d.dp_finalize()

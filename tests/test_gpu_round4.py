@@ -340,3 +340,9 @@ def test_resident_data_parallel_form_at_the_bench_shard_between_processes(amd, o
     for a, b in zip([outs[0]["w0"], outs[0]["w1"], outs[0]["b0"], outs[0]["b1"]], [rw[0], rw[1], rb[0], rb[1]]):
         assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5), float(np.abs(a - b).max())
     np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-4)
+    if Bs == 256:
+        # the phase clocks of a diagnostic launch (rcn_hip_dp_phase_us): owners and members waited a finite, positive time per step, the
+        # launch ran nb steps, and with two ranks both roles exist on each (worker w's owner is rank w % 2)
+        for o in outs:
+            ph = o["phase"]
+            assert ph[7] == nb and np.all(np.isfinite(ph)) and ph[0] > 0 and ph[2] > 0 and ph[4] > 0 and ph[6] > ph[1] * 0.5, ph
