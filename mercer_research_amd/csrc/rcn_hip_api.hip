@@ -162,7 +162,7 @@ struct rcn_hip_ctx {
         bool push = false;                  // the pushed reduce-scatter + all-gather of the resident kernel passed its vote (dp_push.hpp)
         size_t push_off = 0;                // byte offset of its region in every rank's exported buffer
         void* local_buf = nullptr;          // [2][stride] values + [2][stride] tagged words + the pushed exchange's rows, uncached device memory
-        size_t local_bytes = 0;
+        size_t local_bytes = 0, flags_cap = 0;
         bool local_uncached = false;
         unsigned* local_flags = nullptr;    // [kP2PMaxWorld], uncached device memory
         void* peer_buf[rcn::kP2PMaxWorld] = {};

@@ -6,24 +6,41 @@
 // ORDINARY hipMalloc allocations came back on that memory still behaving uncached -- plain stores no longer stayed in the XCD's L2 and
 // the resident kernel's hand-offs (payload, drain, flag: dense_xcd.hpp) were read stale: deterministic wrong costs in the first step
 // of a context created right after a data-parallel one, gone with RCN_HIP_DP_CACHED_BUF=1 and gone with this cache.
+// Bounded (round 4): a request takes the SMALLEST parked block of its device that is large enough (not only an exact match), so a process
+// that builds groups for nets of different sizes re-uses what it parked; what stays parked is the price of never handing such memory
+// back -- at most one block per distinct size class a process ever used, a few MB for the nets this library trains (the default net's
+// exported buffer: 3.9 MB), reported by parked_bytes() for whoever wants to watch it.
 struct UncachedCache {
     std::mutex mu;
-    std::vector<std::tuple<int, size_t, void*>> free_list;        // (device, bytes, pointer)
-    hipError_t alloc(int device, size_t bytes, void** out) {
+    std::vector<std::tuple<int, size_t, void*>> free_list;        // (device, capacity in bytes, pointer)
+    // *cap_out: the capacity of the block handed out (>= bytes) -- what park() must be given back
+    hipError_t alloc(int device, size_t bytes, void** out, size_t* cap_out) {
         {
             std::lock_guard<std::mutex> lk(mu);
+            size_t best = free_list.size();
             for (size_t i = 0; i < free_list.size(); ++i)
-                if (std::get<0>(free_list[i]) == device && std::get<1>(free_list[i]) == bytes) {
-                    *out = std::get<2>(free_list[i]);
-                    free_list.erase(free_list.begin() + i);
-                    return hipSuccess;
-                }
+                if (std::get<0>(free_list[i]) == device && std::get<1>(free_list[i]) >= bytes &&
+                    (best == free_list.size() || std::get<1>(free_list[i]) < std::get<1>(free_list[best])))
+                    best = i;
+            if (best != free_list.size() && std::get<1>(free_list[best]) <= 4 * bytes + (1u << 20)) {      // (not a 100 MB block for a 4 KB request)
+                *out = std::get<2>(free_list[best]);
+                *cap_out = std::get<1>(free_list[best]);
+                free_list.erase(free_list.begin() + best);
+                return hipSuccess;
+            }
         }
+        *cap_out = bytes;
         return hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
     }
-    void park(int device, size_t bytes, void* p) {
+    void park(int device, size_t cap, void* p) {
         std::lock_guard<std::mutex> lk(mu);
-        free_list.emplace_back(device, bytes, p);
+        free_list.emplace_back(device, cap, p);
+    }
+    size_t parked_bytes() {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t s = 0;
+        for (auto& e : free_list) s += std::get<1>(e);
+        return s;
     }
 };
 UncachedCache& uncached_cache() { static UncachedCache* u = new UncachedCache(); return *u; }      // (never destroyed: no hipFree at exit)
@@ -43,7 +60,7 @@ void p2p_release(rcn_hip_ctx* c) {
         q.peer_flags[r] = nullptr;
     }
     if (q.local_buf) { if (q.local_uncached) uncached_cache().park(c->device, q.local_bytes, q.local_buf); else (void)hipFree(q.local_buf); }
-    if (q.local_flags) uncached_cache().park(c->device, kP2PFlagBytes, q.local_flags);
+    if (q.local_flags) uncached_cache().park(c->device, q.flags_cap, q.local_flags);
     if (q.err_dev) (void)hipFree(q.err_dev);
     if (q.err_host) (void)hipHostFree(q.err_host);
     q.raw.release();
@@ -69,8 +86,8 @@ int p2p_export(rcn_hip_ctx* c, void* out) {
     q.local_bytes = bytes;
     q.local_uncached = !c->opt.dp_cached_buf;
     if (c->opt.dp_cached_buf) HIP_TRY(c, hipMalloc(&q.local_buf, bytes));
-    else HIP_TRY(c, uncached_cache().alloc(c->device, bytes, &q.local_buf));
-    HIP_TRY(c, uncached_cache().alloc(c->device, kP2PFlagBytes, (void**)&q.local_flags));
+    else HIP_TRY(c, uncached_cache().alloc(c->device, bytes, &q.local_buf, &q.local_bytes));       // (local_bytes: the block's capacity, what is parked again)
+    HIP_TRY(c, uncached_cache().alloc(c->device, kP2PFlagBytes, (void**)&q.local_flags, &q.flags_cap));
     HIP_TRY(c, hipMalloc((void**)&q.err_dev, 256));
     HIP_TRY(c, hipHostMalloc((void**)&q.err_host, 64, hipHostMallocDefault));
     *q.err_host = 0;
