@@ -62,6 +62,20 @@ int  rcn_hipx_set_tiling(rcn_hipx_net* net, int mode);
  * on their own; with a reduction launch per layer on the second stream (before k_reduce_all) mode 1 was 7 % slower.
  * RCN_HIPX_OVERLAP seeds a new net's mode.  Same kernels, same sums, bit-identical results in every mode. */
 int  rcn_hipx_set_overlap(rcn_hipx_net* net, int on);
+/* Kernel-selection knobs of ONE net (round 4: they used to be process-wide statics read from the environment at first use).  The
+ * environment variable named beside an option only seeds its default when a net -- or a plan -- is created; two nets of one process can
+ * differ, and changing an option drops the net's captured graphs.  -1 for an unknown name or a value out of range.
+ *   "halo"            RCN_HIPX_HALO            0 | 1   bf16 mode: the LDS-tiled 3x3 kernels (1)
+ *   "bf16_pipe"       RCN_HIPX_BF16_PIPE       0 | 1   bf16 mode: their software-pipelined form (1)
+ *   "bf16_1cb"        RCN_HIPX_BF16_1CB        0 | 1   bf16 mode: the resident-weights form for 32-channel layers (1)
+ *   "halo_wgrad"      RCN_HIPX_HALO_WGRAD      0 | 1   the LDS-tiled weight-gradient kernels (1)
+ *   "fuse_pool_bwd"   RCN_HIPX_FUSE_POOL_BWD   0 | 1   the gradient kernels unpool while staging (1)
+ *   "head"            RCN_HIPX_HEAD            0 | 1   the classifier head as one launch (1)
+ *   "xcd_remap"       RCN_HIPX_XCD_REMAP       0 | 1   implicit-GEMM weight gradient: XCD-aware block order (0)
+ *   "pix_per_chunk" "wg_target" "wgh_f32_target" "wgh_target" "wgb_policy" "wgf_policy" "halo_f32_slots"
+ *                                                      weight-gradient chunking and the resident-grid size (csrc/rcn_hipx_api.hip: XOptions) */
+int  rcn_hipx_set_option(rcn_hipx_net* net, const char* name, int value);
+int  rcn_hipx_get_option(const rcn_hipx_net* net, const char* name, int* value);
 int  rcn_hipx_set_params(rcn_hipx_net* net, const float* flat);
 int  rcn_hipx_get_params(rcn_hipx_net* net, float* flat);
 int  rcn_hipx_init_params(rcn_hipx_net* net, uint64_t seed);            /* He-normal weights, zero biases */
@@ -80,6 +94,9 @@ int  rcn_hipx_unpad_host(rcn_hipx_net* net, const float* padded_dev, float* logi
  * Pure host code -- no GPU is needed or touched: the dispatch code of the step runs with its launches replaced by notes, so the text is
  * the library's own decision, not a restatement of it (tests/test_convnet_plan.py holds the BASELINE configurations' plans). */
 int  rcn_hipx_plan(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int batch, int precision, int tiling, char* out, int cap);
+/* The same walk for an EXISTING net at batch `batch` (<= max_batch) with that net's own precision, tiling and options: the plan and the
+ * step that follows agree by construction (rcn_hipx_plan describes a net created now, seeded from the environment). */
+int  rcn_hipx_plan_net(const rcn_hipx_net* net, int batch, char* out, int cap);
 /* algorithmic FLOPs of one training step at batch B (2 * MACs; forward + dgrad + wgrad) */
 int  rcn_hipx_step_flops(const rcn_hipx_net* net, int B, double* flops);
 

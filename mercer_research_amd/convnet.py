@@ -38,6 +38,9 @@ SIGNATURES = {
     "rcn_hipx_set_precision": (_i, [_vp, _i]),
     "rcn_hipx_set_tiling": (_i, [_vp, _i]),
     "rcn_hipx_set_overlap": (_i, [_vp, _i]),
+    "rcn_hipx_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "rcn_hipx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int)]),
+    "rcn_hipx_plan_net": (_i, [_vp, _i, C.c_char_p, _i]),
     "rcn_hipx_step_flops": (_i, [_vp, _i, C.POINTER(C.c_double)]),
     "rcn_hipx_plan": (_i, [_i, _i, _i, C.POINTER(XLayer), _i, _i, _i, _i, C.c_char_p, _i]),
 }
@@ -135,6 +138,24 @@ class ConvNet:
         """Backward pass: weight gradients on a second stream beside the input-gradient chain: 0 / False = no (default: measured no
         gain), 1 / True = every layer's, 2 = the dense layers' only."""
         self._ck(self.lib.rcn_hipx_set_overlap(self.net, int(mode)))
+
+    def set_option(self, name: str, value: int):
+        """A kernel-selection knob of THIS net (rcn_hipx_set_option; the environment only seeds the defaults at creation)."""
+        self._ck(self.lib.rcn_hipx_set_option(self.net, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        if self.lib.rcn_hipx_get_option(self.net, name.encode(), C.byref(v)) != 0:
+            raise ConvNetError(f"unknown option {name!r}")
+        return int(v.value)
+
+    def plan_of_this_net(self, batch: int) -> str:
+        """The launches a training step of THIS net would make, with its own precision, tiling and options (rcn_hipx_plan_net)."""
+        buf = C.create_string_buffer(1 << 16)
+        st = self.lib.rcn_hipx_plan_net(self.net, int(batch), buf, len(buf))
+        if st != 0:
+            raise ConvNetError(f"rcn_hipx_plan_net: {st}: {buf.value.decode()}")
+        return buf.value.decode()
 
     def set_params(self, flat: np.ndarray):
         f = np.ascontiguousarray(flat, dtype=np.float32)

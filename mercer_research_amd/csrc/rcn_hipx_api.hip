@@ -58,7 +58,55 @@ struct Key { const void* x; const void* y; int B; float lr; const void* loss;
 
 }  // namespace
 
+// Kernel-selection knobs, PER NET (round 4; before, most were read from the environment into function-local statics at first use:
+// frozen process-wide, two nets of one process could not differ, and rcn_hipx_plan reported whatever the first call had latched).
+// The environment variable of the same meaning only seeds the default when a net (or a plan) is created.
+struct XOptions {
+    int halo = 1;             // "halo"            RCN_HIPX_HALO            bf16: the LDS-tiled 3x3 kernels (0: implicit GEMM only)
+    int bf16_pipe = 1;        // "bf16_pipe"       RCN_HIPX_BF16_PIPE       bf16: the software-pipelined LDS-tiled kernel (k_conv3x3_halo_bf16p)
+    int bf16_1cb = 1;         // "bf16_1cb"        RCN_HIPX_BF16_1CB        bf16: the resident-weights form for 32-channel layers
+    int halo_wgrad = 1;       // "halo_wgrad"      RCN_HIPX_HALO_WGRAD      the LDS-tiled weight-gradient kernels
+    int fuse_pool_bwd = 1;    // "fuse_pool_bwd"   RCN_HIPX_FUSE_POOL_BWD   gradient kernels unpool while staging (no k_pool_bwd)
+    int head = 1;             // "head"            RCN_HIPX_HEAD            the classifier head as one launch (k_head_f32)
+    int xcd_remap = 0;        // "xcd_remap"       RCN_HIPX_XCD_REMAP       implicit-GEMM weight gradient: XCD-aware block order
+    int pix_per_chunk = 0;    // "pix_per_chunk"   RCN_HIPX_PIX_PER_CHUNK   pixels per weight-gradient chunk (0: by the workgroup target)
+    int wg_target = 4096;     // "wg_target"       RCN_HIPX_WG_TARGET       workgroups aimed at by the implicit-GEMM weight gradient
+    int wgh_f32_target = 512; // "wgh_f32_target"  RCN_HIPX_WGH_F32_TARGET  ... by the fp32 LDS-tiled weight gradient
+    int wgh_target = 256;     // "wgh_target"      RCN_HIPX_WGH_TARGET      ... by the bf16 LDS-tiled weight gradient
+    int wgb_policy = 1;       // "wgb_policy"      RCN_HIPX_WGB_POLICY      bf16 implicit-GEMM weight gradient: narrower tiles / shorter chunks below 2 waves per SIMD
+    int wgf_policy = 1;       // "wgf_policy"      RCN_HIPX_WGF_POLICY      fp32: the same
+    int halo_f32_slots = 0;   // "halo_f32_slots"  RCN_HIPX_HALO_F32_SLOTS  resident workgroups assumed for the looping kernels (0: asked from the runtime)
+};
+namespace {
+struct XOptDesc { const char* name; const char* env; int XOptions::*field; int lo, hi; };
+const XOptDesc kXOptTable[] = {
+    {"halo", "RCN_HIPX_HALO", &XOptions::halo, 0, 1},
+    {"bf16_pipe", "RCN_HIPX_BF16_PIPE", &XOptions::bf16_pipe, 0, 1},
+    {"bf16_1cb", "RCN_HIPX_BF16_1CB", &XOptions::bf16_1cb, 0, 1},
+    {"halo_wgrad", "RCN_HIPX_HALO_WGRAD", &XOptions::halo_wgrad, 0, 1},
+    {"fuse_pool_bwd", "RCN_HIPX_FUSE_POOL_BWD", &XOptions::fuse_pool_bwd, 0, 1},
+    {"head", "RCN_HIPX_HEAD", &XOptions::head, 0, 1},
+    {"xcd_remap", "RCN_HIPX_XCD_REMAP", &XOptions::xcd_remap, 0, 1},
+    {"pix_per_chunk", "RCN_HIPX_PIX_PER_CHUNK", &XOptions::pix_per_chunk, 0, 1 << 20},
+    {"wg_target", "RCN_HIPX_WG_TARGET", &XOptions::wg_target, 1, 1 << 20},
+    {"wgh_f32_target", "RCN_HIPX_WGH_F32_TARGET", &XOptions::wgh_f32_target, 1, 1 << 20},
+    {"wgh_target", "RCN_HIPX_WGH_TARGET", &XOptions::wgh_target, 1, 1 << 20},
+    {"wgb_policy", "RCN_HIPX_WGB_POLICY", &XOptions::wgb_policy, 0, 1},
+    {"wgf_policy", "RCN_HIPX_WGF_POLICY", &XOptions::wgf_policy, 0, 1},
+    {"halo_f32_slots", "RCN_HIPX_HALO_F32_SLOTS", &XOptions::halo_f32_slots, 0, 1 << 20},
+};
+void seed_options(XOptions& o) {
+    for (const XOptDesc& d : kXOptTable) {
+        const char* e = std::getenv(d.env);
+        if (!e || !*e) continue;
+        const long long v = std::atoll(e);
+        if (v >= d.lo && v <= d.hi) o.*(d.field) = (int)v;
+    }
+}
+}  // namespace
+
 struct rcn_hipx_net {
+    XOptions opt;
     int device = 0, in_h = 0, in_w = 0, in_c = 0, max_batch = 0, classes = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     // The backward pass can run a layer's weight gradient on a second stream beside the input-gradient chain: the two only share dZ,
@@ -120,13 +168,14 @@ int grid1d(long long total, int block) { long long g = (total + block - 1) / blo
 // (slab `skbuf`) that k_splitk_epilogue sums in order.
 // epi 4 (bias + ReLU + the following 2x2 max-pool, written to Y = pooled map and pool_idx) exists only in the LDS-tiled bf16 kernel:
 // callers ask conv_pool_fusable() first
-static bool halo_enabled() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO"); return e ? std::atoi(e) : 1; }(); return v != 0; }
+static bool halo_enabled(const rcn_hipx_net* n) { return n->opt.halo != 0; }
 // RCN_HIPX_HALO_F32 only seeds a new net's tiling mode (rcn_hipx_create); rcn_hipx_set_tiling changes it per net
 static int halo_f32_default() { const char* e = std::getenv("RCN_HIPX_HALO_F32"); const int v = e ? std::atoi(e) : 1; return v < 0 || v > 2 ? 1 : v; }
 
 // workgroups of `kernel` (256 threads, static LDS only) the device holds at once: the grid of a kernel whose workgroups loop over
 // work items.  Asked from the runtime once per kernel.
 long long resident_slots(rcn_hipx_net* n, const void* kernel) {
+    if (n->opt.halo_f32_slots > 0) return n->opt.halo_f32_slots;
     static std::mutex mu;
     static std::map<std::pair<int, const void*>, long long> cache;
     const std::lock_guard<std::mutex> lock(mu);
@@ -136,8 +185,7 @@ long long resident_slots(rcn_hipx_net* n, const void* kernel) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, n->device) != hipSuccess || cus < 1) cus = 256;
-    static const int forced = [] { const char* e = std::getenv("RCN_HIPX_HALO_F32_SLOTS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
-    const long long v = forced ? forced : (long long)per_cu * cus;
+    const long long v = (long long)per_cu * cus;
     cache.emplace(key, v);
     return v;
 }
@@ -179,7 +227,7 @@ int conv3_f32_z(const rcn_hipx_net* n, const ConvShape& s) {
 bool conv_pool_fusable(const rcn_hipx_net* n, const ConvShape& s) {
     if (s.H % 2 || s.W % 2) return false;
     if (conv1_f32_shape(n, s)) return true;                            // the first layer's kernels serve both precisions
-    if (n->precision == RCN_HIPX_BF16) return halo_enabled() && (s.Cin == 32 || s.Cin % 64 == 0);
+    if (n->precision == RCN_HIPX_BF16) return halo_enabled(n) && (s.Cin == 32 || s.Cin % 64 == 0);
     return conv_halo_f32_shape(n, s);
 }
 
@@ -187,7 +235,7 @@ bool conv_pool_fusable(const rcn_hipx_net* n, const ConvShape& s) {
 bool conv_halo_runs(const rcn_hipx_net* n, const ConvShape& s) {
     const long long M = (long long)s.N * s.H * s.W;
     if (n->precision != RCN_HIPX_BF16) return conv_halo_f32_shape(n, s) && conv3_f32_z(n, s) == 1;
-    if (!halo_enabled() || !(s.Cin == 32 || s.Cin % 64 == 0) || s.Cout % 32) return false;
+    if (!halo_enabled(n) || !(s.Cin == 32 || s.Cin % 64 == 0) || s.Cout % 32) return false;
     const int bn = s.Cout % 128 == 0 ? 128 : s.Cout % 64 == 0 ? 64 : 32;
     return splitk_z(M, s.Cout, bn, 9 * s.Cin / 32) == 1;
 }
@@ -222,12 +270,12 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
         }
         // thin 3x3 layers: the LDS-tiled kernel (one halo per 8x16 output block serves all nine taps)
         if (epi == 4 && !(ks == 3 && conv_pool_fusable(n, s))) return fail(n, -3, "internal: fused conv+pool epilogue requested for a layer the LDS-tiled kernel does not cover");
-        if (halo_enabled() && ks == 3 && !smallc && Z == 1 && (s.Cin == 32 || s.Cin % 64 == 0)) {
+        if (halo_enabled(n) && ks == 3 && !smallc && Z == 1 && (s.Cin == 32 || s.Cin % 64 == 0)) {
             const int hbn = (s.Cout % 64 == 0) ? 64 : 32;
             const int tw = (s.W + kHaloTW - 1) / kHaloTW, th = (s.H + kHaloTH - 1) / kHaloTH;
             const dim3 hgrid((unsigned)(tw * th * s.N), (unsigned)(s.Cout / hbn));
             const PooledGrad pg = pin ? *pin : PooledGrad{nullptr, nullptr, nullptr};
-            static const int pipe = [] { const char* e = std::getenv("RCN_HIPX_BF16_PIPE"); return e ? std::atoi(e) : 1; }();
+            const int pipe = n->opt.bf16_pipe;
             if (pipe && (long long)(s.N + 1) * s.H * s.W * (s.Cin > s.Cout ? s.Cin : s.Cout) < 0x7fffffffLL) {
                 // the pipelined form (convnet_halo_bf16.hpp): work items (pixel block, column block) on a resident grid, operands loaded a
                 // phase ahead; same LDS images, rounding and MFMA order as k_conv3x3_halo_bf16 below
@@ -242,7 +290,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #define HB1_EPI(BN_) do { if (pin) { if (kepi == 3) HB1_LAUNCH(BN_, 3, true); else if (kepi == 0) HB1_LAUNCH(BN_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
                           else if (kepi == 0) HB1_LAUNCH(BN_, 0, false); else if (kepi == 1) HB1_LAUNCH(BN_, 1, false); else if (kepi == 2) HB1_LAUNCH(BN_, 2, false); \
                           else if (kepi == 3) HB1_LAUNCH(BN_, 3, false); else HB1_LAUNCH(BN_, 4, false); } while (0)
-                static const int onecb = [] { const char* e = std::getenv("RCN_HIPX_BF16_1CB"); return e ? std::atoi(e) : 1; }();
+                const int onecb = n->opt.bf16_1cb;
                 if (items <= 0x7fffffffLL && dry_note(n, "  %s %dx%dx%d->%d epi %d%s: %s, %lld items", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, kepi, pin ? " pooled-in" : "",
                                                       (s.Cin == 32 && onecb && hbn == 32) ? "k_conv3x3_halo_bf16_1cb<32>" : "k_conv3x3_halo_bf16p", items)) return 0;
                 if (items <= 0x7fffffffLL) {
@@ -343,28 +391,28 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     return 0;
 }
 
-static int xcd_remap() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_XCD_REMAP"); return e ? std::atoi(e) : 0; }(); return v; }
+static int xcd_remap(const rcn_hipx_net* n) { return n->opt.xcd_remap; }
 // Pixels per weight-gradient chunk.  Every chunk costs one (K+1) x Cout partial tile written to the slab and read back by
 // k_reduce_all, and a chunk is worked on by `tiles` workgroups (k-blocks x n-tiles), so the chunk size aims at a
 // total number of workgroups -- wide layers need few chunks -- with 1024 pixels as the floor (measured best on the small
 // CIFAR / MNIST nets, where parallelism is what matters).
-static int pix_per_chunk(long long M, long long tiles) {
-    static const int v = [] { const char* e = std::getenv("RCN_HIPX_PIX_PER_CHUNK"); const int x = e ? std::atoi(e) : 0; return x >= 128 ? x / 128 * 128 : 0; }();
+static int pix_per_chunk(const rcn_hipx_net* n, long long M, long long tiles) {
+    const int v = n->opt.pix_per_chunk >= 128 ? n->opt.pix_per_chunk / 128 * 128 : 0;
     if (v) return v;
-    static const long long target = [] { const char* e = std::getenv("RCN_HIPX_WG_TARGET"); const long long x = e ? std::atoll(e) : 0; return x > 0 ? x : 4096; }();
+    const long long target = n->opt.wg_target;
     long long pix = (M * tiles / target + 127) / 128 * 128;
     if (pix < 1024) pix = 1024;
     if (pix > 32768) pix = 32768;
     return (int)pix;
 }
-#define kPixPerChunk (pix_per_chunk(M, (long long)(smallc ? 1 : K / 32) * (s.Cout / bn)))
+#define kPixPerChunk (pix_per_chunk(n, M, (long long)(smallc ? 1 : K / 32) * (s.Cout / bn)))
 
-static bool wgrad_halo_on() { static const int v = [] { const char* e = std::getenv("RCN_HIPX_HALO_WGRAD"); return e ? std::atoi(e) : 1; }(); return v != 0; }
+static bool wgrad_halo_on(const rcn_hipx_net* n) { return n->opt.halo_wgrad != 0; }
 bool wgrad_halo_f32_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) { return ks == 3 && ((ks * ks * s.Cin > 32 && conv_halo_f32_shape(n, s)) || conv1_f32_shape(n, s)); }
 bool wgrad_halo_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) {
-    if (ks == 3 && ks * ks * s.Cin <= 32 && conv1_f32_shape(n, s)) return wgrad_halo_on();      // first layer: fp32 kernels in either precision
-    if (n->precision != RCN_HIPX_BF16) return wgrad_halo_on() && wgrad_halo_f32_runs(n, s, ks);
-    return n->precision == RCN_HIPX_BF16 && wgrad_halo_on() && ks == 3 && ks * ks * s.Cin > 32 && (s.Cin == 32 || s.Cin % 64 == 0) && s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2;
+    if (ks == 3 && ks * ks * s.Cin <= 32 && conv1_f32_shape(n, s)) return wgrad_halo_on(n);      // first layer: fp32 kernels in either precision
+    if (n->precision != RCN_HIPX_BF16) return wgrad_halo_on(n) && wgrad_halo_f32_runs(n, s, ks);
+    return n->precision == RCN_HIPX_BF16 && wgrad_halo_on(n) && ks == 3 && ks * ks * s.Cin > 32 && (s.Cin == 32 || s.Cin % 64 == 0) && s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2;
 }
 
 int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, int ks, int* chunks_out, const PooledGrad* pdz = nullptr) {
@@ -405,7 +453,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         const int tw = halo_plan(n, s).tw, nimg = 16 / tw;
         const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
         const long long blocks = (long long)tiles_w * tiles_h * ((s.N + nimg - 1) / nimg);
-        static const int target = [] { const char* e = std::getenv("RCN_HIPX_WGH_F32_TARGET"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 512; }();
+        const int target = n->opt.wgh_f32_target;
         const long long combos = (long long)(s.Cin / 32) * (s.Cout / 32);
         long long want = (target + combos - 1) / combos;
         if (want > blocks) want = blocks;
@@ -434,7 +482,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         // tiles per chunk and need few chunks.
         // (256 = one per CU: the 576-thread workgroup with its 64+ accumulator registers per wave is alone on its CU anyway, and every
         // chunk fewer is a partial [W | b] less to write and reduce: synth-224 bf16 5.20 ms at 512, 5.05 at 256, 5.49 at 384 -- 1.5 per CU)
-        static const int target = [] { const char* e = std::getenv("RCN_HIPX_WGH_TARGET"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 256; }();
+        const int target = n->opt.wgh_target;
         const long long tiles = (long long)(s.Cin / hb) * (s.Cout / hbn);
         int bpc = (int)((blocks * tiles + target - 1) / target);
         if (bpc < 8) bpc = blocks < 8 ? (int)blocks : 8;
@@ -459,14 +507,14 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         // A wave owns one 32-row k-block x bn columns over the chunk's pixels, so a dense layer behind a pooled map is FEW waves (MNIST shape
         // 3136 -> 128 at B = 4096: 98 x 2 x 4 chunks = 784 on the chip's 1024 SIMDs, 62 us for 7 us of traffic).  Below two waves per SIMD
         // take 32-wide column blocks (no more slab, X re-read from L2), below one per SIMD also shorter chunks (down to 256 pixels).
-        static const int policy = [] { const char* e = std::getenv("RCN_HIPX_WGB_POLICY"); return e ? std::atoi(e) : 1; }();
+        const int policy = n->opt.wgb_policy;
         int bn = bn0, ppc = kPixPerChunk, chunks = chunks0;
         if (policy) {
             if ((long long)nkb * (s.Cout / bn) * chunks < 2048) bn = 32;
             while ((long long)nkb * (s.Cout / bn) * chunks < 1024 && ppc > 256) { ppc /= 2; chunks = (int)((M + ppc - 1) / ppc); }
             XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)chunks * (K + 1) * s.Cout * sizeof(float)));
         }
-        const WgradGrid gdb{nkb / nk, s.Cout / bn, chunks, xcd_remap()};
+        const WgradGrid gdb{nkb / nk, s.Cout / bn, chunks, xcd_remap(n)};
         const dim3 gridb(gdb.launch_blocks());
 #define WGB_CASE(KS_, BN_, NK_) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, ppc, gdb)
 #define WGB_NK(KS_, BN_) do { if (nk == 4) WGB_CASE(KS_, BN_, 4); else if (nk == 3) WGB_CASE(KS_, BN_, 3); else if (nk == 2) WGB_CASE(KS_, BN_, 2); else WGB_CASE(KS_, BN_, 1); } while (0)
@@ -482,9 +530,9 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     }
     // (as in the bf16 branch above: below two waves per SIMD the column blocks are 32 wide -- CIFAR net's 2048 -> 256 at B = 512: 256 -> 512
     // workgroups, step 0.419 -> 0.417 ms; MNIST shape B = 256: 0.165 -> 0.1625 ms)
-    static const int f32_policy = [] { const char* e = std::getenv("RCN_HIPX_WGF_POLICY"); return e ? std::atoi(e) : 1; }();
+    const int f32_policy = n->opt.wgf_policy;
     const int bnf = (f32_policy && !smallc && 4LL * (K / 32) * (s.Cout / bn0) * chunks < 2048) ? 32 : bn0;
-    const WgradGrid gd{smallc ? 1 : K / 32, s.Cout / bnf, chunks, xcd_remap()};
+    const WgradGrid gd{smallc ? 1 : K / 32, s.Cout / bnf, chunks, xcd_remap(n)};
     const dim3 grid(gd.launch_blocks());
 #define WG_CASE(KS_, SM_, BN_) hipLaunchKernelGGL((k_conv_wgrad<KS_, SM_, BN_>), grid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, kPixPerChunk, gd)
 #define WG_BN(KS_, SM_) do { if (bnf == 64) WG_CASE(KS_, SM_, 64); else WG_CASE(KS_, SM_, 32); } while (0)
@@ -656,7 +704,7 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         if (l.kind == RCN_HIPX_MAXPOOL2) {
             // When the LDS-tiled kernels run both consumers of the convolution's dZ (its weight gradient, and its input gradient if
             // it has one), they rebuild dZ from (dP, P, arg-max) at pooled resolution while staging: no k_pool_bwd, no full-size dZ.
-            static const int fuse_on = [] { const char* e = std::getenv("RCN_HIPX_FUSE_POOL_BWD"); return e ? std::atoi(e) : 1; }();
+            const int fuse_on = n->opt.fuse_pool_bwd;
             const Layer& cl = n->L[i - 1];
             const ConvShape cs{B, cl.H, cl.W, cl.Cin, cl.CoutP};
             if (fuse_on && wgrad_halo_runs(n, cs, 3) && (i - 1 == 0 || conv_halo_runs(n, ConvShape{B, cl.H, cl.W, cl.CoutP, cl.Cin}))) {
@@ -738,7 +786,7 @@ int loss_and_dlogits(rcn_hipx_net* n, const int32_t* labels, int B, float* loss_
 // Does the classifier head run as one launch (k_head_f32, fp32 arithmetic in either precision mode)?  Logits layer of at most 32 classes
 // on a ReLU dense layer of at most 256 units.
 bool head_fusable(const rcn_hipx_net* n) {
-    static const int on = [] { const char* e = std::getenv("RCN_HIPX_HEAD"); return e ? std::atoi(e) : 1; }();
+    const int on = n->opt.head;
     // (fp32: not in GEMM tiling mode, which keeps every layer on the implicit-GEMM kernels; bf16: by shape alone -- what the mode rounds
     // must not depend on a tiling switch)
     if (!on || (n->precision == RCN_HIPX_FP32 && n->tiling == RCN_HIPX_TILING_GEMM) || n->L.size() < 2) return false;
@@ -864,6 +912,7 @@ int rcn_hipx_create(int device, int in_h, int in_w, int in_c, const rcn_hipx_lay
     *out = n;
     n->device = device; n->in_h = in_h; n->in_w = in_w; n->in_c = in_c; n->max_batch = max_batch;
     n->tiling = halo_f32_default();
+    seed_options(n->opt);                             // the environment seeds the defaults, once, here
     RTRY(describe_layers(n, in_h, in_w, in_c, layers, n_layers));
     Dev g(device);
     if (stream) { n->stream = (hipStream_t)stream; } else { XTRY(n, hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking)); n->own_stream = true; }
@@ -927,6 +976,28 @@ int rcn_hipx_set_overlap(rcn_hipx_net* n, int on) {
     if (on != n->overlap) { XTRY(n, hipStreamSynchronize(n->stream)); drop_graphs(n); }
     n->overlap = on;
     return 0;
+}
+
+int rcn_hipx_set_option(rcn_hipx_net* n, const char* name, int value) {
+    if (!n || !name) return -1;
+    for (const XOptDesc& d : kXOptTable)
+        if (std::strcmp(d.name, name) == 0) {
+            if (value < d.lo || value > d.hi) return fail(n, -1, std::string("set_option: ") + name + " must be in " + std::to_string(d.lo) + ".." + std::to_string(d.hi));
+            if (n->opt.*(d.field) == value) return 0;
+            Dev g(n->device);
+            XTRY(n, hipStreamSynchronize(n->stream));
+            drop_graphs(n);                             // captured graphs bake in the kernels chosen
+            n->opt.*(d.field) = value;
+            return 0;
+        }
+    return fail(n, -1, std::string("set_option: unknown option '") + name + "'");
+}
+
+int rcn_hipx_get_option(const rcn_hipx_net* n, const char* name, int* value) {
+    if (!n || !name || !value) return -1;
+    for (const XOptDesc& d : kXOptTable)
+        if (std::strcmp(d.name, name) == 0) { *value = n->opt.*(d.field); return 0; }
+    return -1;
 }
 
 int rcn_hipx_set_params(rcn_hipx_net* n, const float* flat) {
@@ -1049,11 +1120,33 @@ int rcn_hipx_plan(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, in
     rcn_hipx_net net;                                   // host-only: no device, no stream, no buffers
     net.in_h = in_h; net.in_w = in_w; net.in_c = in_c; net.max_batch = batch;
     net.precision = precision; net.tiling = tiling; net.overlap = 0; net.dry = true;
+    seed_options(net.opt);                              // as a net created now would be (rcn_hipx_plan_net: an existing net's own options)
     int st = describe_layers(&net, in_h, in_w, in_c, layers, n_layers);
     if (st == 0) {
         net.plan = "forward + loss + backward of one batch of " + std::to_string(batch) + " (" + (precision == RCN_HIPX_BF16 ? "bf16" : "fp32") + " operands), launch by launch:\n";
         st = step_core(&net, nullptr, nullptr, batch, 0.f, nullptr, true, nullptr);
     }
+    const std::string& text = st == 0 ? net.plan : net.err;
+    std::snprintf(out, (size_t)cap, "%s", text.c_str());
+    return st;
+}
+
+// the same walk for an EXISTING net, with that net's own precision, tiling and options: the plan and the step agree by construction
+int rcn_hipx_plan_net(const rcn_hipx_net* n, int batch, char* out, int cap) {
+    if (!n || batch < 1 || batch > n->max_batch || !out || cap < 1) return -1;
+    rcn_hipx_net net;
+    net.in_h = n->in_h; net.in_w = n->in_w; net.in_c = n->in_c; net.max_batch = batch; net.classes = n->classes;
+    net.precision = n->precision; net.tiling = n->tiling; net.overlap = 0; net.dry = true;
+    net.opt = n->opt;
+    for (const Layer& l : n->L) {                       // the layer descriptions without their buffers
+        Layer c;
+        c.kind = l.kind; c.H = l.H; c.W = l.W; c.Cin = l.Cin; c.oH = l.oH; c.oW = l.oW; c.Cout = l.Cout; c.CoutP = l.CoutP; c.K = l.K;
+        c.w_off = l.w_off; c.b_off = l.b_off; c.lw_off = l.lw_off; c.lb_off = l.lb_off; c.pool_follows = l.pool_follows;
+        net.L.push_back(c);
+    }
+    net.n_pad = n->n_pad; net.n_log = n->n_log;
+    net.plan = "forward + loss + backward of one batch of " + std::to_string(batch) + " (" + (net.precision == RCN_HIPX_BF16 ? "bf16" : "fp32") + " operands), launch by launch:\n";
+    const int st = step_core(&net, nullptr, nullptr, batch, 0.f, nullptr, true, nullptr);
     const std::string& text = st == 0 ? net.plan : net.err;
     std::snprintf(out, (size_t)cap, "%s", text.c_str());
     return st;

@@ -346,3 +346,46 @@ def test_resident_data_parallel_form_at_the_bench_shard_between_processes(amd, o
         for o in outs:
             ph = o["phase"]
             assert ph[7] == nb and np.all(np.isfinite(ph)) and ph[0] > 0 and ph[2] > 0 and ph[4] > 0 and ph[6] > ph[1] * 0.5, ph
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Track X: kernel-selection knobs are per net
+
+def test_trackx_options_are_per_net_and_the_plan_of_a_net_is_its_own(monkeypatch):
+    """RCN_HIPX_BF16_1CB / _PIPE / RCN_HIPX_HALO were read into function-local statics at first use: frozen process-wide, and rcn_hipx_plan
+    reported whatever the first call had latched.  Now fields of the net (rcn_hipx_set_option), seeded from the environment at creation:
+    two nets of ONE process run different kernels for the same layer, each net's plan (rcn_hipx_plan_net) names the kernels that net
+    runs, and the two forms of the same arithmetic agree."""
+    import torch
+    from mercer_research_amd.convnet import ConvNet, ConvNetError
+    in_shape, layers, B = (16, 16, 3), (("conv", 32), ("conv", 32), ("pool",), ("dense_relu", 64), ("dense", 10)), 32
+    a = ConvNet(in_shape, layers, B)
+    monkeypatch.setenv("RCN_HIPX_BF16_1CB", "0")                        # seeds only nets created from here on
+    b = ConvNet(in_shape, layers, B)
+    monkeypatch.delenv("RCN_HIPX_BF16_1CB")
+    assert a.get_option("bf16_1cb") == 1 and b.get_option("bf16_1cb") == 0
+    with pytest.raises(ConvNetError):
+        a.set_option("no_such_option", 1)
+    with pytest.raises(ConvNetError):
+        a.set_option("halo", 2)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B,) + in_shape).astype(np.float32)
+    y = rng.integers(0, 10, B).astype(np.int32)
+    outs = []
+    for net in (a, b):
+        net.init_params(7)
+        net.set_precision("bf16")
+        plan = net.plan_of_this_net(B)
+        outs.append(plan)
+        xd, yd = net.to_device(x), net.to_device(y)
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        for _ in range(3):
+            net.train_step(xd, yd, 0.01, loss)
+        net.synchronize()
+        outs.append((float(loss.item()), net.get_params()))
+    assert "k_conv3x3_halo_bf16_1cb" in outs[0] and "k_conv3x3_halo_bf16_1cb" not in outs[2] and "k_conv3x3_halo_bf16p" in outs[2], (outs[0], outs[2])
+    assert abs(outs[1][0] - outs[3][0]) <= 1e-3 * abs(outs[1][0])
+    assert np.allclose(outs[1][1], outs[3][1], rtol=2e-2, atol=2e-3)
+    b.set_option("bf16_1cb", 1)                                         # settable afterwards, per net; the plan follows
+    assert "k_conv3x3_halo_bf16_1cb" in b.plan_of_this_net(B)
+    a.close(); b.close()

@@ -13,15 +13,16 @@ _lib.LIB_PATH = out
 import torch
 from mercer_research_amd.device import DeviceRCN
 from mercer_research_amd.synth import synthetic_params
-d = DeviceRCN()
+F64 = os.environ.get("STAMPS_DTYPE", "f32") == "f64"          # the reference's own type: the kernel's f64 instantiations (batches up to 128)
+d = DeviceRCN(dtype=1 if F64 else 0)
 lib = d.lib
 lib.rcn_hip_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
 ws, bs = synthetic_params([784, 30, 10], seed=42)
 d.set_params(ws, bs)
-N, B = 16384, 256
+N, B = 16384, int(os.environ.get("STAMPS_B", "256"))
 with torch.cuda.stream(d.stream):
-    X = torch.rand(N, 784, device=d.device)
-    Y = torch.zeros(N, 10, device=d.device); Y[:, 3] = 1
+    X = torch.rand(N, 784, device=d.device, dtype=d.tdtype)
+    Y = torch.zeros(N, 10, device=d.device, dtype=d.tdtype); Y[:, 3] = 1
     perm = torch.randperm(N, device=d.device).int()
 d.set_dense_path(5)
 d.synchronize()
@@ -32,7 +33,7 @@ if DP:
 for it in range(3):
     (d.dp_train_epoch if DP else d.train_epoch)(X, Y, perm, B, 64, 3.0, None)
 d.synchronize()
-print("data-parallel instantiation (world 1)" if DP else "single-GPU instantiation")
+print(("data-parallel instantiation (world 1)" if DP else "single-GPU instantiation") + f", {'f64' if F64 else 'f32'}, B = {B}")
 st = np.zeros((2, 512, 16), dtype=np.uint64)
 lib.rcn_hip_debug_read_stamps(d.ctx, st.ctypes.data_as(C.c_void_p))
 r = st[0].astype(np.int64)[:32, :16]
