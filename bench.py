@@ -673,13 +673,13 @@ def main():
         us = us_second if resident else us_pair * (us_first, us_second)[k] / (us_first + us_second)
         flops_step = 2 * B * ((F * H + H * C) * 2 + H * C)
         traffic, traffic_src, traffic_stale = None, None, None
-        pmc_name = next((f for f in ("r3_pmc_summary.json", "r2_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+        pmc_name = next((f for f in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
         pmc = os.path.join(ROOT, "profiles", pmc_name or "none")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get(names[k], {}).get("hbm_bytes_per_launch")
-                traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/prof_r3.sh)"
+                traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/prof_r4.sh)"
                 traffic_stale = pj.get("csrc_sha16") != csrc_sha16()     # True: kernels changed since the counters were collected
             except Exception:
                 traffic = None
@@ -1065,7 +1065,7 @@ def trackx_leg(torch, dev):
     # the conv-GEMM MFMA-busy figures are PMC measurements of a separate profiled run (tools/prof_trackx.sh), relayed here with the
     # fingerprint of the kernel sources they were taken on -- like roofline.traffic, the line says when the sources have changed since
     from tools.mfma_pmc_summary import trackx_sha16
-    for name in ("r3_trackx_mfma_pmc.json", "r2_trackx_mfma_pmc.json"):
+    for name in ("r4_trackx_mfma_pmc.json", "r3_trackx_mfma_pmc.json", "r2_trackx_mfma_pmc.json"):
         pm = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pm):
             continue
