@@ -1017,12 +1017,9 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     } else if (is_t && tvalid) {
         params[tp] = tcur;
     }
-    // (cross-check for the host: this worker's write-back of this launch is complete)
-    __syncthreads();
-    if (tid == 0) {
-        xcd_drain();
-        __hip_atomic_store(bufs.cdone + w, launch_id & 0x3fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // (cross-check for the host, read after the stream has drained: this worker went through its write-back of this launch -- no drain, no
+    // barrier here: a kernel does not end before its stores have, and the host looks only behind a synchronise)
+    if (tid == 0) __hip_atomic_store(bufs.cdone + w, launch_id & 0x3fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // placement probe: the same grid and LDS footprint as k_xcd_epoch; block b reports (XCC_ID, CU slot) -- the host selects the
