@@ -38,6 +38,8 @@ def main():
                     help="GEMM operand precision of forward / dgrad: fp32 MFMA, or bf16 MFMA with fp32 accumulate / storage / update")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (gradients -> all-reduce -> apply) even at one GPU: a group of one over RCCL")
     ap.add_argument("--dp-graph", type=int, default=1, help="data-parallel step: 1 = replay it as a captured hipGraph (the all-reduce inside), 0 = launch it eagerly")
+    ap.add_argument("--dp-buckets", type=int, default=1 << 20, help="data-parallel step: gradient buckets of at least this many bytes, each all-reduced on a second stream "
+                                                                     "while the backward pass of the layers below runs (0: ONE all-reduce of the whole gradient after the backward pass)")
     args = ap.parse_args()
     from mercer_research_amd.launch import spawn_ranks, under_launcher
     if args.gpus > 1 and not under_launcher():
@@ -77,12 +79,30 @@ def main():
         # one process per GPU: shard gradients of the mean loss -> ONE all-reduce (RCCL over xGMI) of the flat padded
         # gradient buffer -> identical update on every rank with lr / world (mean over the global batch)
         grad = torch.empty(net.n_padded, dtype=torch.float32, device=net.device)
+        comm = torch.cuda.Stream(device=net.device)            # the buckets' all-reduces: beside the backward pass of the layers below them
+        n_buckets = [0]
+
+        def dp_body(x, y):
+            """gradients -> all-reduce -> apply, enqueued on net.stream (+ the buckets' collectives on `comm`); captured or eager alike"""
+            if args.dp_buckets <= 0:
+                net.gradients(x, y, grad, loss)
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+            else:
+                # SURVEY section 5: bucket by layer, overlap with the weight gradients of earlier layers.  A bucket's slice of the flat
+                # gradient is final once its launches have run (rcn_hipx_gradients_bucket_dev): `comm` waits for exactly that point of
+                # net.stream and reduces the slice while net.stream goes on with the layers below; net.stream joins `comm` before the update.
+                def on_bucket(piece, k, n):
+                    n_buckets[0] = n
+                    comm.wait_stream(net.stream)
+                    with torch.cuda.stream(comm):
+                        dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                net.gradients_bucketed(x, y, grad, loss, args.dp_buckets, on_bucket)
+                net.stream.wait_stream(comm)
+            net.apply(grad, lr / world)
 
         def eager_step(i):
             with torch.cuda.stream(net.stream):
-                net.gradients(xs[i % nbuf], ys[i % nbuf], grad, loss)
-                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
-                net.apply(grad, lr / world)
+                dp_body(xs[i % nbuf], ys[i % nbuf])
 
         def step(i):
             g = dp_graphs.get(i % nbuf)
@@ -103,9 +123,7 @@ def main():
                 for b in range(nbuf):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=net.stream):
-                        net.gradients(xs[b], ys[b], grad, loss)
-                        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
-                        net.apply(grad, lr / world)
+                        dp_body(xs[b], ys[b])
                     dp_graphs[b] = g
                 ok = torch.ones(1, device=net.device)
             except Exception as ex:                        # capture of the collective not supported here: the eager step stands
@@ -155,7 +173,9 @@ def main():
                           "frac_of_mfma_peak": round(tf / peak, 4),
                           "hbm_floor_ms": round(floor_ms, 4) if floor_ms else None, "frac_of_hbm_floor": round(floor_ms / (el / args.steps * 1e3), 4) if floor_ms else None,
                           "dtype": "f32" if not bf16 else "bf16 MFMA operands (fwd, dgrad, wgrad), f32 accumulate/update", "data": "synthetic", "final_loss": round(loss.item(), 4),
-                          "data_parallel_step": dp_mode}) + "\n"
+                          "data_parallel_step": dp_mode,
+                          "data_parallel_allreduce": (None if not dp else "one all-reduce of the flat gradient after the backward pass" if args.dp_buckets <= 0 else
+                                                      f"{n_buckets[0]} buckets of >= {args.dp_buckets} bytes, each all-reduced on a second stream under the backward pass of the layers below")}) + "\n"
         if real_stdout is not None:
             os.write(real_stdout, out_line.encode())
         else:

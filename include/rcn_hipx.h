@@ -88,6 +88,21 @@ int  rcn_hipx_train_step_dev(rcn_hipx_net* net, const float* x_dev, const int32_
  * `padded`), and p <- p - scale * g from such a buffer. */
 int  rcn_hipx_gradients_dev(rcn_hipx_net* net, const float* x_dev, const int32_t* labels_dev, int B, float* grad_dev, float* loss_dev);
 int  rcn_hipx_apply_dev(rcn_hipx_net* net, const float* grad_dev, float scale);
+/* The same gradients in BUCKETS, so that a data-parallel step can all-reduce one bucket of layers while the backward pass of the layers
+ * below it still runs (6.7 MB of gradient for BASELINE configs[3]).  The layers with parameters, in the order the
+ * backward pass finishes them (last to first), are cut into buckets of at least min_bucket_bytes of gradient; the padded flat layout
+ * is in layer order, so a bucket is ONE contiguous slice of grad_dev.
+ *   _begin_dev:  zeroes grad_dev, runs forward + loss (+ the fused classifier head); *n_buckets = how many buckets follow.
+ *   _bucket_dev: k = 0 .. n_buckets - 1 in order: the backward pass through bucket k's layers and ONE reduction launch of their slabs;
+ *                grad_dev[*off, *off + *len) (floats) is final on the net's stream when the call's work is -- the caller records an
+ *                event there and starts the slice's all-reduce on another stream.
+ * Results are bit-identical to rcn_hipx_gradients_dev (same kernels, same sums; only the reduction launch is split). */
+int  rcn_hipx_gradients_begin_dev(rcn_hipx_net* net, const float* x_dev, const int32_t* labels_dev, int B, float* grad_dev, float* loss_dev,
+                                  int64_t min_bucket_bytes, int* n_buckets);
+int  rcn_hipx_gradients_bucket_dev(rcn_hipx_net* net, int k, int64_t* off, int64_t* len);
+/* rcn_hipx_plan's walk for that bucketed step: per bucket its launches and the slice that becomes final (no GPU needed). */
+int  rcn_hipx_plan_buckets(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int batch, int precision, int tiling,
+                           int64_t min_bucket_bytes, char* out, int cap);
 /* logical-layout copy of a padded gradient buffer (tests) */
 int  rcn_hipx_unpad_host(rcn_hipx_net* net, const float* padded_dev, float* logical_host);
 /* Which kernels a training step of this net WOULD launch, one line per launch, written to `out` (NUL-terminated, truncated at `cap`).

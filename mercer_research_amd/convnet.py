@@ -38,6 +38,9 @@ SIGNATURES = {
     "rcn_hipx_set_precision": (_i, [_vp, _i]),
     "rcn_hipx_set_tiling": (_i, [_vp, _i]),
     "rcn_hipx_set_overlap": (_i, [_vp, _i]),
+    "rcn_hipx_gradients_begin_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, C.c_int64, C.POINTER(C.c_int)]),
+    "rcn_hipx_gradients_bucket_dev": (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rcn_hipx_plan_buckets": (_i, [_i, _i, _i, C.POINTER(XLayer), _i, _i, _i, _i, C.c_int64, C.c_char_p, _i]),
     "rcn_hipx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "rcn_hipx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int)]),
     "rcn_hipx_plan_net": (_i, [_vp, _i, C.c_char_p, _i]),
@@ -65,14 +68,24 @@ class ConvNetError(RuntimeError):
     pass
 
 
-def plan(in_shape: Tuple[int, int, int], layers: Sequence[tuple], batch: int, precision: str = "fp32", tiling: str = "auto") -> str:
+DEFAULT_BUCKET_BYTES = 1 << 20      # gradient buckets of the data-parallel step: at least 1 MiB each (a ring all-reduce below that is latency)
+
+
+def plan(in_shape: Tuple[int, int, int], layers: Sequence[tuple], batch: int, precision: str = "fp32", tiling: str = "auto", buckets: Optional[int] = None) -> str:
     """Which kernels a training step of this net would launch, one line per launch (rcn_hipx_plan): the library's own dispatch code run
-    with its launches replaced by notes.  Needs no GPU."""
+    with its launches replaced by notes.  Needs no GPU.  buckets = N: the bucketed GRADIENT step of a data-parallel rank instead
+    (rcn_hipx_plan_buckets, buckets of at least N bytes): per bucket its launches and the slice of the flat gradient that becomes final."""
     lib = load()
     arr = (XLayer * len(layers))()
     for i, l in enumerate(layers):
         arr[i].kind, arr[i].out = KIND[l[0]], int(l[1]) if len(l) > 1 else 0
     buf = C.create_string_buffer(1 << 16)
+    if buckets is not None:
+        st = lib.rcn_hipx_plan_buckets(in_shape[0], in_shape[1], in_shape[2], arr, len(layers), batch, {"fp32": 0, "bf16": 1}[precision], {"gemm": 0, "auto": 1, "lds": 2}[tiling],
+                                       int(buckets), buf, len(buf))
+        if st != 0:
+            raise ConvNetError(f"rcn_hipx_plan_buckets: {st}: {buf.value.decode()}")
+        return buf.value.decode()
     st = lib.rcn_hipx_plan(in_shape[0], in_shape[1], in_shape[2], arr, len(layers), batch, {"fp32": 0, "bf16": 1}[precision], {"gemm": 0, "auto": 1, "lds": 2}[tiling], buf, len(buf))
     if st != 0:
         raise ConvNetError(f"rcn_hipx_plan: {st}: {buf.value.decode()}")
@@ -187,6 +200,20 @@ class ConvNet:
         grad = grad if grad is not None else self.torch.empty(self.n_padded, dtype=self.torch.float32, device=self.device)
         self._ck(self.lib.rcn_hipx_gradients_dev(self.net, C.c_void_p(x.data_ptr()), C.c_void_p(labels.data_ptr()), x.shape[0], C.c_void_p(grad.data_ptr()),
                                                  C.c_void_p(loss.data_ptr()) if loss is not None else None))
+        return grad
+
+    def gradients_bucketed(self, x, labels, grad, loss=None, min_bucket_bytes: int = DEFAULT_BUCKET_BYTES, on_bucket=None):
+        """The gradients of `gradients`, bucket by bucket (rcn_hipx_gradients_begin_dev / _bucket_dev): after every bucket's launches are
+        enqueued, on_bucket(slice_of_grad, k, n) is called -- a data-parallel step starts that slice's all-reduce there, on another stream,
+        behind an event of this net's stream.  Bit-identical to `gradients`."""
+        nb = C.c_int()
+        self._ck(self.lib.rcn_hipx_gradients_begin_dev(self.net, C.c_void_p(x.data_ptr()), C.c_void_p(labels.data_ptr()), x.shape[0], C.c_void_p(grad.data_ptr()),
+                                                       C.c_void_p(loss.data_ptr()) if loss is not None else None, int(min_bucket_bytes), C.byref(nb)))
+        off, ln = C.c_int64(), C.c_int64()
+        for k in range(nb.value):
+            self._ck(self.lib.rcn_hipx_gradients_bucket_dev(self.net, k, C.byref(off), C.byref(ln)))
+            if on_bucket is not None:
+                on_bucket(grad[off.value:off.value + ln.value], k, nb.value)
         return grad
 
     def apply(self, grad, scale: float):

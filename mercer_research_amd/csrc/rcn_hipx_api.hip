@@ -127,6 +127,18 @@ struct rcn_hipx_net {
     int precision = RCN_HIPX_FP32;          // GEMM operand precision of forward / dgrad (rcn_hipx_set_precision)
     int tiling = RCN_HIPX_TILING_AUTO;      // fp32 3x3 kernels: implicit GEMM only / by shape / LDS-tiled wherever they apply (rcn_hipx_set_tiling)
     std::map<Key, hipGraphExec_t> graphs;
+    // the backward pass as a resumable walk (rcn_hipx_gradients_begin_dev / _bucket_dev: a data-parallel step whose all-reduce of one bucket
+    // of layers overlaps the backward pass of the layers below it)
+    struct BwState {
+        std::vector<char> gated;            // layer's dout already holds dZ (ReLU gate applied by the producer)
+        std::vector<PooledGrad> pooled;     // layer's dZ exists only at pooled resolution
+        bool side_busy = false;
+        int next = -1;                      // the next layer the walk handles (it runs from the last layer down to 0)
+        const float* x = nullptr; int B = 0; float* grad = nullptr;
+        int taken = 0;                      // buckets handed out since rcn_hipx_gradients_begin_dev
+        std::vector<int> lo;                // bucket k ends with layer lo[k] (a layer with parameters; lo.back() == the first such layer)
+        std::vector<long long> off, len;    // its slice of the padded flat gradient
+    } bw;
     std::string err;
 };
 
@@ -687,17 +699,17 @@ int run_reduce_jobs(rcn_hipx_net* n, float lr, bool apply) {
     return 0;
 }
 
-// backward from dlogits (already in L.back().dout); apply: update parameters with lr, else write gradients to grad (padded layout)
-int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply, int first = -1, bool first_gated = false) {
-    std::vector<char> gated(n->L.size(), 0);       // layer's dout already holds dZ (ReLU gate applied by the producer)
-    if (first >= 0 && first_gated) gated[first] = 1;
-    std::vector<PooledGrad> pooled(n->L.size(), PooledGrad{nullptr, nullptr, nullptr});   // layer's dZ exists only at pooled resolution
+// backward from dlogits (already in L.back().dout); apply: update parameters with lr, else write gradients to grad (padded layout).
+// backward_layers handles the layers hi .. lo (downwards) and queues their slab reductions; the state that travels from layer to layer
+// lives in n->bw, so the walk can stop after a bucket of layers (rcn_hipx_gradients_bucket_dev) and go on later.
+int backward_layers(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply, int hi, int lo, bool allow_overlap) {
+    std::vector<char>& gated = n->bw.gated;
+    std::vector<PooledGrad>& pooled = n->bw.pooled;
     hipStream_t const main_s = n->stream;
     struct Restore { rcn_hipx_net* n; hipStream_t s; ~Restore() { n->stream = s; } } restore{n, main_s};   // launch_* enqueue on n->stream: it is switched below
-    const bool ov = n->overlap && n->side;
-    bool side_busy = false;
-    n->ev_next = 0;
-    for (int i = first >= 0 ? first : (int)n->L.size() - 1; i >= 0; --i) {
+    const bool ov = allow_overlap && n->overlap && n->side;
+    bool& side_busy = n->bw.side_busy;
+    for (int i = hi; i >= lo; --i) {
         Layer& l = n->L[i];
         const float* in = i == 0 ? x : (const float*)n->L[i - 1].out.p;
         float* din = i == 0 ? nullptr : n->dry ? reinterpret_cast<float*>(sizeof(float)) : (float*)n->L[i - 1].dout.p;     // (dry run: no buffers; non-null = "has an input gradient")
@@ -758,7 +770,21 @@ int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool
         RTRY(reduce_slab(n, (size_t)i, chunks, ks, s, lr, grad, apply));
         n->stream = main_s;
     }
-    if (side_busy) RTRY(stream_after(n, n->side, main_s));            // join: the step's next kernels (and an end of capture) find everything on the main stream
+    return 0;
+}
+
+void backward_reset(rcn_hipx_net* n, int first, bool first_gated) {
+    n->bw.gated.assign(n->L.size(), 0);
+    if (first >= 0 && first_gated) n->bw.gated[first] = 1;
+    n->bw.pooled.assign(n->L.size(), PooledGrad{nullptr, nullptr, nullptr});
+    n->bw.side_busy = false;
+    n->ev_next = 0;
+}
+
+int backward(rcn_hipx_net* n, const float* x, int B, float lr, float* grad, bool apply, int first = -1, bool first_gated = false) {
+    backward_reset(n, first, first_gated);
+    RTRY(backward_layers(n, x, B, lr, grad, apply, first >= 0 ? first : (int)n->L.size() - 1, 0, true));
+    if (n->bw.side_busy) RTRY(stream_after(n, n->side, n->stream));   // join: the step's next kernels (and an end of capture) find everything on the main stream
     return run_reduce_jobs(n, lr, apply);                             // every layer's slab in one launch; no weight was written before this point
 }
 
@@ -855,6 +881,76 @@ int step_core(rcn_hipx_net* n, const float* x, const int32_t* labels, int B, flo
 }
 
 void drop_graphs(rcn_hipx_net* n) { for (auto& kv : n->graphs) (void)hipGraphExecDestroy(kv.second); n->graphs.clear(); }
+
+// ---- gradient buckets: the data-parallel step with its all-reduce overlapped with the backward pass -------------------------------------
+// The layers with parameters, walked from the last to the first (the order the backward pass finishes them), are cut into buckets of at
+// least min_bytes of gradient; the padded flat layout is in layer order, so a bucket is ONE contiguous slice.  Returns the bucket count.
+int bucket_layout(rcn_hipx_net* n, long long min_bytes) {
+    auto& bw = n->bw;
+    bw.lo.clear(); bw.off.clear(); bw.len.clear();
+    long long acc = 0, end = n->n_pad;
+    int first_param = -1;
+    for (int i = 0; i < (int)n->L.size(); ++i)
+        if (n->L[i].kind != RCN_HIPX_MAXPOOL2) { first_param = i; break; }
+    for (int i = (int)n->L.size() - 1; i >= 0; --i) {
+        const Layer& l = n->L[i];
+        if (l.kind == RCN_HIPX_MAXPOOL2) continue;
+        acc = (end - l.w_off) * (long long)sizeof(float);
+        if (acc >= min_bytes || i == first_param) {
+            bw.lo.push_back(i); bw.off.push_back(l.w_off); bw.len.push_back(end - l.w_off);
+            end = l.w_off;
+        }
+    }
+    // (the layers left over at the bottom are less than a bucket: they join the one above them)
+    if (bw.lo.size() >= 2 && bw.len.back() * (long long)sizeof(float) < min_bytes) {
+        const size_t m = bw.lo.size() - 1;
+        bw.lo[m - 1] = bw.lo[m]; bw.off[m - 1] = bw.off[m]; bw.len[m - 1] += bw.len[m];
+        bw.lo.pop_back(); bw.off.pop_back(); bw.len.pop_back();
+    }
+    return (int)bw.lo.size();
+}
+
+// forward, loss (and, where the classifier head is the fused one, its share of the backward pass): everything in front of bucket 0
+int grad_begin(rcn_hipx_net* n, const float* x, const int32_t* labels, int B, float* grad, float* loss_dev, long long min_bytes) {
+    n->jobs.njobs = 0;
+    const int nb = bucket_layout(n, min_bytes);
+    n->bw.x = x; n->bw.B = B; n->bw.grad = grad; n->bw.taken = 0;
+    RTRY(prep_bf16_weights(n));
+    if (head_fusable(n)) {
+        const int last = (int)n->L.size() - 1;
+        RTRY(forward(n, x, B, (size_t)last));
+        int chunks = 0;
+        n->slab_sel = &n->L[last].slab;
+        RTRY(launch_head(n, labels, B, loss_dev, &chunks));
+        RTRY(reduce_slab(n, (size_t)last, chunks, 1, ConvShape{B, 1, 1, n->L[last].K, n->L[last].CoutP}, 0.f, grad, false));
+        backward_reset(n, last - 1, true);
+        n->bw.next = last - 1;
+    } else {
+        RTRY(forward(n, x, B, (size_t)-1));
+        RTRY(loss_and_dlogits(n, labels, B, loss_dev, true));
+        backward_reset(n, -1, false);
+        n->bw.next = (int)n->L.size() - 1;
+    }
+    return nb;
+}
+
+// the backward pass through bucket k's layers and the reduction of their slabs: grad[off, off + len) is final on the net's stream
+int grad_bucket(rcn_hipx_net* n, int k, long long* off, long long* len) {
+    auto& bw = n->bw;
+    if (k < 0 || k >= (int)bw.lo.size()) return fail(n, -1, "gradients_bucket: no such bucket (rcn_hipx_gradients_begin_dev returns their number)");
+    if (k != bw.taken) return fail(n, -6, "gradients_bucket: buckets are taken in order, 0 .. n - 1, after rcn_hipx_gradients_begin_dev");
+    const int lo = k + 1 == (int)bw.lo.size() ? 0 : bw.lo[k];            // (the last bucket also walks whatever lies below its first layer with parameters: nothing)
+    const int hi = bw.next;                                               // (hi < lo: the fused head has already handled this bucket's only layer)
+    (void)dry_note(n, " bucket %d: layers %d .. %d", k, hi, lo);
+    if (hi >= lo) RTRY(backward_layers(n, bw.x, bw.B, 0.f, bw.grad, false, hi, lo, false));
+    RTRY(run_reduce_jobs(n, 0.f, false));
+    bw.next = hi < lo - 1 ? hi : lo - 1;
+    bw.taken = k + 1;
+    if (off) *off = bw.off[k];
+    if (len) *len = bw.len[k];
+    (void)dry_note(n, " bucket %d done: grad[%lld, +%lld) = %.2f MB is final -- its all-reduce may start while the layers below run", k, bw.off[k], bw.len[k], bw.len[k] * 4.0 / 1e6);
+    return 0;
+}
 
 }  // namespace
 
@@ -1089,6 +1185,27 @@ int rcn_hipx_gradients_dev(rcn_hipx_net* n, const float* x, const int32_t* label
     return step_core(n, x, labels, B, 0.f, grad, false, loss_dev);
 }
 
+int rcn_hipx_gradients_begin_dev(rcn_hipx_net* n, const float* x, const int32_t* labels, int B, float* grad, float* loss_dev, int64_t min_bucket_bytes, int* n_buckets) {
+    if (!n || !x || !labels || !grad || !n_buckets || min_bucket_bytes < 0) return -1;
+    RTRY(ensure_batch(n, B));
+    Dev g(n->device);
+    XTRY(n, hipMemsetAsync(grad, 0, (size_t)n->n_pad * sizeof(float), n->stream));
+    const int nb = grad_begin(n, x, labels, B, grad, loss_dev, (long long)min_bucket_bytes);
+    if (nb < 0) return nb;
+    *n_buckets = nb;
+    return 0;
+}
+
+int rcn_hipx_gradients_bucket_dev(rcn_hipx_net* n, int k, int64_t* off, int64_t* len) {
+    if (!n) return -1;
+    Dev g(n->device);
+    long long o = 0, l = 0;
+    RTRY(grad_bucket(n, k, &o, &l));
+    if (off) *off = o;
+    if (len) *len = l;
+    return 0;
+}
+
 __global__ void k_axpy(float* __restrict__ p, const float* __restrict__ g, float scale, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = p[i] - scale * g[i];
 }
@@ -1125,6 +1242,29 @@ int rcn_hipx_plan(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, in
     if (st == 0) {
         net.plan = "forward + loss + backward of one batch of " + std::to_string(batch) + " (" + (precision == RCN_HIPX_BF16 ? "bf16" : "fp32") + " operands), launch by launch:\n";
         st = step_core(&net, nullptr, nullptr, batch, 0.f, nullptr, true, nullptr);
+    }
+    const std::string& text = st == 0 ? net.plan : net.err;
+    std::snprintf(out, (size_t)cap, "%s", text.c_str());
+    return st;
+}
+
+// The bucketed gradient step of a data-parallel rank, launch by launch and bucket by bucket (no GPU needed): forward + loss, then for every
+// bucket the backward pass of its layers, the ONE reduction launch of their slabs, and the slice of the flat gradient that is final there.
+int rcn_hipx_plan_buckets(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int batch, int precision, int tiling, int64_t min_bucket_bytes,
+                          char* out, int cap) {
+    if (!layers || n_layers < 1 || in_h < 1 || in_w < 1 || in_c < 1 || batch < 1 || !out || cap < 1 || min_bucket_bytes < 0) return -1;
+    if ((precision != RCN_HIPX_FP32 && precision != RCN_HIPX_BF16) || tiling < RCN_HIPX_TILING_GEMM || tiling > RCN_HIPX_TILING_LDS) return -1;
+    rcn_hipx_net net;
+    net.in_h = in_h; net.in_w = in_w; net.in_c = in_c; net.max_batch = batch;
+    net.precision = precision; net.tiling = tiling; net.overlap = 0; net.dry = true;
+    seed_options(net.opt);
+    int st = describe_layers(&net, in_h, in_w, in_c, layers, n_layers);
+    if (st == 0) {
+        net.plan = "gradients of one batch of " + std::to_string(batch) + " in buckets of at least " + std::to_string((long long)min_bucket_bytes) +
+                   " bytes (data-parallel step: a bucket's all-reduce overlaps the backward pass below it):\n";
+        const int nb = grad_begin(&net, nullptr, nullptr, batch, reinterpret_cast<float*>(sizeof(float)), nullptr, (long long)min_bucket_bytes);
+        st = nb < 0 ? nb : 0;
+        for (int k = 0; st == 0 && k < nb; ++k) st = grad_bucket(&net, k, nullptr, nullptr);
     }
     const std::string& text = st == 0 ? net.plan : net.err;
     std::snprintf(out, (size_t)cap, "%s", text.c_str());

@@ -89,3 +89,31 @@ def test_dense_weight_gradients_are_sized_by_waves(plan):
     # a large layer keeps the 64-wide blocks: synth-224's convolutions never reach this kernel, its dense layer has 32 padded columns anyway
     shp, layers, B = CONFIGS["synth224"]
     assert not any("k_conv_wgrad_bf16<3" in l for l in _lines(plan(shp, layers, B, "bf16", "auto")))
+
+
+def test_bucket_plan_cuts_the_gradient_into_contiguous_slices_in_backward_order(plan):
+    """The bucketed gradient step of a data-parallel rank (rcn_hipx_plan_buckets; SURVEY section 5: bucket by layer, overlap with the weight
+    gradients of earlier layers): buckets are final in the order the backward pass finishes them, each is ONE contiguous slice of the
+    padded flat gradient, together they cover it exactly once, none but a net's only bucket is smaller than asked, and every bucket ends
+    in its own reduction launch."""
+    for cfg, prec in (("cifar", "fp32"), ("synth224", "bf16"), ("mnist", "bf16")):
+        shp, layers, B = CONFIGS[cfg]
+        for min_bytes in (0, 1 << 20, 1 << 30):
+            text = plan(shp, layers, B, prec, "auto", buckets=min_bytes)
+            done = [re.search(r"bucket (\d+) done: grad\[(\d+), \+(\d+)\)", l) for l in text.splitlines() if " done: grad[" in l]
+            ks, offs, lens = [int(m.group(1)) for m in done], [int(m.group(2)) for m in done], [int(m.group(3)) for m in done]
+            assert ks == list(range(len(ks))) and len(ks) >= 1
+            assert offs[-1] == 0 and all(offs[i] == offs[i + 1] + lens[i + 1] for i in range(len(ks) - 1))       # contiguous, from the top down to 0
+            if min_bytes == 1 << 30:
+                assert len(ks) == 1
+            if len(ks) > 1:
+                assert all(4 * n >= min_bytes for n in lens)
+            assert text.count("k_reduce_all") == len(ks)
+            lines = text.splitlines()
+            for i, l in enumerate(lines):
+                if " done: grad[" in l:
+                    assert "k_reduce_all" in lines[i - 1]
+    shp, layers, B = CONFIGS["cifar"]
+    t = plan(shp, layers, B, "fp32", "auto", buckets=256 << 10)
+    assert t.count(" done: grad[") == 2 and "bucket 0: layers 6 .. 6" in t              # the two dense layers (2.1 MB), then the three convolutions (0.37 MB)
+    assert plan(shp, layers, B, "fp32", "auto", buckets=1 << 20).count(" done: grad[") == 1     # ... which are less than 1 MiB and join the bucket above them

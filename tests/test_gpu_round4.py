@@ -389,3 +389,42 @@ def test_trackx_options_are_per_net_and_the_plan_of_a_net_is_its_own(monkeypatch
     b.set_option("bf16_1cb", 1)                                         # settable afterwards, per net; the plan follows
     assert "k_conv3x3_halo_bf16_1cb" in b.plan_of_this_net(B)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_trackx_bucketed_gradients_are_the_gradients_bit_for_bit(precision):
+    """rcn_hipx_gradients_begin_dev / _bucket_dev: the backward pass as a resumable walk that stops after every bucket of layers and runs
+    that bucket's slab reduction, so that a data-parallel step can all-reduce the slice while the layers below still run.  Same kernels,
+    same sums: for every bucket size the flat gradient and the loss equal rcn_hipx_gradients_dev's bit for bit, the slices arrive from
+    the top of the buffer down and cover it exactly once, and a slice is already final when its callback runs."""
+    import torch
+    from mercer_research_amd.convnet import ConvNet
+    in_shape, layers, B = (16, 16, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 128), ("dense", 10)), 64
+    net = ConvNet(in_shape, layers, B)
+    net.init_params(5)
+    net.set_precision(precision)
+    rng = np.random.default_rng(11)
+    x = net.to_device(rng.standard_normal((B,) + in_shape).astype(np.float32))
+    y = net.to_device(rng.integers(0, 10, B).astype(np.int32))
+    loss0 = torch.zeros(1, dtype=torch.float32, device=net.device)
+    ref = net.gradients(x, y, None, loss0)
+    net.synchronize()
+    ref_h, l0 = ref.cpu().numpy().copy(), float(loss0.item())
+    for min_bytes in (0, 64 << 10, 1 << 30):
+        grad = torch.full((net.n_padded,), float("nan"), dtype=torch.float32, device=net.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        seen = []
+
+        def on_bucket(piece, k, n):
+            net.synchronize()                                           # (a test may; a step records an event instead)
+            off = piece.storage_offset()
+            seen.append((k, n, off, piece.numel()))
+            assert np.array_equal(piece.cpu().numpy(), ref_h[off:off + piece.numel()]), (min_bytes, k)
+        net.gradients_bucketed(x, y, grad, loss, min_bytes, on_bucket)
+        net.synchronize()
+        assert np.array_equal(grad.cpu().numpy(), ref_h) and float(loss.item()) == l0
+        assert [s[0] for s in seen] == list(range(seen[0][1]))
+        assert seen[-1][2] == 0 and seen[0][2] + seen[0][3] == net.n_padded
+        assert all(seen[i][2] == seen[i + 1][2] + seen[i + 1][3] for i in range(len(seen) - 1))
+        assert (len(seen) == 1) if min_bytes == 1 << 30 else (len(seen) == 4 if min_bytes == 0 else len(seen) >= 2)
+    net.close()
