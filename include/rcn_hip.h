@@ -174,7 +174,7 @@ int  rcn_hip_prepare_epoch_dev(rcn_hip_ctx* ctx, const void* X_dev, const void* 
 int  rcn_hip_train_epoch_gathers(rcn_hip_ctx* ctx, size_t B);
 /* 1 when rcn_hip_train_epoch_dev / rcn_hip_epoch_steps_dev / rcn_hip_train_set_epoch at this batch size run on the resident one-XCD
  * kernel (csrc/dense_xcd.hpp: the reference's two layer stacks, f32 batches of 1..256, f64 -- the reference's own type, rcn.rs:28-31 --
- * batches of 1..128, one XCD verified by the placement probe, not stepped down); 0: the two-kernel pipeline or the sample-tile kernels. */
+ * batches of 1..256 too, one XCD verified by the placement probe, not stepped down); 0: the two-kernel pipeline or the sample-tile kernels. */
 int  rcn_hip_train_epoch_resident(rcn_hip_ctx* ctx, size_t B);
 /* End to end: the same epoch straight from the resident u8 pictures (imgs_dev [N][H][W], perm_dev indexes pictures).  Per
  * segment of the epoch ONE kernel does flatten_feature_set (rcn.rs:317-356), the standardisation with the current scale_set

@@ -1,6 +1,6 @@
 // dense_xcd.hpp -- the feature-sliced pipeline of dense_p2.hpp as ONE resident kernel per epoch segment whose workgroups all sit
 // on ONE XCD (the reference's own network shape class; f32 for batches of 1..256, and -- round 4 -- f64, the reference's own arithmetic
-// type, for batches of 1..128: LDS holds 2 x the bytes per sample).
+// type, for batches of 1..256 too: LDS holds 2 x the bytes per sample, the 256-sample instantiation one batch buffer instead of two).
 //
 // Why.  The two-kernel step (k_p2_b, k_p2_a) is bound by what surrounds its arithmetic: two dependent launch boundaries (~1.5 us
 // each), W_0 and the batch leaving and re-entering the chip, and a 1.6 MB slab of partial sums written to and read back from
@@ -85,9 +85,10 @@ inline bool xcd_one_hidden(const NetDesc& nd) {
 // the samples between B and BT are rows of zeros whose deltas are masked to zero, so they add nothing to any sum, and the update
 // divides by the real batch.len() (rcn.rs:214).
 constexpr int kXcdMaxB = 256;
-// f64 (round 4): every LDS image is twice the bytes, so the instantiations stop at 128 samples (152 KB with the tail tiles' partials laid
-// over the batch buffers they never use); a batch above that runs the two-kernel pipeline as before
-constexpr int kXcdMaxB64 = 128;
+// f64 (round 4): every LDS image is twice the bytes.  Up to 128 samples the layout is the f32 one (152 KB at 128 with the tail tiles'
+// partials laid over the batch buffers they never use); the instantiation for 256 samples keeps ONE batch buffer instead of two (the
+// next batch is fetched into registers under the gradient MFMAs and moves in behind them) and stages delta_1 in two halves: 152 KB too
+constexpr int kXcdMaxB64 = 256;
 inline int xcd_max_b(size_t esz) { return esz == 8 ? kXcdMaxB64 : kXcdMaxB; }
 inline int xcd_bt(size_t B) { return B <= 32 ? 32 : B <= 64 ? 64 : B <= 128 ? 128 : 256; }
 inline bool xcd_supported(const NetDesc& nd, size_t B, size_t esz = 4) {
@@ -111,12 +112,15 @@ inline size_t xcd_buf_bytes(const NetDesc& nd, size_t BT, size_t esz = 4) {
 constexpr int kXcdD1Ld = 48;
 // the tail tiles' partials over the batch buffers (a tail tile is never a feature worker): only where the LDS would not fit otherwise
 template <typename T, int BT> constexpr bool xcd_red_aliased() { return sizeof(T) == 8 && BT >= 128; }
-constexpr size_t xcd_lds_floats(int BT, bool red_aliased = false) {
-    return 2 * (size_t)kXcdSl * BT * 16 + (size_t)BT * kXcdD1Ld + (red_aliased ? 0 : (size_t)kDenseWaves * kMtp * kRedTile) + (size_t)kXcdSl * 16 * kP2H +
-           (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + 3 * kP2C * kLd + 4 * 64 + 64;
+// ONE batch buffer and delta_1 in two halves: only where two buffers and the whole delta_1 do not fit (f64, 256 samples)
+template <typename T, int BT> constexpr bool xcd_single_buffer() { return sizeof(T) == 8 && BT >= 256; }
+constexpr size_t xcd_lds_floats(int BT, bool red_aliased = false, bool single = false) {
+    return (single ? 1 : 2) * (size_t)kXcdSl * BT * 16 + (size_t)(single ? BT / 2 : BT) * kXcdD1Ld + (red_aliased ? 0 : (size_t)kDenseWaves * kMtp * kRedTile) +
+           (size_t)kXcdSl * 16 * kP2H + (size_t)kP2BWaves * 64 * 4 + kP2H * kLd + 3 * kP2C * kLd + 4 * 64 + 64;
 }
-template <typename T, int BT> constexpr size_t xcd_lds_bytes() { return xcd_lds_floats(BT, xcd_red_aliased<T, BT>()) * sizeof(T); }
-static_assert(xcd_lds_bytes<double, 128>() + 64 <= 160 * 1024 && xcd_lds_bytes<float, 256>() + 64 <= 160 * 1024, "k_xcd_epoch: LDS of the largest instantiations");
+template <typename T, int BT> constexpr size_t xcd_lds_bytes() { return xcd_lds_floats(BT, xcd_red_aliased<T, BT>(), xcd_single_buffer<T, BT>()) * sizeof(T); }
+static_assert(xcd_lds_bytes<double, 128>() + 64 <= 160 * 1024 && xcd_lds_bytes<float, 256>() + 64 <= 160 * 1024 && xcd_lds_bytes<double, 256>() + 64 <= 160 * 1024,
+              "k_xcd_epoch: LDS of the largest instantiations");
 static_assert((size_t)2 * kXcdSl * 128 * 16 >= (size_t)kDenseWaves * kMtp * kRedTile, "k_xcd_epoch: the partials fit the batch buffers they are laid over");
 
 // diagnostic build only (-DRCN_STAMPS, tools/stamps_xcd.py): where each worker is at each point of the launch's last-but-one step
@@ -290,6 +294,40 @@ __device__ inline void xcd_frag_scatter3(int cc, int m, int H2, double v, double
     }
 }
 
+// The sigmoid of the resident kernel's single critical wave.  f32: hardware exp2 / rcp (common.hpp).  f64: the reference's
+// 1 / (1 + E^-x) (rcn.rs:478-483) without the library calls' generality -- phase stamps put the f64 step's sample-group wave at 2.0 us of
+// 6.4, most of it eight `exp` + IEEE divisions in two dependent rounds (~40 instructions each on a wave that issues alone): here
+// e^t = 2^n e^r by Cody-Waite reduction (t = n ln2 + r, |r| <= ln2 / 2, ln2 in two pieces), e^r as its degree-13 Taylor polynomial
+// (truncation 4e-18 relative), and the reciprocal as v_rcp_f64 + two Newton steps; |t| clamped to 708 (e^708 is finite; the true
+// sigmoid there is 1 or 3e-308).  Relative error ~2e-16, far inside the f64 bar of 1e-11 per step (tests/test_gpu_round4.py).
+__device__ inline float xcd_sigmoid(float x) { return sigmoid_fast(x); }
+__device__ inline double xcd_sigmoid(double x) {
+    double t = -x;
+    t = t < -708.0 ? -708.0 : (t > 708.0 ? 708.0 : t);
+    const double n = __builtin_rint(t * 1.44269504088896338700e+00);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01, t);
+    r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;                                     // 1 / 13!
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double d = 1.0 + __builtin_ldexp(p, (int)n);
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    return y;
+}
+
 // nb consecutive train_batch steps (rcn.rs:176-223) over the packed batches xs[j] (slice-major, k_pack_epoch), ys[j].
 //
 // DP = true: the data-parallel step (one rank per GPU, this rank's shard of every global batch in xs / ys).  Between the gradient
@@ -331,7 +369,9 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     static_assert(!GA || FULL, "the gather form exists for the full batch only");
     static_assert(BT == 32 || BT == 64 || BT == 128 || BT == 256, "k_xcd_epoch: batch instantiations");
     static_assert(!GA || BT == 256, "the gather form exists for batch 256 only");
-    static_assert(sizeof(T) == 4 || (!DP && !GA && BT <= kXcdMaxB64), "f64: single-GPU forms on the packed image, batches up to 128");
+    static_assert(sizeof(T) == 4 || (!DP && !GA && BT <= kXcdMaxB64), "f64: single-GPU forms on the packed image");
+    constexpr bool SB = xcd_single_buffer<T, BT>();                 // one batch buffer, delta_1 staged in DH parts (f64 at 256 samples)
+    constexpr int DH = SB ? 2 : 1, BH = BT / DH;
     static_assert(!PH || DP, "the phase clocks exist for the data-parallel form");
     constexpr int ES = (int)sizeof(T), VS = 4 * ES;                  // bytes of an element / of a quadruple in the L2 buffers
     constexpr int RI = sizeof(T) == 4 ? 1 : 4;                       // Mfma16<T>::row(lane, i) = row(lane, 0) + RI * i
@@ -354,11 +394,11 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     __shared__ int s_abort;
     T* smem = reinterpret_cast<T*>(smem_dyn);
-    T* xbuf = smem;                                                 // [2][kXcdSl][B][16]
-    T* d1s = xbuf + 2 * kXs;                                        // delta_1 of the batch [BT][48] (32 used)
-    constexpr bool RA = xcd_red_aliased<T, BT>();                   // (f64, BT = 128: laid over the batch buffers a tail tile never uses)
-    T* red = RA ? xbuf : d1s + BT * kXcdD1Ld;                       // tail tiles: [wave][mt][16 x kLd]
-    T* wsl = d1s + BT * kXcdD1Ld + (RA ? 0 : kDenseWaves * kMtp * kRedTile);     // [slice][feature 0..15][32]
+    T* xbuf = smem;                                                 // [2 | SB: 1][kXcdSl][B][16]
+    T* d1s = xbuf + (SB ? 1 : 2) * kXs;                             // delta_1 of the batch [BH][48] (32 used)
+    constexpr bool RA = xcd_red_aliased<T, BT>();                   // (f64, BT >= 128: laid over the batch buffers a tail tile never uses)
+    T* red = RA ? xbuf : d1s + BH * kXcdD1Ld;                       // tail tiles: [wave][mt][16 x kLd]
+    T* wsl = d1s + BH * kXcdD1Ld + (RA ? 0 : kDenseWaves * kMtp * kRedTile);     // [slice][feature 0..15][32]
     vec4* zred = reinterpret_cast<vec4*>(wsl + kXcdSl * 16 * kP2H); // [8 waves][64 lanes]
     T* a1s = reinterpret_cast<T*>(zred) + kP2BWaves * 64 * 4;       // a_1 tile  [hidden 32][kLd]
     T* d2s = a1s + kP2H * kLd;                                      // delta_2   [class 16][kLd]
@@ -470,7 +510,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         }
         // batches 0 and 1 of this launch: [slice pair][sample][16] is one contiguous run of nsl * B * 16 floats per batch
         // (in LDS a slice holds BT rows: rows B .. BT-1, and a missing second slice, are zeros)
-        for (int b = 0; b < 2 && b < nb; ++b) {
+        for (int b = 0; b < (SB ? 1 : 2) && b < nb; ++b) {
             vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(b & 1) * kXs);
             if constexpr (gather) {
                 for (int i = tid; i < kXcdSl * BT * 4; i += kXcdThreads) dst[i] = xrow4(b, i);
@@ -507,7 +547,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 
     // partial z_1 of batch `jn` (LDS buffer jn & 1) from the slice pair in LDS -> this worker's part of the slab
     auto forward = [&](int jn) {
-        const T* xb = xbuf + (size_t)(jn & 1) * kXs;
+        const T* xb = xbuf + (SB ? (size_t)0 : (size_t)(jn & 1) * kXs);
         constexpr int NTILE = BT / 16, UT = NTILE > kDenseWaves ? NTILE / kDenseWaves : 1;      // sample tiles, and how many a wave takes
         T wf[kXcdSl][4][kMtp];
 #pragma unroll
@@ -573,8 +613,16 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
         // (1) the batch after next, a whole step ahead: into registers now, into the LDS buffer step j's gradient frees
         constexpr int XR = (kXcdSl * BT * 4 + kXcdThreads - 1) / kXcdThreads;      // 16-byte pieces of a batch's slice pair per thread: 4 at BT = 256
         vec4 xr[XR];
-        const bool pre = is_a && j + 2 < nb;
-        if (pre) {
+        const bool pre = is_a && (SB ? j + 1 < nb : j + 2 < nb);       // (SB: the NEXT batch, fetched further down, under the gradient MFMAs)
+        auto prefetch = [&](int jb) {
+            const vec4* src = reinterpret_cast<const vec4*>(xs_all + (size_t)jb * xs_stride + (size_t)(kXcdSl * w) * B * 16);
+#pragma unroll
+            for (int r = 0; r < XR; ++r) {
+                const int i = tid + r * kXcdThreads, sl = i / (BT * 4), rr = i % (BT * 4);
+                xr[r] = (sl < nsl && (rr >> 2) < B) ? src[sl * B * 4 + rr] : vec4{0, 0, 0, 0};
+            }
+        };
+        if (pre && !SB) {
             if constexpr (gather) {
 #pragma unroll
                 for (int r = 0; r < XR; ++r) xr[r] = xrow4(j + 2, tid + r * kXcdThreads);
@@ -667,7 +715,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     vec4 a;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const auto sg = sigmoid_fast(z[i] + fr[24 + i]);
+                        const auto sg = xcd_sigmoid(z[i] + fr[24 + i]);
                         a[i] = (h0 + i < H) ? sg : (T)0;
                         a1s[(h0 + i) * kLd + s] = a[i];
                     }
@@ -688,7 +736,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int c = Mfma16<T>::row(lane, i);
-                        const T a2 = sigmoid_fast(acc[i] + fr[16 + i]);
+                        const T a2 = xcd_sigmoid(acc[i] + fr[16 + i]);
                         const T diff = a2 - fr[20 + i];
                         const bool ok = c < C && live;
                         dv[i] = ok ? diff * (a2 * ((T)1 - a2)) : (T)0;
@@ -701,7 +749,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int h2 = Mfma16<T>::row(lane, i);
-                        const T a = sigmoid_fast(acc[i] + fr[16 + i]);
+                        const T a = xcd_sigmoid(acc[i] + fr[16 + i]);
                         a2r[i] = (h2 < Cm && n < kP2Ts) ? a : (T)0;
                         a2s[h2 * kLd + n] = a2r[i];
                     }
@@ -719,7 +767,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int c = Mfma16<T>::row(lane, i);
-                        const T a3 = sigmoid_fast(acc3[i] + fr[36 + i]);
+                        const T a3 = xcd_sigmoid(acc3[i] + fr[36 + i]);
                         const T diff = a3 - fr[20 + i];
                         const bool ok = c < C && live;
                         d3v[i] = ok ? diff * (a3 * ((T)1 - a3)) : (T)0;
@@ -792,27 +840,32 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             // ---- U: dW_0[:, slice pair] = sum_s delta_1[s] (x) x_s[slice pair]; W_0 <- W_0 - (eta/B) dW_0            rcn.rs:310, 214
             // delta_1 of the whole batch into LDS first: 32 KB as 16-byte L1-bypassing loads, 4 per thread (as 4-byte loads straight
             // into MFMA operands it was 16 per lane and the slower part of this phase)
+            // (SB -- f64 at 256 samples: delta_1 in DH = 2 parts of BH samples, each staged and contracted in turn into the same accumulators,
+            // and the next batch fetched into registers under the first part's MFMAs)
+            acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int dh = 0; dh < DH; ++dh) {
             {
-                constexpr int DR = (BT * 8 + kXcdThreads - 1) / kXcdThreads;
+                constexpr int DR = (BH * 8 + kXcdThreads - 1) / kXcdThreads;
                 vec4 dv[DR];
 #pragma unroll
-                for (int r = 0; r < DR; ++r) dv[r] = xcd_ld4<T>(r_d1, (tid + r * kXcdThreads) * VS);    // (past the buffer: zeros, not stored)
+                for (int r = 0; r < DR; ++r) dv[r] = xcd_ld4<T>(r_d1, (dh * BH * 8 + tid + r * kXcdThreads) * VS);    // (past the buffer: zeros, not stored)
 #pragma unroll
                 for (int r = 0; r < DR; ++r) {
-                    const int idx = tid + r * kXcdThreads;                 // vec4 index in [BT][8]
-                    if (BT * 8 >= kXcdThreads || idx < BT * 8) *reinterpret_cast<vec4*>(d1s + (idx >> 3) * kXcdD1Ld + (idx & 7) * 4) = dv[r];
+                    const int idx = tid + r * kXcdThreads;                 // vec4 index in [BH][8]
+                    if (BH * 8 >= kXcdThreads || idx < BH * 8) *reinterpret_cast<vec4*>(d1s + (idx >> 3) * kXcdD1Ld + (idx & 7) * 4) = dv[r];
                 }
             }
             __syncthreads();
-            if (wave == 1) XSTAMP(8);
+            if (wave == 1 && dh == 0) XSTAMP(8);
+            if constexpr (SB) { if (dh == 0 && pre) prefetch(j + 1); }
             // Four 16 x 16 tiles, 64 k-steps each: 256 MFMAs = 2048 cycles of the CU's four matrix pipes whichever way they are cut.
             // Waves 0..3 (one per SIMD) each run ONE tile over the WHOLE batch -- no K-split, so no cross-wave reduction, no partials
             // in LDS, no second barrier -- on two interleaved accumulators (a single chain would be paced by the 40-cycle dependent
             // latency instead of the 32-cycle issue rate).  Waves 4..7 have no arithmetic here; they move the prefetched batch into LDS.
             if (kh == 0) {
-                const T* xb = xbuf + (size_t)(j & 1) * kXs + (size_t)usl * BT * 16;
-                constexpr int NQB = BT / 32;                               // blocks of eight k-steps (four samples each)
-                acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
+                const T* xb = xbuf + (SB ? (size_t)0 : (size_t)(j & 1) * kXs) + (size_t)usl * BT * 16 + (size_t)dh * BH * 16;
+                constexpr int NQB = BH / 32;                               // blocks of eight k-steps (four samples each)
                 // hand-pipelined: the operands of block qb + 1 are requested before the MFMAs of block qb issue, and fences keep the
                 // scheduler from folding that back into load-wait-MFMA triples (which ran at ~100 cycles per MFMA instead of 32)
                 const T* ap = d1s + g4 * kXcdD1Ld + umt * 16 + n;
@@ -837,6 +890,10 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if (dh + 1 < DH) __syncthreads();                              // (every wave is past its reads of this part before the next one is staged)
+            }
+            if (kh == 0) {
                 T gsum[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gsum[i] = acc0[i] + acc1[i];
@@ -875,11 +932,12 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
             // the LDS buffer of batch j is free now (every wave is past its reads): the batch after next moves in; its first reader is
             // the forward of the NEXT iteration, several barriers away
             if (pre) {
-                vec4* dst = reinterpret_cast<vec4*>(xbuf + (size_t)(j & 1) * kXs);
+                vec4* dst = reinterpret_cast<vec4*>(xbuf + (SB ? (size_t)0 : (size_t)(j & 1) * kXs));
 #pragma unroll
                 for (int r = 0; r < XR; ++r)
                     if (kXcdSl * BT * 4 >= kXcdThreads || tid + r * kXcdThreads < kXcdSl * BT * 4) dst[tid + r * kXcdThreads] = xr[r];
             }
+            if constexpr (SB) __syncthreads();                             // (one buffer: the forward below is its first reader)
             if (more) {
                 forward(j + 1);
                 if (wave == 1) XSTAMP(11);

@@ -380,7 +380,7 @@ int rcn_hip_set_dense_path(rcn_hip_ctx* c, int mode) {
     if (mode == 5) {
         if (!xcd_supported(c->nd, 32, c->esz()))
             return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path(5): the resident one-XCD kernel covers one hidden layer <= 32 (or two: <= 32, <= 16), classes <= 16, "
-                                                      "at most 29 feature-slice pairs, batches of 1..256 (f64 context: 1..128)");
+                                                      "at most 29 feature-slice pairs, batches of 1..256");
         RCN_TRY(xcd_probe(c));
         if (c->xcd_probe != 1)
             return fail(c, RCN_HIP_ERR_UNSUPPORTED, "set_dense_path(5): on this device the blocks with blockIdx.x % 8 == 0 do not share one XCD; the resident kernel "

@@ -98,7 +98,7 @@ std::string xcd_describe(rcn_hip_ctx* c, bool with_tables) {
 }
 
 bool use_xcd(rcn_hip_ctx* c, size_t B) {
-    if (!xcd_supported(c->nd, B, c->esz())) return false;           // (f64: batches up to 128 -- dense_xcd.hpp)
+    if (!xcd_supported(c->nd, B, c->esz())) return false;
     if (c->dense_path != 0 && c->dense_path != 5) return false;
     if (c->xcd_stepped_down) return false;                              // (rcn_hip_set_dense_path(ctx, 5) arms it again)
     if (c->dense_path == 0 && c->opt.xcd == 0) return false;
@@ -251,10 +251,7 @@ int enqueue_xcd_steps(rcn_hip_ctx* c, const T* xs, const T* ys, size_t B, size_t
     case 32:  RCN_XCD_BT(32); break;
     case 64:  RCN_XCD_BT(64); break;
     case 128: RCN_XCD_BT(128); break;
-    default:
-        if constexpr (sizeof(T) == 4) RCN_XCD_BT(256);
-        else st = fail(c, RCN_HIP_ERR_UNSUPPORTED, "the resident kernel's f64 form covers batches up to 128");
-        break;
+    default:  RCN_XCD_BT(256); break;
     }
 #undef RCN_XCD_BT
     RCN_TRY(st);

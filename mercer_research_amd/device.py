@@ -224,7 +224,7 @@ class DeviceRCN:
         return bool(self.lib.rcn_hip_train_epoch_gathers(self.ctx, B))
 
     def train_epoch_resident(self, B: int) -> bool:
-        """True when train_epoch / epoch_steps at this batch size run on the resident one-XCD kernel (f32: 1..256, f64: 1..128)."""
+        """True when train_epoch / epoch_steps at this batch size run on the resident one-XCD kernel (batches of 1..256, f32 and f64)."""
         return bool(self.lib.rcn_hip_train_epoch_resident(self.ctx, B))
 
     def dp_phase_us(self) -> dict:

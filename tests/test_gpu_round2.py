@@ -587,7 +587,7 @@ def test_resident_kernel_is_what_auto_selects_for_the_bench_shape_and_not_for_ot
     d.rcn.close()
     d64 = DeviceRCN(dtype=1)
     d64.set_dense_path(5)                                            # f64 context (round 4): the kernel's f64 instantiations, batches of 1..128
-    assert d64.train_epoch_resident(128) and not d64.train_epoch_resident(256)
+    assert d64.train_epoch_resident(128) and d64.train_epoch_resident(256) and not d64.train_epoch_resident(257)
     d64.rcn.close()
     d3 = DeviceRCN(dtype=0, feedforward_cfg=[10, 10])
     d3.set_dense_path(5)                                             # two hidden layers <= 32, <= 16: the kernel's second instantiation

@@ -1,7 +1,7 @@
 """GPU tests added in round 4 (run with -m gpu on an MI355X), all through the C ABI:
 
 * the resident one-XCD kernel in the reference's OWN arithmetic type (f64: rcn.rs:28,31,49) at its own operating points -- batch_size
-  10 (rcn/src/main.rs:36-37, rcn.rs:581), 32 (BASELINE configs[0]) -- and at every other batch of 1..128 samples, both reference nets,
+  10 (rcn/src/main.rs:36-37, rcn.rs:581), 32 (BASELINE configs[0]) -- and at every other batch of 1..256 samples, both reference nets,
   against the CPU restatement at the f64 tolerance (1e-11 per step);
 * the 256-step f64 loss curve at B = 10 and B = 32 on the resident kernel (<= 1e-9 per step);
 * the self-healing step-down in f64.
@@ -44,14 +44,14 @@ def _oracle_steps(oracle, ws, bs, X, Y, perm, B, nb, eta):
 
 def test_f64_context_reaches_the_resident_kernel_by_default(amd):
     """The drop-in crate opens an F64 context (rust/rcn-hip/src/rcn.rs) and trains at batch_size 10: that context, with no option set,
-    must land on the resident kernel for batches of 1..128 and on the pipeline above."""
+    must land on the resident kernel for batches of 1..256 and on the pipeline above."""
     from mercer_research_amd.device import DeviceRCN
     d = DeviceRCN(dtype=F64)
     _xcd_or_skip(d)
     d.set_dense_path(0)
-    for B in (1, 10, 32, 64, 100, 128):
+    for B in (1, 10, 32, 64, 100, 128, 129, 200, 256):
         assert d.train_epoch_resident(B), B
-    for B in (129, 200, 256, 512):
+    for B in (257, 512):
         assert not d.train_epoch_resident(B), B
     d.rcn.close()
     d = DeviceRCN(dtype=F32)
@@ -65,14 +65,14 @@ def test_f64_context_reaches_the_resident_kernel_by_default(amd):
 
 
 @pytest.mark.parametrize("hidden", [[30], [10, 10]], ids=["784-30-10", "reference-test-net-784-10-10-10"])
-@pytest.mark.parametrize("B", [10, 32, 1, 8, 33, 64, 100, 128])
-def test_resident_kernel_f64_at_any_batch_of_1_to_128_is_the_reference_loop(amd, oracle, hidden, B):
+@pytest.mark.parametrize("B", [10, 32, 1, 8, 33, 64, 100, 128, 200, 255, 256])
+def test_resident_kernel_f64_at_any_batch_of_1_to_256_is_the_reference_loop(amd, oracle, hidden, B):
     """train_batch (rcn.rs:176-223, 260-314; sigmoid rcn.rs:478-492) in f64 on the resident kernel's v_mfma_f64_16x16x4_f64
-    instantiations for 32 / 64 / 128 samples: one step from identical parameters within 1e-11 of the CPU restatement, six chained steps
+    instantiations for 32 / 64 / 128 / 256 samples (the last with ONE batch buffer and delta_1 staged in two halves: LDS): one step from identical parameters within 1e-11 of the CPU restatement, six chained steps
     in a shuffled order within 1e-10, and the same calls on the sample-tile kernels (dense path 1)."""
     from mercer_research_amd.device import DeviceRCN
     dims = [784] + hidden + [10]
-    N, nb = 1024, 6
+    N, nb = 2048, 6
     rng = np.random.default_rng(300 + B)
     X = np.maximum(rng.standard_normal((N, 784)), 0.0)
     Y = one_hot(rng.integers(0, 10, N))
