@@ -428,3 +428,81 @@ def test_trackx_bucketed_gradients_are_the_gradients_bit_for_bit(precision):
         assert all(seen[i][2] == seen[i + 1][2] + seen[i + 1][3] for i in range(len(seen) - 1))
         assert (len(seen) == 1) if min_bytes == 1 << 30 else (len(seen) == 4 if min_bytes == 0 else len(seen) >= 2)
     net.close()
+
+
+@pytest.mark.parametrize("B", [10, 200])
+def test_f64_epoch_from_images_on_the_resident_kernel_equals_features_then_train(amd, oracle, B):
+    """The end-to-end form (u8 pictures -> features -> standardise -> packed epoch image in one kernel per segment, then the steps) in the
+    f64 context on the resident kernel (k_features_cpcp_packed<double> feeding k_xcd_epoch<double>): bit-identical to
+    rcn_hip_features_dev(standardize) + rcn_hip_train_epoch_dev, and both within 1e-10 of the oracle's loop on the oracle's features."""
+    from mercer_research_amd.device import DeviceRCN
+    nb, N = 5, 1200
+    imgs, labels = synthetic_images(N, seed=23)
+    ws, bs = synthetic_params([784, 30, 10], seed=9)
+    ws = [w * 0.1 for w in ws]
+    order = np.random.default_rng(4).permutation(N).astype(np.int32)
+    res = []
+    for images_path in (True, False):
+        d = DeviceRCN(dtype=F64)
+        _xcd_or_skip(d)
+        d.set_dense_path(0)
+        assert d.train_epoch_resident(B)
+        d.set_params(ws, bs)
+        dev = d.to_device(imgs)
+        d.gen_scales(d.features(dev))                                   # sets scale_set
+        Y = d.to_device(one_hot(labels), d.tdtype)
+        perm = d.to_device(order)
+        loss = d.empty(nb)
+        if images_path:
+            d.train_epoch_images(dev, Y, perm, B, nb, 3.0, loss)
+        else:
+            d.train_epoch(d.features(dev, standardize=True), Y, perm, B, nb, 3.0, loss)
+        gw, gb = d.get_params()
+        res.append((gw + gb, loss.cpu().numpy().copy()))
+        assert d.fallbacks_taken() == 0
+        d.rcn.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][1], res[1][1])
+    f = oracle.features(imgs, DEFAULT_LAYERS)
+    X = oracle.standardize(f, *oracle.gen_scales(f))
+    rw, rb, cs = _oracle_steps(oracle, ws, bs, X, one_hot(labels), order.astype(np.int64), B, nb, 3.0)
+    np.testing.assert_allclose(res[0][1], cs, rtol=1e-10)
+    for a, b in zip(res[0][0], rw + rb):
+        assert np.all(np.abs(a - b) <= 1e-10 * np.abs(b) + 1e-11), float(np.abs(a - b).max())
+
+
+def test_the_drop_in_call_sequence_in_f64_at_batch_size_10_runs_on_the_resident_kernel(amd, oracle):
+    """What rust/rcn-hip's RCN::train does (rcn.rs:126-167 over rcn_hip_load_data / rcn_hip_train_set_epoch / rcn_hip_evaluate_set) in the
+    F64 context that crate opens, at the reference's own batch_size 10 (rcn/src/main.rs:36-37): the steps run on the resident kernel
+    (rcn_hip_train_epoch_resident) and follow the oracle's restatement -- per-step costs, accepted counts, final parameters."""
+    B, epochs = 10, 2
+    imgs, labels = synthetic_images(205, seed=3)                        # chunks_exact(10) drops the last five (rcn.rs:147)
+    timgs, tlabels = synthetic_images(80, seed=4)
+    ws, bs = synthetic_params([784, 30, 10], seed=21)
+    ws = [w * 0.05 for w in ws]
+    r = amd.RCN(10, amd.default_convpool(), [30], input_shape=(28, 28), dtype=amd.F64)
+    r.set_params(ws, bs)
+    r.load_set(0, imgs, labels); r.load_set(1, timgs, tlabels)
+    if not r._lib.rcn_hip_train_epoch_resident(r._ctx, B):
+        r.close()
+        pytest.skip("the resident one-XCD kernel does not apply on this device")
+    f, tf = oracle.features(imgs, DEFAULT_LAYERS), oracle.features(timgs, DEFAULT_LAYERS)
+    X = oracle.standardize(f, *oracle.gen_scales(f))
+    TX = oracle.standardize(tf, *oracle.gen_scales(tf))
+    Y, TY = one_hot(labels), one_hot(tlabels)
+    rng = np.random.default_rng(99)
+    rw, rb = ws, bs
+    for e in range(epochs):
+        order = rng.permutation(205).astype(np.int32)
+        loss = r.train_set_epoch(0, B, 3.0, perm=order, want_loss=True)
+        assert loss.shape == (20,)
+        rw, rb, cs = _oracle_steps(oracle, rw, rb, X, Y, order.astype(np.int64), B, 20, 3.0)
+        np.testing.assert_allclose(loss, cs, rtol=1e-9)
+        out = oracle.classify_test(rw, rb, TX)
+        assert r.evaluate_set(1) == sum(oracle.eval_accept(out[i], TY[i]) for i in range(len(TX)))
+    gw, gb = r.get_params()
+    for a, b in zip(gw + gb, rw + rb):
+        assert np.all(np.abs(a - b) <= 1e-10 * np.abs(b) + 1e-11)
+    assert r.fallbacks_taken() == 0
+    r.close()
