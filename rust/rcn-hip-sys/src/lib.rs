@@ -169,6 +169,25 @@ impl std::fmt::Display for HipError {
 
 impl std::error::Error for HipError {}
 
+/// `rcn_hip_last_timeout`: site 1 placement vote, 2 tail-tile flag, 3 slab flag, 4 delta flag, 5 pushed reduce-scatter, 6 pushed all-gather,
+/// 7 tail all-to-all, 8 cost all-to-all, 9 closing round; `missing` = the producers / workers / ranks the wait was still missing
+/// (closing round: the arrivals seen); `text` adds the workspace's placement and flag tables as the failed launch left them.
+#[derive(Debug, Clone)]
+pub struct TimeoutRecord {
+    pub site: u32,
+    pub worker: u32,
+    pub step: i32,
+    pub launch: u32,
+    pub missing: u64,
+    pub tag: u32,
+    pub xcc: u32,
+    pub rank: u32,
+    pub world: u32,
+    pub workers: u32,
+    pub code: u32,
+    pub text: String,
+}
+
 /// Safe owner of one context.  `Send` but not `Sync`, like `RCN` behind `&mut self` (rcn.rs:126).
 pub struct Context {
     raw: *mut rcn_hip_ctx,
@@ -321,6 +340,31 @@ impl Context {
         let mut acc = 0i64;
         let st = unsafe { rcn_hip_evaluate_set(self.raw, slot, &mut acc) };
         self.check(st).map(|_| acc as usize)
+    }
+
+    /// Does `train_set_epoch` at this batch size run on the resident one-XCD kernel (f32 and f64 contexts, batches of 1..256)?
+    pub fn train_epoch_resident(&mut self, batch_size: usize) -> bool {
+        unsafe { rcn_hip_train_epoch_resident(self.raw, batch_size) != 0 }
+    }
+
+    /// How often this context stepped down from the resident kernel to the two-kernel pipeline by itself (a co-tenant on the device).
+    pub fn fallbacks_taken(&self) -> i32 {
+        unsafe { rcn_hip_fallbacks_taken(self.raw) }
+    }
+
+    /// The record of the newest bounded wait of the resident kernel that expired in this context (kept after the library healed it):
+    /// which wait, which worker, at which step of which launch, and who was still missing.
+    pub fn last_timeout(&self) -> Option<TimeoutRecord> {
+        let mut w = [0u32; 16];
+        let n = unsafe { rcn_hip_last_timeout(self.raw, w.as_mut_ptr(), w.len()) };
+        if n < 13 {
+            return None;
+        }
+        let text = unsafe { CStr::from_ptr(rcn_hip_last_timeout_text(self.raw)).to_string_lossy().into_owned() };
+        Some(TimeoutRecord {
+            site: w[0], worker: w[1], step: w[2] as i32, launch: w[3], missing: (w[4] as u64) | ((w[5] as u64) << 32), tag: w[6], xcc: w[7],
+            rank: w[8], world: w[9], workers: w[11], code: w[12], text,
+        })
     }
 
     /// `RCN::classify` minus the image decode (rcn.rs:84-97): features, standardise with `scale_set`, forward, last arg-max.
