@@ -188,8 +188,11 @@ enum XcdSite : unsigned {
     kXcdSiteClosing = 9,        // the closing round: not every worker finished the launch's last step in time
 };
 constexpr int kXcdRecWords = 12;    // record at err_host + 4: site, worker, step, launch id, missing lo, missing hi, awaited tag, XCC_ID, rank, world, xsel, NW
-__device__ inline void xcd_raise(unsigned* err_host, unsigned* err_dev, unsigned code, unsigned site, int worker, int step, unsigned launch,
-                                 unsigned long long missing, unsigned tag, int rank = 0, int world = 1, int xsel = 0, int nw = 0) {
+// NOT inlined, on purpose (measured, A/B on one box, tools/ab_variants.py): inlined at its eleven sites the record's thirteen stores and their
+// operands grew the step loop's code and cost the B = 256 step 1.4 % (6.53 against 6.44 us) although none of it ever runs -- instruction
+// fetch of a loop whose cold branches are interleaved with its hot path; as one out-of-line copy the step is back at round 3's 6.44 us.
+__device__ __attribute__((noinline)) void xcd_raise(unsigned* err_host, unsigned* err_dev, unsigned code, unsigned site, int worker, int step, unsigned launch,
+                                                    unsigned long long missing, unsigned tag, int rank = 0, int world = 1, int xsel = 0, int nw = 0) {
     unsigned expect = 0u;
     if (!__hip_atomic_compare_exchange_strong(err_dev, &expect, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     unsigned id;
@@ -214,6 +217,8 @@ __device__ inline unsigned long long xcd_wait(const unsigned* f0, int n0, const 
     for (unsigned it = 0;; ++it) {
         const unsigned f = p ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
         if (__all((int)(f - tag) >= 0)) return 0ull;
+        // (the rare part stays inline: as an out-of-line call it cost the B = 256 step 1.8 % -- 6.55 against 6.43 us, A/B on one box --
+        // where moving the never-taken xcd_raise out of line had GAINED 1.4 %: a call inside the poll loop is paid on every exit)
         if ((it & 255u) == 255u) {
             const long long now = wall_clock64();
             if (t0 == 0) t0 = now;
