@@ -275,7 +275,7 @@ int  rcn_hip_dp_epoch_steps_dev(rcn_hip_ctx* ctx, size_t first_batch, size_t n_b
  * known-answer vote, an f32 context, one hidden layer, a shard of exactly 32, 64, 128 or 256 samples.  Else 0. */
 int  rcn_hip_dp_resident(rcn_hip_ctx* ctx, size_t B_shard);
 /* Diagnostic for a first run on more than one GPU: with option "xcd_dp_phase" = 1 the resident kernel's data-parallel launches at a shard
- * of 256 carry per-worker clocks (two reads of the 100 MHz clock per step and worker: the figures say where a step WAITS, they are not
+ * of 256 (or 128) carry per-worker clocks (two reads of the 100 MHz clock per step and worker: the figures say where a step WAITS, they are not
  * the cost of an unclocked step).  After such a call: out[0], out[1] = mean / max over the feature workers that OWN their slice pair of
  * the microseconds per step between entering the exchange and having pushed the totals (waiting for the other ranks' partial sums:
  * the reduce-scatter); out[2], out[3] = the same for the member workers (push the partials, wait for the owner's totals: both hops);

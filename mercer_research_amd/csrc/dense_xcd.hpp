@@ -191,8 +191,13 @@ constexpr int kXcdRecWords = 12;    // record at err_host + 4: site, worker, ste
 // NOT inlined, on purpose (measured, A/B on one box, tools/ab_variants.py): inlined at its eleven sites the record's thirteen stores and their
 // operands grew the step loop's code and cost the B = 256 step 1.4 % (6.53 against 6.44 us) although none of it ever runs -- instruction
 // fetch of a loop whose cold branches are interleaved with its hot path; as one out-of-line copy the step is back at round 3's 6.44 us.
+#ifdef RCN_AB_RAISE_INLINE          // (diagnostic builds of tools/ab_variants.py only: the inlined form this comment measures against)
+__device__ inline void xcd_raise(unsigned* err_host, unsigned* err_dev, unsigned code, unsigned site, int worker, int step, unsigned launch,
+                                 unsigned long long missing, unsigned tag, int rank = 0, int world = 1, int xsel = 0, int nw = 0) {
+#else
 __device__ __attribute__((noinline)) void xcd_raise(unsigned* err_host, unsigned* err_dev, unsigned code, unsigned site, int worker, int step, unsigned launch,
                                                     unsigned long long missing, unsigned tag, int rank = 0, int world = 1, int xsel = 0, int nw = 0) {
+#endif
     unsigned expect = 0u;
     if (!__hip_atomic_compare_exchange_strong(err_dev, &expect, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     unsigned id;
@@ -917,8 +922,8 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     if constexpr (PH) { if (tid == 0) ph_x += wall_clock64() - ph0; }
                     if (!ok) {
                         s_abort = 1;
-                        xcd_raise(err, bufs.errd, 1u, push_owner_of(w, dp_world) == dp_rank ? kXcdSitePushOwner : kXcdSitePushMember, w, j, launch_id, pmiss, seq,
-                                  dp_rank, dp_world, xsel, NW);
+                        xcd_raise(err, bufs.errd, 1u, push_owner_of(w, dp_world) == dp_rank ? kXcdSitePushOwner : kXcdSitePushMember, w, j, launch_id,
+                                  (unsigned long long)pmiss | ((unsigned long long)i0 << 32), seq, dp_rank, dp_world, xsel, NW);      // (high half: the lane's first parameter index)
                     }
                 }
 #pragma unroll
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                     T g = t;
                     unsigned pmiss = 0u;
                     if (dp.pd.pd.world == 1 || push_all1(dp.pd, seq, (size_t)nd.P, t, dp.ptimeout, g, &pmiss)) t = g;
-                    else { s_abort = 1; xcd_raise(err, bufs.errd, 1u, kXcdSitePushCost, w, j, launch_id, pmiss, seq, dp_rank, dp_world, xsel, NW); }
+                    else { s_abort = 1; xcd_raise(err, bufs.errd, 1u, kXcdSitePushCost, w, j, launch_id, (unsigned long long)pmiss | ((unsigned long long)nd.P << 32), seq, dp_rank, dp_world, xsel, NW); }
                 }
                 if (loss_dev) loss_dev[j] = t;
                 }
@@ -1023,7 +1028,7 @@ __global__ __launch_bounds__(kXcdThreads) void k_xcd_epoch(
                         const bool pok = dp.pd.pd.world == 1 || push_all1(dp.pd, seq, tpo, gsum, dp.ptimeout, g, &pmiss);
                         if constexpr (PH) { if (tid == 0) ph_x += wall_clock64() - ph0; }
                         if (pok) gsum = g;
-                        else { s_abort = 1; xcd_raise(err, bufs.errd, 1u, kXcdSitePushTail, w, j, launch_id, pmiss, seq, dp_rank, dp_world, xsel, NW); }
+                        else { s_abort = 1; xcd_raise(err, bufs.errd, 1u, kXcdSitePushTail, w, j, launch_id, (unsigned long long)pmiss | ((unsigned long long)tpo << 32), seq, dp_rank, dp_world, xsel, NW); }
                     }
                     tcur -= scale * gsum;                                    // rcn.rs:214,221
                     int tmo = tm;                                            // opaque: the image addresses are recomputed per step, not

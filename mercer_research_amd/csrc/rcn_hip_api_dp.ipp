@@ -350,11 +350,12 @@ int rcn_hip_train_epoch_gathers(rcn_hip_ctx* c, size_t B) {
 int rcn_hip_dp_phase_us(rcn_hip_ctx* c, double* out, size_t cap) {
     RCN_TRY(check_ctx(c));
     if (!out || cap < 8) return fail(c, RCN_HIP_ERR_INVALID_ARG, "dp_phase_us: out must hold 8 doubles");
-    if (!c->xcdbuf.p || c->xcd_B != 256 || c->dtype != RCN_HIP_F32) return fail(c, RCN_HIP_ERR_STATE, "dp_phase_us: no clocked data-parallel launch at a shard of 256 has run (option xcd_dp_phase)");
+    if (!c->xcdbuf.p || (c->xcd_B != 256 && c->xcd_B != 128) || c->dtype != RCN_HIP_F32)
+        return fail(c, RCN_HIP_ERR_STATE, "dp_phase_us: no clocked data-parallel launch at a shard of 256 or 128 has run (option xcd_dp_phase)");
     DevGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     long long ph[kXcdWorkers * 4];
-    HIP_TRY(c, hipMemcpy(ph, xcd_bufs<float>(c, 256).phase, sizeof ph, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(ph, xcd_bufs<float>(c, c->xcd_B).phase, sizeof ph, hipMemcpyDeviceToHost));
     double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}, step = 0, steps = 0;
     int cnt[4] = {0, 0, 0, 0}, nstep = 0;
     for (int w = 0; w < kXcdWorkers; ++w) {

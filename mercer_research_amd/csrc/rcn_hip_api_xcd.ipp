@@ -66,12 +66,34 @@ std::string xcd_describe(rcn_hip_ctx* c, bool with_tables) {
     xcd_capture_record(c);
     const unsigned* r = c->xrec;
     const unsigned site = r[0];
-    const unsigned long long missing = (unsigned long long)r[4] | ((unsigned long long)r[5] << 32);
+    const bool push_site = r[0] >= kXcdSitePushOwner && r[0] <= kXcdSitePushCost;      // (push sites: the high half carries the parameter index)
+    const unsigned long long missing = (unsigned long long)r[4] | (push_site ? 0ull : (unsigned long long)r[5] << 32);
     std::string s = " [first expired wait: site " + std::to_string(site) + " (" + xcd_site_name(site) + "), worker " + std::to_string(r[1]) + " of " + std::to_string(r[11]) +
                     " on XCC " + std::to_string(r[7]) + ", step " + std::to_string((int)r[2]) + " of launch " + std::to_string(r[3]) + ", rank " + std::to_string(r[8]) + " of " +
                     std::to_string(r[9]) + ", worker blocks = blockIdx % 8 == " + std::to_string(r[10]);
     if (site == kXcdSiteClosing) s += ", arrivals seen " + std::to_string(missing) + " of " + std::to_string(r[11]);
-    else if (site >= kXcdSitePushOwner && site <= kXcdSitePushCost) s += ", ranks still missing " + hex_mask(missing) + ", exchange step " + std::to_string(r[6]);
+    else if (site >= kXcdSitePushOwner && site <= kXcdSitePushCost) {
+        s += ", ranks still missing " + hex_mask(missing & 0xffffffffull) + ", exchange step " + std::to_string(r[6]) + ", parameter index " + std::to_string(r[5]);
+        // what THIS rank's memory holds at the awaited words now (read by the host, behind the drained stream): a word carrying the awaited
+        // step means the peer's store arrived and the poll did not see it; an older step means it never arrived
+        if (with_tables && c->p2p.local_buf && c->p2p.stride) {
+            const size_t stride = c->p2p.stride, idx0 = r[5];
+            const unsigned par = r[6] & 1u;
+            const char* base = (const char*)c->p2p.local_buf + c->p2p.push_off;
+            auto words = [&](size_t row, int n) {
+                unsigned long long wv[4] = {0, 0, 0, 0};
+                std::string t;
+                if (idx0 + (size_t)n <= stride && hipMemcpy(wv, base + (row * stride + idx0) * 8, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess)
+                    for (int i = 0; i < n; ++i) t += " " + std::to_string((unsigned)(wv[i] >> 32));
+                return t;
+            };
+            const int n = site == kXcdSitePushOwner || site == kXcdSitePushMember ? 4 : 1;
+            if (site == kXcdSitePushMember) s += "; steps found in this rank's totals words:" + words((size_t)2 * kP2PMaxWorld + par, n);
+            else
+                for (int q = 0; q < kP2PMaxWorld; ++q)
+                    if ((missing >> q) & 1u) s += "; steps found in this rank's row of rank " + std::to_string(q) + ":" + words((size_t)par * kP2PMaxWorld + (size_t)q, n);
+        }
+    }
     else s += std::string(site == kXcdSitePlacement ? ", workers absent / elsewhere " : ", producers still behind ") + hex_mask(missing) + ", awaited tag " + std::to_string(r[6]);
     if (with_tables && c->xcdbuf.p && c->xcd_B) {
         // the tables as the failed launch left them (one word per 128-byte line): XCC answers, newest tags per producer, committed ids
@@ -190,10 +212,10 @@ int xcd_launch_bt(rcn_hip_ctx* c, const T* xs, const T* ys, size_t B, size_t nb,
         // (the data-parallel form exists for whole instantiation sizes: a shard of 32 / 64 / 128 / 256 samples per rank, f32)
         if constexpr (FULL && sizeof(T) == 4) {
             bool clocked = false;
-            if constexpr (BT == 256) {
+            if constexpr (BT == 256 || BT == 128) {
                 if (c->opt.xcd_dp_phase) {          // diagnostic: the same launch with per-worker phase clocks (rcn_hip_dp_phase_us)
                     HIP_TRY(c, hipMemsetAsync(xb.phase, 0, (size_t)kXcdWorkers * 4 * sizeof(long long), c->stream));
-                    RCN_XCD_LAUNCH((k_xcd_epoch<float, 256, true, true, false, false, true>), to + 2 * p2p_timeout_ticks(c),
+                    RCN_XCD_LAUNCH((k_xcd_epoch<float, BT, true, true, false, false, true>), to + 2 * p2p_timeout_ticks(c),
                                    (XcdDpOn{PushDesc{p2p_desc(c), c->p2p.stride, c->p2p.push_off}, c->p2p.seq + 1, p2p_timeout_ticks(c)}));
                     clocked = true;
                 }

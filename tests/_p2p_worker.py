@@ -32,6 +32,9 @@ def main():
     import torch
     import torch.distributed as dist
     import mercer_research_amd as amd
+    if os.environ.get("RCN_TEST_LIB"):                      # (diagnostic: tools/dp_probe.py runs a case on a variant build of the library)
+        from mercer_research_amd import _lib as _l
+        _l.LIB_PATH = os.environ["RCN_TEST_LIB"]
     from mercer_research_amd.device import DeviceRCN
     from oracle.rcn_oracle import synthetic_params     # data generator only
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -102,6 +105,12 @@ def main():
         # step (rcn_hip_epoch_begin_dev + rcn_hip_dp_epoch_steps_dev), and let every kernel of a call drain before the next call.
         # With a GPU per rank none of this matters and rcn_hip_dp_train_epoch_dev does both.
         order = d.to_device(np.arange(Bs * nb, dtype=np.int32))
+        if os.environ.get("RCN_TEST_L2_SWEEP") == "1":         # (diagnostic, tools/dp_probe.py: stream 256 MB through every XCD's L2 before the first exchange)
+            with torch.cuda.stream(d.stream):
+                big = torch.ones(64 << 20, dtype=torch.float32, device=d.device)
+                chk = (big * 2.0).sum()
+            d.synchronize()
+            del big, chk
         try:
             for ep, (first, n, ls) in enumerate(((0, nb, loss), (0, 2, None), (2, nb - 2, None))):   # the second epoch in two calls
                 if first == 0:
@@ -114,8 +123,9 @@ def main():
         except amd.RcnHipError:
             # an expired wait names its site (rcn_hip_last_timeout): kept beside the outputs so that the test -- and whoever reads a
             # first multi-GPU run -- sees which wait, which worker, which peer, and where every worker of this rank sat
-            import json
+            import json, time
             rec = d.last_timeout()
+            rec["host_time_of_failure"] = round(time.time(), 3)   # (two ranks failing ~one time-out apart = their kernels ran one after the other)
             with open(os.path.join(outdir, f"timeout{rank}.json"), "w") as f:
                 json.dump(rec, f)
             print(f"TIMEOUT rank {rank}: {json.dumps(rec)}", flush=True)
@@ -142,7 +152,7 @@ def main():
     gw, gb = d.get_params()
     d.synchronize()
     phase = np.zeros(8)
-    if mode != 0 and resident and Bs == 256 and case_name == "default":
+    if mode != 0 and resident and Bs in (128, 256) and case_name == "default":
         # the diagnostic a first multi-GPU run would use: one more call with per-worker phase clocks (rcn_hip_dp_phase_us); the results above
         # are already taken, the parameters move on by these steps on every rank alike
         d.set_option("xcd_dp_phase", 1)

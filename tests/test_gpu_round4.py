@@ -321,10 +321,15 @@ def test_steps_on_index_rows_the_caller_wrote_are_not_replayed_silently(amd, ora
 @pytest.mark.parametrize("world,Bs", [(2, 256), (2, 128)], ids=["2-ranks-shard-256-the-bench-shard", "2-ranks-shard-128"])
 def test_resident_data_parallel_form_at_the_bench_shard_between_processes(amd, oracle, tmp_path, world, Bs):
     """bench.py --gpus N runs 256 images per rank: k_xcd_epoch<float, 256, true, true> -- 32 workers, 25 owners of slice pairs, 148 KB of
-    LDS each -- had exchanged between processes only at shards of 64 and 32.  Two processes on this box's one device, rank r's workers on
-    PHYSICAL XCD r (xcd_select = 8 + r): each rank's 32 workers fill their XCD's 32 CUs, and a rank's 32 idle blocks bound for the peer's
-    XCD can only start once the peer's workers have left -- which works because every XCD dispatches its share of a launch on its own.
-    Replicas bit-identical; two epochs equal the oracle's train_batch on the concatenated global batches."""
+    LDS each.  Between processes on ONE device that shard is opt-in (RCN_TEST_DP_SHARD256_ON_ONE_GPU=1): a rank's 32 workers fill their
+    XCD, the peer's launch has 32 blocks bound for that XCD which cannot be placed, and the dispatcher does not run past them -- the two
+    kernels run one after the other and every wait expires.  Measured, not guessed (profiles/r4_dp_shard256_two_process_probe.txt: 10 of
+    20 runs expired; the two ranks fail exactly one time-out apart and the early one finds the late one's words in its memory right after
+    giving up).  What the case would add over the shards that DO run here is little: the exchange's indices (woff0, wvalid, the tail
+    tiles' tp, the cost's P) do not depend on the batch instantiation -- shards of 128 (default-on here), 64 and 32 push the same words.
+    Two processes, rank r's workers on PHYSICAL XCD r: replicas bit-identical; two epochs equal the oracle on the concatenated batches."""
+    if Bs == 256 and os.environ.get("RCN_TEST_DP_SHARD256_ON_ONE_GPU") != "1":
+        pytest.skip("two resident kernels of 32 workers each on ONE device serialise (profiles/r4_dp_shard256_two_process_probe.txt); RCN_TEST_DP_SHARD256_ON_ONE_GPU=1 runs it")
     from test_gpu_round3 import _oracle_global_epochs, _spawn_ranks
     nb, dims = 3, (784, 30, 10)
     env = {"RCN_HIP_XCD_TIMEOUT_TICKS": "400000000", "RCN_HIP_DP_TIMEOUT_TICKS": "400000000"}
@@ -340,7 +345,7 @@ def test_resident_data_parallel_form_at_the_bench_shard_between_processes(amd, o
     for a, b in zip([outs[0]["w0"], outs[0]["w1"], outs[0]["b0"], outs[0]["b1"]], [rw[0], rw[1], rb[0], rb[1]]):
         assert np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-5), float(np.abs(a - b).max())
     np.testing.assert_allclose(outs[0]["loss"], costs, rtol=1e-4)
-    if Bs == 256:
+    if Bs in (128, 256):
         # the phase clocks of a diagnostic launch (rcn_hip_dp_phase_us): owners and members waited a finite, positive time per step, the
         # launch ran nb steps, and with two ranks both roles exist on each (worker w's owner is rank w % 2)
         for o in outs:
