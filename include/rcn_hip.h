@@ -332,7 +332,8 @@ int  rcn_hip_fallbacks_taken(const rcn_hip_ctx* ctx);      /* not a status: the 
  * gave up (csrc/dense_xcd.hpp: xcd_raise), kept after the library has healed the context.  words[0..12] = site (1 placement vote,
  * 2 tail-tile flag, 3 slab flag, 4 delta flag, 5 pushed reduce-scatter, 6 pushed all-gather, 7 tail all-to-all, 8 cost all-to-all,
  * 9 closing round), worker, step within the launch, launch id, missing producers / workers / ranks (low, high 32 bits; closing round:
- * the arrivals seen), awaited tag or exchange step, XCC_ID of the worker, rank, world, which blocks were workers (blockIdx % 8), workers
+ * the arrivals seen; sites 5-8: the low word is the rank mask, the high word the waiting lane's first parameter index -- the text then
+ * also says which exchange steps this rank's memory holds at the awaited words), awaited tag or exchange step, XCC_ID of the worker, rank, world, which blocks were workers (blockIdx % 8), workers
  * of the launch, error code (1 expired, 2 workers on different XCDs).  Returns the number of words written, 0 when nothing is on record.
  * _text: the same in words plus the workspace's placement / flag tables as the failed launch left them ("" when nothing is on record). */
 int  rcn_hip_last_timeout(const rcn_hip_ctx* ctx, uint32_t* words, size_t cap);

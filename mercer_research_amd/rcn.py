@@ -164,7 +164,11 @@ class RCN:
             return None
         rec = {k: int(w[i]) for i, k in enumerate(self.TIMEOUT_FIELDS[:n])}
         rec["step"] = rec["step"] - (1 << 32) if rec["step"] >= (1 << 31) else rec["step"]
-        rec["missing"] = rec.pop("missing_lo") | (rec.pop("missing_hi") << 32)
+        lo, hi = rec.pop("missing_lo"), rec.pop("missing_hi")
+        if 5 <= rec["site"] <= 8:                                   # pushed exchange: rank mask, and the waiting lane's first parameter index
+            rec["missing"], rec["param_index"] = lo, hi
+        else:
+            rec["missing"] = lo | (hi << 32)
         rec["text"] = (self._lib.rcn_hip_last_timeout_text(self._ctx) or b"").decode()
         return rec
 

@@ -171,7 +171,7 @@ impl std::error::Error for HipError {}
 
 /// `rcn_hip_last_timeout`: site 1 placement vote, 2 tail-tile flag, 3 slab flag, 4 delta flag, 5 pushed reduce-scatter, 6 pushed all-gather,
 /// 7 tail all-to-all, 8 cost all-to-all, 9 closing round; `missing` = the producers / workers / ranks the wait was still missing
-/// (closing round: the arrivals seen); `text` adds the workspace's placement and flag tables as the failed launch left them.
+/// (closing round: the arrivals seen; sites 5-8: rank mask in the low half, the waiting lane's first parameter index in the high half); `text` adds the workspace's placement and flag tables as the failed launch left them.
 #[derive(Debug, Clone)]
 pub struct TimeoutRecord {
     pub site: u32,
