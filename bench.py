@@ -158,6 +158,10 @@ def main():
     ap.add_argument("--dp", action="store_true", help="use the data-parallel step (gradient -> all-reduce -> apply) even at world size 1")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous the ranks over gloo on the CPU and print the line; no GPU work")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the spawning parent waits for its ranks")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="DIAGNOSTIC, not a measurement: run the N > 1 flow of this script -- rehearsal, voted trial of the exchange forms, timed loop, replica check, "
+                         "phase clocks -- with all N ranks on GPU 0 (gloo carries the votes, the library's admission runs over it, every rank's resident workers sit on "
+                         "a physical XCD of their own, shards of 128 so that the peers' other kernels find free CUs); what a one-GPU box can check of that flow before a node runs it")
     args = ap.parse_args()
 
     from mercer_research_amd.launch import spawn_ranks, under_launcher
@@ -184,8 +188,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0                                    # every rank on this box's one GPU; RCCL refuses two ranks on one device: gloo
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = world
 
     import mercer_research_amd as amd
@@ -203,8 +212,15 @@ def main():
         imgs_d = torch.from_numpy(imgs).to(d.device)
         labels_d = torch.from_numpy(labels).to(d.device)
     X, Y = d.load_data(imgs_d, labels_d)                                 # HIP features + gen_scales + standardise (load time)
-    nb_epoch = N_IMAGES // B_PER_GPU
-    B = B_PER_GPU
+    rehearse = bool(use_dp and args.rehearse_on_one_gpu and world > 1)
+    B = 128 if rehearse else B_PER_GPU                       # (rehearsal: 28 workers per rank leave four CUs of an XCD free for the peers' other kernels)
+    nb_epoch = N_IMAGES // B
+    vdev = torch.device("cpu") if rehearse else d.device     # where the small vote / timing tensors of torch.distributed live
+    if rehearse:
+        d.set_option("xcd_select", 8 + rank % 8)
+        d.set_option("xcd_exact_lds", 1)
+        d.set_option("xcd_timeout_ticks", 400000000)
+        d.set_option("dp_timeout_ticks", 400000000)
     step_no = [0]
     epoch_no = [0]
     perm = torch.empty(N_IMAGES, dtype=torch.int32, device=d.device)
@@ -287,14 +303,21 @@ def main():
         # one process per GPU: every rank shuffles its own resident shard of the data, takes 256 rows per step, and the
         # summed shard gradients meet once per step (xGMI peer exchange inside the kernels, or ONE ncclAllReduce of the flat
         # parameter-shaped buffer)
+        def bcast_params():
+            if not rehearse:                  # (rehearsal: no RCCL communicator -- every rank sets the identical seed-42 parameters itself)
+                d.dp_broadcast_params(0)
+
         def dp_native_setup() -> bool:
             try:
-                d.dp_init()                   # RCCL communicator owned by the library; torch only carried its 128-byte id
-                ok = 1
+                if rehearse:
+                    ok = 1 if d.dp_p2p_admit() != 0 else 0      # the library's admission procedure with gloo as its transport
+                else:
+                    d.dp_init()               # RCCL communicator owned by the library; torch only carried its 128-byte id
+                    ok = 1
             except Exception as e:            # e.g. librccl not loadable: every rank falls back together
                 print(f"[bench] native data-parallel loop unavailable on rank {rank}: {e}", file=sys.stderr, flush=True)
                 ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
+            flag = torch.tensor([ok], dtype=torch.int32, device=vdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return bool(flag.item())
 
@@ -340,6 +363,7 @@ def main():
                 pf = d.params_flat().to(torch.float64)
                 chk = torch.stack([pf.sum(), (pf * pf).sum(), pf.abs().max()])
             d.stream.synchronize()
+            chk = chk.to(vdev)
             lo, hi = chk.clone(), chk.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -356,7 +380,7 @@ def main():
                 print(f"[bench] rank {rank}: data-parallel loop failed its rehearsal: {e}", file=sys.stderr, flush=True)
                 note_timeout("rehearsal")
                 ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
+            flag = torch.tensor([ok], dtype=torch.int32, device=vdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             same = replicas_check() if flag.item() else False
             return bool(flag.item()) and same
@@ -371,7 +395,7 @@ def main():
                 print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
                 note_timeout("a voted stretch")
                 ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=d.device)
+            flag = torch.tensor([ok], dtype=torch.int32, device=vdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return bool(flag.item()), val
 
@@ -391,7 +415,7 @@ def main():
                 if d.dp_p2p_mode() != 0 and d.dp_resident(B):
                     resident_offered = True
                     d.set_dense_path(2)                     # same group, the exchange between the halves of the two-kernel pipeline
-                d.dp_broadcast_params(0)
+                bcast_params()
                 allreduce_kind = dp_kind()
             else:
                 allreduce_kind = "torch.distributed all_reduce (RCCL)"
@@ -400,6 +424,8 @@ def main():
             if healthy(rehearsal):
                 break
             fallbacks.append(allreduce_kind)
+            if rehearse:
+                raise SystemExit(f"[bench] one-GPU rehearsal: the form '{allreduce_kind}' failed its rehearsal (RCCL / torch fall-backs need a GPU per rank)")
             if args.dp_impl != "native":
                 raise SystemExit("[bench] the torch.distributed data-parallel loop failed its rehearsal too")
             was_p2p = d.dp_p2p_mode() != 0
@@ -430,7 +456,7 @@ def main():
 
             def timed_trial(k: int):
                 ok, el = voted(lambda: stretch(k))
-                t = torch.tensor([el if ok and el is not None else float("inf")], dtype=torch.float64, device=d.device)
+                t = torch.tensor([el if ok and el is not None else float("inf")], dtype=torch.float64, device=vdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 return ok, float(t.item()) * 1e6 / k
 
@@ -439,7 +465,7 @@ def main():
             reset_session()
             ok_sw, _ = voted(lambda: d.set_dense_path(0))
             if ok_sw:
-                d.dp_broadcast_params(0)
+                bcast_params()
             ok_res = ok_sw and healthy(rehearsal)
             t_res = float("inf")
             if ok_res:
@@ -463,11 +489,11 @@ def main():
                     d.set_dense_path(2)
             dp_form_trial["kept"] = "resident kernel" if keep_resident else "two-kernel pipeline"
             reset_session()
-            d.dp_broadcast_params(0)
+            bcast_params()
             if not healthy(rehearsal):
                 raise SystemExit("[bench] the selected data-parallel form failed its final rehearsal")
             reset_session()
-            d.dp_broadcast_params(0)
+            bcast_params()
             allreduce_kind = dp_kind()
 
     def sync():
@@ -500,7 +526,7 @@ def main():
         sync()
         dev_ms = ev0.elapsed_time(ev1)
         if use_dp:
-            t = torch.tensor([el], dtype=torch.float64, device=d.device)
+            t = torch.tensor([el], dtype=torch.float64, device=vdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, dev_ms
@@ -610,7 +636,9 @@ def main():
         "value": round(images / elapsed, 1), "unit": "images/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": WORKLOAD,
+        "config": {"workload": WORKLOAD if not rehearse else WORKLOAD.replace("B=256 per GPU", "B=128 per rank (ONE-GPU REHEARSAL)"),
+                   **({"one_gpu_rehearsal": f"DIAGNOSTIC, NOT A MEASUREMENT: all {world} ranks share GPU 0 (gloo votes, the library's admission over gloo, rank r's resident "
+                                            "workers on physical XCD r, shards of 128); it exercises this script's N > 1 flow, its numbers mean nothing"} if rehearse else {}),
                    "global_batch": B * world, "parallelism": f"dp{world}", "step_form": f"gradient -> exchange -> apply ({args.dp_impl} loop)" if use_dp else "fused update", "images_per_rank": N_IMAGES,
                    "session": f"steps {args.warmup}..{args.warmup + args.steps} of one continuous training session (64 steps per epoch; device shuffle "
                               + ("at every epoch boundary, rows fetched by the step kernel itself in the shuffled order -- no packed copy of the epoch"
