@@ -511,3 +511,27 @@ def test_the_drop_in_call_sequence_in_f64_at_batch_size_10_runs_on_the_resident_
         assert np.all(np.abs(a - b) <= 1e-10 * np.abs(b) + 1e-11)
     assert r.fallbacks_taken() == 0
     r.close()
+
+
+def test_bench_n2_flow_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2 --rehearse-on-one-gpu`: the script's N > 1 flow -- admission, rehearsal of the two-kernel form, the voted trial of
+    the resident form, the timed loop (barrier, max over ranks), the replica check, the clocked diagnostic epoch -- executed by two real
+    processes on this box's GPU (gloo votes, shards of 128, rank r's workers on physical XCD r).  A diagnostic of the FLOW the driver
+    would start on a node; its numbers mean nothing and the line says so."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "64", "--warmup", "16"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    c = j["config"]
+    assert j["n_gpus"] == 2 and j["steps"] == 64 and c["parallelism"] == "dp2" and "one_gpu_rehearsal" in c
+    assert c["replicas_identical"] is True and c["dp_fallbacks_taken"] == [] and c["dp_timeout_site"] is None
+    assert c["dp_form_trial"]["kept"] in ("resident kernel", "two-kernel pipeline") and c["dp_form_trial"]["resident_healthy"] is True
+    if c["dp_form_trial"]["kept"] == "resident kernel":
+        ph = c["dp_phase_us"]
+        assert ph and ph["steps"] == 128 and ph["owner_wait_mean"] > 0 and ph["member_wait_mean"] > 0 and c["dp_rs_wait_us"] == ph["owner_wait_mean"]
+    assert j["value"] > 0 and np.isfinite(c["final_cost_rank0"])
