@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 from bench import csrc_sha16          # the fingerprint bench.py compares with: the sources librcn_hip.so is built from
 shutil.copy(one(f"{G}/prof4_stats/**/*kernel_stats.csv"), "profiles/r4_bench_kernel_stats.csv")
 for f in ("r4_bench_n1.json", "r4_bench_n1_steps20.json", "r4_bench_under_rocprof.json"):
-    shutil.copy(f"{G}/{f}", f"profiles/{f}")
+    line = [l for l in open(f"{G}/{f}").read().splitlines() if l.startswith("{")][-1]      # (a log of the run may precede the line)
+    open(f"profiles/{f}", "w").write(line + "\n")
 tr = list(csv.DictReader(open(one(f"{G}/prof4_stats/**/*kernel_trace.csv"))))
 by = {}
 for r in tr:
