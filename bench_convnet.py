@@ -34,8 +34,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
-                    help="GEMM operand precision of forward / dgrad: fp32 MFMA, or bf16 MFMA with fp32 accumulate / storage / update")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_stored"], default="fp32",
+                    help="GEMM operand precision of forward / dgrad: fp32 MFMA, bf16 MFMA with fp32 accumulate / storage / update, or bf16 MFMA with the "
+                         "convolutional stage's activations and gradients also STORED as bf16 (RCN_HIPX_BF16_STORED)")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (gradients -> all-reduce -> apply) even at one GPU: a group of one over RCCL")
     ap.add_argument("--dp-graph", type=int, default=1, help="data-parallel step: 1 = replay it as a captured hipGraph (the all-reduce inside), 0 = launch it eagerly")
     ap.add_argument("--dp-buckets", type=int, default=1 << 20, help="data-parallel step: gradient buckets of at least this many bytes, each all-reduced on a second stream "
@@ -162,7 +163,7 @@ def main():
         # the peak a fraction is quoted against is the peak of the MFMA the GEMMs actually issue: fp32 MFMA (157.3 TF) in fp32
         # mode, dense bf16 MFMA (~2.5 PF) in bf16 mode -- and for the bf16 path, which is HBM-bound, the step's HBM floor
         # (every activation and activation gradient written once and read once per pass, as stored) is the more telling roof
-        bf16 = args.precision == "bf16"
+        bf16 = args.precision != "fp32"
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS
         floor_bytes = net.step_hbm_floor_bytes(B) if hasattr(net, "step_hbm_floor_bytes") else None
         floor_ms = floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 if floor_bytes else None

@@ -47,8 +47,16 @@ int  rcn_hipx_classes(const rcn_hipx_net* net);
  * units).  RCN_HIPX_FP32 (default): fp32 MFMA
  * (v_mfma_f32_32x32x2_f32), exact fp32 products.  RCN_HIPX_BF16: operands rounded to bf16 on their way into LDS,
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations, gradients, parameters and the SGD update stay fp32 in HBM.
- * Results then agree with an f64 evaluation to ~1e-2 relative instead of ~1e-4. */
-enum { RCN_HIPX_FP32 = 0, RCN_HIPX_BF16 = 1 };
+ * Results then agree with an f64 evaluation to ~1e-2 relative instead of ~1e-4.
+ * RCN_HIPX_BF16_STORED: RCN_HIPX_BF16, and the convolutional stage's tensors -- every convolution's and pool's output map and its
+ * gradient -- are KEPT in HBM as bf16 (parameters, dense-layer tensors, the input batch, the SGD update stay fp32).  What the
+ * arithmetic rounds is the same as in RCN_HIPX_BF16 -- every consumer of those tensors rounds them to bf16 on the way into LDS anyway
+ * -- with two exceptions: the first layer's weight gradient (fp32 kernel) and every layer's bias gradient (summed in fp32 from dZ)
+ * now see dZ already rounded.  The stage's HBM traffic halves.  Covers nets whose first layer has 1 or 3 input channels, whose other
+ * convolutions run on the LDS-tiled bf16 kernels (32 or a multiple of 64 input channels, options "halo" and "bf16_pipe" on) and
+ * whose pools are fused into the convolution in front of them (even maps); rcn_hipx_set_precision walks the net's plan first and
+ * returns -3 -- nothing changed -- with the reason in rcn_hipx_last_error if a layer is not covered. */
+enum { RCN_HIPX_FP32 = 0, RCN_HIPX_BF16 = 1, RCN_HIPX_BF16_STORED = 2 };
 int  rcn_hipx_set_precision(rcn_hipx_net* net, int mode);
 /* logical layout, host memory, all layers back to back: W_0[K][Cout], b_0[Cout], W_1 ... */
 /* Which fp32 3x3 convolution kernels run (bf16 mode has its own rule).  GEMM: the implicit-GEMM kernels only.  AUTO (default): the

@@ -71,6 +71,9 @@ class ConvNetError(RuntimeError):
 DEFAULT_BUCKET_BYTES = 1 << 20      # gradient buckets of the data-parallel step: at least 1 MiB each (a ring all-reduce below that is latency)
 
 
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_stored": 2}
+
+
 def plan(in_shape: Tuple[int, int, int], layers: Sequence[tuple], batch: int, precision: str = "fp32", tiling: str = "auto", buckets: Optional[int] = None) -> str:
     """Which kernels a training step of this net would launch, one line per launch (rcn_hipx_plan): the library's own dispatch code run
     with its launches replaced by notes.  Needs no GPU.  buckets = N: the bucketed GRADIENT step of a data-parallel rank instead
@@ -81,12 +84,12 @@ def plan(in_shape: Tuple[int, int, int], layers: Sequence[tuple], batch: int, pr
         arr[i].kind, arr[i].out = KIND[l[0]], int(l[1]) if len(l) > 1 else 0
     buf = C.create_string_buffer(1 << 16)
     if buckets is not None:
-        st = lib.rcn_hipx_plan_buckets(in_shape[0], in_shape[1], in_shape[2], arr, len(layers), batch, {"fp32": 0, "bf16": 1}[precision], {"gemm": 0, "auto": 1, "lds": 2}[tiling],
+        st = lib.rcn_hipx_plan_buckets(in_shape[0], in_shape[1], in_shape[2], arr, len(layers), batch, PRECISIONS[precision], {"gemm": 0, "auto": 1, "lds": 2}[tiling],
                                        int(buckets), buf, len(buf))
         if st != 0:
             raise ConvNetError(f"rcn_hipx_plan_buckets: {st}: {buf.value.decode()}")
         return buf.value.decode()
-    st = lib.rcn_hipx_plan(in_shape[0], in_shape[1], in_shape[2], arr, len(layers), batch, {"fp32": 0, "bf16": 1}[precision], {"gemm": 0, "auto": 1, "lds": 2}[tiling], buf, len(buf))
+    st = lib.rcn_hipx_plan(in_shape[0], in_shape[1], in_shape[2], arr, len(layers), batch, PRECISIONS[precision], {"gemm": 0, "auto": 1, "lds": 2}[tiling], buf, len(buf))
     if st != 0:
         raise ConvNetError(f"rcn_hipx_plan: {st}: {buf.value.decode()}")
     return buf.value.decode()
@@ -140,8 +143,9 @@ class ConvNet:
         self._ck(self.lib.rcn_hipx_synchronize(self.net))
 
     def set_precision(self, mode: str):
-        """"fp32" (fp32 MFMA, default) or "bf16" (bf16 MFMA operands, fp32 accumulate / storage / update)."""
-        self._ck(self.lib.rcn_hipx_set_precision(self.net, {"fp32": 0, "bf16": 1}[mode]))
+        """"fp32" (fp32 MFMA, default), "bf16" (bf16 MFMA operands, fp32 accumulate / storage / update) or "bf16_stored" (bf16 operands
+        AND the convolutional stage's activations / gradients kept in HBM as bf16: include/rcn_hipx.h, RCN_HIPX_BF16_STORED)."""
+        self._ck(self.lib.rcn_hipx_set_precision(self.net, PRECISIONS[mode]))
 
     def set_tiling(self, mode: str):
         """fp32 3x3 kernels: "gemm" (implicit GEMM only), "auto" (by shape, the default) or "lds" (LDS-tiled wherever they apply)."""

@@ -27,6 +27,24 @@ namespace rcnx {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// Storage type of an activation / gradient tensor of the convolutional stage: float, or __bf16 (rcn_hipx_set_precision
+// RCN_HIPX_BF16_STORED: every consumer of these tensors rounds them to bf16 on the way into LDS anyway, so storing them rounded halves
+// the stage's HBM traffic and changes the arithmetic only where the first layer's fp32 weight-gradient kernel reads dZ).
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+template <typename TS> struct Chunk4;
+template <> struct Chunk4<float> { using type = f32x4; };
+template <> struct Chunk4<__bf16> { using type = bf16x4; };
+template <typename TS> using chunk4_t = typename Chunk4<TS>::type;      // four consecutive channels as they lie in memory
+__device__ inline f32x4 widen4(const f32x4& v) { return v; }
+__device__ inline f32x4 widen4(const bf16x4& v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+__device__ inline float widen(float v) { return v; }
+__device__ inline float widen(__bf16 v) { return (float)v; }
+template <typename TS> __device__ inline TS narrow(float v) { return (TS)v; }                      // (float -> __bf16: round to nearest even)
+template <typename TS> __device__ inline chunk4_t<TS> narrow4(const f32x4& v);
+template <> __device__ inline f32x4 narrow4<float>(const f32x4& v) { return v; }
+template <> __device__ inline bf16x4 narrow4<__bf16>(const f32x4& v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
+
+
 constexpr int kBM = 128, kBK = 32, kThreads = 256;
 constexpr int kLdA = kBK + 1;
 
@@ -61,8 +79,8 @@ __device__ inline ARows decode_rows(const ConvShape& s, long long M, long long m
 }
 
 // A-tile element source: row m of the implicit im2col matrix, K-tile kt (32 consecutive k)
-template <int KS, bool SMALLC>
-__device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape& s, const ARows& rows, int kt, int tid, f32x4 (&v)[4]) {
+template <int KS, bool SMALLC, typename TX = float>
+__device__ inline void load_a_regs(const TX* __restrict__ X, const ConvShape& s, const ARows& rows, int kt, int tid, f32x4 (&v)[4]) {
     // thread t loads rows (t>>3) + 32 q, q = 0..3, columns 4*(t&7) .. +3 of the 128 x 32 tile
     const int c4 = (tid & 7) * 4;
     if (!SMALLC) {
@@ -73,7 +91,7 @@ __device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape&
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool ok = rows.base[q] >= 0 && (unsigned)(rows.oh[q] + dh) < (unsigned)s.H && (unsigned)(rows.ow[q] + dw) < (unsigned)s.W;
-            const f32x4 val = *reinterpret_cast<const f32x4*>(X + (ok ? rows.base[q] + toff : 0));     // unconditional load, masked by value
+            const f32x4 val = widen4(*reinterpret_cast<const chunk4_t<TX>*>(X + (ok ? rows.base[q] + toff : 0)));     // unconditional load, masked by value
             v[q] = ok ? val : f32x4{0, 0, 0, 0};
         }
     } else {
@@ -104,7 +122,7 @@ __device__ inline void load_a_regs(const float* __restrict__ X, const ConvShape&
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = rows.base[q] >= 0 && kv[i] && (unsigned)(rows.oh[q] + dh[i]) < (unsigned)s.H && (unsigned)(rows.ow[q] + dw[i]) < (unsigned)s.W;
-                const float x = X[ok ? rows.base[q] + off[i] : 0];                  // unconditional load, masked by value
+                const float x = widen(X[ok ? rows.base[q] + off[i] : 0]);           // unconditional load, masked by value
                 val[i] = ok ? x : 0.f;
             }
             v[q] = val;
@@ -416,14 +434,16 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
 }
 
 // split-K epilogue: Y[m][co] = act(bias[co] + sum_z part[z][m][co]), z in order
-__global__ void k_splitk_epilogue(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ Y, long long MN, int Cout, int Z, int epi) {
+// TY: storage type of Y and of epi 3's gate tensor (which arrives through `bias`)
+template <typename TY = float>
+__global__ void k_splitk_epilogue(const float* __restrict__ part, const float* __restrict__ bias, TY* __restrict__ Y, long long MN, int Cout, int Z, int epi) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < MN; e += (long long)gridDim.x * blockDim.x) {
         float v = 0.f;
         for (int z = 0; z < Z; ++z) v += part[(long long)z * MN + e];
         if (epi == 1 || epi == 2) v += bias[(int)(e % Cout)];
         if (epi == 2) v = v > 0.f ? v : 0.f;
-        if (epi == 3) v = bias[e] > 0.f ? v : 0.f;
-        Y[e] = v;
+        if (epi == 3) v = widen(reinterpret_cast<const TY*>(bias)[e]) > 0.f ? v : 0.f;
+        Y[e] = narrow<TY>(v);
     }
 }
 
@@ -646,11 +666,13 @@ namespace rcnx {
 //     dZ[n, y, x, c] = (arg-max of its window == (y & 1, x & 1) && pooled value > 0) ? dP[n, y/2, x/2, c] : 0
 // (k_pool_bwd); the LDS-tiled kernels can rebuild it while staging instead of reading a full-resolution copy that another
 // kernel wrote: three reads at quarter resolution (4 + 4 + 1 bytes per channel) replace one write and one read of 4 x 4.
-struct PooledGrad {
-    const float* dP;          // [N][H/2][W/2][C] gradient wrt the pooled map; nullptr: the tensor is materialised, read it directly
-    const float* P;           // pooled activations (the ReLU gate)
+template <typename TS> struct PooledGradT {
+    const TS* dP;             // [N][H/2][W/2][C] gradient wrt the pooled map; nullptr: the tensor is materialised, read it directly
+    const TS* P;              // pooled activations (the ReLU gate)
     const uint8_t* idx;       // arg-max position 0..3 = dy * 2 + dx
 };
+using PooledGrad = PooledGradT<float>;
+
 
 // The full-resolution values of one pooled gradient chunk (four channels): position pos = dy * 2 + dx of the window gets the pooled
 // gradient where it was the arg-max and the pooled activation is positive (k_pool_bwd's rule), zero elsewhere.  All four positions at

@@ -74,9 +74,10 @@ __device__ inline bf16x4 to_bf16x4(const f32x4& v) {
 // kernels use them too)
 
 // Same tiling, split-K and epilogues as k_conv_fwd; WB = weights as bf16 [Cout][Kp], Kp = K rounded up to 32
-template <int KS, bool SMALLC, int BN, int EPI>
-__global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restrict__ X, const __bf16* __restrict__ WB,
-                                                            const float* __restrict__ bias, float* __restrict__ Y, ConvShape s) {
+// TX / TY: storage types of X and of Y (and of EPI 3's gate tensor, which arrives through `bias`); a split-K launch writes float partials
+template <int KS, bool SMALLC, int BN, int EPI, typename TX = float, typename TY = float>
+__global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const TX* __restrict__ X, const __bf16* __restrict__ WB,
+                                                            const float* __restrict__ bias, TY* __restrict__ Y, ConvShape s) {
     constexpr int NT = BN / 32;
     constexpr int BCH = (BN * 4 + kThreads - 1) / kThreads;          // 16-byte chunks of the B tile per thread
     __shared__ __attribute__((aligned(16))) __bf16 As[2][kBM * kLdH];
@@ -122,14 +123,14 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
     };
 
     const ARows rows = decode_rows(s, M, m0, tid);
-    load_a_regs<KS, SMALLC>(X, s, rows, kt0, tid, av);
+    load_a_regs<KS, SMALLC, TX>(X, s, rows, kt0, tid, av);
     load_b(kt0);
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) {
-            load_a_regs<KS, SMALLC>(X, s, rows, kt0 + kt + 1, tid, av);
+            load_a_regs<KS, SMALLC, TX>(X, s, rows, kt0 + kt + 1, tid, av);
             load_b(kt0 + kt + 1);
         }
         const __bf16* a = &As[cur][(wave * 32 + (lane & 31)) * kLdH + 8 * (lane >> 5)];
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_fwd_bf16(const float* __restr
             if (m < M) {
                 float v = acc[t][r] + bb;
                 if (EPI == 2) v = v > 0.f ? v : 0.f;
-                if (EPI == 3) v = bias[m * s.Cout + co] > 0.f ? v : 0.f;      // dgrad: ReLU mask of the layer below, `bias` = its output
-                Y[m * s.Cout + co] = v;
+                if (EPI == 3) v = widen(reinterpret_cast<const TY*>(bias)[m * s.Cout + co]) > 0.f ? v : 0.f;      // dgrad: ReLU mask of the layer below, `bias` = its output
+                Y[m * s.Cout + co] = narrow<TY>(v);
             }
         }
     }
@@ -199,8 +200,9 @@ __device__ inline bf16x8 tr_fragment(const __bf16* img, int ld, int px0, int col
 // plain 8-byte stores of converted fp32 rows); the MFMA wants 8 consecutive contraction indices per lane, i.e. a column of
 // those images -- the hardware transposed read delivers exactly that, so no operand is ever transposed by software.
 // A k-block lies inside one filter tap (Cin % 32 == 0), different waves' blocks may be different taps.
-template <int KS, int BN, int NKB>
-__global__ __launch_bounds__(64 * NKB) void k_conv_wgrad_bf16(const float* __restrict__ X, const float* __restrict__ dZ,
+// TX: storage type of X (the first dense layer's input is the convolutional stage's last map)
+template <int KS, int BN, int NKB, typename TX = float>
+__global__ __launch_bounds__(64 * NKB) void k_conv_wgrad_bf16(const TX* __restrict__ X, const float* __restrict__ dZ,
                                                               float* __restrict__ slab, ConvShape s, int pix_per_chunk, WgradGrid gd) {
     constexpr int NT = BN / 32, kPT = 128, NTHR = 64 * NKB;
     constexpr int LDX = 32 * NKB + 8, LDD = BN + 8;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(64 * NKB) void k_conv_wgrad_bf16(const float* __res
         for (int q = 0; q < XCH; ++q) {
             const bool in = xlive && row_m < (int)p1;
             const bool ok = in && (unsigned)(row_oh + dh) < (unsigned)s.H && (unsigned)(row_ow + dw) < (unsigned)s.W;
-            const f32x4 val = *reinterpret_cast<const f32x4*>(X + (ok ? (long long)row_m * s.Cin + toff : 0));   // unconditional, masked by value
+            const f32x4 val = widen4(*reinterpret_cast<const chunk4_t<TX>*>(X + (ok ? (long long)row_m * s.Cin + toff : 0)));   // unconditional, masked by value
             xv[q] = ok ? val : f32x4{0, 0, 0, 0};
             row_m += 8; row_ow += adv_w; row_oh += adv_h;
             if (row_ow >= s.W) { row_ow -= s.W; ++row_oh; }
@@ -492,10 +494,14 @@ namespace rcnx {
 // k_conv_wgrad (row K = bias partial, fp32 sums of the unrounded dZ), so k_reduce_all finishes either.
 constexpr int kWgHaloThreads = 9 * 64;
 
-template <int CB, int BN, bool PDZ = false>
-__global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const float* __restrict__ X, const float* __restrict__ dZ,
+__device__ inline bf16x4 stored_bf16x4(const f32x4& v) { return to_bf16x4(v); }
+__device__ inline bf16x4 stored_bf16x4(const bf16x4& v) { return v; }
+
+// TS: storage type of X, dZ and the pooled gradient (convnet.hpp, Chunk4)
+template <int CB, int BN, bool PDZ = false, typename TS = float>
+__global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const TS* __restrict__ X, const TS* __restrict__ dZ,
                                                                        float* __restrict__ slab, ConvShape s, int tiles_w, int tiles_h,
-                                                                       int blocks_per_chunk, int n_chunks, PooledGrad pdz) {
+                                                                       int blocks_per_chunk, int n_chunks, PooledGradT<TS> pdz) {
     constexpr int NA = CB / 32, NT = BN / 32, LDC = CB + 8, LDD = BN + 8;
     constexpr int HH = kHaloTH + 2, HW = kHaloTW + 2, NPX = kHaloTH * kHaloTW;
     constexpr int HCH = HH * HW * (CB / 4), DCH = NPX * (BN / 4);
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
         hpk[q] = e < HCH ? (hy | (hx << 8)) : -1;
         hrel[q] = (hy * s.W + hx) * Cin + c4;
     }
-    f32x4 hv[NHQ], dv[NDQ], dpv = {0.f, 0.f, 0.f, 0.f};
+    chunk4_t<TS> hv[NHQ], dv[NDQ], dpv = {};
     unsigned dii = 0, okm = 0;
     auto gload = [&](int blk) {
         int q0 = blk;
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
             const int pk = hpk[q];
             const bool ok = pk >= 0 && (unsigned)(oh0 - 1 + (pk & 255)) < (unsigned)s.H && (unsigned)(ow0 - 1 + (pk >> 8)) < (unsigned)s.W;
             okm |= (ok ? 1u : 0u) << q;
-            hv[q] = *reinterpret_cast<const f32x4*>(X + (ok ? hbase + hrel[q] : 0));
+            hv[q] = *reinterpret_cast<const chunk4_t<TS>*>(X + (ok ? hbase + hrel[q] : 0));
         }
         if (PDZ) {
             const int pp = tid / (BN / 4), c4 = (tid - pp * (BN / 4)) * 4;
@@ -557,8 +563,8 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
             const bool ok = tid < 32 * (BN / 4) && poh < (s.H >> 1) && pow_ < (s.W >> 1);
             okm |= (ok ? 1u : 0u) << 16;
             const long long o = ok ? (((long long)img * (s.H >> 1) + poh) * (s.W >> 1) + pow_) * s.Cout + n0 + c4 : 0;
-            dv[0] = *reinterpret_cast<const f32x4*>(pdz.dP + o);
-            dpv = *reinterpret_cast<const f32x4*>(pdz.P + o);
+            dv[0] = *reinterpret_cast<const chunk4_t<TS>*>(pdz.dP + o);
+            dpv = *reinterpret_cast<const chunk4_t<TS>*>(pdz.P + o);
             dii = *reinterpret_cast<const unsigned*>(pdz.idx + o);
         } else {
 #pragma unroll
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
                 const int oh = oh0 + pix / kHaloTW, ow = ow0 + pix % kHaloTW;
                 const bool ok = e < DCH && oh < s.H && ow < s.W;
                 okm |= (ok ? 1u : 0u) << (16 + q);
-                dv[q] = *reinterpret_cast<const f32x4*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
+                dv[q] = *reinterpret_cast<const chunk4_t<TS>*>(dZ + (ok ? (((long long)img * s.H + oh) * s.W + ow) * s.Cout + n0 + c4 : 0));
             }
         }
     };
@@ -577,14 +583,14 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
         for (int q = 0; q < NHQ; ++q) {
             const int e = tid + kWgHaloThreads * q;
             const int pix = e / (CB / 4), c4 = (e - pix * (CB / 4)) * 4;
-            if (NHQ * kWgHaloThreads == HCH || e < HCH) *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = to_bf16x4(((okm >> q) & 1u) ? hv[q] : f32x4{0, 0, 0, 0});
+            if (NHQ * kWgHaloThreads == HCH || e < HCH) *reinterpret_cast<bf16x4*>(&Hs[pix * LDC + c4]) = ((okm >> q) & 1u) ? stored_bf16x4(hv[q]) : bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
         }
         if (PDZ) {
             if (tid < 32 * (BN / 4)) {
                 const int pp = tid / (BN / 4), c4 = (tid - pp * (BN / 4)) * 4;
                 const int ppy = pp >> 3, ppx = pp & 7;
                 f32x4 v[4];
-                unpool4x4(((okm >> 16) & 1u) ? dv[0] : f32x4{0, 0, 0, 0}, dpv, dii, v);
+                unpool4x4(((okm >> 16) & 1u) ? widen4(dv[0]) : f32x4{0, 0, 0, 0}, widen4(dpv), dii, v);
 #pragma unroll
                 for (int pos = 0; pos < 4; ++pos) {
                     *reinterpret_cast<bf16x4*>(&Ds[((2 * ppy + (pos >> 1)) * kHaloTW + 2 * ppx + (pos & 1)) * LDD + c4]) = to_bf16x4(v[pos]);
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const flo
                 const int e = tid + kWgHaloThreads * q;
                 const int pix = e / (BN / 4), c4 = (e - pix * (BN / 4)) * 4;
                 if (NDQ * kWgHaloThreads == DCH || e < DCH) {
-                    const f32x4 v = ((okm >> (16 + q)) & 1u) ? dv[q] : f32x4{0, 0, 0, 0};
+                    const f32x4 v = ((okm >> (16 + q)) & 1u) ? widen4(dv[q]) : f32x4{0, 0, 0, 0};
                     *reinterpret_cast<bf16x4*>(&Ds[pix * LDD + c4]) = to_bf16x4(v);
                     colsum += v;                                      // fp32, unrounded: the bias gradient (same columns every time: 576 % (BN/4) == 0)
                 }

@@ -77,9 +77,9 @@ __device__ inline bool stage_ok(int pk, int y0, int x0, int img0, int Himg, int 
 // EPI 3's gate values (the layer below's output at the positions this lane is about to write) loaded AHEAD of the item's last MFMAs:
 // inside the epilogue their latency sat on every item's critical path (a 32-channel layer at 224 x 224: 18 MFMAs per item, then
 // sixteen dependent loads, then the stores).
-template <int TW, int NT>
+template <int TW, int NT, typename TG = float>
 __device__ inline void halo_gate_prefetch(float (&g)[NT][16], int lane, int wave, int img0, int oh0, int ow0, int n0, const ConvShape& s,
-                                          const float* __restrict__ G) {
+                                          const TG* __restrict__ G) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int co = n0 + 32 * t + (lane & 31);
@@ -89,14 +89,15 @@ __device__ inline void halo_gate_prefetch(float (&g)[NT][16], int lane, int wave
             const int colb = pr & 15;
             const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
             const bool ok = img < s.N && oh < s.H && ow < s.W;
-            g[t][i] = G[ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co) : 0u];
+            g[t][i] = widen(G[ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co) : 0u]);
         }
     }
 }
 
-template <int TW, int NT, int EPI>
+// TY: storage type of Y; TG: of EPI 3's gate tensor, which arrives through `bias` (convnet.hpp, Chunk4).
+template <int TW, int NT, int EPI, typename TY = float, typename TG = float>
 __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave, int img0, int oh0, int ow0, int n0, const ConvShape& s,
-                                     const float* __restrict__ bias, float* __restrict__ Y, uint8_t* __restrict__ pool_idx,
+                                     const float* __restrict__ bias, TY* __restrict__ Y, uint8_t* __restrict__ pool_idx,
                                      const float (*gate)[16] = nullptr) {
     const int h = lane >> 5;
     if (EPI == 4) {
@@ -127,7 +128,7 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                     const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
                     const bool ok = img < s.N && poh < OH && pow_ < OW;         // the same for the 32 lanes of a half-wave
                     const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co);
-                    if (ok) Y[o] = best;
+                    if (ok) Y[o] = narrow<TY>(best);
                     store_idx_quad(pool_idx, o, bk, ok, lane);
                 }
         }
@@ -145,8 +146,8 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                     const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co);      // the host keeps tensors below 2^31 elements
                     float v = acc[t][i] + bb;
                     if (EPI == 2) v = v > 0.f ? v : 0.f;
-                    if (EPI == 3) v = (gate ? gate[t][i] : bias[o]) > 0.f ? v : 0.f;
-                    Y[o] = v;
+                    if (EPI == 3) v = (gate ? gate[t][i] : widen(reinterpret_cast<const TG*>(bias)[o])) > 0.f ? v : 0.f;
+                    Y[o] = narrow<TY>(v);
                 }
             }
         }
@@ -555,9 +556,9 @@ __device__ inline void stage1_init(Stage1Map<NL>& m, int tid, int Himg, int Wimg
     }
 }
 
-template <int CIN, int TW, int EPI>
+template <int CIN, int TW, int EPI, typename TY = float>
 __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restrict__ X, const float* __restrict__ Wk, const float* __restrict__ bias,
-                                                            float* __restrict__ Y, ConvShape s, int tiles_w, int tiles_h, int n_items,
+                                                            TY* __restrict__ Y, ConvShape s, int tiles_w, int tiles_h, int n_items,
                                                             uint8_t* __restrict__ pool_idx) {
     using Gm = HaloGeom<TW>;
     constexpr int K = 9 * CIN, KS2 = (K + 1) / 2;
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
                     const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
                     const bool ok = img < s.N && poh < OH && pow_ < OW;
                     const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co);
-                    if (ok) Y[o] = best;
+                    if (ok) Y[o] = narrow<TY>(best);
                     store_idx_quad(pool_idx, o, bk, ok, lane);
                 }
         } else {
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
                 const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
                 if (img < s.N && oh < s.H && ow < s.W) {
                     const float v = acc[i] + bb;
-                    Y[(unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co)] = v > 0.f ? v : 0.f;
+                    Y[(unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co)] = narrow<TY>(v > 0.f ? v : 0.f);
                 }
             }
         }
@@ -692,9 +693,9 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
 // k_conv1_wgrad_f32: dW[k][co] = sum over pixels of patch element k times dZ[pixel][co], one 32 x 32 tile (rows k < 9 CIN real) per
 // workgroup (co block, chunk of pixel blocks); the MFMA's row index is k -- lane r reads element koff(r) of pixel p + h, a lane
 // constant plus an immediate -- and its contraction index the pixel, as in k_wgrad3x3_halo_f32.  Same slab layout.
-template <int CIN, int TW, bool PDZ>
-__global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ slab, ConvShape s,
-                                                              int tiles_w, int tiles_h, int blocks_per_chunk, PooledGrad pdz) {
+template <int CIN, int TW, bool PDZ, typename TD = float>       // TD: storage type of dZ / of the pooled gradient and gate
+__global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __restrict__ X, const TD* __restrict__ dZ, float* __restrict__ slab, ConvShape s,
+                                                              int tiles_w, int tiles_h, int blocks_per_chunk, PooledGradT<TD> pdz) {
     using Gm = HaloGeom<TW>;
     constexpr int K = 9 * CIN, BN = 32, NPX = 128;
     constexpr int HF = Gm::NPIX * CIN, NL = (HF + kThreads - 1) / kThreads;
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
     const int dximg = dcolb / TW, dxcol = PDZ ? (dcolb % TW) >> 1 : dcolb % TW;
     const int drel0 = ((dximg * DH + drow0) * DW + dxcol) * s.Cout + (tid & 7) * 4;
     float hv[NL];
-    f32x4 dv[ND], dp[1];
+    chunk4_t<TD> dv[ND], dp[1];
     unsigned di = 0, okm = 0;
     auto gload = [&](int blk) {
         int q0 = blk;
@@ -746,11 +747,11 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
             okm |= (ok ? 1u : 0u) << (16 + q);
             const unsigned off = ok ? (unsigned)(dbase + drel0 + 2 * q * DW * s.Cout) : 0u;
             if (PDZ) {
-                dv[q] = *reinterpret_cast<const f32x4*>(pdz.dP + off);
-                dp[q] = *reinterpret_cast<const f32x4*>(pdz.P + off);
+                dv[q] = *reinterpret_cast<const chunk4_t<TD>*>(pdz.dP + off);
+                dp[q] = *reinterpret_cast<const chunk4_t<TD>*>(pdz.P + off);
                 di = *reinterpret_cast<const unsigned*>(pdz.idx + off);
             } else {
-                dv[q] = *reinterpret_cast<const f32x4*>(dZ + off);
+                dv[q] = *reinterpret_cast<const chunk4_t<TD>*>(dZ + off);
             }
         }
     };
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
         if (PDZ) {
             const bool ok = (okm >> 16) & 1u;
             f32x4 v[4];
-            unpool4x4(ok ? dv[0] : f32x4{0, 0, 0, 0}, dp[0], di, v);
+            unpool4x4(ok ? widen4(dv[0]) : f32x4{0, 0, 0, 0}, widen4(dp[0]), di, v);
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos) {
                 *reinterpret_cast<f32x4*>(&Ds[((2 * drow0 + (pos >> 1)) * 16 + dcolb + (pos & 1)) * BN + c4]) = v[pos];
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(kThreads) void k_conv1_wgrad_f32(const float* __res
         } else {
 #pragma unroll
             for (int q = 0; q < ND; ++q) {
-                const f32x4 v = ((okm >> (16 + q)) & 1u) ? dv[q] : f32x4{0, 0, 0, 0};
+                const f32x4 v = ((okm >> (16 + q)) & 1u) ? widen4(dv[q]) : f32x4{0, 0, 0, 0};
                 *reinterpret_cast<f32x4*>(&Ds[(tid + kThreads * q) * 4]) = v;
                 colsum += v;
             }

@@ -16,10 +16,15 @@
 
 namespace rcnx {
 
-template <int CB, int BN, int EPI, bool PIN = false>
+// TS: storage type of X, Y, EPI 3's gate tensor (passed through `bias`) and the pooled-resolution input (convnet.hpp, Chunk4): with
+// __bf16 the halo chunks go from global memory to LDS as they are -- no conversion, half the bytes.
+__device__ inline bf16x4 as_bf16x4(const f32x4& v) { return to_bf16x4(v); }
+__device__ inline bf16x4 as_bf16x4(const bf16x4& v) { return v; }
+
+template <int CB, int BN, int EPI, bool PIN = false, typename TS = float>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 64 && BN == 64 ? 2 : 3))) void k_conv3x3_halo_bf16p(
-    const float* __restrict__ X, const __bf16* __restrict__ WB, const float* __restrict__ bias, float* __restrict__ Y, ConvShape s, int tiles_w,
-    int tiles_h, int n_items, uint8_t* __restrict__ pool_idx, PooledGrad pin) {
+    const TS* __restrict__ X, const __bf16* __restrict__ WB, const float* __restrict__ bias, TS* __restrict__ Y, ConvShape s, int tiles_w,
+    int tiles_h, int n_items, uint8_t* __restrict__ pool_idx, PooledGradT<TS> pin) {
     static_assert(CB % 16 == 0 && BN % 32 == 0, "channel blocks of the 32x32x16 MFMA");
     using Gm = HaloGeom<16>;
     constexpr int TW = 16, NT = BN / 32, LDC = CB + 8;                // halves per pixel / per weight row in LDS (16-byte aligned, bank-skewed)
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
     // ---- staging: registers first (loads fly under the MFMAs), LDS after the barrier
     StageMap<NH> hm;
     stage_map_init<NH, GR, GC, 1, CPP>(hm, tid);
-    f32x4 hv[NH], hp[PIN ? NH : 1];
+    chunk4_t<TS> hv[NH], hp[PIN ? NH : 1];
     unsigned hi[PIN ? NH : 1];
     unsigned okm = 0;
     auto halo_load = [&](const Item& it, int cb) {
@@ -67,11 +72,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             okm |= (ok ? 1u : 0u) << q;
             const unsigned off = ok ? (unsigned)(base + stage_rel<CPP>(pk, tid, GH, GW, Cin)) : 0u;
             if (PIN) {
-                hv[q] = *reinterpret_cast<const f32x4*>(pin.dP + off);
-                hp[q] = *reinterpret_cast<const f32x4*>(pin.P + off);
+                hv[q] = *reinterpret_cast<const chunk4_t<TS>*>(pin.dP + off);
+                hp[q] = *reinterpret_cast<const chunk4_t<TS>*>(pin.P + off);
                 hi[q] = *reinterpret_cast<const unsigned*>(pin.idx + off);
             } else {
-                hv[q] = *reinterpret_cast<const f32x4*>(X + off);
+                hv[q] = *reinterpret_cast<const chunk4_t<TS>*>(X + off);
             }
         }
     };
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             if (PIN) {
                 const int pr = pk & 255, pc = (pk >> 8) & 255;
                 f32x4 v[4];
-                unpool4x4(ok ? hv[q] : f32x4{0, 0, 0, 0}, hp[q], hi[q], v);
+                unpool4x4(ok ? widen4(hv[q]) : f32x4{0, 0, 0, 0}, widen4(hp[q]), hi[q], v);
                 __bf16* w0 = &Hs[((2 * pr - 1) * Gm::HWD + 2 * pc - 1) * LDC + c4];              // window position 0 (may lie outside the halo)
 #pragma unroll
                 for (int pos = 0; pos < 4; ++pos) {
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
                     if (in) *reinterpret_cast<bf16x4*>(w0 + ((pos >> 1) * Gm::HWD + (pos & 1)) * LDC) = to_bf16x4(v[pos]);
                 }
             } else {
-                *reinterpret_cast<bf16x4*>(&Hs[(tid / CPP + (kThreads / CPP) * q) * LDC + c4]) = to_bf16x4(ok ? hv[q] : f32x4{0, 0, 0, 0});
+                *reinterpret_cast<bf16x4*>(&Hs[(tid / CPP + (kThreads / CPP) * q) * LDC + c4]) = ok ? as_bf16x4(hv[q]) : bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             }
         }
     };
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
             }
             kh = nkh; cb = ncb;
         }
-        halo_epilogue<TW, NT, EPI>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx);
+        halo_epilogue<TW, NT, EPI, TS, TS>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx);
         cur = nxt;
     }
 }
@@ -183,10 +188,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
 // at 2.2 x its HBM floor.  Here ALL nine taps' weights of a column block (9 x BN x 32 halves: 23 / 46 KB) are staged once and stay
 // while the workgroup walks its items (the column block only changes when the layer has more than BN output channels); an item is its
 // halo (prefetched under the previous item's MFMAs), 18 / 36 MFMAs, its epilogue: two barriers per item.
-template <int BN, int EPI, bool PIN = false>
-__global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const float* __restrict__ X, const __bf16* __restrict__ WB, const float* __restrict__ bias,
-                                                                   float* __restrict__ Y, ConvShape s, int tiles_w, int tiles_h, int n_items,
-                                                                   uint8_t* __restrict__ pool_idx, PooledGrad pin) {
+template <int BN, int EPI, bool PIN = false, typename TS = float>
+__global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const TS* __restrict__ X, const __bf16* __restrict__ WB, const float* __restrict__ bias,
+                                                                   TS* __restrict__ Y, ConvShape s, int tiles_w, int tiles_h, int n_items,
+                                                                   uint8_t* __restrict__ pool_idx, PooledGradT<TS> pin) {
     using Gm = HaloGeom<16>;
     constexpr int CB = 32, TW = 16, NT = BN / 32, LDC = CB + 8, CPP = CB / 4, K = 9 * CB;
     constexpr int PPW = TW / 2 + 2;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const float*
 
     StageMap<NH> hm;
     stage_map_init<NH, GR, GC, 1, CPP>(hm, tid);
-    f32x4 hv[NH], hp[PIN ? NH : 1];
+    chunk4_t<TS> hv[NH], hp[PIN ? NH : 1];
     unsigned hi[PIN ? NH : 1];
     unsigned okm = 0;
     auto halo_load = [&](const Item& it) {
@@ -230,11 +235,11 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const float*
             okm |= (ok ? 1u : 0u) << q;
             const unsigned off = ok ? (unsigned)(base + stage_rel<CPP>(pk, tid, GH, GW, CB)) : 0u;
             if (PIN) {
-                hv[q] = *reinterpret_cast<const f32x4*>(pin.dP + off);
-                hp[q] = *reinterpret_cast<const f32x4*>(pin.P + off);
+                hv[q] = *reinterpret_cast<const chunk4_t<TS>*>(pin.dP + off);
+                hp[q] = *reinterpret_cast<const chunk4_t<TS>*>(pin.P + off);
                 hi[q] = *reinterpret_cast<const unsigned*>(pin.idx + off);
             } else {
-                hv[q] = *reinterpret_cast<const f32x4*>(X + off);
+                hv[q] = *reinterpret_cast<const chunk4_t<TS>*>(X + off);
             }
         }
     };
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const float*
             if (PIN) {
                 const int pr = pk & 255, pc = (pk >> 8) & 255;
                 f32x4 v[4];
-                unpool4x4(ok ? hv[q] : f32x4{0, 0, 0, 0}, hp[q], hi[q], v);
+                unpool4x4(ok ? widen4(hv[q]) : f32x4{0, 0, 0, 0}, widen4(hp[q]), hi[q], v);
                 __bf16* w0 = &Hs[((2 * pr - 1) * Gm::HWD + 2 * pc - 1) * LDC + c4];
 #pragma unroll
                 for (int pos = 0; pos < 4; ++pos) {
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const float*
                     if (in) *reinterpret_cast<bf16x4*>(w0 + ((pos >> 1) * Gm::HWD + (pos & 1)) * LDC) = to_bf16x4(v[pos]);
                 }
             } else {
-                *reinterpret_cast<bf16x4*>(&Hs[(tid / CPP + (kThreads / CPP) * q) * LDC + c4]) = to_bf16x4(ok ? hv[q] : f32x4{0, 0, 0, 0});
+                *reinterpret_cast<bf16x4*>(&Hs[(tid / CPP + (kThreads / CPP) * q) * LDC + c4]) = ok ? as_bf16x4(hv[q]) : bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             }
         }
     };
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const float*
         // (EPI 3, one column tile: the gate values are loaded ahead of the MFMAs -- sixteen registers; with two tiles they spill)
         constexpr bool GATE_AHEAD = EPI == 3 && NT == 1;
         float gate[NT][16];
-        if constexpr (GATE_AHEAD) halo_gate_prefetch<TW, NT>(gate, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias);
+        if constexpr (GATE_AHEAD) halo_gate_prefetch<TW, NT, TS>(gate, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, reinterpret_cast<const TS*>(bias));
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const float*
                     }
                 }
             }
-        halo_epilogue<TW, NT, EPI>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx, GATE_AHEAD ? gate : nullptr);
+        halo_epilogue<TW, NT, EPI, TS, TS>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx, GATE_AHEAD ? gate : nullptr);
         cur = nxt;
     }
 }

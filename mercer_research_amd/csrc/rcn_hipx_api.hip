@@ -125,6 +125,9 @@ struct rcn_hipx_net {
     ReduceJobs jobs{};                      // the step's pending slab reductions
     Buf wb16; PrepJobs prep{}; long long prep_blocks = 0;      // bf16 mode: every layer's bf16 operand copies, made by ONE launch per step
     int precision = RCN_HIPX_FP32;          // GEMM operand precision of forward / dgrad (rcn_hipx_set_precision)
+    // RCN_HIPX_BF16_STORED: bf16 operands AND the convolutional stage's activations / gradients (every conv and pool layer's out and dout)
+    // kept in memory as bf16.  precision == RCN_HIPX_BF16 then too: what is ROUNDED does not change, only where.
+    bool store16 = false;
     int tiling = RCN_HIPX_TILING_AUTO;      // fp32 3x3 kernels: implicit GEMM only / by shape / LDS-tiled wherever they apply (rcn_hipx_set_tiling)
     std::map<Key, hipGraphExec_t> graphs;
     // the backward pass as a resumable walk (rcn_hipx_gradients_begin_dev / _bucket_dev: a data-parallel step whose all-reduce of one bucket
@@ -249,11 +252,19 @@ bool conv_halo_runs(const rcn_hipx_net* n, const ConvShape& s) {
     if (n->precision != RCN_HIPX_BF16) return conv_halo_f32_shape(n, s) && conv3_f32_z(n, s) == 1;
     if (!halo_enabled(n) || !(s.Cin == 32 || s.Cin % 64 == 0) || s.Cout % 32) return false;
     const int bn = s.Cout % 128 == 0 ? 128 : s.Cout % 64 == 0 ? 64 : 32;
-    return splitk_z(M, s.Cout, bn, 9 * s.Cin / 32) == 1;
+    return n->store16 || splitk_z(M, s.Cout, bn, 9 * s.Cin / 32) == 1;
 }
 
+// Storage of a launch's tensors (RCN_HIPX_BF16_STORED): x16 -- the input X (and a pooled-resolution input) is bf16; y16 -- the output Y and
+// epilogue 3's gate tensor (both belong to the layer below in the input-gradient pass) are bf16.  The host passes every tensor as
+// float*; the launch sites cast.
+struct Store { bool x16 = false, y16 = false; };
+// layer i's out / dout (i < 0: the net's input, always fp32)
+bool stage16(const rcn_hipx_net* n, int i) { return n->store16 && i >= 0 && (n->L[i].kind == RCN_HIPX_CONV3X3_RELU || n->L[i].kind == RCN_HIPX_MAXPOOL2); }
+static const char* kStoreGap = "bf16 storage (RCN_HIPX_BF16_STORED) covers nets whose convolutions run on the LDS-tiled kernels with fused pooling: this layer does not (rcn_hipx_plan shows the kernels chosen)";
+
 int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* bias, float* Y, ConvShape s, int ks, int epi, uint8_t* pool_idx = nullptr,
-                const PooledGrad* pin = nullptr, bool force_fp32 = false, const __bf16* wb_ready = nullptr) {
+                const PooledGrad* pin = nullptr, bool force_fp32 = false, const __bf16* wb_ready = nullptr, Store st = Store{}) {
     const long long M = (long long)s.N * s.H * s.W;
     const bool smallc = ks * ks * s.Cin <= 32 && s.Cin % 32 != 0;   // the per-element gather loader: only where a k-tile is not 32 whole channels
     if (!smallc && s.Cin % 32) return fail(n, -3, "input channels must be a multiple of 32 (or the whole 3x3xCin patch <= 32)");
@@ -263,7 +274,8 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     const bool bf16 = n->precision == RCN_HIPX_BF16 && !(ks == 3 && smallc) && !force_fp32;
     const int bn = (bf16 && s.Cout % 128 == 0) ? 128 : (s.Cout % 64 == 0) ? 64 : 32;
     const int nkt = smallc ? 1 : ks * ks * s.Cin / 32;
-    const int Z = epi == 4 ? 1 : (!bf16 && ks == 3 && !smallc) ? conv3_f32_z(n, s) : splitk_z(M, s.Cout, bn, nkt);
+    // (bf16 storage: a 3x3 layer never splits K -- whatever the batch size, it stays on the LDS-tiled kernels, the ones that take bf16 tensors)
+    const int Z = (epi == 4 || (n->store16 && ks == 3)) ? 1 : (!bf16 && ks == 3 && !smallc) ? conv3_f32_z(n, s) : splitk_z(M, s.Cout, bn, nkt);
     float* out = Y;
     int kepi = epi;
     if (Z > 1) {
@@ -292,17 +304,22 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
                 // the pipelined form (convnet_halo_bf16.hpp): work items (pixel block, column block) on a resident grid, operands loaded a
                 // phase ahead; same LDS images, rounding and MFMA order as k_conv3x3_halo_bf16 below
                 const long long items = (long long)tw * th * s.N * (s.Cout / hbn);
-#define HBP_LAUNCH(CI_, BN_, EPI_, PIN_) do { const long long slots = resident_slots(n, (const void*)k_conv3x3_halo_bf16p<CI_, BN_, EPI_, PIN_>); \
-                hipLaunchKernelGGL((k_conv3x3_halo_bf16p<CI_, BN_, EPI_, PIN_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, (int)items, pool_idx, pg); } while (0)
+#define HBP_LAUNCH_T(CI_, BN_, EPI_, PIN_, TS_) do { const long long slots = resident_slots(n, (const void*)k_conv3x3_halo_bf16p<CI_, BN_, EPI_, PIN_, TS_>); \
+                hipLaunchKernelGGL((k_conv3x3_halo_bf16p<CI_, BN_, EPI_, PIN_, TS_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, (const TS_*)X, WB, bias, (TS_*)out, s, tw, th, (int)items, pool_idx, \
+                                   PooledGradT<TS_>{(const TS_*)pg.dP, (const TS_*)pg.P, pg.idx}); } while (0)
+#define HBP_LAUNCH(CI_, BN_, EPI_, PIN_) do { if (st.x16) HBP_LAUNCH_T(CI_, BN_, EPI_, PIN_, __bf16); else HBP_LAUNCH_T(CI_, BN_, EPI_, PIN_, float); } while (0)
 #define HBP_EPI(CI_, BN_) do { if (pin) { if (kepi == 3) HBP_LAUNCH(CI_, BN_, 3, true); else if (kepi == 0) HBP_LAUNCH(CI_, BN_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
                                else if (kepi == 0) HBP_LAUNCH(CI_, BN_, 0, false); else if (kepi == 1) HBP_LAUNCH(CI_, BN_, 1, false); else if (kepi == 2) HBP_LAUNCH(CI_, BN_, 2, false); \
                                else if (kepi == 3) HBP_LAUNCH(CI_, BN_, 3, false); else HBP_LAUNCH(CI_, BN_, 4, false); } while (0)
-#define HB1_LAUNCH(BN_, EPI_, PIN_) do { const long long slots = resident_slots(n, (const void*)k_conv3x3_halo_bf16_1cb<BN_, EPI_, PIN_>); \
-                hipLaunchKernelGGL((k_conv3x3_halo_bf16_1cb<BN_, EPI_, PIN_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, (int)items, pool_idx, pg); } while (0)
+#define HB1_LAUNCH_T(BN_, EPI_, PIN_, TS_) do { const long long slots = resident_slots(n, (const void*)k_conv3x3_halo_bf16_1cb<BN_, EPI_, PIN_, TS_>); \
+                hipLaunchKernelGGL((k_conv3x3_halo_bf16_1cb<BN_, EPI_, PIN_, TS_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, (const TS_*)X, WB, bias, (TS_*)out, s, tw, th, (int)items, pool_idx, \
+                                   PooledGradT<TS_>{(const TS_*)pg.dP, (const TS_*)pg.P, pg.idx}); } while (0)
+#define HB1_LAUNCH(BN_, EPI_, PIN_) do { if (st.x16) HB1_LAUNCH_T(BN_, EPI_, PIN_, __bf16); else HB1_LAUNCH_T(BN_, EPI_, PIN_, float); } while (0)
 #define HB1_EPI(BN_) do { if (pin) { if (kepi == 3) HB1_LAUNCH(BN_, 3, true); else if (kepi == 0) HB1_LAUNCH(BN_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
                           else if (kepi == 0) HB1_LAUNCH(BN_, 0, false); else if (kepi == 1) HB1_LAUNCH(BN_, 1, false); else if (kepi == 2) HB1_LAUNCH(BN_, 2, false); \
                           else if (kepi == 3) HB1_LAUNCH(BN_, 3, false); else HB1_LAUNCH(BN_, 4, false); } while (0)
                 const int onecb = n->opt.bf16_1cb;
+                if (st.x16 != st.y16) return fail(n, -3, kStoreGap);
                 if (items <= 0x7fffffffLL && dry_note(n, "  %s %dx%dx%d->%d epi %d%s: %s, %lld items", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, kepi, pin ? " pooled-in" : "",
                                                       (s.Cin == 32 && onecb && hbn == 32) ? "k_conv3x3_halo_bf16_1cb<32>" : "k_conv3x3_halo_bf16p", items)) return 0;
                 if (items <= 0x7fffffffLL) {
@@ -316,9 +333,12 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
                 }
 #undef HB1_EPI
 #undef HB1_LAUNCH
+#undef HB1_LAUNCH_T
 #undef HBP_EPI
 #undef HBP_LAUNCH
+#undef HBP_LAUNCH_T
             }
+            if (st.x16 || st.y16) return fail(n, -3, kStoreGap);
 #define HALO_CASE(CI_, BN_, EPI_) do { if (pin) hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_, true>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx, pg); \
                                        else hipLaunchKernelGGL((k_conv3x3_halo_bf16<CI_, BN_, EPI_, false>), hgrid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s, tw, th, pool_idx, pg); } while (0)
 #define HALO_EPI(CI_, BN_) do { if (kepi == 0) HALO_CASE(CI_, BN_, 0); else if (kepi == 1) HALO_CASE(CI_, BN_, 1); else if (kepi == 2) HALO_CASE(CI_, BN_, 2); else if (kepi == 3) HALO_CASE(CI_, BN_, 3); else HALO_CASE(CI_, BN_, 4); } while (0)
@@ -331,6 +351,28 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
             return 0;
         }
         if (pin) return fail(n, -3, "internal: pooled-resolution input requested for a layer the LDS-tiled kernel does not cover");
+        if (st.x16 || st.y16) {
+            // the dense layer on top of the convolutional stage: its forward pass and weight gradient READ a bf16 map, its input gradient
+            // WRITES one (gated by the map, epilogue 3, or raw into a pooled gradient, epilogue 0).  A split-K launch leaves float partials.
+            if (ks != 1 || smallc || (st.x16 && st.y16)) return fail(n, -3, kStoreGap);
+            const bool y16k = st.y16 && Z == 1;                     // the kernel itself writes the bf16 tensor
+#define CONVS_CASE(BN_, EPI_) do { if (st.x16) hipLaunchKernelGGL((k_conv_fwd_bf16<1, false, BN_, EPI_, __bf16, float>), grid, dim3(kThreads), 0, n->stream, (const __bf16*)X, WB, bias, out, s); \
+                                   else if (y16k) hipLaunchKernelGGL((k_conv_fwd_bf16<1, false, BN_, EPI_, float, __bf16>), grid, dim3(kThreads), 0, n->stream, X, WB, bias, (__bf16*)out, s); \
+                                   else hipLaunchKernelGGL((k_conv_fwd_bf16<1, false, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s); } while (0)
+#define CONVS_EPI(BN_) do { if (kepi == 0) CONVS_CASE(BN_, 0); else if (kepi == 1) CONVS_CASE(BN_, 1); else if (kepi == 2) CONVS_CASE(BN_, 2); else CONVS_CASE(BN_, 3); } while (0)
+            if (dry_note(n, "  dense %d->%d epi %d: k_conv_fwd_bf16<1, tile, %d>%s, %s", s.Cin, s.Cout, epi, bn, Z > 1 ? (" split-K " + std::to_string(Z) + " + k_splitk_epilogue").c_str() : "",
+                         st.x16 ? "bf16 input map" : "bf16 output map")) return 0;
+            if (bn == 128) CONVS_EPI(128); else if (bn == 64) CONVS_EPI(64); else CONVS_EPI(32);
+#undef CONVS_EPI
+#undef CONVS_CASE
+            XTRY(n, hipGetLastError());
+            if (Z > 1) {
+                if (st.y16) hipLaunchKernelGGL(k_splitk_epilogue<__bf16>, dim3(grid1d(M * s.Cout, 256)), dim3(256), 0, n->stream, (const float*)n->skbuf.p, bias, (__bf16*)Y, M * s.Cout, s.Cout, Z, epi);
+                else hipLaunchKernelGGL(k_splitk_epilogue<float>, dim3(grid1d(M * s.Cout, 256)), dim3(256), 0, n->stream, (const float*)n->skbuf.p, bias, Y, M * s.Cout, s.Cout, Z, epi);
+                XTRY(n, hipGetLastError());
+            }
+            return 0;
+        }
 #define CONVB_CASE(KS_, SM_, BN_, EPI_) hipLaunchKernelGGL((k_conv_fwd_bf16<KS_, SM_, BN_, EPI_>), grid, dim3(kThreads), 0, n->stream, X, WB, bias, out, s)
 #define CONVB_EPI(KS_, SM_, BN_) do { if (kepi == 0) CONVB_CASE(KS_, SM_, BN_, 0); else if (kepi == 1) CONVB_CASE(KS_, SM_, BN_, 1); else if (kepi == 2) CONVB_CASE(KS_, SM_, BN_, 2); else CONVB_CASE(KS_, SM_, BN_, 3); } while (0)
 #define CONVB_BN(KS_, SM_) do { if (bn == 128) CONVB_EPI(KS_, SM_, 128); else if (bn == 64) CONVB_EPI(KS_, SM_, 64); else CONVB_EPI(KS_, SM_, 32); } while (0)
@@ -343,20 +385,23 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
 #undef CONVB_CASE
     } else {
         if (epi == 4 && !(ks == 3 && conv_pool_fusable(n, s))) return fail(n, -3, "internal: fused conv+pool epilogue requested for a layer the LDS-tiled kernel does not cover");
+        if (st.x16 || (st.y16 && !(ks == 3 && smallc && (epi == 2 || epi == 4) && conv1_f32_shape(n, s)))) return fail(n, -3, kStoreGap);
         if (ks == 3 && smallc && (epi == 2 || epi == 4) && conv1_f32_shape(n, s)) {
             // first layer (convnet_halo.hpp): weights in registers, the block's input halo in LDS
             const int tw = halo_plan(n, s).tw, nimg = 16 / tw;
             const int tiles_w = (s.W + tw - 1) / tw, tiles_h = (s.H + 7) / 8;
             const long long items = (long long)tiles_w * tiles_h * ((s.N + nimg - 1) / nimg) * (s.Cout / 32);
             if (items > 0x7fffffffLL) return fail(n, -3, "too many pixel blocks in one layer");
-#define C1_LAUNCH(CIN_, TW_, EPI_) do { const long long slots = resident_slots(n, (const void*)k_conv1_fwd_f32<CIN_, TW_, EPI_>); \
-            hipLaunchKernelGGL((k_conv1_fwd_f32<CIN_, TW_, EPI_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, Wk, bias, Y, s, tiles_w, tiles_h, (int)items, pool_idx); } while (0)
+#define C1_LAUNCH_T(CIN_, TW_, EPI_, TY_) do { const long long slots = resident_slots(n, (const void*)k_conv1_fwd_f32<CIN_, TW_, EPI_, TY_>); \
+            hipLaunchKernelGGL((k_conv1_fwd_f32<CIN_, TW_, EPI_, TY_>), dim3((unsigned)(items < slots ? items : slots)), dim3(kThreads), 0, n->stream, X, Wk, bias, (TY_*)Y, s, tiles_w, tiles_h, (int)items, pool_idx); } while (0)
+#define C1_LAUNCH(CIN_, TW_, EPI_) do { if (st.y16) C1_LAUNCH_T(CIN_, TW_, EPI_, __bf16); else C1_LAUNCH_T(CIN_, TW_, EPI_, float); } while (0)
 #define C1_EPI(CIN_, TW_) do { if (epi == 4) C1_LAUNCH(CIN_, TW_, 4); else C1_LAUNCH(CIN_, TW_, 2); } while (0)
             if (dry_note(n, "  conv3x3 %dx%dx%d->%d epi %d: k_conv1_fwd_f32<%d, %d>, %lld items", s.H, s.W, s.Cin, s.Cout, epi, s.Cin, tw, items)) return 0;
             if (s.Cin == 3) { if (tw == 16) C1_EPI(3, 16); else C1_EPI(3, 8); }
             else { if (tw == 16) C1_EPI(1, 16); else C1_EPI(1, 8); }
 #undef C1_EPI
 #undef C1_LAUNCH
+#undef C1_LAUNCH_T
             XTRY(n, hipGetLastError());
             return 0;
         }
@@ -397,7 +442,7 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
     }
     XTRY(n, hipGetLastError());
     if (Z > 1) {
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3(grid1d(M * s.Cout, 256)), dim3(256), 0, n->stream, (const float*)n->skbuf.p, bias, Y, M * s.Cout, s.Cout, Z, epi);
+        hipLaunchKernelGGL(k_splitk_epilogue<float>, dim3(grid1d(M * s.Cout, 256)), dim3(256), 0, n->stream, (const float*)n->skbuf.p, bias, Y, M * s.Cout, s.Cout, Z, epi);
         XTRY(n, hipGetLastError());
     }
     return 0;
@@ -427,7 +472,8 @@ bool wgrad_halo_runs(const rcn_hipx_net* n, const ConvShape& s, int ks) {
     return n->precision == RCN_HIPX_BF16 && wgrad_halo_on(n) && ks == 3 && ks * ks * s.Cin > 32 && (s.Cin == 32 || s.Cin % 64 == 0) && s.H >= kHaloTH / 2 && s.W >= kHaloTW / 2;
 }
 
-int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, int ks, int* chunks_out, const PooledGrad* pdz = nullptr) {
+// st.x16: X is a bf16 tensor; st.y16: dZ (and a pooled-resolution dZ) is
+int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, int ks, int* chunks_out, const PooledGrad* pdz = nullptr, Store st = Store{}) {
     const long long M = (long long)s.N * s.H * s.W;
     const int K = ks * ks * s.Cin;
     const bool smallc = K <= 32 && s.Cin % 32 != 0;
@@ -448,16 +494,21 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
         const dim3 hgrid((unsigned)(s.Cout / 32), (unsigned)hchunks);
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
-#define W1_CASE(CIN_, TW_) do { if (pdz) hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, true>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); \
-                                else hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, false>), hgrid, dim3(kThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pg); } while (0)
+#define W1_CASE_T(CIN_, TW_, TD_) do { const PooledGradT<TD_> pgt{(const TD_*)pg.dP, (const TD_*)pg.P, pg.idx}; \
+                                if (pdz) hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, true, TD_>), hgrid, dim3(kThreads), 0, n->stream, X, (const TD_*)dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pgt); \
+                                else hipLaunchKernelGGL((k_conv1_wgrad_f32<CIN_, TW_, false, TD_>), hgrid, dim3(kThreads), 0, n->stream, X, (const TD_*)dZ, (float*)(*n->slab_sel).p, s, tiles_w, tiles_h, bpc, pgt); } while (0)
+#define W1_CASE(CIN_, TW_) do { if (st.y16) W1_CASE_T(CIN_, TW_, __bf16); else W1_CASE_T(CIN_, TW_, float); } while (0)
+        if (st.x16) return fail(n, -3, kStoreGap);
         if (dry_note(n, "  wgrad conv3x3 %dx%dx%d->%d%s: k_conv1_wgrad_f32<%d, %d>, %d chunks", s.H, s.W, s.Cin, s.Cout, pdz ? " pooled-dZ" : "", s.Cin, tw, hchunks)) { *chunks_out = hchunks; return 0; }
         if (s.Cin == 3) { if (tw == 16) W1_CASE(3, 16); else W1_CASE(3, 8); }
         else { if (tw == 16) W1_CASE(1, 16); else W1_CASE(1, 8); }
 #undef W1_CASE
+#undef W1_CASE_T
         XTRY(n, hipGetLastError());
         *chunks_out = hchunks;
         return 0;
     }
+    if ((st.x16 || st.y16) && n->precision != RCN_HIPX_BF16) return fail(n, -3, kStoreGap);
     if (n->precision != RCN_HIPX_BF16 && wgrad_halo_runs(n, s, ks)) {
         // fp32 LDS-tiled (convnet_halo.hpp): workgroup = (32 input channels, 32 output channels, chunk of pixel blocks), all nine taps.
         // Every chunk costs one (K+1) x Cout partial written and read back by the reduce whatever the number of (ci, co) workgroups
@@ -502,12 +553,16 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         XTRY(n, scratch_ensure(n, (*n->slab_sel), (size_t)hchunks * (K + 1) * s.Cout * sizeof(float)));
         const dim3 hgrid((unsigned)(s.Cin / hb), (unsigned)(s.Cout / hbn), (unsigned)hchunks);
         const PooledGrad pg = pdz ? *pdz : PooledGrad{nullptr, nullptr, nullptr};
-#define WGH_CASE(CB_, BN_) do { if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, true>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tw, th, bpc, hchunks, pg); \
-                                else hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, false>), hgrid, dim3(kWgHaloThreads), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, tw, th, bpc, hchunks, pg); } while (0)
+#define WGH_CASE_T(CB_, BN_, TS_) do { const PooledGradT<TS_> pgt{(const TS_*)pg.dP, (const TS_*)pg.P, pg.idx}; \
+                                if (pdz) hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, true, TS_>), hgrid, dim3(kWgHaloThreads), 0, n->stream, (const TS_*)X, (const TS_*)dZ, (float*)(*n->slab_sel).p, s, tw, th, bpc, hchunks, pgt); \
+                                else hipLaunchKernelGGL((k_wgrad3x3_halo_bf16<CB_, BN_, false, TS_>), hgrid, dim3(kWgHaloThreads), 0, n->stream, (const TS_*)X, (const TS_*)dZ, (float*)(*n->slab_sel).p, s, tw, th, bpc, hchunks, pgt); } while (0)
+#define WGH_CASE(CB_, BN_) do { if (st.x16) WGH_CASE_T(CB_, BN_, __bf16); else WGH_CASE_T(CB_, BN_, float); } while (0)
+        if (st.x16 != st.y16) return fail(n, -3, kStoreGap);
         if (dry_note(n, "  wgrad conv3x3 %dx%dx%d->%d%s: k_wgrad3x3_halo_bf16<%d, %d>, %d chunks x %lld tiles", s.H, s.W, s.Cin, s.Cout, pdz ? " pooled-dZ" : "", hb, hbn, hchunks, tiles)) { *chunks_out = hchunks; return 0; }
         if (hb == 32) { if (hbn == 64) WGH_CASE(32, 64); else WGH_CASE(32, 32); }
         else { if (hbn == 64) WGH_CASE(64, 64); else WGH_CASE(64, 32); }
 #undef WGH_CASE
+#undef WGH_CASE_T
         XTRY(n, hipGetLastError());
         *chunks_out = hchunks;
         return 0;
@@ -528,7 +583,9 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
         }
         const WgradGrid gdb{nkb / nk, s.Cout / bn, chunks, xcd_remap(n)};
         const dim3 gridb(gdb.launch_blocks());
-#define WGB_CASE(KS_, BN_, NK_) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, ppc, gdb)
+#define WGB_CASE(KS_, BN_, NK_) do { if (st.x16) hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_, __bf16>), gridb, dim3(64 * NK_), 0, n->stream, (const __bf16*)X, dZ, (float*)(*n->slab_sel).p, s, ppc, gdb); \
+                                     else hipLaunchKernelGGL((k_conv_wgrad_bf16<KS_, BN_, NK_>), gridb, dim3(64 * NK_), 0, n->stream, X, dZ, (float*)(*n->slab_sel).p, s, ppc, gdb); } while (0)
+        if (st.y16 || (st.x16 && ks != 1)) return fail(n, -3, kStoreGap);
 #define WGB_NK(KS_, BN_) do { if (nk == 4) WGB_CASE(KS_, BN_, 4); else if (nk == 3) WGB_CASE(KS_, BN_, 3); else if (nk == 2) WGB_CASE(KS_, BN_, 2); else WGB_CASE(KS_, BN_, 1); } while (0)
 #define WGB_BN(KS_) do { if (bn == 64) WGB_NK(KS_, 64); else WGB_NK(KS_, 32); } while (0)
         if (dry_note(n, "  wgrad %s %dx%dx%d->%d: k_conv_wgrad_bf16<%d, %d, %d>, %d chunks", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, ks, bn, nk, chunks)) { *chunks_out = chunks; return 0; }
@@ -542,6 +599,7 @@ int launch_wgrad(rcn_hipx_net* n, const float* X, const float* dZ, ConvShape s, 
     }
     // (as in the bf16 branch above: below two waves per SIMD the column blocks are 32 wide -- CIFAR net's 2048 -> 256 at B = 512: 256 -> 512
     // workgroups, step 0.419 -> 0.417 ms; MNIST shape B = 256: 0.165 -> 0.1625 ms)
+    if (st.x16 || st.y16) return fail(n, -3, kStoreGap);
     const int f32_policy = n->opt.wgf_policy;
     const int bnf = (f32_policy && !smallc && 4LL * (K / 32) * (s.Cout / bn0) * chunks < 2048) ? 32 : bn0;
     const WgradGrid gd{smallc ? 1 : K / 32, s.Cout / bnf, chunks, xcd_remap(n)};
@@ -636,10 +694,12 @@ int prep_bf16_weights(rcn_hipx_net* n) {
 // forward for batch B; returns pointer to logits (padded rows of CoutP)
 int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1) {
     const float* cur = x;
+    bool cur16 = false;                                  // `cur` is a bf16 tensor (RCN_HIPX_BF16_STORED)
     if (n_layers > n->L.size()) n_layers = n->L.size();
     for (size_t i = 0; i < n_layers; ++i) {
         Layer& l = n->L[i];
         if (l.kind == RCN_HIPX_MAXPOOL2) {
+            if (n->store16) return fail(n, -3, kStoreGap);          // (a pool that no convolution kernel could fuse)
             const long long tot = (long long)B * l.oH * l.oW * (l.Cin / 4);
             if (dry_note(n, "  pool %dx%dx%d: k_pool_fwd", l.H, l.W, l.Cin)) { cur = (const float*)l.out.p; continue; }
             hipLaunchKernelGGL(k_pool_fwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, cur, (float*)l.out.p, (uint8_t*)l.idx.p, B, l.H, l.W, l.Cin);
@@ -649,18 +709,23 @@ int forward(rcn_hipx_net* n, const float* x, int B, size_t n_layers = (size_t)-1
             if (l.pool_follows && conv_pool_fusable(n, cs)) {
                 // the pool that follows runs in this kernel's epilogue: only the pooled map (and its arg-max image) is written
                 Layer& pl = n->L[i + 1];
-                RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)pl.out.p, cs, 3, 4, (uint8_t*)pl.idx.p, nullptr, false, wb_of(n, l.wbf_off)));
+                RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)pl.out.p, cs, 3, 4, (uint8_t*)pl.idx.p, nullptr, false, wb_of(n, l.wbf_off), Store{cur16, n->store16}));
                 cur = (const float*)pl.out.p;
+                cur16 = n->store16;
                 ++i;
                 continue;
             }
-            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, cs, 3, 2, nullptr, nullptr, false, wb_of(n, l.wbf_off)));
+            RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, cs, 3, 2, nullptr, nullptr, false, wb_of(n, l.wbf_off), Store{cur16, n->store16}));
+            cur = (const float*)l.out.p;
+            cur16 = n->store16;
+            continue;
         } else {
             // (the logits layer of a head that training runs as k_head_f32 is fp32 here too: what bf16 mode rounds is a matter of shape)
             RTRY(launch_conv(n, cur, P(n, l.w_off), P(n, l.b_off), (float*)l.out.p, ConvShape{B, 1, 1, l.K, l.CoutP}, 1, l.kind == RCN_HIPX_DENSE_RELU ? 2 : 1, nullptr, nullptr,
-                             i + 1 == n->L.size() && head_fusable(n), wb_of(n, l.wbf_off)));
+                             i + 1 == n->L.size() && head_fusable(n), wb_of(n, l.wbf_off), Store{cur16, false}));
         }
         cur = (const float*)l.out.p;
+        cur16 = false;
     }
     return 0;
 }
@@ -719,7 +784,9 @@ int backward_layers(rcn_hipx_net* n, const float* x, int B, float lr, float* gra
             const int fuse_on = n->opt.fuse_pool_bwd;
             const Layer& cl = n->L[i - 1];
             const ConvShape cs{B, cl.H, cl.W, cl.Cin, cl.CoutP};
-            if (fuse_on && wgrad_halo_runs(n, cs, 3) && (i - 1 == 0 || conv_halo_runs(n, ConvShape{B, cl.H, cl.W, cl.CoutP, cl.Cin}))) {
+            const bool fusable = fuse_on && wgrad_halo_runs(n, cs, 3) && (i - 1 == 0 || conv_halo_runs(n, ConvShape{B, cl.H, cl.W, cl.CoutP, cl.Cin}));
+            if (n->store16 && !fusable) return fail(n, -3, kStoreGap);
+            if (fusable) {
                 pooled[i - 1] = PooledGrad{(const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p};
                 if (dry_note(n, "  pool-bwd %dx%dx%d: none (the convolution's gradient kernels unpool while staging)", l.H, l.W, l.Cin))
                     pooled[i - 1].dP = reinterpret_cast<const float*>(sizeof(float));      // (dry run: no buffers; any non-null marks "pooled")
@@ -740,6 +807,7 @@ int backward_layers(rcn_hipx_net* n, const float* x, int B, float lr, float* gra
         // dZ: gradient wrt the pre-activation
         const float* dZ = (const float*)l.dout.p;
         if (l.kind != RCN_HIPX_DENSE && !l.pool_follows && !gated[i]) {
+            if (stage16(n, i)) return fail(n, -3, kStoreGap);
             XTRY(n, scratch_ensure(n, n->dz, (size_t)M * l.CoutP * sizeof(float)));
             if (!dry_note(n, "  relu-bwd: k_relu_bwd")) {
                 hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d(M * l.CoutP, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (float*)n->dz.p, M * l.CoutP);
@@ -760,13 +828,13 @@ int backward_layers(rcn_hipx_net* n, const float* x, int B, float lr, float* gra
             const Layer& below = n->L[i - 1];
             const bool gate = below.kind == RCN_HIPX_CONV3X3_RELU || below.kind == RCN_HIPX_DENSE_RELU;
             RTRY(launch_conv(n, dZ, wt, gate ? (const float*)below.out.p : nullptr, din, ConvShape{s.N, s.H, s.W, s.Cout, s.Cin}, ks, gate ? 3 : 0,
-                             nullptr, pooled[i].dP ? &pooled[i] : nullptr, false, wb_of(n, l.wbb_off)));
+                             nullptr, pooled[i].dP ? &pooled[i] : nullptr, false, wb_of(n, l.wbb_off), Store{stage16(n, i), stage16(n, i - 1)}));
             gated[i - 1] = gate;
         }
         int chunks = 0;
         if (on_side) n->stream = n->side;
         n->slab_sel = &l.slab;
-        RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks, pooled[i].dP ? &pooled[i] : nullptr));
+        RTRY(launch_wgrad(n, in, dZ, s, ks, &chunks, pooled[i].dP ? &pooled[i] : nullptr, Store{stage16(n, i - 1), stage16(n, i)}));
         RTRY(reduce_slab(n, (size_t)i, chunks, ks, s, lr, grad, apply));
         n->stream = main_s;
     }
@@ -994,6 +1062,19 @@ int describe_layers(rcn_hipx_net* n, int in_h, int in_w, int in_c, const rcn_hip
     return 0;
 }
 
+// the layer descriptions of `from` without their buffers (host-only dry-run nets)
+void copy_layer_table(rcn_hipx_net& to, const rcn_hipx_net& from) {
+    for (const Layer& l : from.L) {
+        Layer c;
+        c.kind = l.kind; c.H = l.H; c.W = l.W; c.Cin = l.Cin; c.oH = l.oH; c.oW = l.oW; c.Cout = l.Cout; c.CoutP = l.CoutP; c.K = l.K;
+        c.w_off = l.w_off; c.b_off = l.b_off; c.lw_off = l.lw_off; c.lb_off = l.lb_off; c.pool_follows = l.pool_follows;
+        to.L.push_back(c);
+    }
+    to.n_pad = from.n_pad; to.n_log = from.n_log;
+}
+
+const char* precision_name(int precision, bool store16) { return precision != RCN_HIPX_BF16 ? "fp32 operands" : store16 ? "bf16 operands, the convolutional stage's tensors stored as bf16" : "bf16 operands"; }
+
 }  // namespace
 
 extern "C" {
@@ -1050,10 +1131,23 @@ int rcn_hipx_classes(const rcn_hipx_net* n) { return n ? n->classes : -1; }
 
 int rcn_hipx_set_precision(rcn_hipx_net* n, int mode) {
     if (!n) return -1;
-    if (mode != RCN_HIPX_FP32 && mode != RCN_HIPX_BF16) return fail(n, -1, "set_precision: mode must be RCN_HIPX_FP32 or RCN_HIPX_BF16");
+    if (mode != RCN_HIPX_FP32 && mode != RCN_HIPX_BF16 && mode != RCN_HIPX_BF16_STORED)
+        return fail(n, -1, "set_precision: mode must be RCN_HIPX_FP32, RCN_HIPX_BF16 or RCN_HIPX_BF16_STORED");
+    const int prec = mode == RCN_HIPX_FP32 ? RCN_HIPX_FP32 : RCN_HIPX_BF16;
+    const bool st16 = mode == RCN_HIPX_BF16_STORED;
+    if (st16) {
+        // does every layer of this net run on kernels that take bf16 tensors?  Asked of the plan (the same walk as the step), before anything changes.
+        rcn_hipx_net probe;
+        probe.in_h = n->in_h; probe.in_w = n->in_w; probe.in_c = n->in_c; probe.max_batch = n->max_batch; probe.classes = n->classes;
+        probe.precision = prec; probe.store16 = true; probe.tiling = n->tiling; probe.overlap = 0; probe.dry = true; probe.opt = n->opt;
+        copy_layer_table(probe, *n);
+        const int ps = step_core(&probe, nullptr, nullptr, n->max_batch, 0.f, nullptr, true, nullptr);
+        if (ps != 0) return fail(n, ps, probe.err);
+    }
     Dev g(n->device);
-    if (mode != n->precision) { XTRY(n, hipStreamSynchronize(n->stream)); drop_graphs(n); }
-    n->precision = mode;
+    if (prec != n->precision || st16 != n->store16) { XTRY(n, hipStreamSynchronize(n->stream)); drop_graphs(n); }
+    n->precision = prec;
+    n->store16 = st16;
     return 0;
 }
 
@@ -1233,14 +1327,16 @@ int rcn_hipx_step_flops(const rcn_hipx_net* n, int B, double* flops) {
 
 int rcn_hipx_plan(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int batch, int precision, int tiling, char* out, int cap) {
     if (!layers || n_layers < 1 || in_h < 1 || in_w < 1 || in_c < 1 || batch < 1 || !out || cap < 1) return -1;
-    if ((precision != RCN_HIPX_FP32 && precision != RCN_HIPX_BF16) || tiling < RCN_HIPX_TILING_GEMM || tiling > RCN_HIPX_TILING_LDS) return -1;
+    if ((precision != RCN_HIPX_FP32 && precision != RCN_HIPX_BF16 && precision != RCN_HIPX_BF16_STORED) || tiling < RCN_HIPX_TILING_GEMM || tiling > RCN_HIPX_TILING_LDS) return -1;
     rcn_hipx_net net;                                   // host-only: no device, no stream, no buffers
     net.in_h = in_h; net.in_w = in_w; net.in_c = in_c; net.max_batch = batch;
+    net.store16 = precision == RCN_HIPX_BF16_STORED;
+    if (net.store16) precision = RCN_HIPX_BF16;
     net.precision = precision; net.tiling = tiling; net.overlap = 0; net.dry = true;
     seed_options(net.opt);                              // as a net created now would be (rcn_hipx_plan_net: an existing net's own options)
     int st = describe_layers(&net, in_h, in_w, in_c, layers, n_layers);
     if (st == 0) {
-        net.plan = "forward + loss + backward of one batch of " + std::to_string(batch) + " (" + (precision == RCN_HIPX_BF16 ? "bf16" : "fp32") + " operands), launch by launch:\n";
+        net.plan = "forward + loss + backward of one batch of " + std::to_string(batch) + " (" + precision_name(precision, net.store16) + "), launch by launch:\n";
         st = step_core(&net, nullptr, nullptr, batch, 0.f, nullptr, true, nullptr);
     }
     const std::string& text = st == 0 ? net.plan : net.err;
@@ -1253,9 +1349,11 @@ int rcn_hipx_plan(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, in
 int rcn_hipx_plan_buckets(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int batch, int precision, int tiling, int64_t min_bucket_bytes,
                           char* out, int cap) {
     if (!layers || n_layers < 1 || in_h < 1 || in_w < 1 || in_c < 1 || batch < 1 || !out || cap < 1 || min_bucket_bytes < 0) return -1;
-    if ((precision != RCN_HIPX_FP32 && precision != RCN_HIPX_BF16) || tiling < RCN_HIPX_TILING_GEMM || tiling > RCN_HIPX_TILING_LDS) return -1;
+    if ((precision != RCN_HIPX_FP32 && precision != RCN_HIPX_BF16 && precision != RCN_HIPX_BF16_STORED) || tiling < RCN_HIPX_TILING_GEMM || tiling > RCN_HIPX_TILING_LDS) return -1;
     rcn_hipx_net net;
     net.in_h = in_h; net.in_w = in_w; net.in_c = in_c; net.max_batch = batch;
+    net.store16 = precision == RCN_HIPX_BF16_STORED;
+    if (net.store16) precision = RCN_HIPX_BF16;
     net.precision = precision; net.tiling = tiling; net.overlap = 0; net.dry = true;
     seed_options(net.opt);
     int st = describe_layers(&net, in_h, in_w, in_c, layers, n_layers);
@@ -1276,16 +1374,10 @@ int rcn_hipx_plan_net(const rcn_hipx_net* n, int batch, char* out, int cap) {
     if (!n || batch < 1 || batch > n->max_batch || !out || cap < 1) return -1;
     rcn_hipx_net net;
     net.in_h = n->in_h; net.in_w = n->in_w; net.in_c = n->in_c; net.max_batch = batch; net.classes = n->classes;
-    net.precision = n->precision; net.tiling = n->tiling; net.overlap = 0; net.dry = true;
+    net.precision = n->precision; net.store16 = n->store16; net.tiling = n->tiling; net.overlap = 0; net.dry = true;
     net.opt = n->opt;
-    for (const Layer& l : n->L) {                       // the layer descriptions without their buffers
-        Layer c;
-        c.kind = l.kind; c.H = l.H; c.W = l.W; c.Cin = l.Cin; c.oH = l.oH; c.oW = l.oW; c.Cout = l.Cout; c.CoutP = l.CoutP; c.K = l.K;
-        c.w_off = l.w_off; c.b_off = l.b_off; c.lw_off = l.lw_off; c.lb_off = l.lb_off; c.pool_follows = l.pool_follows;
-        net.L.push_back(c);
-    }
-    net.n_pad = n->n_pad; net.n_log = n->n_log;
-    net.plan = "forward + loss + backward of one batch of " + std::to_string(batch) + " (" + (net.precision == RCN_HIPX_BF16 ? "bf16" : "fp32") + " operands), launch by launch:\n";
+    copy_layer_table(net, *n);
+    net.plan = "forward + loss + backward of one batch of " + std::to_string(batch) + " (" + precision_name(net.precision, net.store16) + "), launch by launch:\n";
     const int st = step_core(&net, nullptr, nullptr, batch, 0.f, nullptr, true, nullptr);
     const std::string& text = st == 0 ? net.plan : net.err;
     std::snprintf(out, (size_t)cap, "%s", text.c_str());

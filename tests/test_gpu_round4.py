@@ -435,6 +435,91 @@ def test_trackx_bucketed_gradients_are_the_gradients_bit_for_bit(precision):
     net.close()
 
 
+def _layer_slices(in_shape, layers):
+    """(kind, w slice, b slice) of every layer with parameters in the logical flat layout (W[K][Cout] then b[Cout], layers back to back)."""
+    H, W, Cc = in_shape
+    off, out, flat = 0, [], False
+    for l in layers:
+        if l[0] == "conv":
+            k, o = 9 * Cc, l[1]
+            Cc = o
+        elif l[0] == "pool":
+            H, W = H // 2, W // 2
+            continue
+        else:
+            k, o = (Cc if flat else H * W * Cc), l[1]
+            Cc, flat = o, True
+        out.append((l[0], slice(off, off + k * o), slice(off + k * o, off + k * o + o)))
+        off += k * o + o
+    return out
+
+
+@pytest.mark.parametrize("shape", ["pool_pairs", "conv_conv"])
+def test_trackx_bf16_storage_rounds_what_bf16_mode_rounds(shape):
+    """RCN_HIPX_BF16_STORED: the convolutional stage's activations and gradients live in HBM as bf16.  Every consumer
+    of those tensors rounds them to bf16 on the way into LDS in bf16 mode anyway, so storing them rounded changes WHERE the rounding
+    happens, not what is rounded: logits and loss equal bf16 mode's bit for bit, and so does the weight gradient of every layer but the
+    first (whose fp32 kernel now reads a rounded dZ); bias gradients (summed in fp32 from dZ) and the first layer's weights agree to bf16
+    resolution.  Then ten training steps in each mode end at the same loss to 2 %."""
+    import torch
+    from mercer_research_amd.convnet import ConvNet
+    if shape == "pool_pairs":
+        in_shape, layers, B = (16, 16, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 128), ("dense", 10)), 64
+    else:
+        in_shape, layers, B = (32, 32, 1), (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("conv", 128), ("pool",), ("dense", 10)), 128    # (a batch at which bf16 mode does not split K either: same sums)
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((B,) + in_shape).astype(np.float32)
+    y = rng.integers(0, 10, B).astype(np.int32)
+    res = {}
+    for mode in ("bf16", "bf16_stored"):
+        net = ConvNet(in_shape, layers, B)
+        net.init_params(9)
+        net.set_precision(mode)
+        plan = net.plan_of_this_net(B)
+        assert ("stored as bf16" in plan) == (mode == "bf16_stored"), plan
+        xd, yd = net.to_device(x), net.to_device(y)
+        logits_d = net.forward(xd)
+        net.synchronize()
+        logits = logits_d.cpu().numpy().copy()
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        g = net.gradients(xd, yd, None, loss)
+        net.synchronize()
+        grad, l0 = net.unpad(g), float(loss.item())
+        for _ in range(10):
+            net.train_step(xd, yd, 0.02, loss)
+        net.synchronize()
+        res[mode] = (logits, l0, grad, float(loss.item()))
+        net.close()
+    a, b = res["bf16"], res["bf16_stored"]
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1], (a[1], b[1])
+    assert np.isfinite(b[2]).all() and np.abs(b[2]).max() > 0
+    for li, (kind, ws, bs) in enumerate(_layer_slices(in_shape, layers)):
+        if li > 0:
+            assert np.array_equal(a[2][ws], b[2][ws]), (li, kind, float(np.abs(a[2][ws] - b[2][ws]).max()))
+        else:
+            assert np.linalg.norm(a[2][ws] - b[2][ws]) <= 1e-2 * np.linalg.norm(a[2][ws]), (li, kind)
+        assert np.linalg.norm(a[2][bs] - b[2][bs]) <= 1e-2 * np.linalg.norm(a[2][bs]) + 1e-7, (li, kind)
+    assert b[3] < b[1] and abs(a[3] - b[3]) <= 2e-2 * abs(a[3]), (a[1], a[3], b[3])
+
+
+def test_trackx_bf16_storage_refuses_a_net_it_does_not_cover():
+    """rcn_hipx_set_precision walks the net's plan first: a net with a layer that no bf16-tensor kernel runs (here: the LDS-tiled kernels
+    switched off) gets -3 with the reason, and stays in the mode it was in."""
+    from mercer_research_amd.convnet import ConvNet, ConvNetError
+    in_shape, layers, B = (16, 16, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense", 10)), 16
+    net = ConvNet(in_shape, layers, B)
+    net.init_params(1)
+    net.set_precision("bf16")
+    net.set_option("halo", 0)
+    with pytest.raises(ConvNetError, match="bf16 storage"):
+        net.set_precision("bf16_stored")
+    assert "stored as bf16" not in net.plan_of_this_net(B)
+    net.set_option("halo", 1)
+    net.set_precision("bf16_stored")
+    assert "stored as bf16" in net.plan_of_this_net(B)
+    net.close()
+
+
 @pytest.mark.parametrize("B", [10, 200])
 def test_f64_epoch_from_images_on_the_resident_kernel_equals_features_then_train(amd, oracle, B):
     """The end-to-end form (u8 pictures -> features -> standardise -> packed epoch image in one kernel per segment, then the steps) in the
