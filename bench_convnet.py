@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_stored"], default="fp32",
                     help="GEMM operand precision of forward / dgrad: fp32 MFMA, bf16 MFMA with fp32 accumulate / storage / update, or bf16 MFMA with the "
                          "convolutional stage's activations and gradients also STORED as bf16 (RCN_HIPX_BF16_STORED)")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="a kernel-selection option of the net (rcn_hipx_set_option), e.g. fuse_pool_bwd=0; repeatable")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel step (gradients -> all-reduce -> apply) even at one GPU: a group of one over RCCL")
     ap.add_argument("--dp-graph", type=int, default=1, help="data-parallel step: 1 = replay it as a captured hipGraph (the all-reduce inside), 0 = launch it eagerly")
     ap.add_argument("--dp-buckets", type=int, default=1 << 20, help="data-parallel step: gradient buckets of at least this many bytes, each all-reduced on a second stream "
@@ -67,6 +68,8 @@ def main():
     B = args.batch or B                                    # per GPU (weak scaling)
     net = ConvNet(in_shape, layers, B, device=local_rank)
     net.init_params(1)                                     # same seed on every rank: identical replicas
+    for kv in args.set:
+        net.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     net.set_precision(args.precision)
     rng = np.random.default_rng(rank)
     nbuf = 8 if args.config != "synth224" else 2           # rotate over several resident batches
@@ -165,7 +168,7 @@ def main():
         # (every activation and activation gradient written once and read once per pass, as stored) is the more telling roof
         bf16 = args.precision != "fp32"
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else F32_MFMA_PEAK_TFLOPS
-        floor_bytes = net.step_hbm_floor_bytes(B) if hasattr(net, "step_hbm_floor_bytes") else None
+        floor_bytes = net.step_hbm_floor_bytes(B, stored16=args.precision == "bf16_stored")
         floor_ms = floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 if floor_bytes else None
         out_line = json.dumps({"metric": "training images/sec (Track X, trainable conv net; not the BASELINE metric)", "config": args.config, "batch_per_gpu": B, "n_gpus": world,
                           "scaling": "weak", "value": round(world * B * args.steps / el, 1), "unit": "images/s", "ms_per_step": round(el / args.steps * 1e3, 4),
@@ -173,7 +176,7 @@ def main():
                           "mfma_peak_tflops": peak, "mfma_peak_kind": "bf16 dense MFMA" if bf16 else "fp32 MFMA",
                           "frac_of_mfma_peak": round(tf / peak, 4),
                           "hbm_floor_ms": round(floor_ms, 4) if floor_ms else None, "frac_of_hbm_floor": round(floor_ms / (el / args.steps * 1e3), 4) if floor_ms else None,
-                          "dtype": "f32" if not bf16 else "bf16 MFMA operands (fwd, dgrad, wgrad), f32 accumulate/update", "data": "synthetic", "final_loss": round(loss.item(), 4),
+                          "dtype": "f32" if not bf16 else "bf16 MFMA operands (fwd, dgrad, wgrad), f32 accumulate/update" + (", conv-stage activations and gradients stored as bf16" if args.precision == "bf16_stored" else ""), "data": "synthetic", "final_loss": round(loss.item(), 4),
                           "data_parallel_step": dp_mode,
                           "data_parallel_allreduce": (None if not dp else "one all-reduce of the flat gradient after the backward pass" if args.dp_buckets <= 0 else
                                                       f"{n_buckets[0]} buckets of >= {args.dp_buckets} bytes, each all-reduced on a second stream under the backward pass of the layers below")}) + "\n"

@@ -228,26 +228,29 @@ class ConvNet:
         self._ck(self.lib.rcn_hipx_unpad_host(self.net, C.c_void_p(padded.data_ptr()), f.ctypes.data_as(C.POINTER(C.c_float))))
         return f
 
-    def step_hbm_floor_bytes(self, B: int) -> float:
-        """HBM floor of one training step with activations stored fp32: every layer's input read and output written once in the forward
+    def step_hbm_floor_bytes(self, B: int, stored16: bool = False) -> float:
+        """HBM floor of one training step with activations stored as they are (fp32; stored16: the convolutional stage's maps and their
+        gradients as bf16, "bf16_stored"): every layer's input read and output written once in the forward
         pass; in the backward pass dZ read and dX written once by the input-gradient GEMM (not for the first layer) and the input and dZ
         read once more by the weight-gradient GEMM; parameters read twice and written once.  Fusion (pool in the epilogue, ReLU masks in
         the consumer) can go below it only by not materialising a tensor at all."""
         H, W, Cc = self.in_shape
         total, first = 0.0, True
+        es_in = 4                                            # bytes per element of the current layer's input tensor
+        es_stage = 2 if stored16 else 4
         for l in self.layers:
             if l[0] == "conv":
-                i, o = H * W * Cc, H * W * l[1]
-                total += B * ((i + o) + (0 if first else (i + o)) + (i + o)) * 4 + 3 * (9 * Cc * l[1] + l[1]) * 4
-                Cc, first = l[1], False
+                i, o = H * W * Cc * es_in, H * W * l[1] * es_stage
+                total += B * ((i + o) + (0 if first else (i + o)) + (i + o)) + 3 * (9 * Cc * l[1] + l[1]) * 4
+                Cc, first, es_in = l[1], False, es_stage
             elif l[0] == "pool":
-                i, o = H * W * Cc, (H // 2) * (W // 2) * Cc
-                total += B * 2 * (i + o) * 4
+                i, o = H * W * Cc * es_stage, (H // 2) * (W // 2) * Cc * es_stage
+                total += B * 2 * (i + o)
                 H, W = H // 2, W // 2
             else:
-                i, o = H * W * Cc, l[1]
-                total += B * ((i + o) + (0 if first else (i + o)) + (i + o)) * 4 + 3 * (i * o + o) * 4
-                H, W, Cc, first = 1, 1, l[1], False
+                i, o = H * W * Cc * es_in, l[1] * 4
+                total += B * ((i + o) + (0 if first else (i + o)) + (i + o)) + 3 * (H * W * Cc * l[1] + l[1]) * 4
+                H, W, Cc, first, es_in = 1, 1, l[1], False, 4
         return total
 
     def step_flops(self, B: int) -> float:

@@ -574,7 +574,8 @@ __global__ void k_pool_fwd(const float* __restrict__ Y, float* __restrict__ P, u
 
 // dZ[n,h,w,c] = (position is the arg-max of its window && pooled value > 0) ? dP : 0   (max-pool backward + ReLU mask).
 // One thread per pooled element group of 4 channels writes all four window positions.
-__global__ void k_pool_bwd(const float* __restrict__ dP, const float* __restrict__ P, const uint8_t* __restrict__ idx, float* __restrict__ dZ,
+template <typename TS = float>       // storage type of all three tensors
+__global__ void k_pool_bwd(const TS* __restrict__ dP, const TS* __restrict__ P, const uint8_t* __restrict__ idx, TS* __restrict__ dZ,
                            int N, int H, int W, int C) {
     const int OH = H / 2, OW = W / 2, C4 = C / 4;
     const long long total = (long long)N * OH * OW * C4;
@@ -585,15 +586,16 @@ __global__ void k_pool_bwd(const float* __restrict__ dP, const float* __restrict
         const int oh = (int)(t % OH);
         const long long n = t / OH;
         const long long o = e * 4;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dP + o), pv = *reinterpret_cast<const f32x4*>(P + o);
+        const chunk4_t<TS> g = *reinterpret_cast<const chunk4_t<TS>*>(dP + o);
+        const f32x4 pv = widen4(*reinterpret_cast<const chunk4_t<TS>*>(P + o));
         const uint32_t ii = *reinterpret_cast<const uint32_t*>(idx + o);
-        float* dst = dZ + ((n * H + 2 * oh) * W + 2 * ow) * (long long)C + c;
+        TS* dst = dZ + ((n * H + 2 * oh) * W + 2 * ow) * (long long)C + c;
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
-            f32x4 v;
+            chunk4_t<TS> v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (((ii >> (8 * i)) & 3u) == (uint32_t)pos && pv[i] > 0.f) ? g[i] : 0.f;
-            *reinterpret_cast<f32x4*>(dst + (long long)(pos >> 1) * W * C + (pos & 1) * C) = v;
+            for (int i = 0; i < 4; ++i) v[i] = (((ii >> (8 * i)) & 3u) == (uint32_t)pos && pv[i] > 0.f) ? g[i] : (TS)0.f;
+            *reinterpret_cast<chunk4_t<TS>*>(dst + (long long)(pos >> 1) * W * C + (pos & 1) * C) = v;
         }
     }
 }

@@ -80,6 +80,23 @@ __device__ inline bool stage_ok(int pk, int y0, int x0, int img0, int Himg, int 
 template <int TW, int NT, typename TG = float>
 __device__ inline void halo_gate_prefetch(float (&g)[NT][16], int lane, int wave, int img0, int oh0, int ow0, int n0, const ConvShape& s,
                                           const TG* __restrict__ G) {
+    if constexpr (sizeof(TG) == 2) {
+        // bf16 tensors: the epilogue writes channel PAIRS (halo_epilogue, below) -- lane (l, l ^ 1) = channels (co, co + 1): the even lane
+        // rows 2j, the odd lane rows 2j + 1 -- so a lane's gates are the eight dwords at (its row of pair j, co & ~1): g[t][j], as bits
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int co2 = n0 + 32 * t + (lane & 30);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pr = mfma32_row(lane, 2 * j) + (lane & 1);
+                const int colb = pr & 15;
+                const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+                const bool ok = img < s.N && oh < s.H && ow < s.W;
+                g[t][j] = __uint_as_float(*reinterpret_cast<const unsigned*>(G + (ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co2) : 0u)));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int co = n0 + 32 * t + (lane & 31);
@@ -100,6 +117,79 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                                      const float* __restrict__ bias, TY* __restrict__ Y, uint8_t* __restrict__ pool_idx,
                                      const float (*gate)[16] = nullptr) {
     const int h = lane >> 5;
+    if constexpr (sizeof(TY) == 2) {
+        // bf16 output: two-byte stores are half a dword each -- sixteen store instructions per tile for 2 KB.  Lanes l and l ^ 1 hold
+        // adjacent channels of the same sixteen rows: they swap half of their values (one DPP move per row pair) so that the even lane
+        // holds both channels of rows 2j and the odd lane both channels of rows 2j + 1, and each writes eight DWORDS (the gate tensor
+        // of EPI 3 is read the same way).  Same values, same rounding.
+        static_assert(EPI != 3 || sizeof(TG) == 2, "a bf16 gradient is gated by a bf16 map");
+        using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+        const bool odd = lane & 1;
+        auto swap = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); };   // quad_perm [1, 0, 3, 2]
+        if (EPI == 4) {
+            const int OH = s.H / 2, OW = s.W / 2;
+            const int poh = oh0 / 2 + wave;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = n0 + 32 * t + (lane & 31);
+                const float bb = bias[co];
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                    float best[2];
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const int i0 = 4 * gq + 2 * pp;
+                        const float v[4] = {acc[t][i0], acc[t][i0 + 1], acc[t][8 + i0], acc[t][8 + i0 + 1]};
+                        float b = v[0];
+                        int bk = 0;
+#pragma unroll
+                        for (int k = 1; k < 4; ++k)
+                            if (v[k] > b) { b = v[k]; bk = k; }
+                        b += bb;
+                        best[pp] = b > 0.f ? b : 0.f;
+                        const int colb = 4 * h + 8 * gq + 2 * pp;
+                        const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
+                        const bool ok = img < s.N && poh < OH && pow_ < OW;
+                        store_idx_quad(pool_idx, (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co), bk, ok, lane);
+                    }
+                    // the even lane writes window pp = 0 for both channels, the odd lane window pp = 1
+                    const float recv = swap(odd ? best[0] : best[1]);
+                    const int colb = 4 * h + 8 * gq + (odd ? 2 : 0);
+                    const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
+                    const bool ok = img < s.N && poh < OH && pow_ < OW;
+                    const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + (co & ~1));
+                    const bf16x2 pk = {(__bf16)(odd ? recv : best[0]), (__bf16)(odd ? best[1] : recv)};
+                    if (ok) *reinterpret_cast<bf16x2*>(Y + o) = pk;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = n0 + 32 * t + (lane & 31);
+                const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v0 = acc[t][2 * j] + bb, v1 = acc[t][2 * j + 1] + bb;
+                    if (EPI == 2) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+                    const float recv = swap(odd ? v0 : v1);
+                    float lo = odd ? recv : v0, hi = odd ? v1 : recv;                 // channels co & ~1, (co & ~1) + 1 of this lane's row
+                    const int pr = mfma32_row(lane, 2 * j) + (lane & 1);
+                    const int colb = pr & 15;
+                    const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+                    const bool ok = img < s.N && oh < s.H && ow < s.W;
+                    const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + (co & ~1));
+                    if (EPI == 3) {
+                        const unsigned gb = gate ? __float_as_uint(gate[t][j]) : *reinterpret_cast<const unsigned*>(reinterpret_cast<const TG*>(bias) + (ok ? o : 0u));
+                        lo = __uint_as_float(gb << 16) > 0.f ? lo : 0.f;
+                        hi = __uint_as_float(gb & 0xffff0000u) > 0.f ? hi : 0.f;
+                    }
+                    const bf16x2 pk = {(__bf16)lo, (__bf16)hi};
+                    if (ok) *reinterpret_cast<bf16x2*>(Y + o) = pk;
+                }
+            }
+        }
+        return;
+    }
     if (EPI == 4) {
         // bias + ReLU + the 2x2 max-pool that follows: a lane's sixteen rows are block columns 4h..4h+3 and 8+4h..8+4h+3 of BOTH
         // pixel rows of its wave -- four complete pooling windows (TW = 8: columns 0..7 are image 0, 8..15 image 1: still whole
@@ -648,7 +738,11 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
         const int img0 = cur.img0, oh0 = cur.oh0, ow0 = cur.ow0;
         const int co = cur.n0 + r;
         const float bb = bias[co];
-        if (EPI == 4) {
+        if constexpr (sizeof(TY) == 2) {
+            // bf16 output: the shared epilogue's channel-pair stores (same layout of the accumulator rows, one column tile)
+            const f32x16 a1[1] = {acc};
+            halo_epilogue<TW, 1, EPI, TY, TY>(a1, lane, wave, img0, oh0, ow0, cur.n0, s, bias, Y, pool_idx);
+        } else if (EPI == 4) {
             // max-pool of relu(x + b) = relu(max(x) + b): the maximum (first of equals, order 00 01 10 11) is taken on the raw sums
             const int OH = s.H / 2, OW = s.W / 2;
             const int poh = oh0 / 2 + wave;

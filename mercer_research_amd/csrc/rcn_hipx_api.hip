@@ -785,7 +785,6 @@ int backward_layers(rcn_hipx_net* n, const float* x, int B, float lr, float* gra
             const Layer& cl = n->L[i - 1];
             const ConvShape cs{B, cl.H, cl.W, cl.Cin, cl.CoutP};
             const bool fusable = fuse_on && wgrad_halo_runs(n, cs, 3) && (i - 1 == 0 || conv_halo_runs(n, ConvShape{B, cl.H, cl.W, cl.CoutP, cl.Cin}));
-            if (n->store16 && !fusable) return fail(n, -3, kStoreGap);
             if (fusable) {
                 pooled[i - 1] = PooledGrad{(const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p};
                 if (dry_note(n, "  pool-bwd %dx%dx%d: none (the convolution's gradient kernels unpool while staging)", l.H, l.W, l.Cin))
@@ -795,8 +794,10 @@ int backward_layers(rcn_hipx_net* n, const float* x, int B, float lr, float* gra
             // gradient wrt the pool INPUT, with the preceding conv's ReLU mask folded in (pooled value > 0)
             const long long tot = (long long)B * l.oH * l.oW * (l.Cin / 4);
             if (dry_note(n, "  pool-bwd %dx%dx%d: k_pool_bwd", l.H, l.W, l.Cin)) continue;
-            hipLaunchKernelGGL(k_pool_bwd, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p,
-                               din, B, l.H, l.W, l.Cin);
+            if (n->store16) hipLaunchKernelGGL(k_pool_bwd<__bf16>, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, (const __bf16*)l.dout.p, (const __bf16*)l.out.p, (const uint8_t*)l.idx.p,
+                                               (__bf16*)din, B, l.H, l.W, l.Cin);
+            else hipLaunchKernelGGL(k_pool_bwd<float>, dim3(grid1d(tot, 256)), dim3(256), 0, n->stream, (const float*)l.dout.p, (const float*)l.out.p, (const uint8_t*)l.idx.p,
+                                    din, B, l.H, l.W, l.Cin);
             XTRY(n, hipGetLastError());
             continue;
         }
