@@ -68,9 +68,12 @@ def head_is_fp32(layers) -> bool:
     return len(layers) >= 2 and layers[-1][0] == "dense" and layers[-1][1] <= 32 and layers[-2][0] == "dense_relu" and layers[-2][1] <= 256
 
 
-def forward(x, ws, bs, layers, cache=None, operand="f64"):
+def forward(x, ws, bs, layers, cache=None, operand="f64", stored=False):
     """operand="bf16": both operands of every forward GEMM are rounded to bf16 first (products and sums stay f64) -- except in the
-    first layer when its patch is one k-block, and in the fused classifier head (head_is_fp32)."""
+    first layer when its patch is one k-block, and in the fused classifier head (head_is_fp32).
+    stored=True mirrors RCN_HIPX_BF16_STORED (include/rcn_hipx.h): the maps the convolutional stage keeps in memory -- a convolution's
+    output, or the pooled map when a pool follows it (the device then never writes the full-resolution one; its arg-max is taken on the
+    unrounded sums) -- are rounded to bf16 where they are written."""
     a = np.asarray(x, dtype=np.float64)
     pi = 0
     for li, l in enumerate(layers):
@@ -80,6 +83,8 @@ def forward(x, ws, bs, layers, cache=None, operand="f64"):
             op = "f64" if cols.shape[1] <= 32 else operand
             z = _op(cols, op) @ _op(ws[pi], op) + bs[pi]
             y = np.maximum(z, 0).reshape(N, H, W, -1)
+            if stored and not (li + 1 < len(layers) and layers[li + 1][0] == "pool"):
+                y = round_bf16(y)
             if cache is not None:
                 cache.append(("conv", cols, y, a.shape))
             a = y; pi += 1
@@ -88,6 +93,8 @@ def forward(x, ws, bs, layers, cache=None, operand="f64"):
             win = a.reshape(N, H // 2, 2, W // 2, 2, C).transpose(0, 1, 3, 2, 4, 5).reshape(N, H // 2, W // 2, 4, C)
             idx = win.argmax(axis=3)                      # first maximum, positions ordered (dy, dx) = 00, 01, 10, 11
             p = np.take_along_axis(win, idx[:, :, :, None, :], axis=3)[:, :, :, 0, :]
+            if stored:
+                p = round_bf16(p)
             if cache is not None:
                 cache.append(("pool", idx, a.shape))
             a = p
@@ -102,12 +109,15 @@ def forward(x, ws, bs, layers, cache=None, operand="f64"):
     return a
 
 
-def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
+def loss_and_grads(x, labels, ws, bs, layers, operand="f64", stored=False):
     """operand="bf16": every GEMM takes bf16-rounded operands -- forward, input gradient and weight gradient -- except a first layer
     whose whole patch fits one k-block (9*Cin <= 32) and the fused classifier head (head_is_fp32), which run fp32 kernels on the
-    device in either mode.  Bias gradients are plain sums of the unrounded dZ."""
+    device in either mode.  Bias gradients are plain sums of the unrounded dZ.
+    stored=True (RCN_HIPX_BF16_STORED): besides the maps (forward), the gradient with respect to every map of the convolutional stage is
+    rounded to bf16 where the input-gradient kernel of the layer above writes it; the bias gradients and the first layer's weight
+    gradient are then sums over that rounded dZ."""
     cache = []
-    logits = forward(x, ws, bs, layers, cache, operand)
+    logits = forward(x, ws, bs, layers, cache, operand, stored)
     B = logits.shape[0]
     z = logits - logits.max(axis=1, keepdims=True)
     p = np.exp(z); p /= p.sum(axis=1, keepdims=True)
@@ -144,11 +154,14 @@ def loss_and_grads(x, labels, ws, bs, layers, operand="f64"):
             gws[pi] = _op(f, op).T @ _op(dz, op); gbs[pi] = dz.sum(axis=0)
             d = (_op(dz, op) @ _op(ws[pi], op).T).reshape(shp)
             pi -= 1
+        li = len(layers) - 1 - bi
+        if stored and c[0] != "pool" and li > 0 and layers[li - 1][0] in ("conv", "pool"):
+            d = round_bf16(d)                              # written by this layer's input-gradient kernel into a bf16 tensor
     return loss, logits, gws, gbs
 
 
-def sgd_step(x, labels, ws, bs, layers, lr, operand="f64"):
-    loss, logits, gws, gbs = loss_and_grads(x, labels, ws, bs, layers, operand)
+def sgd_step(x, labels, ws, bs, layers, lr, operand="f64", stored=False):
+    loss, logits, gws, gbs = loss_and_grads(x, labels, ws, bs, layers, operand, stored)
     return [w - lr * g for w, g in zip(ws, gws)], [b - lr * g for b, g in zip(bs, gbs)], loss
 
 

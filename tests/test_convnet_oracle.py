@@ -49,3 +49,30 @@ def test_round_bf16_is_round_to_nearest_even():
     r = np.random.default_rng(0).standard_normal(1000)
     q = co.round_bf16(r)
     assert np.all(np.abs(q - r) <= np.abs(r) * 2.0 ** -8) and np.array_equal(co.round_bf16(q), q)
+
+
+def test_stored_rounding_is_where_the_maps_and_their_gradients_are_written():
+    """stored=True (the mirror of RCN_HIPX_BF16_STORED): the convolutional stage's maps and the gradients with respect to them are bf16
+    values; with bf16 operands that changes nothing in the forward pass (every consumer rounds the same values again: idempotent) and
+    nothing in a weight gradient whose GEMM rounds dZ anyway -- only the first layer's (exact products) and the bias gradients move, by
+    bf16 resolution."""
+    rng = np.random.default_rng(5)
+    in_shape = (8, 8, 3)
+    layers = (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 32), ("dense", 10))
+    shapes = co.param_shapes(in_shape, layers)
+    ws = [rng.standard_normal(k) * np.sqrt(2.0 / k[0]) for k, _ in shapes]
+    bs = [rng.standard_normal(n) * 0.1 for _, n in shapes]
+    x = rng.standard_normal((4,) + in_shape)
+    y = rng.integers(0, 10, 4)
+    l0, lg0, gw0, gb0 = co.loss_and_grads(x, y, ws, bs, layers, operand="bf16")
+    l1, lg1, gw1, gb1 = co.loss_and_grads(x, y, ws, bs, layers, operand="bf16", stored=True)
+    assert l0 == l1 and np.array_equal(lg0, lg1)
+    for i in range(1, len(ws)):
+        assert np.array_equal(gw0[i], gw1[i]), i
+    assert not np.array_equal(gw0[0], gw1[0]) and np.linalg.norm(gw0[0] - gw1[0]) <= 1e-2 * np.linalg.norm(gw0[0])
+    for i in range(3):
+        assert np.linalg.norm(gb0[i] - gb1[i]) <= 1e-2 * np.linalg.norm(gb0[i])
+    # with exact (f64) operands the storage rounding is the only rounding there is: visible, and of bf16 size
+    l2 = co.loss_and_grads(x, y, ws, bs, layers)[0]
+    l3 = co.loss_and_grads(x, y, ws, bs, layers, stored=True)[0]
+    assert l2 != l3 and abs(l2 - l3) <= 2e-2 * abs(l2)

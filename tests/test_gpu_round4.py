@@ -502,6 +502,56 @@ def test_trackx_bf16_storage_rounds_what_bf16_mode_rounds(shape):
     assert b[3] < b[1] and abs(a[3] - b[3]) <= 2e-2 * abs(a[3]), (a[1], a[3], b[3])
 
 
+@pytest.mark.parametrize("in_shape,layers,B", [
+    ((16, 16, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 32), ("dense", 10)), 5),
+    ((32, 32, 1), (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense", 7)), 3),
+    ((16, 32, 3), (("conv", 64), ("pool",), ("conv", 128), ("conv", 128), ("pool",), ("dense_relu", 128), ("dense_relu", 32), ("dense", 3)), 9),
+])
+def test_trackx_bf16_storage_matches_the_oracle_with_the_storage_rounding_mirrored(in_shape, layers, B):
+    """RCN_HIPX_BF16_STORED against oracle/convnet_oracle.py evaluated with the same operand rounding AND the same storage rounding
+    (stored=True: maps rounded where they are written, gradients with respect to maps rounded where the input-gradient kernel writes
+    them): logits, loss, every gradient and two training steps within the tolerances of the bf16-operand test (5e-3 of each tensor's
+    scale; 2e-2 after two steps)."""
+    import torch
+    from mercer_research_amd.convnet import ConvNet
+    from oracle import convnet_oracle as co
+    rng = np.random.default_rng(B + 3)
+    net = ConvNet(in_shape, layers, B)
+    shapes = co.param_shapes(in_shape, layers)
+    ws = [rng.standard_normal(k) * np.sqrt(2.0 / k[0]) for k, _ in shapes]
+    bs = [rng.standard_normal(n) * 0.1 for _, n in shapes]
+    net.set_params(co.flatten(ws, bs).astype(np.float32))
+    x = rng.standard_normal((B,) + in_shape)
+    y = rng.integers(0, layers[-1][1], B).astype(np.int32)
+    xd, yd = net.to_device(x.astype(np.float32)), net.to_device(y)
+    x64 = x.astype(np.float32).astype(np.float64)
+    w32 = [w.astype(np.float32).astype(np.float64) for w in ws]
+    b32 = [b.astype(np.float32).astype(np.float64) for b in bs]
+    loss_ref, logits_ref, gws, gbs = co.loss_and_grads(x64, y, w32, b32, layers, operand="bf16", stored=True)
+    net.set_precision("bf16_stored")
+
+    def close(a, b, rtol):
+        scale = max(1e-3, float(np.abs(b).max()))                      # (tests/test_gpu_convnet.py _close: of each tensor's scale)
+        assert np.abs(np.asarray(a, dtype=np.float64) - b).max() <= rtol * scale + 1e-6, (float(np.abs(np.asarray(a, dtype=np.float64) - b).max()), scale)
+    logits = net.forward(xd)
+    loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+    grad = net.gradients(xd, yd, loss=loss)
+    net.synchronize()
+    close(logits.cpu().numpy(), logits_ref, 5e-3)
+    assert abs(loss.item() - loss_ref) <= 5e-3 * max(1.0, loss_ref)
+    got, ref = net.unpad(grad), co.flatten(gws, gbs)
+    for kind, wsl, bsl in _layer_slices(in_shape, layers):
+        close(got[wsl], ref[wsl], 5e-3)
+        close(got[bsl], ref[bsl], 5e-3)
+    net.train_step(xd, yd, 0.05, loss)
+    net.train_step(xd, yd, 0.05, loss)
+    net.synchronize()
+    nw, nb, _ = co.sgd_step(x64, y, w32, b32, layers, 0.05, operand="bf16", stored=True)
+    nw, nb, _ = co.sgd_step(x64, y, nw, nb, layers, 0.05, operand="bf16", stored=True)
+    close(net.get_params(), co.flatten(nw, nb), 2e-2)
+    net.close()
+
+
 def test_trackx_bf16_storage_refuses_a_net_it_does_not_cover():
     """rcn_hipx_set_precision walks the net's plan first: a net with a layer that no bf16-tensor kernel runs (here: the LDS-tiled kernels
     switched off) gets -3 with the reason, and stays in the mode it was in."""
