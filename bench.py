@@ -800,6 +800,9 @@ def main():
             "x_cifar_f32_ms": _g(tx, "fp32", "ms_per_step"), "x_cifar_f32_frac": _g(tx, "fp32", "frac_of_mfma_peak"), "x_cifar_bf16_ms": _g(tx, "bf16", "ms_per_step"),
             "x_224_f32_ms": _g(tx, "synth224", "fp32", "ms_per_step"), "x_224_f32_frac": _g(tx, "synth224", "fp32", "frac_of_mfma_peak"),
             "x_224_bf16_ms": _g(tx, "synth224", "bf16", "ms_per_step"), "x_mnist4096_bf16_ms": _g(tx, "mnist4096_bf16", "ms_per_step"),
+            "x_cifar_bf16_stored_ms": _g(tx, "bf16_stored", "ms_per_step"), "x_224_bf16_stored_ms": _g(tx, "synth224", "bf16_stored", "ms_per_step"),
+            "x_224_bf16_stored_frac_of_hbm_floor": _g(tx, "synth224", "bf16_stored", "frac_of_hbm_floor"),
+            "x_mnist4096_bf16_stored_ms": _g(tx, "mnist4096_bf16_stored", "ms_per_step"),
             "x_conv_gemm_mfma_busy": _g(tx, "conv_gemm_mfma_busy", "time_weighted_over_3x3_conv_gemm_kernels"),
         }
         for k, v in flat.items():
@@ -1000,7 +1003,7 @@ def trackx_leg(torch, dev):
     in_shape, layers, B = CONFIGS["cifar"]
     out = {"config": "CIFAR-10 shape 32x32x3, conv3x3 3->32, pool, 32->64, pool, 64->128, pool -> 2048 -> 256 -> 10, batch 512, softmax + cross-entropy, SGD"}
     rng = np.random.default_rng(0)
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "bf16_stored"):
         net = ConvNet(in_shape, layers, B, device=dev)
         net.init_params(1)
         net.set_precision(prec)
@@ -1024,15 +1027,17 @@ def trackx_leg(torch, dev):
         flops = net.step_flops(B)
         tf = flops / (ms * 1e-3) / 1e12
         peak = F32_MFMA_PEAK_TFLOPS if prec == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        floor_ms = net.step_hbm_floor_bytes(B, stored16=prec == "bf16_stored") / (HBM_PEAK_GBS * 1e9) * 1e3
         out[prec] = {"ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1), "step_gflop": round(flops / 1e9, 2), "tflops": round(tf, 2),
                      "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4), "final_loss": round(float(loss.item()), 4),
+                     "hbm_floor_ms_as_stored": round(floor_ms, 4), "frac_of_hbm_floor": round(floor_ms / ms, 4),
                      "ms_per_step_of_each_stretch": [round(r, 4) for r in runs]}
         net.close()
     # BASELINE configs[3] on one GPU: synthetic 224x224x3, 8 conv layers, 128 images per GPU (fewer timed steps: 20 ms each)
     try:
         in_shape, layers, B = CONFIGS["synth224"]
         out["synth224"] = {"config": "synthetic 224x224x3, conv 3->32->32 | 64->64 | 128->128 | 256->256 (pool after each pair) -> 10, 128 images per GPU"}
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", "bf16", "bf16_stored"):
             net = ConvNet(in_shape, layers, B, device=dev)
             net.init_params(1)
             net.set_precision(prec)
@@ -1053,43 +1058,50 @@ def trackx_leg(torch, dev):
             flops = net.step_flops(B)
             tf = flops / (ms * 1e-3) / 1e12
             peak = F32_MFMA_PEAK_TFLOPS if prec == "fp32" else BF16_MFMA_PEAK_TFLOPS
+            floor_ms = net.step_hbm_floor_bytes(B, stored16=prec == "bf16_stored") / (HBM_PEAK_GBS * 1e9) * 1e3
             out["synth224"][prec] = {"ms_per_step": round(ms, 3), "images_per_s": round(B / ms * 1e3, 1), "step_gflop": round(flops / 1e9, 1), "tflops": round(tf, 2),
-                                     "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4)}
+                                     "mfma_peak_tflops": peak, "frac_of_mfma_peak": round(tf / peak, 4),
+                                     "hbm_floor_ms_as_stored": round(floor_ms, 3), "frac_of_hbm_floor": round(floor_ms / ms, 4)}
             net.close()
             del xs, ys
             torch.cuda.empty_cache()
     except Exception as ex:                                     # the extension must not take the BASELINE line down with it
         out["synth224"] = {"error": str(ex)[:300]}
-    # BASELINE configs[4] on one GPU: MNIST shape, bf16 MFMA, batch 4096, the step replayed as a captured hipGraph
-    try:
-        in_shape, layers, _ = CONFIGS["mnist"]
-        B = 4096
-        net = ConvNet(in_shape, layers, B, device=dev)
-        net.init_params(1)
-        net.set_precision("bf16")
-        xs = [net.to_device(rng.standard_normal((B,) + in_shape).astype(np.float32)) for _ in range(2)]
-        ys = [net.to_device(rng.integers(0, 10, B).astype(np.int32)) for _ in range(2)]
-        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
-        for i in range(8):
-            net.train_step(xs[i % 2], ys[i % 2], 0.01, loss)
-        net.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 50
-        a.record(net.stream)
-        for i in range(n):
-            net.train_step(xs[i % 2], ys[i % 2], 0.01, loss)
-        b.record(net.stream)
-        net.synchronize()
-        ms = a.elapsed_time(b) / n
-        flops = net.step_flops(B)
-        out["mnist4096_bf16"] = {"config": "MNIST shape 28x28x1, conv 1->32, pool, 32->64, pool -> 128 -> 10, batch 4096, bf16 MFMA operands, hipGraph step",
-                                 "ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1), "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
-                                 "frac_of_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
-        net.close()
-        del xs, ys
-        torch.cuda.empty_cache()
-    except Exception as ex:
-        out["mnist4096_bf16"] = {"error": str(ex)[:300]}
+    # BASELINE configs[4] on one GPU: MNIST shape, bf16 MFMA, batch 4096, the step replayed as a captured hipGraph; then the same with the
+    # convolutional stage's tensors stored as bf16
+    for prec, key in (("bf16", "mnist4096_bf16"), ("bf16_stored", "mnist4096_bf16_stored")):
+        try:
+            in_shape, layers, _ = CONFIGS["mnist"]
+            B = 4096
+            net = ConvNet(in_shape, layers, B, device=dev)
+            net.init_params(1)
+            net.set_precision(prec)
+            xs = [net.to_device(rng.standard_normal((B,) + in_shape).astype(np.float32)) for _ in range(2)]
+            ys = [net.to_device(rng.integers(0, 10, B).astype(np.int32)) for _ in range(2)]
+            loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+            for i in range(8):
+                net.train_step(xs[i % 2], ys[i % 2], 0.01, loss)
+            net.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 50
+            a.record(net.stream)
+            for i in range(n):
+                net.train_step(xs[i % 2], ys[i % 2], 0.01, loss)
+            b.record(net.stream)
+            net.synchronize()
+            ms = a.elapsed_time(b) / n
+            flops = net.step_flops(B)
+            floor_ms = net.step_hbm_floor_bytes(B, stored16=prec == "bf16_stored") / (HBM_PEAK_GBS * 1e9) * 1e3
+            out[key] = {"config": "MNIST shape 28x28x1, conv 1->32, pool, 32->64, pool -> 128 -> 10, batch 4096, bf16 MFMA operands, hipGraph step" +
+                                  (", conv-stage activations and gradients stored as bf16" if prec == "bf16_stored" else ""),
+                        "ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1), "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                        "frac_of_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "hbm_floor_ms_as_stored": round(floor_ms, 4), "frac_of_hbm_floor": round(floor_ms / ms, 4)}
+            net.close()
+            del xs, ys
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            out[key] = {"error": str(ex)[:300]}
     # the conv-GEMM MFMA-busy figures are PMC measurements of a separate profiled run (tools/prof_trackx.sh), relayed here with the
     # fingerprint of the kernel sources they were taken on -- like roofline.traffic, the line says when the sources have changed since
     from tools.mfma_pmc_summary import trackx_sha16

@@ -76,6 +76,7 @@ int  rcn_hipx_set_overlap(rcn_hipx_net* net, int on);
  *   "halo"            RCN_HIPX_HALO            0 | 1   bf16 mode: the LDS-tiled 3x3 kernels (1)
  *   "bf16_pipe"       RCN_HIPX_BF16_PIPE       0 | 1   bf16 mode: their software-pipelined form (1)
  *   "bf16_1cb"        RCN_HIPX_BF16_1CB        0 | 1   bf16 mode: the resident-weights form for 32-channel layers (1)
+ *   "bf16_rows16"     RCN_HIPX_BF16_ROWS16     0 | 1   bf16 storage: 16 x 16 pixel blocks (two row groups per wave) where the map's height allows
  *   "halo_wgrad"      RCN_HIPX_HALO_WGRAD      0 | 1   the LDS-tiled weight-gradient kernels (1)
  *   "fuse_pool_bwd"   RCN_HIPX_FUSE_POOL_BWD   0 | 1   the gradient kernels unpool while staging (1)
  *   "head"            RCN_HIPX_HEAD            0 | 1   the classifier head as one launch (1)

@@ -56,7 +56,7 @@ def load():
         if not os.path.exists(LIBX_PATH):
             raise ImportError(f"{LIBX_PATH} not found: build it with `python -m mercer_research_amd.build`; there is no CPU fallback")
         _lib.preload_hip_runtime()
-        lib = C.CDLL(LIBX_PATH)
+        lib = C.CDLL(os.environ.get("RCN_HIPX_TEST_LIB") or LIBX_PATH)          # (RCN_HIPX_TEST_LIB: diagnostic builds, tools/ablate_halo_bf16.sh)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

@@ -167,6 +167,20 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
             for (int t = 0; t < NT; ++t) {
                 const int co = n0 + 32 * t + (lane & 31);
                 const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
+                // every gate word FIRST, in one burst: loaded where it is used, each load sat between the previous row's store and its own
+                // s_waitcnt vmcnt(0) (the compiler may not move a load above a store it cannot tell apart) -- eight serial round trips per
+                // tile, and, vmcnt being in order, each of them also waited for the next phase's prefetched operands (ISA, round 4)
+                unsigned gb[8];
+                if (EPI == 3 && !gate) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int pr = mfma32_row(lane, 2 * j) + (lane & 1);
+                        const int colb = pr & 15;
+                        const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+                        const bool ok = img < s.N && oh < s.H && ow < s.W;
+                        gb[j] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const TG*>(bias) + (ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + (co & ~1)) : 0u));
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float v0 = acc[t][2 * j] + bb, v1 = acc[t][2 * j + 1] + bb;
@@ -179,11 +193,12 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                     const bool ok = img < s.N && oh < s.H && ow < s.W;
                     const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + (co & ~1));
                     if (EPI == 3) {
-                        const unsigned gb = gate ? __float_as_uint(gate[t][j]) : *reinterpret_cast<const unsigned*>(reinterpret_cast<const TG*>(bias) + (ok ? o : 0u));
-                        lo = __uint_as_float(gb << 16) > 0.f ? lo : 0.f;
-                        hi = __uint_as_float(gb & 0xffff0000u) > 0.f ? hi : 0.f;
+                        const unsigned g = gate ? __float_as_uint(gate[t][j]) : gb[j];
+                        lo = __uint_as_float(g << 16) > 0.f ? lo : 0.f;
+                        hi = __uint_as_float(g & 0xffff0000u) > 0.f ? hi : 0.f;
                     }
-                    const bf16x2 pk = {(__bf16)lo, (__bf16)hi};
+                    bf16x2 pk = {(__bf16)lo, (__bf16)hi};
+                    asm volatile("" : "+v"(pk));                                       // (the value is complete BEFORE the branch around its store: nothing waits inside it)
                     if (ok) *reinterpret_cast<bf16x2*>(Y + o) = pk;
                 }
             }
@@ -227,16 +242,31 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
         for (int t = 0; t < NT; ++t) {
             const int co = n0 + 32 * t + (lane & 31);
             const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
+            // (all gate values first, and every value complete before the branch around its store: see the bf16 form above -- as written
+            // before, each row's gate load waited behind the previous row's store, and the bias add sat inside the branch behind an
+            // s_waitcnt vmcnt(0) that, after the first store, waited for that store)
+            float gv[16];
+            if (EPI == 3 && !gate) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int pr = mfma32_row(lane, i);
+                    const int colb = pr & 15;
+                    const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+                    const bool ok = img < s.N && oh < s.H && ow < s.W;
+                    gv[i] = widen(reinterpret_cast<const TG*>(bias)[ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co) : 0u]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int pr = mfma32_row(lane, i);
                 const int colb = pr & 15;
                 const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
+                float v = acc[t][i] + bb;
+                if (EPI == 2) v = v > 0.f ? v : 0.f;
+                if (EPI == 3) v = (gate ? gate[t][i] : gv[i]) > 0.f ? v : 0.f;
+                asm volatile("" : "+v"(v));
                 if (img < s.N && oh < s.H && ow < s.W) {
                     const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co);      // the host keeps tensors below 2^31 elements
-                    float v = acc[t][i] + bb;
-                    if (EPI == 2) v = v > 0.f ? v : 0.f;
-                    if (EPI == 3) v = (gate ? gate[t][i] : widen(reinterpret_cast<const TG*>(bias)[o])) > 0.f ? v : 0.f;
                     Y[o] = narrow<TY>(v);
                 }
             }
@@ -405,12 +435,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
             __syncthreads();
             RCNX_STAMP(stamp_slot); ++stamp_slot;                     // operands staged (slot 1: end of the prologue)
             const int nkh = kh == 2 ? 0 : kh + 1, ncb = kh == 2 ? cb + CB : cb;
-            if (ph + 1 < nph) {
-                b_load(cur, ncb, nkh);
-                if (nkh == 0) halo_load(cur, ncb);
-            } else if (nitem < n_items) {                             // the next item's first phase
-                b_load(nxt, 0, 0);
-                halo_load(nxt, 0);
+            {
+                // ONE load site for "this item's next phase" and "the next item's first phase" (as two sites the second one's registers were
+                // copied over behind an s_waitcnt vmcnt(0), and phases waited for just-issued loads before their MFMAs: convnet_halo_bf16.hpp)
+                const bool same = ph + 1 < nph;
+                const Item li = same ? cur : nxt;
+                const int lcb = same ? ncb : 0, lkh = same ? nkh : 0;
+                if (same || nitem < n_items) {
+                    b_load(li, lcb, lkh);
+                    if (lkh == 0) halo_load(li, lcb);
+                }
             }
             RCNX_STAMP(stamp_slot); ++stamp_slot;                     // the next phase's loads issued
             const float* ak = arow + kh * Gm::HWD * LDC;

@@ -14,6 +14,10 @@
 #include "convnet_bf16.hpp"
 #include "convnet_halo.hpp"
 
+#ifndef RCNX_ABL
+#define RCNX_ABL 0
+#endif
+
 namespace rcnx {
 
 // TS: storage type of X, Y, EPI 3's gate tensor (passed through `bias`) and the pooled-resolution input (convnet.hpp, Chunk4): with
@@ -21,16 +25,23 @@ namespace rcnx {
 __device__ inline bf16x4 as_bf16x4(const f32x4& v) { return to_bf16x4(v); }
 __device__ inline bf16x4 as_bf16x4(const bf16x4& v) { return v; }
 
-template <int CB, int BN, int EPI, bool PIN = false, typename TS = float>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 64 && BN == 64 ? 2 : 3))) void k_conv3x3_halo_bf16p(
+// HaloGeom<16> with MG x 8 rows of output pixels
+template <int MG> struct HaloRows { static constexpr int TH = 8 * MG, HH = TH + 2, HWD = 16 + 2, NPIX = HH * HWD; };
+
+// MG: pixel-block rows per item in units of eight (1: 8 x 16 pixels, 2: 16 x 16).  With MG = 2 a wave computes TWO 32-pixel row groups
+// against the same weights: the weights of a filter row are staged (L2 -> registers -> LDS) once per 256 pixels instead of once per 128,
+// every B fragment read from LDS feeds two MFMAs, and the two barriers of a phase are paid per 48 MFMAs instead of 24 -- for 64 more
+// accumulator registers (two workgroups per CU instead of three).
+template <int CB, int BN, int EPI, bool PIN = false, typename TS = float, int MG = 1>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((CB == 64 && BN == 64) || MG == 2 ? 2 : 3))) void k_conv3x3_halo_bf16p(
     const TS* __restrict__ X, const __bf16* __restrict__ WB, const float* __restrict__ bias, TS* __restrict__ Y, ConvShape s, int tiles_w,
     int tiles_h, int n_items, uint8_t* __restrict__ pool_idx, PooledGradT<TS> pin) {
     static_assert(CB % 16 == 0 && BN % 32 == 0, "channel blocks of the 32x32x16 MFMA");
-    using Gm = HaloGeom<16>;
+    using Gm = HaloRows<MG>;
     constexpr int TW = 16, NT = BN / 32, LDC = CB + 8;                // halves per pixel / per weight row in LDS (16-byte aligned, bank-skewed)
     constexpr int CPP = CB / 4;                                       // f32x4 chunks per pixel of a channel block
     constexpr int PPW = TW / 2 + 2;                                   // PIN: pooled pixels under the halo: 6 rows x 10
-    constexpr int GR = PIN ? 6 : Gm::HH, GC = PIN ? PPW : Gm::HWD;    // the grid that is loaded: pooled pixels, or the halo itself
+    constexpr int GR = PIN ? Gm::TH / 2 + 2 : Gm::HH, GC = PIN ? PPW : Gm::HWD;    // the grid that is loaded: pooled pixels, or the halo itself
     constexpr int NH = (GR * GC * CPP + kThreads - 1) / kThreads;
     constexpr int BCH = 3 * BN * (CB / 8);                            // 16-byte chunks of one filter row's weights for a channel block
     constexpr int NB = (BCH + kThreads - 1) / kThreads;
@@ -138,47 +149,73 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CB == 
     bool first = true;
 #pragma unroll 1
     for (; item < n_items; item += gridDim.x) {
-        f32x16 acc[NT];
+        f32x16 acc[MG][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int g = 0; g < MG; ++g)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[g][t][q] = 0.f;
         const int nitem = item + gridDim.x;
         pos = advance(pos);
         const Item nxt = item_of(pos);
         int cb = 0, kh = 0;
 #pragma unroll 1
         for (int ph = 0; ph < nph; ++ph) {
-            if (!first) __syncthreads();                              // the previous phase's operands have been consumed
+            // RCNX_ABL (diagnostic builds only, tools/ablate_halo_bf16.sh; never defined in the library): what a phase costs without its
+            // global loads (1), without its LDS stores too (2), without its barriers too (3); 4: everything but the MFMAs
+            const bool abl_first = first;
+            if (!first && RCNX_ABL != 3) __syncthreads();             // the previous phase's operands have been consumed
             first = false;
-            if (kh == 0) halo_store();
-            b_store();
-            __syncthreads();
-            const int nkh = kh == 2 ? 0 : kh + 1, ncb = kh == 2 ? cb + CB : cb;
-            if (ph + 1 < nph) {
-                b_load(cur, ncb, nkh);
-                if (nkh == 0) halo_load(cur, ncb);
-            } else if (nitem < n_items) {                             // the next item's first phase
-                b_load(nxt, 0, 0);
-                halo_load(nxt, 0);
+            if (RCNX_ABL < 2 || RCNX_ABL >= 4 || abl_first) {
+                if (kh == 0) halo_store();
+                b_store();
             }
+            if (RCNX_ABL != 3) __syncthreads();
+            const int nkh = kh == 2 ? 0 : kh + 1, ncb = kh == 2 ? cb + CB : cb;
+            if (RCNX_ABL == 0 || RCNX_ABL >= 4) {
+                // ONE load site for "this item's next phase" and "the next item's first phase": as two sites the compiler loaded the
+                // second one into other registers, copied them over behind an s_waitcnt vmcnt(0), and -- those registers doubling as
+                // LDS-read destinations -- made every phase wait for most of its just-issued loads BEFORE its MFMAs (ISA, round 4)
+                const bool same = ph + 1 < nph;
+                const Item li = same ? cur : nxt;
+                const int lcb = same ? ncb : 0, lkh = same ? nkh : 0;
+                if (same || nitem < n_items) {
+                    b_load(li, lcb, lkh);
+                    if (lkh == 0) halo_load(li, lcb);
+                }
+            }
+            if (RCNX_ABL != 4)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const __bf16* a = &Hs[((py + kh) * Gm::HWD + px + kw) * LDC + 8 * h];
                 const __bf16* b = &Bs[(kw * BN + r) * LDC + 8 * h];
 #pragma unroll
                 for (int ks = 0; ks < CB / 16; ++ks) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a + 16 * ks);
+                    bf16x8 af[MG];
+#pragma unroll
+                    for (int g = 0; g < MG; ++g) {
+                        if (RCNX_ABL == 5) { asm volatile("" : "=v"(af[g])); continue; }                 // 5: the MFMAs without their LDS reads
+                        af[g] = *reinterpret_cast<const bf16x8*>(a + g * 8 * Gm::HWD * LDC + 16 * ks);
+                    }
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(b + 32 * t * LDC + 16 * ks);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                        bf16x8 bf;
+                        if (RCNX_ABL == 5) asm volatile("" : "=v"(bf));
+                        else bf = *reinterpret_cast<const bf16x8*>(b + 32 * t * LDC + 16 * ks);
+                        if (RCNX_ABL == 6) {                                                             // 6: the LDS reads without the MFMAs
+                            asm volatile("" :: "v"(bf), "v"(af[0]));
+                            continue;
+                        }
+#pragma unroll
+                        for (int g = 0; g < MG; ++g) acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g], bf, acc[g][t], 0, 0, 0);
                     }
                 }
             }
             kh = nkh; cb = ncb;
         }
-        halo_epilogue<TW, NT, EPI, TS, TS>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx);
+#pragma unroll
+        for (int g = 0; g < MG; ++g) halo_epilogue<TW, NT, EPI, TS, TS>(acc[g], lane, wave, cur.img0, cur.oh0 + 8 * g, cur.ow0, cur.n0, s, bias, Y, pool_idx);
         cur = nxt;
     }
 }

@@ -65,6 +65,7 @@ struct XOptions {
     int halo = 1;             // "halo"            RCN_HIPX_HALO            bf16: the LDS-tiled 3x3 kernels (0: implicit GEMM only)
     int bf16_pipe = 1;        // "bf16_pipe"       RCN_HIPX_BF16_PIPE       bf16: the software-pipelined LDS-tiled kernel (k_conv3x3_halo_bf16p)
     int bf16_1cb = 1;         // "bf16_1cb"        RCN_HIPX_BF16_1CB        bf16: the resident-weights form for 32-channel layers
+    int bf16_rows16 = 0;      // "bf16_rows16"     RCN_HIPX_BF16_ROWS16     bf16 storage: 16 x 16 pixel blocks (two row groups per wave) where the map's height allows
     int halo_wgrad = 1;       // "halo_wgrad"      RCN_HIPX_HALO_WGRAD      the LDS-tiled weight-gradient kernels
     int fuse_pool_bwd = 1;    // "fuse_pool_bwd"   RCN_HIPX_FUSE_POOL_BWD   gradient kernels unpool while staging (no k_pool_bwd)
     int head = 1;             // "head"            RCN_HIPX_HEAD            the classifier head as one launch (k_head_f32)
@@ -83,6 +84,7 @@ const XOptDesc kXOptTable[] = {
     {"halo", "RCN_HIPX_HALO", &XOptions::halo, 0, 1},
     {"bf16_pipe", "RCN_HIPX_BF16_PIPE", &XOptions::bf16_pipe, 0, 1},
     {"bf16_1cb", "RCN_HIPX_BF16_1CB", &XOptions::bf16_1cb, 0, 1},
+    {"bf16_rows16", "RCN_HIPX_BF16_ROWS16", &XOptions::bf16_rows16, 0, 1},
     {"halo_wgrad", "RCN_HIPX_HALO_WGRAD", &XOptions::halo_wgrad, 0, 1},
     {"fuse_pool_bwd", "RCN_HIPX_FUSE_POOL_BWD", &XOptions::fuse_pool_bwd, 0, 1},
     {"head", "RCN_HIPX_HEAD", &XOptions::head, 0, 1},
@@ -320,6 +322,25 @@ int launch_conv(rcn_hipx_net* n, const float* X, const float* Wk, const float* b
                           else if (kepi == 3) HB1_LAUNCH(BN_, 3, false); else HB1_LAUNCH(BN_, 4, false); } while (0)
                 const int onecb = n->opt.bf16_1cb;
                 if (st.x16 != st.y16) return fail(n, -3, kStoreGap);
+                // 16 x 16 pixel blocks (k_conv3x3_halo_bf16p<..., MG = 2>): bf16 tensors, 64-wide column blocks, a height that 16-row blocks
+                // cover with no more padding than 8-row blocks do, and still at least one item per resident workgroup
+                const int th2 = (s.H + 15) / 16;
+                const long long items2 = (long long)tw * th2 * s.N * (s.Cout / hbn);
+                const bool mg2 = n->opt.bf16_rows16 && st.x16 && hbn == 64 && !(s.Cin == 32 && onecb && hbn == 32) && th2 * 16 == th * kHaloTH && items2 >= 512;
+                if (mg2 && dry_note(n, "  conv3x3 %dx%dx%d->%d epi %d%s: k_conv3x3_halo_bf16p (16 x 16 pixel blocks), %lld items", s.H, s.W, s.Cin, s.Cout, kepi, pin ? " pooled-in" : "", items2)) return 0;
+                if (mg2) {
+#define HB2_LAUNCH(CI_, EPI_, PIN_) do { const long long slots = resident_slots(n, (const void*)k_conv3x3_halo_bf16p<CI_, 64, EPI_, PIN_, __bf16, 2>); \
+                    hipLaunchKernelGGL((k_conv3x3_halo_bf16p<CI_, 64, EPI_, PIN_, __bf16, 2>), dim3((unsigned)(items2 < slots ? items2 : slots)), dim3(kThreads), 0, n->stream, (const __bf16*)X, WB, bias, (__bf16*)out, s, tw, th2, (int)items2, pool_idx, \
+                                       PooledGradT<__bf16>{(const __bf16*)pg.dP, (const __bf16*)pg.P, pg.idx}); } while (0)
+#define HB2_EPI(CI_) do { if (pin) { if (kepi == 3) HB2_LAUNCH(CI_, 3, true); else if (kepi == 0) HB2_LAUNCH(CI_, 0, true); else return fail(n, -3, "internal: pooled-resolution input with a forward epilogue"); } \
+                          else if (kepi == 0) HB2_LAUNCH(CI_, 0, false); else if (kepi == 1) HB2_LAUNCH(CI_, 1, false); else if (kepi == 2) HB2_LAUNCH(CI_, 2, false); \
+                          else if (kepi == 3) HB2_LAUNCH(CI_, 3, false); else HB2_LAUNCH(CI_, 4, false); } while (0)
+                    if (s.Cin == 32) HB2_EPI(32); else HB2_EPI(64);
+#undef HB2_EPI
+#undef HB2_LAUNCH
+                    XTRY(n, hipGetLastError());
+                    return 0;
+                }
                 if (items <= 0x7fffffffLL && dry_note(n, "  %s %dx%dx%d->%d epi %d%s: %s, %lld items", ks == 3 ? "conv3x3" : "dense", s.H, s.W, s.Cin, s.Cout, kepi, pin ? " pooled-in" : "",
                                                       (s.Cin == 32 && onecb && hbn == 32) ? "k_conv3x3_halo_bf16_1cb<32>" : "k_conv3x3_halo_bf16p", items)) return 0;
                 if (items <= 0x7fffffffLL) {

@@ -552,6 +552,41 @@ def test_trackx_bf16_storage_matches_the_oracle_with_the_storage_rounding_mirror
     net.close()
 
 
+def test_trackx_bf16_storage_16x16_pixel_blocks_compute_the_same_bits():
+    """Option "bf16_rows16": k_conv3x3_halo_bf16p<..., MG = 2> -- a wave computes two 32-pixel row groups against the same staged weights.
+    Same operands, same accumulation order per output: logits, loss, gradients and three training steps equal the 8-row form's bit for
+    bit, and the plan names the form for the layers whose height it covers without extra padding."""
+    import torch
+    from mercer_research_amd.convnet import ConvNet
+    in_shape, layers, B = (32, 32, 3), (("conv", 32), ("conv", 64), ("pool",), ("conv", 64), ("conv", 128), ("pool",), ("dense_relu", 64), ("dense", 10)), 128
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((B,) + in_shape).astype(np.float32)
+    y = rng.integers(0, 10, B).astype(np.int32)
+    res = []
+    for rows16 in (0, 1):
+        net = ConvNet(in_shape, layers, B)
+        net.init_params(4)
+        net.set_option("bf16_rows16", rows16)
+        net.set_precision("bf16_stored")
+        plan = net.plan_of_this_net(B)
+        assert ("16 x 16 pixel blocks" in plan) == bool(rows16), plan
+        xd, yd = net.to_device(x), net.to_device(y)
+        logits = net.forward(xd)
+        loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+        g = net.gradients(xd, yd, None, loss)
+        net.synchronize()
+        out = [logits.cpu().numpy().copy(), float(loss.item()), g.cpu().numpy().copy()]
+        for _ in range(3):
+            net.train_step(xd, yd, 0.002, loss)
+        net.synchronize()
+        out += [net.get_params(), float(loss.item())]
+        res.append(out)
+        net.close()
+    a, b = res
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and a[4] == b[4]
+    assert np.isfinite(b[3]).all() and np.isfinite(b[4])
+
+
 def test_trackx_bf16_storage_refuses_a_net_it_does_not_cover():
     """rcn_hipx_set_precision walks the net's plan first: a net with a layer that no bf16-tensor kernel runs (here: the LDS-tiled kernels
     switched off) gets -3 with the reason, and stays in the mode it was in."""
