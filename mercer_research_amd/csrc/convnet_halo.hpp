@@ -115,7 +115,7 @@ __device__ inline void halo_gate_prefetch(float (&g)[NT][16], int lane, int wave
 template <int TW, int NT, int EPI, typename TY = float, typename TG = float>
 __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave, int img0, int oh0, int ow0, int n0, const ConvShape& s,
                                      const float* __restrict__ bias, TY* __restrict__ Y, uint8_t* __restrict__ pool_idx,
-                                     const float (*gate)[16] = nullptr) {
+                                     const float (*gate)[16] = nullptr, const float* bias_ready = nullptr) {      // bias_ready[t]: the lane's bias, already in registers
     const int h = lane >> 5;
     if constexpr (sizeof(TY) == 2) {
         // bf16 output: two-byte stores are half a dword each -- sixteen store instructions per tile for 2 KB.  Lanes l and l ^ 1 hold
@@ -132,7 +132,7 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int co = n0 + 32 * t + (lane & 31);
-                const float bb = bias[co];
+                const float bb = bias_ready ? bias_ready[t] : bias[co];
 #pragma unroll
                 for (int gq = 0; gq < 2; ++gq) {
                     float best[2];
@@ -166,7 +166,7 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int co = n0 + 32 * t + (lane & 31);
-                const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
+                const float bb = (EPI == 1 || EPI == 2) ? (bias_ready ? bias_ready[t] : bias[co]) : 0.f;
                 // every gate word FIRST, in one burst: loaded where it is used, each load sat between the previous row's store and its own
                 // s_waitcnt vmcnt(0) (the compiler may not move a load above a store it cannot tell apart) -- eight serial round trips per
                 // tile, and, vmcnt being in order, each of them also waited for the next phase's prefetched operands (ISA, round 4)
@@ -214,7 +214,7 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int co = n0 + 32 * t + (lane & 31);
-            const float bb = bias[co];
+            const float bb = bias_ready ? bias_ready[t] : bias[co];
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
@@ -241,7 +241,7 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int co = n0 + 32 * t + (lane & 31);
-            const float bb = (EPI == 1 || EPI == 2) ? bias[co] : 0.f;
+            const float bb = (EPI == 1 || EPI == 2) ? (bias_ready ? bias_ready[t] : bias[co]) : 0.f;
             // (all gate values first, and every value complete before the branch around its store: see the bf16 form above -- as written
             // before, each row's gate load waited behind the previous row's store, and the bias add sat inside the branch behind an
             // s_waitcnt vmcnt(0) that, after the first store, waited for that store)
@@ -738,7 +738,8 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
     Item cur = item_of(pos);
     halo_load(cur);
     float wreg[KS2];
-    int wn0 = -1;
+    float bb = 0.f;                                                   // the lane's bias: loaded WITH the weights -- a load in the epilogue is waited
+    int wn0 = -1;                                                     // for with vmcnt(0), i.e. together with the next block's halo just prefetched
     bool first = true;
 #pragma unroll 1
     for (; item < n_items; item += gridDim.x) {
@@ -748,7 +749,12 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
                 const int k = 2 * ks + h;
                 wreg[ks] = k < K ? Wk[(long long)k * s.Cout + cur.n0 + r] : 0.f;
             }
+            bb = bias[cur.n0 + r];
             wn0 = cur.n0;
+            // The weights are complete HERE, once per column block.  Left pending, the compiler's wait for them sat in front of every
+            // MFMA of every item as "at most 13, 12, ... 0 loads outstanding" -- counted from the youngest load, which in the steady state
+            // is the next block's halo just prefetched: every item waited for its own prefetch before its last MFMAs (ISA, round 4).
+            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), expcnt and lgkmcnt untouched
         }
         const int nitem = item + gridDim.x;
         pos = advance(pos);
@@ -771,11 +777,11 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
         RCNX_STAMP(stamp_slot); ++stamp_slot;                         // MFMAs issued
         const int img0 = cur.img0, oh0 = cur.oh0, ow0 = cur.ow0;
         const int co = cur.n0 + r;
-        const float bb = bias[co];
         if constexpr (sizeof(TY) == 2) {
             // bf16 output: the shared epilogue's channel-pair stores (same layout of the accumulator rows, one column tile)
             const f32x16 a1[1] = {acc};
-            halo_epilogue<TW, 1, EPI, TY, TY>(a1, lane, wave, img0, oh0, ow0, cur.n0, s, bias, Y, pool_idx);
+            const float bb1[1] = {bb};
+            halo_epilogue<TW, 1, EPI, TY, TY>(a1, lane, wave, img0, oh0, ow0, cur.n0, s, bias, Y, pool_idx, nullptr, bb1);
         } else if (EPI == 4) {
             // max-pool of relu(x + b) = relu(max(x) + b): the maximum (first of equals, order 00 01 10 11) is taken on the raw sums
             const int OH = s.H / 2, OW = s.W / 2;

@@ -320,6 +320,9 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const TS* __
     Item cur = item_of(pos);
     halo_load(cur);
     int loaded_n0 = -1;
+    float bbr[NT];                                                    // the lane's bias values, loaded with the column block's weights (below)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bbr[t] = 0.f;
     bool first = true;
 #pragma unroll 1
     for (; item < n_items; item += gridDim.x) {
@@ -333,14 +336,27 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const TS* __
         const Item nxt = item_of(pos);
         if (!first) __syncthreads();                                  // the previous item's operands have been consumed
         first = false;
-        if (cur.n0 != loaded_n0) { weights_in(cur.n0); loaded_n0 = cur.n0; }
+        if (cur.n0 != loaded_n0) {
+            weights_in(cur.n0);
+            if (EPI == 1 || EPI == 2 || EPI == 4) {
+                // the bias with the weights, complete here: loaded in the epilogue it is the YOUNGEST load, and the wait for it (vmcnt counts
+                // in order) is a wait for the next item's halo just prefetched -- every item paid its own prefetch latency (ISA, round 4)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bbr[t] = bias[cur.n0 + 32 * t + (lane & 31)];
+                __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+            }
+            loaded_n0 = cur.n0;
+        }
         halo_store();
         __syncthreads();
-        if (nitem < n_items) halo_load(nxt);
-        // (EPI 3, one column tile: the gate values are loaded ahead of the MFMAs -- sixteen registers; with two tiles they spill)
+        // (EPI 3, one column tile: the gate values are loaded ahead of the MFMAs -- sixteen registers; with two tiles they spill.  Issued
+        // BEFORE the prefetch, and the prefetch unconditional (past the last item: this item's halo again, never used): the epilogue's wait
+        // for the gates then allows exactly the prefetch's loads to stay in flight)
         constexpr bool GATE_AHEAD = EPI == 3 && NT == 1;
         float gate[NT][16];
         if constexpr (GATE_AHEAD) halo_gate_prefetch<TW, NT, TS>(gate, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, reinterpret_cast<const TS*>(bias));
+        if (GATE_AHEAD) halo_load(nitem < n_items ? nxt : cur);
+        else if (nitem < n_items) halo_load(nxt);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -357,7 +373,9 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_halo_bf16_1cb(const TS* __
                     }
                 }
             }
-        halo_epilogue<TW, NT, EPI, TS, TS>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx, GATE_AHEAD ? gate : nullptr);
+        __builtin_amdgcn_sched_barrier(0);                            // (nothing of the epilogue -- its waits least of all -- moves in front of the MFMAs)
+        halo_epilogue<TW, NT, EPI, TS, TS>(acc, lane, wave, cur.img0, cur.oh0, cur.ow0, cur.n0, s, bias, Y, pool_idx, GATE_AHEAD ? gate : nullptr,
+                                           (EPI == 1 || EPI == 2 || EPI == 4) ? bbr : nullptr);
         cur = nxt;
     }
 }
