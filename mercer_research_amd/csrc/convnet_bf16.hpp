@@ -540,9 +540,17 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const TS*
         hpk[q] = e < HCH ? (hy | (hx << 8)) : -1;
         hrel[q] = (hy * s.W + hx) * Cin + c4;
     }
-    chunk4_t<TS> hv[NHQ], dv[NDQ], dpv = {};
-    unsigned dii = 0, okm = 0;
-    auto gload = [&](int blk) {
+    // S blocks' operands are in flight at once (round 4; one was: a 32-channel layer's block is 8 MFMAs per wave against a load latency
+    // of more than a microsecond, with ONE workgroup per CU -- the kernel ran at exactly blocks x latency).  A stage is a handful of
+    // registers, refilled with the block S further on as soon as its own block has gone to LDS; every gload issues the same number of
+    // loads whatever the block (past the chunk's last block: that block again), so the wait in front of a stage's LDS stores is an exact
+    // count that leaves the younger stages in flight.  (64 x 64 tiles: 64 accumulator registers, and a block is 32 MFMAs per wave; fp32
+    // tensors: twice the registers per stage.)
+    constexpr int S = sizeof(TS) == 4 ? (NA * NT == 4 ? 1 : 2) : (NA * NT == 1 ? 4 : NA * NT == 2 ? 3 : PDZ ? 2 : 1);
+    struct Stage { chunk4_t<TS> hv[NHQ], dv[NDQ], dpv; unsigned dii, okm; };
+    Stage stg[S];
+    auto gload = [&](int blk, Stage& g) {
+        chunk4_t<TS> (&hv)[NHQ] = g.hv; chunk4_t<TS> (&dv)[NDQ] = g.dv; chunk4_t<TS>& dpv = g.dpv; unsigned& dii = g.dii; unsigned& okm = g.okm;
         int q0 = blk;
         const int tw = q0 % tiles_w; q0 /= tiles_w;
         const int th = q0 % tiles_h;
@@ -578,7 +586,8 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const TS*
             }
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](const Stage& g) {
+        const chunk4_t<TS> (&hv)[NHQ] = g.hv; const chunk4_t<TS> (&dv)[NDQ] = g.dv; const chunk4_t<TS>& dpv = g.dpv; const unsigned dii = g.dii, okm = g.okm;
 #pragma unroll
         for (int q = 0; q < NHQ; ++q) {
             const int e = tid + kWgHaloThreads * q;
@@ -611,12 +620,20 @@ __global__ __launch_bounds__(kWgHaloThreads) void k_wgrad3x3_halo_bf16(const TS*
         }
     };
 
-    if (b0 < b1) gload(b0);
-    for (int blk = b0; blk < b1; ++blk) {
+    if (b0 < b1) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) gload(b0 + u < b1 ? b0 + u : b1 - 1, stg[u]);
+    }
+#pragma unroll 1
+    for (int blk0 = b0; blk0 < b1; blk0 += S)
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int blk = blk0 + u;
+        if (blk >= b1) break;
         if (blk != b0) __syncthreads();                               // the previous block's images have been consumed
-        lstore();
+        lstore(stg[u]);
         __syncthreads();
-        if (blk + 1 < b1) gload(blk + 1);                             // the next block's loads fly under this block's MFMAs
+        gload(blk + S < b1 ? blk + S : b1 - 1, stg[u]);              // S blocks ahead, under this and the next blocks' MFMAs
 #pragma unroll
         for (int py = 0; py < kHaloTH; ++py) {                        // one 16-pixel contraction step per block row
             bf16x8 af[NA], bf[NT];

@@ -6,6 +6,6 @@ for k in ${ABL_SET:-0 1 2 3 4}; do
   D=$R/gpurun_out/abl_$k
   rm -rf $D
   if [ $k = 0 ]; then unset RCN_HIPX_TEST_LIB; else export RCN_HIPX_TEST_LIB=$R/mercer_research_amd/variants/librcn_hipx_abl$k.so; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench_convnet.py --config synth224 --precision bf16_stored --steps 10 --warmup 2 > $D.json 2> $D.err || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench_convnet.py --config synth224 --precision bf16_stored --steps 10 --warmup 2 $EXTRA > $D.json 2> $D.err || exit 1
   find $D -type f ! -name '*kernel_stats.csv' -delete
 done
