@@ -396,7 +396,7 @@ def test_trackx_options_are_per_net_and_the_plan_of_a_net_is_its_own(monkeypatch
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16_stored"])
 def test_trackx_bucketed_gradients_are_the_gradients_bit_for_bit(precision):
     """rcn_hipx_gradients_begin_dev / _bucket_dev: the backward pass as a resumable walk that stops after every bucket of layers and runs
     that bucket's slab reduction, so that a data-parallel step can all-reduce the slice while the layers below still run.  Same kernels,
