@@ -74,6 +74,28 @@ __device__ inline bool stage_ok(int pk, int y0, int x0, int img0, int Himg, int 
 
 // Epilogue of the LDS-tiled forward / input-gradient kernels (fp32 and bf16 operands alike: the accumulators are fp32): accumulator
 // row i of a lane is block pixel mfma32_row(lane, i) of its wave's 32 pixels (block rows 2 wave, 2 wave + 1).
+//
+// Addresses (round 4).  Row i sits at block column 4 h + (i & 3) + 8 ((i >> 2) & 1) and block row 2 wave + (i >> 3), so its element
+// offset is the lane's offset of row 0 plus a delta that is the SAME for every lane -- a few scalar products of the shape.  Computed
+// per row as ((img * H + oh) * W + ow) * Cout + co the compiler used v_mad_u64_u32 with an undefined upper half for every row, and
+// whichever register it picked for that half usually had one of the NEXT item's prefetched loads pending: an s_waitcnt vmcnt(0) in
+// front of every store (ISA) -- and four vector instructions per row where one add does.
+template <int TW> struct EpiRows {
+    int img, oh, ow;          // row 0 of the lane
+    unsigned base;            // its element offset at channel `co`
+    __device__ EpiRows(int lane, int wave, int img0, int oh0, int ow0, const ConvShape& s, int co)
+        : img(img0), oh(oh0 + 2 * wave), ow(ow0 + 4 * (lane >> 5)), base((unsigned)(((img0 * s.H + oh0 + 2 * wave) * s.W + ow0 + 4 * (lane >> 5)) * s.Cout + co)) {}
+    // (i is a compile-time constant where this is used: scalar arithmetic)
+    __device__ static unsigned delta(int i, const ConvShape& s) {
+        const int dc = i & 3, half = (i >> 2) & 1, dy = i >> 3;
+        return TW == 16 ? (unsigned)((dy * s.W + dc + 8 * half) * s.Cout) : (unsigned)(((half * s.H + dy) * s.W + dc) * s.Cout);
+    }
+    __device__ bool ok(int i, const ConvShape& s) const {
+        const int dc = i & 3, half = (i >> 2) & 1, dy = i >> 3;
+        return (TW == 16 ? img : img + half) < s.N && oh + dy < s.H && (TW == 16 ? ow + dc + 8 * half : ow + dc) < s.W;
+    }
+};
+
 // EPI 3's gate values (the layer below's output at the positions this lane is about to write) loaded AHEAD of the item's last MFMAs:
 // inside the epilogue their latency sat on every item's critical path (a 32-channel layer at 224 x 224: 18 MFMAs per item, then
 // sixteen dependent loads, then the stores).
@@ -83,31 +105,22 @@ __device__ inline void halo_gate_prefetch(float (&g)[NT][16], int lane, int wave
     if constexpr (sizeof(TG) == 2) {
         // bf16 tensors: the epilogue writes channel PAIRS (halo_epilogue, below) -- lane (l, l ^ 1) = channels (co, co + 1): the even lane
         // rows 2j, the odd lane rows 2j + 1 -- so a lane's gates are the eight dwords at (its row of pair j, co & ~1): g[t][j], as bits
+        const int odd = lane & 1;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int co2 = n0 + 32 * t + (lane & 30);
+            EpiRows<TW> R(lane, wave, img0, oh0, ow0, s, n0 + 32 * t + (lane & 30));
+            R.ow += odd; R.base += odd ? (unsigned)s.Cout : 0u;       // row 2j + 1 is one block column to the right of row 2j
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int pr = mfma32_row(lane, 2 * j) + (lane & 1);
-                const int colb = pr & 15;
-                const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
-                const bool ok = img < s.N && oh < s.H && ow < s.W;
-                g[t][j] = __uint_as_float(*reinterpret_cast<const unsigned*>(G + (ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co2) : 0u)));
-            }
+            for (int j = 0; j < 8; ++j)
+                g[t][j] = __uint_as_float(*reinterpret_cast<const unsigned*>(G + (R.ok(2 * j, s) ? R.base + R.delta(2 * j, s) : 0u)));
         }
         return;
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int co = n0 + 32 * t + (lane & 31);
+        const EpiRows<TW> R(lane, wave, img0, oh0, ow0, s, n0 + 32 * t + (lane & 31));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int pr = mfma32_row(lane, i);
-            const int colb = pr & 15;
-            const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
-            const bool ok = img < s.N && oh < s.H && ow < s.W;
-            g[t][i] = widen(G[ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co) : 0u]);
-        }
+        for (int i = 0; i < 16; ++i) g[t][i] = widen(G[R.ok(i, s) ? R.base + R.delta(i, s) : 0u]);
     }
 }
 
@@ -117,6 +130,14 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                                      const float* __restrict__ bias, TY* __restrict__ Y, uint8_t* __restrict__ pool_idx,
                                      const float (*gate)[16] = nullptr, const float* bias_ready = nullptr) {      // bias_ready[t]: the lane's bias, already in registers
     const int h = lane >> 5;
+    // EPI 4 (bias + ReLU + the 2x2 max-pool that follows): a lane's sixteen rows are block columns 4h..4h+3 and 8+4h..8+4h+3 of BOTH pixel
+    // rows of its wave -- four complete pooling windows (gq, pp) whose left pixel is block column 4 h + 8 gq + 2 pp (TW = 8: columns 0..7
+    // are image 0, 8..15 image 1: still whole windows).  Pooled offset = the lane's offset of window (0, 0) + a uniform delta.
+    const int OH = s.H / 2, OW = s.W / 2;
+    const int poh = oh0 / 2 + wave, pow0 = ow0 / 2 + 2 * h;
+    auto pool_base = [&](int co) { return (unsigned)(((img0 * OH + poh) * OW + pow0) * s.Cout + co); };
+    auto pool_delta = [&](int gq, int pp) { return TW == 16 ? (unsigned)((4 * gq + pp) * s.Cout) : (unsigned)((gq * OH * OW + pp) * s.Cout); };
+    auto pool_ok = [&](int gq, int pp) { return (TW == 16 ? img0 : img0 + gq) < s.N && poh < OH && (TW == 16 ? pow0 + 4 * gq + pp : pow0 + pp) < OW; };
     if constexpr (sizeof(TY) == 2) {
         // bf16 output: two-byte stores are half a dword each -- sixteen store instructions per tile for 2 KB.  Lanes l and l ^ 1 hold
         // adjacent channels of the same sixteen rows: they swap half of their values (one DPP move per row pair) so that the even lane
@@ -124,15 +145,14 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
         // of EPI 3 is read the same way).  Same values, same rounding.
         static_assert(EPI != 3 || sizeof(TG) == 2, "a bf16 gradient is gated by a bf16 map");
         using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-        const bool odd = lane & 1;
+        const int odd = lane & 1;
         auto swap = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); };   // quad_perm [1, 0, 3, 2]
         if (EPI == 4) {
-            const int OH = s.H / 2, OW = s.W / 2;
-            const int poh = oh0 / 2 + wave;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int co = n0 + 32 * t + (lane & 31);
                 const float bb = bias_ready ? bias_ready[t] : bias[co];
+                const unsigned pb = pool_base(co), pb2 = pool_base(co & ~1);
 #pragma unroll
                 for (int gq = 0; gq < 2; ++gq) {
                     float best[2];
@@ -147,18 +167,14 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                             if (v[k] > b) { b = v[k]; bk = k; }
                         b += bb;
                         best[pp] = b > 0.f ? b : 0.f;
-                        const int colb = 4 * h + 8 * gq + 2 * pp;
-                        const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
-                        const bool ok = img < s.N && poh < OH && pow_ < OW;
-                        store_idx_quad(pool_idx, (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co), bk, ok, lane);
+                        store_idx_quad(pool_idx, pb + pool_delta(gq, pp), bk, pool_ok(gq, pp), lane);
                     }
                     // the even lane writes window pp = 0 for both channels, the odd lane window pp = 1
                     const float recv = swap(odd ? best[0] : best[1]);
-                    const int colb = 4 * h + 8 * gq + (odd ? 2 : 0);
-                    const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
-                    const bool ok = img < s.N && poh < OH && pow_ < OW;
-                    const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + (co & ~1));
-                    const bf16x2 pk = {(__bf16)(odd ? recv : best[0]), (__bf16)(odd ? best[1] : recv)};
+                    bf16x2 pk = {(__bf16)(odd ? recv : best[0]), (__bf16)(odd ? best[1] : recv)};
+                    asm volatile("" : "+v"(pk));
+                    const bool ok = odd ? pool_ok(gq, 1) : pool_ok(gq, 0);
+                    const unsigned o = pb2 + (odd ? pool_delta(gq, 1) : pool_delta(gq, 0));
                     if (ok) *reinterpret_cast<bf16x2*>(Y + o) = pk;
                 }
             }
@@ -167,19 +183,16 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
             for (int t = 0; t < NT; ++t) {
                 const int co = n0 + 32 * t + (lane & 31);
                 const float bb = (EPI == 1 || EPI == 2) ? (bias_ready ? bias_ready[t] : bias[co]) : 0.f;
+                EpiRows<TW> R(lane, wave, img0, oh0, ow0, s, co & ~1);
+                R.ow += odd; R.base += odd ? (unsigned)s.Cout : 0u;   // this lane's row of pair j is 2j + odd: one block column to the right
                 // every gate word FIRST, in one burst: loaded where it is used, each load sat between the previous row's store and its own
                 // s_waitcnt vmcnt(0) (the compiler may not move a load above a store it cannot tell apart) -- eight serial round trips per
                 // tile, and, vmcnt being in order, each of them also waited for the next phase's prefetched operands (ISA, round 4)
                 unsigned gb[8];
                 if (EPI == 3 && !gate) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int pr = mfma32_row(lane, 2 * j) + (lane & 1);
-                        const int colb = pr & 15;
-                        const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
-                        const bool ok = img < s.N && oh < s.H && ow < s.W;
-                        gb[j] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const TG*>(bias) + (ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + (co & ~1)) : 0u));
-                    }
+                    for (int j = 0; j < 8; ++j)
+                        gb[j] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const TG*>(bias) + (R.ok(2 * j, s) ? R.base + R.delta(2 * j, s) : 0u));
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -187,11 +200,6 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                     if (EPI == 2) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
                     const float recv = swap(odd ? v0 : v1);
                     float lo = odd ? recv : v0, hi = odd ? v1 : recv;                 // channels co & ~1, (co & ~1) + 1 of this lane's row
-                    const int pr = mfma32_row(lane, 2 * j) + (lane & 1);
-                    const int colb = pr & 15;
-                    const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
-                    const bool ok = img < s.N && oh < s.H && ow < s.W;
-                    const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + (co & ~1));
                     if (EPI == 3) {
                         const unsigned g = gate ? __float_as_uint(gate[t][j]) : gb[j];
                         lo = __uint_as_float(g << 16) > 0.f ? lo : 0.f;
@@ -199,22 +207,19 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                     }
                     bf16x2 pk = {(__bf16)lo, (__bf16)hi};
                     asm volatile("" : "+v"(pk));                                       // (the value is complete BEFORE the branch around its store: nothing waits inside it)
-                    if (ok) *reinterpret_cast<bf16x2*>(Y + o) = pk;
+                    if (R.ok(2 * j, s)) *reinterpret_cast<bf16x2*>(Y + R.base + R.delta(2 * j, s)) = pk;
                 }
             }
         }
         return;
     }
     if (EPI == 4) {
-        // bias + ReLU + the 2x2 max-pool that follows: a lane's sixteen rows are block columns 4h..4h+3 and 8+4h..8+4h+3 of BOTH
-        // pixel rows of its wave -- four complete pooling windows (TW = 8: columns 0..7 are image 0, 8..15 image 1: still whole
-        // windows).  First maximum in the order 00, 01, 10, 11, as k_pool_fwd.
-        const int OH = s.H / 2, OW = s.W / 2;
-        const int poh = oh0 / 2 + wave;
+        // First maximum in the order 00, 01, 10, 11, as k_pool_fwd.
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int co = n0 + 32 * t + (lane & 31);
             const float bb = bias_ready ? bias_ready[t] : bias[co];
+            const unsigned pb = pool_base(co);
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
@@ -229,10 +234,9 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
                         if (v[k] > best) { best = v[k]; bk = k; }
                     best += bb;
                     best = best > 0.f ? best : 0.f;
-                    const int colb = 4 * h + 8 * gq + 2 * pp;                   // block column of the window's left pixel
-                    const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
-                    const bool ok = img < s.N && poh < OH && pow_ < OW;         // the same for the 32 lanes of a half-wave
-                    const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co);
+                    asm volatile("" : "+v"(best));
+                    const bool ok = pool_ok(gq, pp);                            // the same for the 32 lanes of a half-wave
+                    const unsigned o = pb + pool_delta(gq, pp);
                     if (ok) Y[o] = narrow<TY>(best);
                     store_idx_quad(pool_idx, o, bk, ok, lane);
                 }
@@ -242,33 +246,22 @@ __device__ inline void halo_epilogue(const f32x16 (&acc)[NT], int lane, int wave
         for (int t = 0; t < NT; ++t) {
             const int co = n0 + 32 * t + (lane & 31);
             const float bb = (EPI == 1 || EPI == 2) ? (bias_ready ? bias_ready[t] : bias[co]) : 0.f;
+            const EpiRows<TW> R(lane, wave, img0, oh0, ow0, s, co);
             // (all gate values first, and every value complete before the branch around its store: see the bf16 form above -- as written
             // before, each row's gate load waited behind the previous row's store, and the bias add sat inside the branch behind an
             // s_waitcnt vmcnt(0) that, after the first store, waited for that store)
             float gv[16];
             if (EPI == 3 && !gate) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int pr = mfma32_row(lane, i);
-                    const int colb = pr & 15;
-                    const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
-                    const bool ok = img < s.N && oh < s.H && ow < s.W;
-                    gv[i] = widen(reinterpret_cast<const TG*>(bias)[ok ? (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co) : 0u]);
-                }
+                for (int i = 0; i < 16; ++i) gv[i] = widen(reinterpret_cast<const TG*>(bias)[R.ok(i, s) ? R.base + R.delta(i, s) : 0u]);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int pr = mfma32_row(lane, i);
-                const int colb = pr & 15;
-                const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
                 float v = acc[t][i] + bb;
                 if (EPI == 2) v = v > 0.f ? v : 0.f;
                 if (EPI == 3) v = (gate ? gate[t][i] : gv[i]) > 0.f ? v : 0.f;
                 asm volatile("" : "+v"(v));
-                if (img < s.N && oh < s.H && ow < s.W) {
-                    const unsigned o = (unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co);      // the host keeps tensors below 2^31 elements
-                    Y[o] = narrow<TY>(v);
-                }
+                if (R.ok(i, s)) Y[R.base + R.delta(i, s)] = narrow<TY>(v);       // the host keeps tensors below 2^31 elements
             }
         }
     }
