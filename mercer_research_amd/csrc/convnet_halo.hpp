@@ -769,47 +769,11 @@ __global__ __launch_bounds__(kThreads) void k_conv1_fwd_f32(const float* __restr
         }
         RCNX_STAMP(stamp_slot); ++stamp_slot;                         // MFMAs issued
         const int img0 = cur.img0, oh0 = cur.oh0, ow0 = cur.ow0;
-        const int co = cur.n0 + r;
-        if constexpr (sizeof(TY) == 2) {
-            // bf16 output: the shared epilogue's channel-pair stores (same layout of the accumulator rows, one column tile)
+        {
+            // the shared epilogue (same layout of the accumulator rows, one column tile): uniform row deltas, channel-pair stores for bf16
             const f32x16 a1[1] = {acc};
             const float bb1[1] = {bb};
             halo_epilogue<TW, 1, EPI, TY, TY>(a1, lane, wave, img0, oh0, ow0, cur.n0, s, bias, Y, pool_idx, nullptr, bb1);
-        } else if (EPI == 4) {
-            // max-pool of relu(x + b) = relu(max(x) + b): the maximum (first of equals, order 00 01 10 11) is taken on the raw sums
-            const int OH = s.H / 2, OW = s.W / 2;
-            const int poh = oh0 / 2 + wave;
-#pragma unroll
-            for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {
-                    const int i0 = 4 * gq + 2 * pp;
-                    const float v[4] = {acc[i0], acc[i0 + 1], acc[8 + i0], acc[8 + i0 + 1]};
-                    float best = v[0];
-                    int bk = 0;
-#pragma unroll
-                    for (int k = 1; k < 4; ++k)
-                        if (v[k] > best) { best = v[k]; bk = k; }
-                    best += bb;
-                    best = best > 0.f ? best : 0.f;
-                    const int colb = 4 * h + 8 * gq + 2 * pp;
-                    const int img = img0 + colb / TW, pow_ = (ow0 + colb % TW) / 2;
-                    const bool ok = img < s.N && poh < OH && pow_ < OW;
-                    const unsigned o = (unsigned)(((img * OH + poh) * OW + pow_) * s.Cout + co);
-                    if (ok) Y[o] = narrow<TY>(best);
-                    store_idx_quad(pool_idx, o, bk, ok, lane);
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int pr = mfma32_row(lane, i);
-                const int colb = pr & 15;
-                const int img = img0 + colb / TW, oh = oh0 + 2 * wave + (pr >> 4), ow = ow0 + colb % TW;
-                if (img < s.N && oh < s.H && ow < s.W) {
-                    const float v = acc[i] + bb;
-                    Y[(unsigned)(((img * s.H + oh) * s.W + ow) * s.Cout + co)] = narrow<TY>(v > 0.f ? v : 0.f);
-                }
-            }
         }
         RCNX_STAMP(stamp_slot); ++stamp_slot;                         // epilogue issued
         cur = nxt;
