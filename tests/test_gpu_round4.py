@@ -506,6 +506,9 @@ def test_trackx_bf16_storage_rounds_what_bf16_mode_rounds(shape):
     ((16, 16, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 32), ("dense", 10)), 5),
     ((32, 32, 1), (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense", 7)), 3),
     ((16, 32, 3), (("conv", 64), ("pool",), ("conv", 128), ("conv", 128), ("pool",), ("dense_relu", 128), ("dense_relu", 32), ("dense", 3)), 9),
+    # 24-pixel-wide maps: the first layer's kernels take 8 x 8 blocks of TWO images side by side (an odd batch leaves the last block half empty)
+    ((24, 24, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 64), ("dense", 10)), 5),
+    ((24, 24, 1), (("conv", 32), ("conv", 32), ("pool",), ("dense", 10)), 6),
 ])
 def test_trackx_bf16_storage_matches_the_oracle_with_the_storage_rounding_mirrored(in_shape, layers, B):
     """RCN_HIPX_BF16_STORED against oracle/convnet_oracle.py evaluated with the same operand rounding AND the same storage rounding
