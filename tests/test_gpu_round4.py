@@ -590,6 +590,38 @@ def test_trackx_bf16_storage_16x16_pixel_blocks_compute_the_same_bits():
     assert np.isfinite(b[3]).all() and np.isfinite(b[4])
 
 
+def test_trackx_bf16_storage_partial_batches_and_mode_switches():
+    """A net built for 32 pictures steps batches of 7 and 32 in bf16-storage mode (in this mode a 3 x 3 layer's kernels do not depend on
+    the batch size), then is switched to bf16 and fp32 mode and back: every forward pass agrees with the oracle evaluated in that mode on
+    the parameters the net has at that point."""
+    import torch
+    from mercer_research_amd.convnet import ConvNet
+    from oracle import convnet_oracle as co
+    in_shape, layers, MB = (16, 16, 3), (("conv", 32), ("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense_relu", 64), ("dense", 10)), 32
+    rng = np.random.default_rng(31)
+    net = ConvNet(in_shape, layers, MB)
+    net.init_params(3)
+    net.set_precision("bf16_stored")
+    loss = torch.zeros(1, dtype=torch.float32, device=net.device)
+    for B in (7, 32, 7):
+        x = rng.standard_normal((B,) + in_shape).astype(np.float32)
+        y = rng.integers(0, 10, B).astype(np.int32)
+        net.train_step(net.to_device(x), net.to_device(y), 0.01, loss)
+    net.synchronize()
+    assert np.isfinite(loss.item())
+    x = rng.standard_normal((7,) + in_shape).astype(np.float32)
+    xd = net.to_device(x)
+    ws, bs = co.unflatten(net.get_params().astype(np.float64), in_shape, layers)
+    for mode, kw, tol in (("bf16_stored", dict(operand="bf16", stored=True), 5e-3), ("bf16", dict(operand="bf16"), 5e-3), ("fp32", dict(), 2e-4),
+                          ("bf16_stored", dict(operand="bf16", stored=True), 5e-3)):
+        net.set_precision(mode)
+        lg = net.forward(xd)
+        net.synchronize()
+        ref = co.forward(x.astype(np.float64), ws, bs, layers, **kw)
+        assert np.abs(lg.cpu().numpy() - ref).max() <= tol * max(1e-3, np.abs(ref).max()) + 1e-6, mode
+    net.close()
+
+
 def test_trackx_bf16_storage_refuses_a_net_it_does_not_cover():
     """rcn_hipx_set_precision walks the net's plan first: a net with a layer that no bf16-tensor kernel runs (here: the LDS-tiled kernels
     switched off) gets -3 with the reason, and stays in the mode it was in."""
