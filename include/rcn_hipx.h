@@ -116,7 +116,9 @@ int  rcn_hipx_plan_buckets(int in_h, int in_w, int in_c, const rcn_hipx_layer* l
 int  rcn_hipx_unpad_host(rcn_hipx_net* net, const float* padded_dev, float* logical_host);
 /* Which kernels a training step of this net WOULD launch, one line per launch, written to `out` (NUL-terminated, truncated at `cap`).
  * Pure host code -- no GPU is needed or touched: the dispatch code of the step runs with its launches replaced by notes, so the text is
- * the library's own decision, not a restatement of it (tests/test_convnet_plan.py holds the BASELINE configurations' plans). */
+ * the library's own decision, not a restatement of it (tests/test_convnet_plan.py holds the BASELINE configurations' plans).
+ * `precision` takes all three modes; for RCN_HIPX_BF16_STORED the call returns -3 with the reason in `out` when a layer of the net is not
+ * covered by the kernels that take bf16 tensors. */
 int  rcn_hipx_plan(int in_h, int in_w, int in_c, const rcn_hipx_layer* layers, int n_layers, int batch, int precision, int tiling, char* out, int cap);
 /* The same walk for an EXISTING net at batch `batch` (<= max_batch) with that net's own precision, tiling and options: the plan and the
  * step that follows agree by construction (rcn_hipx_plan describes a net created now, seeded from the environment). */

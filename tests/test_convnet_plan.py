@@ -117,3 +117,21 @@ def test_bucket_plan_cuts_the_gradient_into_contiguous_slices_in_backward_order(
     t = plan(shp, layers, B, "fp32", "auto", buckets=256 << 10)
     assert t.count(" done: grad[") == 2 and "bucket 0: layers 6 .. 6" in t              # the two dense layers (2.1 MB), then the three convolutions (0.37 MB)
     assert plan(shp, layers, B, "fp32", "auto", buckets=1 << 20).count(" done: grad[") == 1     # ... which are less than 1 MiB and join the bucket above them
+
+
+def test_bf16_storage_plans_name_the_bf16_tensor_kernels_and_refuse_what_they_do_not_cover():
+    """RCN_HIPX_BF16_STORED (no GPU needed): the three BASELINE nets are covered -- every convolution on the LDS-tiled bf16 kernels or the
+    first layer's own, every pool fused, no k_pool_fwd / k_pool_bwd / k_relu_bwd launch, the dense layer on top of the stage reading and
+    writing bf16 maps; a net whose maps are too small for the LDS-tiled weight gradient is refused with the reason."""
+    import pytest
+    from mercer_research_amd.convnet import ConvNetError, plan
+    import bench_convnet as bc
+    for name in ("cifar", "mnist", "synth224"):
+        in_shape, layers, B = bc.CONFIGS[name]
+        text = plan(in_shape, layers, B, precision="bf16_stored")
+        assert "stored as bf16" in text
+        assert "k_pool_fwd" not in text and "k_pool_bwd" not in text and "k_relu_bwd" not in text, text
+        assert "bf16 input map" in text and "bf16 output map" in text
+        assert "k_conv_fwd<" not in text and "k_conv3x3_halo_f32" not in text          # no fp32 convolution kernel but the first layer's
+    with pytest.raises(ConvNetError, match="bf16 storage"):
+        plan((8, 8, 3), (("conv", 32), ("pool",), ("conv", 64), ("pool",), ("dense", 10)), 16, precision="bf16_stored")
